@@ -1,0 +1,184 @@
+/*
+ * ptoracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference path tracer's hot path
+ * (CIS565 Project3-CUDA-Path-Tracer, src/pathtrace.cu, src/intersections.h,
+ * src/interactions.h, src/sceneStructs.h, thrust minstd_rand) plus the
+ * canonical completion spec of SURVEY.md section 8.0 for the stages the
+ * reference leaves as TODO (scatter, bounce loop, compaction, material sort,
+ * dielectric, triangles).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product (libptmi355.so) never links or calls it.
+ *
+ * Parity status: PINNED for every function that exists in the reference
+ * (checked bit-for-bit against oracle/_ref, a build of the reference's own
+ * headers, and against the committed vectors in tests/golden/).  The
+ * completion-spec stages have no reference implementation to pin against;
+ * they are build-defined and are exercised through the
+ * reference's own headers by oracle/ref_wrapper.cpp where possible.
+ *
+ * All structs are byte-compatible with src/sceneStructs.h:15-76 on x86-64
+ * (sizes/offsets measured in SURVEY.md section 8b) and are _Static_assert'ed
+ * in ptoracle.c.
+ */
+#ifndef PTORACLE_H
+#define PTORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z; } pto_vec3;            /* glm::vec3, 12 B */
+typedef struct { float x, y, z, w; } pto_vec4;         /* glm::vec4, 16 B */
+typedef struct { float m[4][4]; } pto_mat4;            /* glm::mat4, m[col][row], 64 B */
+
+enum { PTO_SPHERE = 0, PTO_CUBE = 1, PTO_TRIMESH = 2 }; /* sceneStructs.h:10-13 (+mesh) */
+
+typedef struct { pto_vec3 origin, direction; } pto_ray;            /* sceneStructs.h:15-18 */
+
+typedef struct {                                                    /* sceneStructs.h:20-29 */
+    int type;
+    int materialid;
+    pto_vec3 translation, rotation, scale;
+    pto_mat4 transform, inverseTransform, invTranspose;
+} pto_geom;                                                         /* 236 B */
+
+typedef struct {                                                    /* sceneStructs.h:31-41 */
+    pto_vec3 color;
+    struct { float exponent; pto_vec3 color; } specular;
+    float hasReflective, hasRefractive, indexOfRefraction, emittance;
+} pto_material;                                                     /* 44 B */
+
+typedef struct {                                                    /* sceneStructs.h:43-52 */
+    int resolution[2];
+    pto_vec3 position, lookAt, view, up, right;
+    float fov[2];
+    float pixelLength[2];
+} pto_camera;                                                       /* 84 B */
+
+typedef struct {                                                    /* sceneStructs.h:62-67 */
+    pto_ray ray;
+    pto_vec3 color;
+    int pixelIndex;
+    int remainingBounces;
+} pto_path;                                                         /* 44 B */
+
+typedef struct {                                                    /* sceneStructs.h:72-76 */
+    float t;
+    pto_vec3 surfaceNormal;
+    int materialId;
+} pto_isect;                                                        /* 20 B */
+
+typedef struct { pto_vec3 v0, v1, v2; } pto_tri;       /* world-space triangle, 36 B */
+typedef struct { int geom_index, first_tri, tri_count; } pto_mesh;
+
+/* trig binding for calculateRandomDirectionInHemisphere (interactions.h:40-41):
+ * the reference calls unqualified cos/sin, which bind to the platform libm.
+ * PTO_TRIG_LIBM binds to this host's libm (sinf/cosf); PTO_TRIG_SHARED binds
+ * to pto_sincos(), the double-precision polynomial that the HIP kernels also
+ * implement op-for-op, so CPU and GPU agree bit-for-bit. */
+enum { PTO_TRIG_LIBM = 0, PTO_TRIG_SHARED = 1 };
+
+/* flags for pto_trace_iteration */
+enum {
+    PTO_F_COMPACT   = 1,   /* stable partition of live paths after each bounce */
+    PTO_F_SORT      = 2,   /* stable sort of live paths by materialId before shading */
+    PTO_F_FAKESHADE = 4    /* run the reference's as-is one-bounce fake shader */
+};
+
+/* ---- integer / RNG (intersections.h:12-20, pathtrace.cu:41-45, thrust) ---- */
+uint32_t pto_utilhash(uint32_t a);
+uint32_t pto_make_seeded_engine(int iter, int index, int depth);  /* returns LCG state */
+uint32_t pto_lcg_seed(uint32_t s);
+uint32_t pto_lcg_next(uint32_t *state);
+float    pto_u01(uint32_t *state);
+
+/* ---- shared trig ---- */
+void pto_sincos(float x, float *s, float *c);
+
+/* ---- geometry helpers ---- */
+pto_vec3 pto_get_point_on_ray(pto_ray r, float t);                       /* intersections.h:27-29 */
+pto_vec3 pto_multiply_mv(const pto_mat4 *m, pto_vec4 v);                 /* intersections.h:34-36 */
+float pto_box_test(const pto_geom *box, pto_ray r, pto_vec3 *point,
+                   pto_vec3 *normal, int *outside);                      /* intersections.h:48-90 */
+float pto_sphere_test(const pto_geom *sphere, pto_ray r, pto_vec3 *point,
+                      pto_vec3 *normal, int *outside);                   /* intersections.h:102-144 */
+int   pto_ray_triangle(pto_vec3 orig, pto_vec3 dir, pto_vec3 v0, pto_vec3 v1,
+                       pto_vec3 v2, pto_vec3 *bary);                     /* glm/gtx/intersect.inl:37-74 */
+float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r,
+                    pto_vec3 *point, pto_vec3 *normal, int *outside);    /* spec 8.0 */
+pto_vec3 pto_hemisphere(pto_vec3 normal, uint32_t *rng, int trig);       /* interactions.h:10-42 */
+pto_vec3 pto_reflect(pto_vec3 I, pto_vec3 N);                            /* glm func_geometric.inl:175-179 */
+
+/* ---- kernels restated as loops (pathtrace.cu) ---- */
+void pto_generate_rays(const pto_camera *cam, int traceDepth, pto_path *paths);       /* :122-143 */
+void pto_compute_intersections(int n, const pto_path *paths, const pto_geom *geoms,
+                               int ngeoms, const pto_tri *tris, const pto_mesh *meshes,
+                               int nmeshes, pto_isect *isects, uint8_t *outside_or_null); /* :149-213 */
+void pto_shade_fake(int iter, int n, const pto_isect *isects, pto_path *paths,
+                    const pto_material *materials);                                    /* :224-266 */
+void pto_final_gather(int n, pto_vec3 *image, const pto_path *paths);                 /* :269-278 */
+void pto_send_image_to_pbo(uint8_t *pbo_rgba, int w, int h, int iter,
+                           const pto_vec3 *image);                                     /* :48-68 */
+
+/* ---- completion spec ---- */
+void pto_scatter_ray(pto_path *path, pto_vec3 intersect, pto_vec3 normal, int outside,
+                     const pto_material *m, uint32_t *rng, int trig);                  /* interactions.h:69-79 */
+void pto_shade_scatter(int iter, int depth, int n, const pto_isect *isects,
+                       const uint8_t *outside, pto_path *paths,
+                       const pto_material *materials, int trig);
+int  pto_compact(int n, pto_path *paths, pto_path *scratch);   /* stable partition, returns n_live */
+void pto_sort_by_material(int n, pto_path *paths, pto_isect *isects, uint8_t *outside,
+                          void *scratch);                      /* stable, scratch >= n*(44+20+1) B */
+
+typedef struct {
+    const pto_geom *geoms;         int ngeoms;
+    const pto_material *materials; int nmaterials;
+    const pto_tri *tris;           int ntris;
+    const pto_mesh *meshes;        int nmeshes;
+    pto_camera camera;
+    int traceDepth;
+    int flags;
+    int trig;
+} pto_scene;
+
+typedef struct {
+    int      bounces;              /* bounces actually executed */
+    int64_t  rays;                 /* sum over bounces of paths traced */
+    int32_t  live[64];             /* live[d] = paths traced at bounce d */
+    uint64_t seq_hash[64];         /* FNV-1a of pixelIndex[0..n_live) AFTER bounce d */
+    double   sec_intersect, sec_shade, sec_other;
+} pto_stats;
+
+/* One full iteration (pathtrace.cu:284-393 with the 8.0 loop). `paths`/`isects`
+ * are caller scratch of N entries; image (N vec3) accumulates the running sum.
+ * Optional per-bounce snapshot callback for parity tests. */
+typedef void (*pto_bounce_cb)(void *user, int depth, int n_before, int n_live,
+                              const pto_path *paths, const pto_isect *isects);
+void pto_trace_iteration(const pto_scene *sc, int iter, pto_vec3 *image,
+                         pto_path *paths, pto_isect *isects, pto_stats *stats,
+                         pto_bounce_cb cb, void *user);
+
+/* multi-threaded variant for the CPU baseline (same results: paths are
+ * independent; compaction is done with per-thread counts + prefix). */
+void pto_trace_iteration_mt(const pto_scene *sc, int iter, pto_vec3 *image,
+                            pto_path *paths, pto_isect *isects, pto_stats *stats,
+                            int nthreads);
+
+uint64_t pto_fnv1a_i32(const int32_t *v, int stride_bytes, int n);
+
+/* ---- host-side scene math ("next" row f1: scene.cpp / utilities.cpp / main.cpp) ---- */
+pto_mat4 pto_build_transformation_matrix(pto_vec3 translation, pto_vec3 rotation,
+                                         pto_vec3 scale);      /* utilities.cpp:65-72 */
+pto_mat4 pto_mat4_inverse(const pto_mat4 *m);                  /* glm func_matrix.inl inverse */
+pto_mat4 pto_mat4_inverse_transpose(const pto_mat4 *m);        /* glm gtc/matrix_inverse.inl */
+void pto_camera_from_scene(pto_camera *cam, float fovy_deg);   /* scene.cpp:133-142 */
+void pto_camera_orbit_recompute(pto_camera *cam);              /* main.cpp:53-67,102-120 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
