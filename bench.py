@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the wavefront path tracer on the BASELINE.json workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config c2|c3|c5tile]
+
+A *step* is one pass of the hot path over one batch of synthetic input: B
+iterations (samples per pixel) of the 800x800 depth-8 Cornell box with the
+mirror ball (BASELINE.json configs[1], "c2"), traced as one path pool through
+ray generation, the fused intersect/shade/compact bounce kernels and the final
+gather, with every buffer resident in HBM.  value = rays traced (sum over
+bounces of live paths, counted on the device) / wall time, in Mrays/s.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is tiled
+across the ranks in interleaved row strips, every rank traces B*N iterations of
+its tile per step (per-GPU work fixed -> weak scaling) and the float3
+accumulation buffers are summed onto rank 0 with one RCCL reduce per step.
+
+Extra JSON objects (see the task statement): `roofline` for the dominant kernel
+(k_bounce: algorithmic bytes / HIP-event time on the launch stream) and
+`cpu_baseline` (the plain-C oracle on this host's cores, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+# SURVEY 8(d) algorithmic bytes: intersect 44 B/ray + shade/scatter 104 B/ray +
+# compaction 4 B/ray, + 88 B per surviving path -- all done by the fused k_bounce launch
+BYTES_PER_RAY = 44 + 104 + 4
+BYTES_PER_SURVIVOR = 88
+
+
+def load_scene(pt, name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+    g = lambda k: z["%s__%s" % (name, k)]
+    return pt.Scene(g("geoms"), g("materials"), g("camera"), int(g("depth")), name=name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="iterations (spp) per step per full frame")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--flags", default="compact", help="comma list: compact,sort,unfused")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--strip-rows", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    pt = ge.load_package()
+    pt.library()
+    scene_name = {"c2": "cornell", "c3": "cornell_glass"}[args.config]
+    scene = load_scene(pt, scene_name)
+    W, H = scene.resolution
+    npix = W * H
+    flags = 0
+    for f in args.flags.split(","):
+        flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED, "": 0}[f]
+    per_step_iters = args.batch * world          # iterations of this rank's tile per step
+
+    stream = torch.cuda.current_stream()
+    image = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")     # accumulation buffer (torch-owned)
+    frame = torch.zeros_like(image) if world > 1 else None                # reduce target / staging
+    pt.pathtraceInit(scene, flags=flags, device=local_rank, stream=stream.cuda_stream,
+                     tile=(rank, world, args.strip_rows), max_batch=per_step_iters,
+                     device_image=image.data_ptr())
+
+    def step(i):
+        pt.trace_batch_async(1 + i * per_step_iters, per_step_iters)
+        if world > 1:
+            frame.copy_(image)
+            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)      # RCCL over xGMI, once per step
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        step(it); it += 1
+    barrier()
+    # HIP events bracket every kernel launch of the timed region on the launch stream
+    # (2 events per launch from a preallocated pool; no host sync until the region ends)
+    profile_on = not args.no_roofline and args.steps * (scene.traceDepth + 2) <= 2000
+    if profile_on:
+        pt.set_profiling(True)
+    rays0, first0, _ = pt.counters()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(it); it += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    rays1, first1, _ = pt.counters()
+    rays, first = rays1 - rays0, first1 - first0
+    rank_rays = rays
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rsum = torch.tensor([float(rays)], dtype=torch.float64, device="cuda"); dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+        dt, rays = float(tmax.item()), float(rsum.item())
+    value = rays / dt / 1e6
+
+    # ---- roofline of the dominant kernel (this rank's launches in the timed region) ----
+    roofline = None
+    if profile_on:
+        prof = pt.get_profile()
+        pt.set_profiling(False)
+        survivors = rank_rays - first                 # paths that survived a compaction = rays of bounces >= 1
+        ms, launches = prof["bounce"]
+        algo_bytes = rank_rays * BYTES_PER_RAY + survivors * BYTES_PER_SURVIVOR
+        achieved = algo_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": "k_bounce<fused,compact>", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None, "launches": int(launches),
+                    "avg_launch_us": round(ms * 1e3 / max(1, launches), 2),
+                    "algorithmic_bytes_per_launch": int(algo_bytes / max(1, launches)),
+                    "stage_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]},
+                    "grays_per_s_in_kernel": round(rank_rays / (ms * 1e-3) / 1e9, 3) if ms > 0 else 0.0}
+
+    # ---- CPU baseline: the oracle (plain-C port) on this host, rank 0, N = 1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(scene)
+
+    pt.pathtraceFree()
+    if rank == 0:
+        out = {
+            "metric": "Mrays/sec (live paths x bounces) at 800x800 Cornell depth 8",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "scenes/cornell.txt (%s) %dx%d depth %d, compaction on, %d spp per step per GPU-tile"
+                                   % (scene_name, W, H, scene.traceDepth, per_step_iters),
+                       "batch_spp": args.batch, "flags": args.flags,
+                       "sharding": "whole frame" if world == 1 else
+                       "interleaved %d-row strips over %d GPUs, RCCL reduce(SUM) of the float3 buffer per step"
+                       % (args.strip_rows, world),
+                       "rays_per_step": int(rays / args.steps)},
+        }
+        if roofline:
+            out["roofline"] = roofline
+        if cpu:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _total_rays(pt):
+    return pt.total_rays()            # device-side counter; synchronises the stream
+
+
+def cpu_baseline(scene):
+    from oracle import pyoracle as po
+    ncores = os.cpu_count() or 1
+    tr = po.Tracer(scene.geoms.view(po.GEOM_DT), scene.materials.view(po.MATERIAL_DT),
+                   scene.camera.view(po.CAMERA_DT), scene.traceDepth, flags=po.F_COMPACT,
+                   trig=po.TRIG_SHARED)
+    rays, t0, iters = 0, time.perf_counter(), 0
+    while True:
+        iters += 1
+        rays += tr.iterate(iters, threads=ncores).rays
+        el = time.perf_counter() - t0
+        if el > 10.0 or iters >= 64:
+            break
+    return {"value": round(rays / el / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "kind": "port",
+            "sample": "%d iterations of the same 800x800 depth-8 Cornell workload (%.1f s), oracle/ptoracle.c "
+                      "pto_trace_iteration_mt with %d pthreads" % (iters, el, ncores)}
+
+
+if __name__ == "__main__":
+    main()

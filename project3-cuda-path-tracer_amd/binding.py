@@ -1,0 +1,283 @@
+"""ctypes binding of libptmi355.so.  Mirrors the reference's renderer interface:
+
+    pathtraceInit(scene)            src/pathtrace.h:6   (pathtrace.cu:79-98)
+    pathtraceFree()                 src/pathtrace.h:7   (pathtrace.cu:100-112)
+    pathtrace(pbo, frame, iter)     src/pathtrace.h:8   (pathtrace.cu:284-393)
+
+`Scene` carries what the reference's Scene/RenderState carry for this path
+(scene.h:13-26, sceneStructs.h:54-60) as numpy arrays with the reference's
+struct layouts.  There is no CPU fallback: if the HIP library is missing or no
+GPU is present, calls raise PtError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# byte-compatible with src/sceneStructs.h (x86-64): 236 / 44 / 84 / 44 / 20 bytes
+GEOM_DT = np.dtype([("type", "<i4"), ("materialid", "<i4"), ("translation", "<f4", 3),
+                    ("rotation", "<f4", 3), ("scale", "<f4", 3), ("transform", "<f4", (4, 4)),
+                    ("inverseTransform", "<f4", (4, 4)), ("invTranspose", "<f4", (4, 4))])
+MATERIAL_DT = np.dtype([("color", "<f4", 3), ("spec_exponent", "<f4"), ("spec_color", "<f4", 3),
+                        ("hasReflective", "<f4"), ("hasRefractive", "<f4"),
+                        ("indexOfRefraction", "<f4"), ("emittance", "<f4")])
+CAMERA_DT = np.dtype([("resolution", "<i4", 2), ("position", "<f4", 3), ("lookAt", "<f4", 3),
+                      ("view", "<f4", 3), ("up", "<f4", 3), ("right", "<f4", 3),
+                      ("fov", "<f4", 2), ("pixelLength", "<f4", 2)])
+PATH_DT = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("color", "<f4", 3),
+                    ("pixelIndex", "<i4"), ("remainingBounces", "<i4")])
+ISECT_DT = np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("materialId", "<i4")])
+TRI_DT = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3)])
+MESH_DT = np.dtype([("geom_index", "<i4"), ("first_triangle", "<i4"), ("triangle_count", "<i4")])
+
+PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED = 1, 2, 4, 8, 16
+
+
+class PtError(RuntimeError):
+    pass
+
+
+class _Camera(C.Structure):
+    _fields_ = [("raw", C.c_uint8 * 84)]
+
+
+class _SceneDesc(C.Structure):
+    _fields_ = [("geoms", C.c_void_p), ("num_geoms", C.c_int32),
+                ("materials", C.c_void_p), ("num_materials", C.c_int32),
+                ("triangles", C.c_void_p), ("num_triangles", C.c_int32),
+                ("meshes", C.c_void_p), ("num_meshes", C.c_int32),
+                ("camera", _Camera), ("trace_depth", C.c_int32), ("flags", C.c_uint32),
+                ("device", C.c_int32), ("stream", C.c_void_p),
+                ("tile_index", C.c_int32), ("tile_count", C.c_int32), ("strip_rows", C.c_int32),
+                ("max_batch", C.c_int32), ("device_image", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("bounces", C.c_int32), ("rays", C.c_int64), ("live", C.c_int32 * 64),
+                ("total_rays", C.c_int64), ("total_iterations", C.c_int64)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 5), ("launches", C.c_int64 * 5)]
+
+
+STAGES = ("raygen", "bounce", "intersect", "sort", "gather")
+
+
+class Scene:
+    """What pathtraceInit reads from the reference's Scene* (scene.h:23-25)."""
+
+    def __init__(self, geoms, materials, camera, trace_depth, iterations=1, triangles=None,
+                 meshes=None, name="scene"):
+        self.geoms = np.ascontiguousarray(geoms, dtype=GEOM_DT)
+        self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DT)
+        self.camera = np.ascontiguousarray(camera, dtype=CAMERA_DT).reshape(1)
+        self.traceDepth = int(trace_depth)
+        self.iterations = int(iterations)
+        self.triangles = None if triangles is None else np.ascontiguousarray(triangles, dtype=TRI_DT)
+        self.meshes = None if meshes is None else np.ascontiguousarray(meshes, dtype=MESH_DT)
+        self.name = name
+        w, h = self.camera[0]["resolution"]
+        self.image = np.zeros((int(w) * int(h), 3), dtype=np.float32)     # state.image (running sum)
+
+    @property
+    def resolution(self):
+        w, h = self.camera[0]["resolution"]
+        return int(w), int(h)
+
+
+_lib = None
+_scene = None
+
+
+def library():
+    """Load libptmi355.so; raise loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "libptmi355.so")
+        if not os.path.exists(path):
+            raise PtError("libptmi355.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+        L = C.CDLL(path)
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_version.restype = C.c_char_p
+        L.pt_device_image.restype = C.c_void_p
+        L.pt_init.argtypes = [C.POINTER(_SceneDesc)]
+        L.pt_set_camera.argtypes = [C.c_void_p, C.c_int]
+        L.pt_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.pt_trace_batch.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.pt_trace_batch_async.argtypes = [C.c_int, C.c_int]
+        L.pt_trace_begin.argtypes = [C.c_int, C.c_int]
+        L.pt_trace_bounce.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.pt_export_paths.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.pt_export_intersections.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.pt_intersect_once.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.pt_get_image.argtypes = [C.c_void_p]
+        L.pt_tonemap.argtypes = [C.c_void_p, C.c_int]
+        L.pt_get_stats.argtypes = [C.POINTER(Stats)]
+        L.pt_total_rays.restype = C.c_int64
+        L.pt_get_counters.argtypes = [C.POINTER(C.c_int64)] * 3
+        L.pt_set_profiling.argtypes = [C.c_int]
+        L.pt_get_profile.argtypes = [C.POINTER(Profile)]
+        L.pt_free.restype = None
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc < 0:
+        raise PtError("ptmi355 error %d: %s" % (rc, library().pt_last_error().decode()))
+    return rc
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def version():
+    return library().pt_version().decode()
+
+
+def pathtraceInit(scene, flags=PT_COMPACT, device=0, stream=None, tile=(0, 1, 8), max_batch=1,
+                  device_image=None):
+    """pathtraceInit(Scene*) (pathtrace.cu:79-98) + the run-time toggles of include/ptmi355.h."""
+    global _scene
+    d = _SceneDesc()
+    d.geoms, d.num_geoms = _p(scene.geoms), len(scene.geoms)
+    d.materials, d.num_materials = _p(scene.materials), len(scene.materials)
+    d.triangles, d.num_triangles = _p(scene.triangles), 0 if scene.triangles is None else len(scene.triangles)
+    d.meshes, d.num_meshes = _p(scene.meshes), 0 if scene.meshes is None else len(scene.meshes)
+    C.memmove(C.byref(d.camera), scene.camera.tobytes(), 84)
+    d.trace_depth, d.flags, d.device = scene.traceDepth, flags, device
+    d.stream = stream
+    d.tile_index, d.tile_count, d.strip_rows = tile
+    d.max_batch = max_batch
+    d.device_image = device_image
+    _chk(library().pt_init(C.byref(d)))
+    _scene = scene
+
+
+def pathtraceFree():
+    """pathtraceFree() (pathtrace.cu:100-112): idempotent."""
+    global _scene
+    library().pt_free()
+    _scene = None
+
+
+def pathtrace(pbo, frame, iteration, copy_image=True):
+    """pathtrace(uchar4 *pbo, int frame, int iter) (pathtrace.cu:284-393).  `pbo` is a device
+    pointer (int) or None.  Like the reference (pathtrace.cu:285-286, 389-390) it re-reads the
+    camera / traceDepth from the scene and refreshes scene.image (the running sum)."""
+    if _scene is None:
+        raise PtError("pathtrace: pathtraceInit has not been called")
+    L = library()
+    _chk(L.pt_set_camera(_p(_scene.camera), _scene.traceDepth))
+    _chk(L.pt_trace(pbo, frame, iteration, _p(_scene.image) if copy_image else None))
+    return _scene.image
+
+
+def set_camera(camera, trace_depth):
+    cam = np.ascontiguousarray(camera, dtype=CAMERA_DT).reshape(1)
+    _chk(library().pt_set_camera(_p(cam), trace_depth))
+
+
+def trace_batch(iter0, count, host_image=None):
+    _chk(library().pt_trace_batch(iter0, count, _p(host_image)))
+
+
+def trace_batch_async(iter0, count):
+    _chk(library().pt_trace_batch_async(iter0, count))
+
+
+def synchronize():
+    _chk(library().pt_synchronize())
+
+
+def trace_begin(iter0, count=1):
+    _chk(library().pt_trace_begin(iter0, count))
+
+
+def trace_bounce(depth):
+    n = C.c_int(0)
+    _chk(library().pt_trace_bounce(depth, C.byref(n)))
+    return n.value
+
+
+def trace_end():
+    _chk(library().pt_trace_end())
+
+
+def export_paths(capacity):
+    buf = np.zeros(capacity, dtype=PATH_DT)
+    live = C.c_int(0)
+    n = _chk(library().pt_export_paths(_p(buf), capacity, C.byref(live)))
+    return buf[:n], live.value
+
+
+def export_intersections(capacity):
+    buf = np.zeros(capacity, dtype=ISECT_DT)
+    out = np.zeros(capacity, dtype=np.uint8)
+    n = _chk(library().pt_export_intersections(_p(buf), _p(out), capacity))
+    return buf[:n], out[:n]
+
+
+def intersect_once(paths):
+    paths = np.ascontiguousarray(paths, dtype=PATH_DT)
+    isects = np.zeros(len(paths), dtype=ISECT_DT)
+    outside = np.zeros(len(paths), dtype=np.uint8)
+    _chk(library().pt_intersect_once(_p(paths), len(paths), _p(isects), _p(outside)))
+    return isects, outside
+
+
+def get_image(npix):
+    img = np.zeros((npix, 3), dtype=np.float32)
+    _chk(library().pt_get_image(_p(img)))
+    return img
+
+
+def tonemap(npix, iteration):
+    out = np.zeros((npix, 4), dtype=np.uint8)
+    _chk(library().pt_tonemap(_p(out), iteration))
+    return out
+
+
+def clear_image():
+    _chk(library().pt_clear_image())
+
+
+def device_image_ptr():
+    return library().pt_device_image()
+
+
+def get_stats():
+    s = Stats()
+    _chk(library().pt_get_stats(C.byref(s)))
+    return s
+
+
+def set_profiling(enable):
+    _chk(library().pt_set_profiling(1 if enable else 0))
+
+
+def get_profile():
+    """{stage: (summed ms, launches)} measured with HIP events on the launch stream."""
+    p = Profile()
+    _chk(library().pt_get_profile(C.byref(p)))
+    return {name: (p.ms[i], p.launches[i]) for i, name in enumerate(STAGES)}
+
+
+def total_rays():
+    """Rays traced since pathtraceInit (device-side counter; synchronises)."""
+    r = library().pt_total_rays()
+    if r < 0:
+        _chk(int(r))
+    return int(r)
+
+
+def counters():
+    """(rays, first-bounce rays, iterations) since pathtraceInit, from the device; synchronises."""
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    _chk(library().pt_get_counters(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value

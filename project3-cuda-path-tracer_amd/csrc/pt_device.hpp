@@ -1,0 +1,321 @@
+// pt_device.hpp -- gfx950 device-side arithmetic of the path tracer's hot path.
+//
+// Everything here is written for one wave64 lane = one path.  The arithmetic
+// reproduces, operation for operation and in binary32 without FMA contraction
+// (the library is built with -ffp-contract=off), what the reference computes
+// through GLM 0.9.6.3 in
+//   src/intersections.h:12-144   utilhash, getPointOnRay, multiplyMV, box / sphere tests
+//   src/interactions.h:10-42     calculateRandomDirectionInHemisphere
+//   src/pathtrace.cu:41-45       makeSeededRandomEngine (+ thrust minstd_rand / u01)
+// and the build-defined completion of src/interactions.h:69-79 (scatterRay;
+// DESIGN.md section 3).  The data layout is NOT the reference's: geometry lives in
+// LDS as 40-dword records, path state in SoA planes, normals are evaluated
+// once for the winning primitive instead of once per primitive.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptd {
+
+struct f3 { float x, y, z; };
+
+#define PTD __device__ __forceinline__
+
+PTD f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PTD f3 add(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+PTD f3 sub(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+PTD f3 mul(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+PTD f3 scale(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+PTD f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
+// glm dot(vec3): (x*x' + y*y') + z*z'   (func_geometric.inl:64-72)
+PTD float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// correctly rounded sqrt / divide: hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt)
+PTD float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
+// glm normalize: x * (1 / sqrt(dot(x,x)))   (func_geometric.inl:153-159)
+PTD f3 normalize(f3 a) { return scale(a, 1.0f / __builtin_sqrtf(dot(a, a))); }
+PTD f3 cross(f3 x, f3 y) {
+    return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+// glm reflect: I - N * dot(N, I) * 2   (func_geometric.inl:175-179)
+PTD f3 reflect(f3 I, f3 N) { return sub(I, scale(scale(N, dot(N, I)), 2.0f)); }
+
+// ---------------------------------------------------------------------------
+// RNG: utilhash (intersections.h:12-20), minstd_rand, uniform_real<float>(0,1)
+// ---------------------------------------------------------------------------
+PTD uint32_t utilhash(uint32_t a) {
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+
+// x mod (2^31-1) by Mersenne folding; valid for x < 2^47
+PTD uint32_t mod_m31(uint64_t x) {
+    uint32_t r = (uint32_t)(x & 0x7fffffffull) + (uint32_t)(x >> 31);
+    return r >= 0x7fffffffu ? r - 0x7fffffffu : r;
+}
+
+// thrust::default_random_engine(h): seed = h % m, 0 -> 1
+PTD uint32_t lcg_seed(uint32_t s) {
+    uint32_t r = mod_m31((uint64_t)s);
+    return r == 0u ? 1u : r;
+}
+
+// pathtrace.cu:41-45
+PTD uint32_t seeded_engine(int iter, int index, int depth) {
+    uint32_t k = (1u << 31) | ((uint32_t)depth << 22) | (uint32_t)iter;
+    return lcg_seed(utilhash(k) ^ utilhash((uint32_t)index));
+}
+
+// one minstd step (a = 48271) followed by thrust's u01 map: float(x-1) / 2^31
+PTD float u01(uint32_t &state) {
+    state = mod_m31(48271ull * (uint64_t)state);
+    return (float)(state - 1u) / 2147483648.0f;
+}
+
+// ---------------------------------------------------------------------------
+// shared sin/cos: binary64 polynomial, +,-,* only; rounds once to binary32.
+// Same sequence as the build's CPU oracle (DESIGN.md "shared trig").
+// ---------------------------------------------------------------------------
+PTD void sincos_shared(float x, float &s, float &c) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00;
+    const double PIO2_1T = 6.07710050650619224932e-11;
+    const double MAGIC = 6755399441055744.0;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double xd = (double)x;
+    double kd = (xd * TWO_OVER_PI + MAGIC) - MAGIC;
+    double r = (xd - kd * PIO2_1) - kd * PIO2_1T;
+    double z = r * r;
+    double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
+    double sn = r + (r * z) * ps;
+    double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
+    double cs = (1.0 - 0.5 * z) + (z * z) * pc;
+    int q = (int)kd & 3;
+    double so = (q & 1) ? cs : sn;
+    double co = (q & 1) ? sn : cs;
+    so = (q & 2) ? -so : so;
+    co = ((q + 1) & 2) ? -co : co;
+    s = (float)so;
+    c = (float)co;
+}
+
+// interactions.h:10-42
+PTD f3 hemisphere(f3 normal, uint32_t &rng) {
+    const float TWO_PI = 6.2831853071795864769252867665590057683943f;
+    const float SQRT_OF_ONE_THIRD = 0.5773502691896257645091487805019574556476f;
+    float up = __builtin_sqrtf(u01(rng));
+    float over = __builtin_sqrtf(1 - up * up);
+    float around = u01(rng) * TWO_PI;
+    f3 notN;
+    if (__builtin_fabsf(normal.x) < SQRT_OF_ONE_THIRD) notN = mk(1, 0, 0);
+    else if (__builtin_fabsf(normal.y) < SQRT_OF_ONE_THIRD) notN = mk(0, 1, 0);
+    else notN = mk(0, 0, 1);
+    f3 p1 = normalize(cross(normal, notN));
+    f3 p2 = normalize(cross(normal, p1));
+    float sa, ca;
+    sincos_shared(around, sa, ca);
+    return add(add(scale(normal, up), scale(p1, ca * over)), scale(p2, sa * over));
+}
+
+// ---------------------------------------------------------------------------
+// scene records in LDS
+// ---------------------------------------------------------------------------
+// geom record: 40 dwords.  [0] type [1] materialid [2] first_tri [3] tri_count
+// [4..15] inverseTransform cols 0..3 x rows 0..2   [16..27] transform   [28..39] invTranspose
+constexpr int GEOM_WORDS = 40;
+constexpr int G_INV = 4, G_FWD = 16, G_INVT = 28;
+// material record: 12 dwords. color[3] spec_color[3] hasReflective hasRefractive ior emittance pad pad
+constexpr int MAT_WORDS = 12;
+
+// vec3(m * vec4(v, 1)): (m0*v.x + m1*v.y) + (m2*v.z + m3*1)   (type_mat4x4.inl:617-628)
+PTD f3 mv_point(const float *m, f3 v) {
+    f3 r;
+    r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9]);
+    r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10]);
+    r.z = (m[2] * v.x + m[5] * v.y) + (m[8] * v.z + m[11]);
+    return r;
+}
+// vec3(m * vec4(v, 0)): the m3 * 0.0f product is kept (it is +-0, or NaN for a non-finite matrix)
+PTD f3 mv_dir(const float *m, f3 v) {
+    f3 r;
+    r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9] * 0.0f);
+    r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10] * 0.0f);
+    r.z = (m[2] * v.x + m[5] * v.y) + (m[8] * v.z + m[11] * 0.0f);
+    return r;
+}
+
+// getPointOnRay (intersections.h:27-29): o + (t - .0001f) * normalize(d)
+PTD f3 point_on_ray(f3 o, f3 d, float t) { return add(o, scale(normalize(d), (t - .0001f))); }
+
+struct Hit {
+    float t;        // world distance, FLT_MAX while nothing is hit
+    int geom;       // winning geom index, -1 = miss
+    int outside;    // `outside` flag of the winning test
+    f3 aux;         // cube: object-space face normal; sphere: object-space hit point;
+                    // mesh: (bits of) the winning triangle index in aux.x
+};
+
+// boxIntersectionTest (intersections.h:48-90) without the normal (deferred).
+PTD float box_test(const float *g, f3 ro, f3 rd, f3 &face_n, int &outside) {
+    f3 qo = mv_point(g + G_INV, ro);
+    f3 qd = normalize(mv_dir(g + G_INV, rd));
+    float tmin = -1e38f, tmax = 1e38f;
+    f3 tmin_n = mk(0, 0, 0), tmax_n = mk(0, 0, 0);
+#define PTD_SLAB(QO, QD, NX, NY, NZ)                                      \
+    {                                                                     \
+        float t1 = (-0.5f - (QO)) / (QD);                                 \
+        float t2 = (+0.5f - (QO)) / (QD);                                 \
+        float ta = t1 < t2 ? t1 : t2;                                     \
+        float tb = t1 > t2 ? t1 : t2;                                     \
+        float sgn = t2 < t1 ? 1.0f : -1.0f;                               \
+        if (ta > 0 && ta > tmin) { tmin = ta; tmin_n = mk(NX, NY, NZ); }  \
+        if (tb < tmax) { tmax = tb; tmax_n = mk(NX, NY, NZ); }            \
+    }
+    PTD_SLAB(qo.x, qd.x, sgn, 0.0f, 0.0f)
+    PTD_SLAB(qo.y, qd.y, 0.0f, sgn, 0.0f)
+    PTD_SLAB(qo.z, qd.z, 0.0f, 0.0f, sgn)
+#undef PTD_SLAB
+    if (tmax >= tmin && tmax > 0) {
+        outside = 1;
+        if (tmin <= 0) { tmin = tmax; tmin_n = tmax_n; outside = 0; }
+        f3 p = mv_point(g + G_FWD, point_on_ray(qo, qd, tmin));
+        face_n = tmin_n;
+        return length(sub(ro, p));
+    }
+    return -1.0f;
+}
+
+// sphereIntersectionTest (intersections.h:102-144) without the normal (deferred).
+PTD float sphere_test(const float *g, f3 ro, f3 rd, f3 &obj_p, int &outside) {
+    f3 o = mv_point(g + G_INV, ro);
+    f3 d = normalize(mv_dir(g + G_INV, rd));
+    float vDotDirection = dot(o, d);
+    float radicand = vDotDirection * vDotDirection - (dot(o, o) - (0.5f * 0.5f));
+    if (radicand < 0) return -1.0f;
+    float squareRoot = __builtin_sqrtf(radicand);
+    float firstTerm = -vDotDirection;
+    float t1 = firstTerm + squareRoot;
+    float t2 = firstTerm - squareRoot;
+    float t;
+    if (t1 < 0 && t2 < 0) {
+        return -1.0f;
+    } else if (t1 > 0 && t2 > 0) {
+        t = (t2 < t1) ? t2 : t1;      // std::min(t1, t2)
+        outside = 1;
+    } else {
+        t = (t1 < t2) ? t2 : t1;      // std::max(t1, t2)
+        outside = 0;
+    }
+    f3 op = point_on_ray(o, d, t);
+    f3 p = mv_point(g + G_FWD, op);
+    obj_p = op;
+    return length(sub(ro, p));
+}
+
+// surface normal of the winning primitive (the part of the two tests above
+// that the reference evaluates for every candidate)
+PTD f3 cube_normal(const float *g, f3 face_n) { return normalize(mv_dir(g + G_FWD, face_n)); }
+PTD f3 sphere_normal(const float *g, f3 obj_p, int outside) {
+    f3 n = normalize(mv_dir(g + G_INVT, obj_p));
+    return outside ? n : neg(n);
+}
+
+// glm::intersectRayTriangle (gtx/intersect.inl:37-74) on (v0, e1 = v1-v0, e2 = v2-v0);
+// returns true and bary.z in tz on a hit.
+PTD bool ray_triangle(f3 orig, f3 dir, f3 v0, f3 e1, f3 e2, float &tz) {
+    f3 p = cross(dir, e2);
+    float a = dot(e1, p);
+    if (a < 1.1920928955078125e-07f) return false;
+    float f = 1.0f / a;
+    f3 s = sub(orig, v0);
+    float bx = f * dot(s, p);
+    if (bx < 0.0f) return false;
+    if (bx > 1.0f) return false;
+    f3 q = cross(s, e1);
+    float by = f * dot(dir, q);
+    if (by < 0.0f) return false;
+    if (by + bx > 1.0f) return false;
+    tz = f * dot(e2, q);
+    return tz >= 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// shading / scattering (completion of interactions.h:69-79)
+// ---------------------------------------------------------------------------
+struct PathState {
+    f3 o, d, c;
+};
+
+// returns true when the path stays alive; on false `ps.c` is the final colour
+PTD bool shade_scatter(PathState &ps, float t, f3 n, int matId, int outside, const float *mats,
+                       int iter, int pixel, int depth, bool last_bounce) {
+    if (t > 0.0f) {
+        const float *m = mats + matId * MAT_WORDS;
+        f3 mcol = mk(m[0], m[1], m[2]);
+        float emittance = m[9];
+        if (emittance > 0.0f) {
+            ps.c = mul(ps.c, scale(mcol, emittance));      // pathtrace.cu:247-249
+            return false;
+        }
+        uint32_t rng = seeded_engine(iter, pixel, depth);
+        f3 P = point_on_ray(ps.o, ps.d, t);
+        f3 I = ps.d;
+        f3 scol = mk(m[3], m[4], m[5]);
+        if (m[6] > 0.0f) {                                 // mirror
+            ps.d = reflect(I, n);
+            ps.o = P;
+            ps.c = mul(ps.c, scol);
+        } else if (m[7] > 0.0f) {                          // Fresnel dielectric
+            float d0 = dot(I, n);
+            f3 nn = d0 > 0.0f ? neg(n) : n;
+            float ior = m[8];
+            float eta = outside ? (1.0f / ior) : ior;
+            float dv = dot(nn, I);
+            float k = 1.0f - eta * eta * (1.0f - dv * dv);
+            bool refl;
+            if (k < 0.0f) {
+                refl = true;
+            } else {
+                float r0 = (1.0f - ior) / (1.0f + ior);
+                r0 = r0 * r0;
+                float cm = 1.0f - (-dv);
+                float c5 = (((cm * cm) * cm) * cm) * cm;
+                float R = r0 + (1.0f - r0) * c5;
+                float u = u01(rng);
+                refl = u < R;
+                if (!refl) {
+                    ps.d = sub(scale(I, eta), scale(nn, (eta * dv + __builtin_sqrtf(k))));
+                    ps.o = add(P, scale(I, 0.0002f));
+                }
+            }
+            if (refl) {
+                ps.d = reflect(I, nn);
+                ps.o = P;
+            }
+            ps.c = mul(ps.c, scol);
+        } else {                                           // diffuse
+            ps.d = hemisphere(n, rng);
+            ps.o = P;
+            ps.c = mul(ps.c, mcol);
+        }
+        if (last_bounce) {
+            ps.c = mk(0.0f, 0.0f, 0.0f);
+            return false;
+        }
+        return true;
+    }
+    ps.c = mk(0.0f, 0.0f, 0.0f);                           // pathtrace.cu:262-264
+    return false;
+}
+
+#undef PTD
+}  // namespace ptd

@@ -1,0 +1,1170 @@
+// ptmi355.hip -- libptmi355.so: kernels + C-ABI (include/ptmi355.h).
+//
+// MI355X-native replacement for the hot path of the reference's
+// src/pathtrace.cu (pathtraceInit / pathtrace / pathtraceFree and its five
+// kernels).  Design:
+//   * path state lives in SoA planes (ox..oz, dx..dz, cr..cb, pid) of a pool
+//     that holds `batch` iterations of the tile's pixels; two pools ping-pong;
+//   * one fused kernel per bounce: intersect (scene records broadcast from
+//     LDS) -> shade/scatter -> stable compaction (wave64 ballot + rank, block
+//     scan in LDS, decoupled look-back across workgroups) -> write survivors;
+//   * workgroups pull 256-path tiles from an atomic ticket, so tile order ==
+//     ticket order and the look-back can never wait on an unscheduled tile;
+//   * the live count stays on the device: the next bounce reads it from HBM,
+//     no host round trip inside an iteration;
+//   * terminated paths drop their final colour into final[sample][pixel];
+//     one gather kernel adds the samples into the float3 accumulation buffer
+//     in iteration order (bit-identical to sequential iterations).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction:
+// parity with the reference arithmetic is bit-exact, tests/test_gpu_parity.py).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ptmi355.h"
+#include "pt_device.hpp"
+
+static_assert(sizeof(pt_vec3) == 12 && sizeof(pt_mat4) == 64 && sizeof(pt_ray) == 24, "ABI");
+static_assert(sizeof(pt_geom) == 236 && offsetof(pt_geom, transform) == 44 &&
+              offsetof(pt_geom, inverseTransform) == 108 && offsetof(pt_geom, invTranspose) == 172, "Geom ABI");
+static_assert(sizeof(pt_material) == 44 && offsetof(pt_material, hasReflective) == 28 &&
+              offsetof(pt_material, emittance) == 40, "Material ABI");
+static_assert(sizeof(pt_camera) == 84 && offsetof(pt_camera, view) == 32 &&
+              offsetof(pt_camera, pixelLength) == 76, "Camera ABI");
+static_assert(sizeof(pt_path_segment) == 44 && offsetof(pt_path_segment, pixelIndex) == 36, "PathSegment ABI");
+static_assert(sizeof(pt_shadeable_intersection) == 20 && offsetof(pt_shadeable_intersection, materialId) == 16,
+              "ShadeableIntersection ABI");
+static_assert(sizeof(pt_triangle) == 36, "triangle ABI");
+
+using ptd::f3;
+
+namespace {
+
+constexpr int BLOCK = 256;                 // 4 waves of 64
+constexpr int WAVES = BLOCK / 64;
+constexpr int TRI_TILE = 1024;             // triangles staged in LDS per pass (36 KiB)
+constexpr int MAX_DEPTH = 64;
+constexpr uint32_t DEAD_PID = 0xffffffffu;
+
+// ---------------------------------------------------------------------------
+// device-side parameter blocks
+// ---------------------------------------------------------------------------
+struct Pool {            // SoA planes, each `cap` elements
+    float *ox, *oy, *oz, *dx, *dy, *dz, *cr, *cg, *cb;
+    uint32_t *pid;       // sample_local * tile_pixels + local_pixel ; DEAD_PID = terminated (no-compaction mode)
+};
+
+struct Isect {           // ShadeableIntersection planes (unfused / sort / fake-shader modes)
+    float *t, *nx, *ny, *nz;
+    int *mat;            // bit 31 carries the winning test's !outside
+};
+
+struct TileMap {         // local pixel index -> global pixelIndex (x + y*W)
+    int W, H;
+    int tile_index, tile_count, strip_rows;
+    int tile_pixels;     // pixels owned by this tile
+};
+
+struct Control {         // zeroed by one hipMemsetAsync per batch
+    uint32_t ticket[MAX_DEPTH];     // tile tickets, one counter per bounce
+    uint32_t nlive[MAX_DEPTH + 1];  // nlive[d] = paths entering bounce d (compaction on)
+    uint32_t alive[MAX_DEPTH + 1];  // paths actually traced at bounce d
+    uint32_t error;                 // watchdog flag
+    uint32_t pad[61];
+};
+
+struct Persist {         // survives the per-batch memset
+    unsigned long long rays;        // sum over bounces of paths traced since pt_init
+    unsigned long long iterations;
+    unsigned long long first_rays;  // paths traced at bounce 0 (rays - first_rays = compaction survivors)
+};
+
+struct SceneDev {
+    const float *geoms;  int ngeoms;       // GEOM_WORDS dwords each
+    const float *mats;   int nmats;        // MAT_WORDS dwords each
+    const float *tris;   int ntris;        // v0, e1, e2 (9 dwords each)
+};
+
+struct BounceArgs {
+    Pool in, out;
+    Isect isect;
+    SceneDev scene;
+    TileMap map;
+    Control *ctl;
+    uint64_t *status;      // look-back words for this bounce: (flag << 32) | value
+    float *fin_r, *fin_g, *fin_b;   // final colour planes, index = pid
+    const uint32_t *perm;  // optional sort permutation (material sort)
+    int depth, trace_depth, iter0;
+    uint32_t pool_n;       // paths in the pool when compaction is off
+};
+
+__device__ __forceinline__ int local_to_pixel(const TileMap &m, int j) {
+    if (m.tile_count == 1) return j;
+    int ly = j / m.W;
+    int x = j - ly * m.W;
+    int ls = ly / m.strip_rows;
+    int y = (ls * m.tile_count + m.tile_index) * m.strip_rows + (ly - ls * m.strip_rows);
+    return x + y * m.W;
+}
+
+// ---------------------------------------------------------------------------
+// generateRayFromCamera (pathtrace.cu:122-143) -> SoA pool, `count` samples
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, TileMap map, int count,
+                                                  Control *ctl) {
+    uint32_t total = (uint32_t)map.tile_pixels * (uint32_t)count;
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) { ctl->nlive[0] = total; }
+    if (i >= total) return;
+    uint32_t j = i % (uint32_t)map.tile_pixels;
+    int pix = local_to_pixel(map, (int)j);
+    int y = pix / map.W;
+    int x = pix - y * map.W;
+    f3 view = ptd::mk(cam.view.x, cam.view.y, cam.view.z);
+    f3 right = ptd::mk(cam.right.x, cam.right.y, cam.right.z);
+    f3 up = ptd::mk(cam.up.x, cam.up.y, cam.up.z);
+    f3 a = ptd::scale(ptd::scale(right, cam.pixelLength[0]), ((float)x - (float)cam.resolution[0] * 0.5f));
+    f3 b = ptd::scale(ptd::scale(up, cam.pixelLength[1]), ((float)y - (float)cam.resolution[1] * 0.5f));
+    f3 d = ptd::normalize(ptd::sub(ptd::sub(view, a), b));
+    p.ox[i] = cam.position.x; p.oy[i] = cam.position.y; p.oz[i] = cam.position.z;
+    p.dx[i] = d.x; p.dy[i] = d.y; p.dz[i] = d.z;
+    p.cr[i] = 1.0f; p.cg[i] = 1.0f; p.cb[i] = 1.0f;
+    p.pid[i] = i;
+}
+
+// ---------------------------------------------------------------------------
+// scene staging + intersection (computeIntersections, pathtrace.cu:149-213)
+// ---------------------------------------------------------------------------
+// Dynamic LDS carve (no static __shared__: the dynamic base stays 16-B aligned, guide G17):
+// [ctl: 8 dwords][geoms: ngeoms*40 dwords][mats: nmats*12 dwords][tri tile: TRI_TILE*9 dwords (if any)]
+constexpr int LDS_CTL_WORDS = 8;     // [0] tile ticket  [1] tile base  [2..5] per-wave live counts
+__device__ __forceinline__ void stage_scene(float *lds, const SceneDev &sc) {
+    const int gw = sc.ngeoms * ptd::GEOM_WORDS;
+    const int mw = sc.nmats * ptd::MAT_WORDS;
+    for (int k = threadIdx.x; k < gw; k += BLOCK) lds[k] = sc.geoms[k];
+    for (int k = threadIdx.x; k < mw; k += BLOCK) lds[gw + k] = sc.mats[k];
+    __syncthreads();
+}
+
+// All 256 threads of the block must call this together (mesh geoms stage
+// triangle tiles through LDS with block-wide barriers); `active` masks lanes
+// beyond the end of the pool.
+__device__ __forceinline__ void intersect_scene(const float *lds, const SceneDev &sc, bool active, f3 ro,
+                                                f3 rd, ptd::Hit &h) {
+    h.t = FLT_MAX; h.geom = -1; h.outside = 1; h.aux = ptd::mk(0, 0, 0);
+    float *tri_lds = const_cast<float *>(lds) + sc.ngeoms * ptd::GEOM_WORDS + sc.nmats * ptd::MAT_WORDS;
+    int outside = 1;                                    // shared across tests, pathtrace.cu:169
+    for (int g = 0; g < sc.ngeoms; ++g) {
+        const float *rec = lds + g * ptd::GEOM_WORDS;
+        const int type = __builtin_amdgcn_readfirstlane(__float_as_int(rec[0]));
+        float t = -1.0f;
+        f3 aux = ptd::mk(0, 0, 0);
+        if (type == PT_CUBE) {
+            if (active) t = ptd::box_test(rec, ro, rd, aux, outside);
+        } else if (type == PT_SPHERE) {
+            if (active) t = ptd::sphere_test(rec, ro, rd, aux, outside);
+        } else if (type == PT_TRIANGLE_MESH) {
+            // completion spec 8.0: nearest triangle by strictly smaller bary.z, first wins ties
+            const int first = __builtin_amdgcn_readfirstlane(__float_as_int(rec[2]));
+            const int count = __builtin_amdgcn_readfirstlane(__float_as_int(rec[3]));
+            float best = FLT_MAX;
+            int best_i = -1;
+            for (int base = 0; base < count; base += TRI_TILE) {
+                const int nt = min(TRI_TILE, count - base);
+                __syncthreads();
+                const float *src = sc.tris + (size_t)(first + base) * 9;
+                for (int k = threadIdx.x; k < nt * 9; k += BLOCK) tri_lds[k] = src[k];
+                __syncthreads();
+                if (active) {
+                    for (int k = 0; k < nt; ++k) {
+                        const float *tv = tri_lds + k * 9;
+                        float tz;
+                        if (ptd::ray_triangle(ro, rd, ptd::mk(tv[0], tv[1], tv[2]), ptd::mk(tv[3], tv[4], tv[5]),
+                                              ptd::mk(tv[6], tv[7], tv[8]), tz)) {
+                            if (tz > 0.0f && best > tz) { best = tz; best_i = first + base + k; }
+                        }
+                    }
+                }
+            }
+            if (active && best_i >= 0) {
+                outside = 1;
+                f3 p = ptd::add(ro, ptd::scale(rd, best));
+                t = ptd::length(ptd::sub(ro, p));
+                aux.x = __int_as_float(best_i);
+            }
+        }
+        if (t > 0.0f && h.t > t) {                      // pathtrace.cu:192 (first geom wins ties)
+            h.t = t; h.geom = g; h.outside = outside; h.aux = aux;
+        }
+    }
+}
+
+// normal + materialId of the winning primitive
+__device__ __forceinline__ void resolve_hit(const float *lds, const SceneDev &sc, const ptd::Hit &h, float &t,
+                                            f3 &n, int &mat) {
+    if (h.geom < 0) { t = -1.0f; n = ptd::mk(0, 0, 0); mat = 0; return; }
+    const float *rec = lds + h.geom * ptd::GEOM_WORDS;
+    const int type = __float_as_int(rec[0]);
+    t = h.t;
+    mat = __float_as_int(rec[1]);
+    if (type == PT_CUBE) n = ptd::cube_normal(rec, h.aux);
+    else if (type == PT_SPHERE) n = ptd::sphere_normal(rec, h.aux, h.outside);
+    else {
+        const float *tv = sc.tris + (size_t)__float_as_int(h.aux.x) * 9;
+        n = ptd::normalize(ptd::cross(ptd::mk(tv[3], tv[4], tv[5]), ptd::mk(tv[6], tv[7], tv[8])));
+    }
+}
+
+// standalone computeIntersections: materialises the ShadeableIntersection planes
+__global__ __launch_bounds__(BLOCK) void k_intersect(Pool in, Isect out, SceneDev sc, const uint32_t *n_ptr,
+                                                     uint32_t n_fixed) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    float *lds = lds_raw + LDS_CTL_WORDS;
+    stage_scene(lds, sc);
+    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    const uint32_t tiles = (n + BLOCK - 1) / BLOCK;
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t i = tile * BLOCK + threadIdx.x;
+        bool active = i < n;
+        f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
+        if (active) {
+            if (in.pid[i] == DEAD_PID) active = false;
+            ro = ptd::mk(in.ox[i], in.oy[i], in.oz[i]);
+            rd = ptd::mk(in.dx[i], in.dy[i], in.dz[i]);
+        }
+        ptd::Hit h;
+        intersect_scene(lds, sc, active, ro, rd, h);
+        if (i < n) {
+            float t; f3 nrm; int mat;
+            resolve_hit(lds, sc, h, t, nrm, mat);
+            // a miss writes only t; the other fields read as the zeros of pathtrace.cu:343's memset
+            out.t[i] = t; out.nx[i] = nrm.x; out.ny[i] = nrm.y; out.nz[i] = nrm.z;
+            out.mat[i] = mat | (h.outside ? 0 : (int)0x80000000u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stable compaction across workgroups: decoupled look-back on 64-bit words
+// ---------------------------------------------------------------------------
+constexpr uint64_t ST_AGG = 1ull << 32, ST_PREFIX = 2ull << 32;
+
+__device__ __forceinline__ uint64_t st_load(uint64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_store(uint64_t *p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by wave 0 of the block (all 64 lanes).  Returns the exclusive prefix
+// of `agg` over all earlier tiles and publishes this tile's inclusive prefix.
+__device__ __forceinline__ uint32_t lookback_exclusive(uint64_t *status, uint32_t tile, uint32_t agg,
+                                                       Control *ctl) {
+    const int lane = threadIdx.x & 63;
+    if (tile == 0) {
+        if (lane == 0) st_store(&status[0], ST_PREFIX | agg);
+        return 0;
+    }
+    if (lane == 0) st_store(&status[tile], ST_AGG | agg);
+    uint32_t running = 0;
+    int look = (int)tile - 1;
+    uint32_t spins = 0;
+    while (true) {
+        const int idx = look - lane;
+        uint64_t s = idx >= 0 ? st_load(&status[idx]) : ST_PREFIX;
+        const uint32_t flag = (uint32_t)(s >> 32);
+        const uint64_t invalid = __ballot(flag == 0);
+        const uint64_t prefix = __ballot(flag == 2);
+        if (prefix) {
+            const int p = __ffsll((unsigned long long)prefix) - 1;          // nearest tile with a full prefix
+            const uint64_t below = (p == 63) ? ~0ull : ((1ull << (p + 1)) - 1);
+            if ((invalid & below) == 0) {
+                uint32_t v = (lane <= p) ? (uint32_t)s : 0u;
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                running += v;
+                break;
+            }
+        } else if (invalid == 0) {
+            uint32_t v = (uint32_t)s;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            running += v;
+            look -= 64;
+            continue;
+        }
+        if (++spins > (1u << 24)) {             // watchdog: every wave reaches an exit
+            if (lane == 0) atomicOr(&ctl->error, 1u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0) st_store(&status[tile], ST_PREFIX | (uint64_t)(running + agg));
+    return running;
+}
+
+// ---------------------------------------------------------------------------
+// the fused bounce kernel
+// ---------------------------------------------------------------------------
+// MODE_FUSED   : intersect inline (ShadeableIntersection never touches HBM)
+// MODE_ISECT   : read the materialised planes written by k_intersect (PT_UNFUSED / sort)
+enum { MODE_FUSED = 0, MODE_ISECT = 1 };
+
+template <int MODE, bool COMPACT>
+__global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);      // barriers order every access below
+    float *lds = lds_raw + LDS_CTL_WORDS;
+    stage_scene(lds, a.scene);
+    const float *mats = lds + a.scene.ngeoms * ptd::GEOM_WORDS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = COMPACT ? a.ctl->nlive[a.depth] : a.pool_n;
+    const uint32_t tiles = (n + BLOCK - 1) / BLOCK;
+    const bool last_bounce = (a.depth == a.trace_depth - 1);
+
+    while (true) {
+        if (threadIdx.x == 0) sctl[0] = atomicAdd(&a.ctl->ticket[a.depth], 1u);
+        __syncthreads();
+        const uint32_t tile = sctl[0];
+        if (tile >= tiles) break;                       // uniform exit
+        const uint32_t i = tile * BLOCK + threadIdx.x;
+        const uint32_t src = (MODE == MODE_ISECT && a.perm && i < n) ? a.perm[i] : i;
+        bool active = i < n;
+        uint32_t pid = DEAD_PID;
+        ptd::PathState ps;
+        ps.o = ptd::mk(0, 0, 0); ps.d = ptd::mk(0, 0, 1); ps.c = ptd::mk(0, 0, 0);
+        if (active) {
+            pid = a.in.pid[src];
+            if (pid == DEAD_PID) active = false;
+        }
+        if (active) {
+            ps.o = ptd::mk(a.in.ox[src], a.in.oy[src], a.in.oz[src]);
+            ps.d = ptd::mk(a.in.dx[src], a.in.dy[src], a.in.dz[src]);
+            ps.c = ptd::mk(a.in.cr[src], a.in.cg[src], a.in.cb[src]);
+        }
+        float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
+        if (MODE == MODE_FUSED) {
+            ptd::Hit h;
+            intersect_scene(lds, a.scene, active, ps.o, ps.d, h);
+            if (active) { resolve_hit(lds, a.scene, h, t, nrm, mat); outside = h.outside; }
+        } else if (active) {
+            t = a.isect.t[src]; nrm = ptd::mk(a.isect.nx[src], a.isect.ny[src], a.isect.nz[src]);
+            const int m = a.isect.mat[src];
+            mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
+        }
+        bool alive = false;
+        if (active) {
+            const uint32_t s = pid / (uint32_t)a.map.tile_pixels;
+            const uint32_t j = pid - s * (uint32_t)a.map.tile_pixels;
+            const int pixel = local_to_pixel(a.map, (int)j);
+            alive = ptd::shade_scatter(ps, t, nrm, mat, outside, mats, a.iter0 + (int)s, pixel, a.depth,
+                                       last_bounce);
+            if (!alive) { a.fin_r[pid] = ps.c.x; a.fin_g[pid] = ps.c.y; a.fin_b[pid] = ps.c.z; }
+        }
+        // ---- where does the survivor go? ----
+        uint32_t dst = i;
+        const uint64_t bal = __ballot(alive);
+        const uint32_t wave_cnt = (uint32_t)__popcll((unsigned long long)bal);
+        const uint64_t act = __ballot(active);
+        if (COMPACT) {
+            const uint32_t rank = (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
+            if (lane == 0) sctl[2 + wave] = wave_cnt;
+            __syncthreads();
+            uint32_t wave_off = 0, agg = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const uint32_t c = sctl[2 + w];
+                if (w < wave) wave_off += c;
+                agg += c;
+            }
+            if (wave == 0) {
+                const uint32_t excl = lookback_exclusive(a.status, tile, agg, a.ctl);
+                if (lane == 0) {
+                    sctl[1] = excl;
+                    if (tile == tiles - 1) a.ctl->nlive[a.depth + 1] = excl + agg;
+                }
+            }
+            __syncthreads();
+            dst = sctl[1] + wave_off + rank;
+        }
+        if (lane == 0) {
+            const uint32_t na = (uint32_t)__popcll((unsigned long long)act);
+            if (na) atomicAdd(&a.ctl->alive[a.depth], na);
+        }
+        if (alive) {
+            a.out.ox[dst] = ps.o.x; a.out.oy[dst] = ps.o.y; a.out.oz[dst] = ps.o.z;
+            a.out.dx[dst] = ps.d.x; a.out.dy[dst] = ps.d.y; a.out.dz[dst] = ps.d.z;
+            a.out.cr[dst] = ps.c.x; a.out.cg[dst] = ps.c.y; a.out.cb[dst] = ps.c.z;
+            a.out.pid[dst] = pid;
+        } else if (!COMPACT && i < n) {
+            a.out.pid[dst] = DEAD_PID;
+        }
+        // COMPACT: s_tile / s_wave_cnt / s_base are next rewritten behind barriers that every
+        // thread reaches only after its reads above.  Without compaction there is no barrier
+        // after the ticket read, so fence the ticket word before thread 0 pulls the next one.
+        if (!COMPACT) __syncthreads();
+    }
+}
+
+// shadeFakeMaterial (pathtrace.cu:224-266): one bounce, never spawns a ray
+__global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const float *mats_g, TileMap map,
+                                                      int iter0, uint32_t n, float *fr, float *fg, float *fb) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pid = p.pid[i];
+    const uint32_t s = pid / (uint32_t)map.tile_pixels;
+    const int idx = local_to_pixel(map, (int)(pid - s * (uint32_t)map.tile_pixels));
+    f3 c = ptd::mk(p.cr[i], p.cg[i], p.cb[i]);
+    const float t = is.t[i];
+    if (t > 0.0f) {
+        uint32_t rng = ptd::seeded_engine(iter0 + (int)s, idx, 0);
+        const float *m = mats_g + (is.mat[i] & 0x7fffffff) * ptd::MAT_WORDS;
+        f3 mc = ptd::mk(m[0], m[1], m[2]);
+        if (m[9] > 0.0f) {
+            c = ptd::mul(c, ptd::scale(mc, m[9]));
+        } else {
+            f3 nrm = ptd::mk(is.nx[i], is.ny[i], is.nz[i]);
+            float lightTerm = ptd::dot(nrm, ptd::mk(0.0f, 1.0f, 0.0f));
+            f3 x = ptd::scale(ptd::scale(mc, lightTerm), 0.3f);
+            f3 y = ptd::scale(ptd::scale(mc, (1.0f - t * 0.02f)), 0.7f);
+            c = ptd::mul(c, ptd::add(x, y));
+            c = ptd::scale(c, ptd::u01(rng));
+        }
+    } else {
+        c = ptd::mk(0.0f, 0.0f, 0.0f);
+    }
+    p.cr[i] = c.x; p.cg[i] = c.y; p.cb[i] = c.z;
+    fr[pid] = c.x; fg[pid] = c.y; fb[pid] = c.z;
+}
+
+// finalGather (pathtrace.cu:269-278): image[pixelIndex] += colour, one add per
+// pixel per iteration, samples added in iteration order
+__global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fr, const float *fg,
+                                                  const float *fb, TileMap map, int count, const Control *ctl,
+                                                  Persist *per, int depths, uint32_t fake_rays) {
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j == 0) {                    // fold this batch's ray count into the persistent counter
+        unsigned long long r = fake_rays;
+        for (int d = 0; d < depths; ++d) r += ctl->alive[d];
+        per->rays += r;
+        per->iterations += (unsigned long long)count;
+        per->first_rays += depths > 0 ? ctl->alive[0] : fake_rays;
+    }
+    if (j >= (uint32_t)map.tile_pixels) return;
+    const int pix = local_to_pixel(map, (int)j);
+    float r = image[3 * pix + 0], g = image[3 * pix + 1], b = image[3 * pix + 2];
+    for (int s = 0; s < count; ++s) {
+        const size_t k = (size_t)s * map.tile_pixels + j;
+        r += fr[k]; g += fg[k]; b += fb[k];
+    }
+    image[3 * pix + 0] = r; image[3 * pix + 1] = g; image[3 * pix + 2] = b;
+}
+
+// sendImageToPBO (pathtrace.cu:48-68)
+__global__ __launch_bounds__(BLOCK) void k_tonemap(uint8_t *pbo, const float *image, int npix, int iter) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= npix) return;
+    int c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double v = (double)(image[3 * i + k] / (float)iter) * 255.0;
+        int q = (int)v;                      // v_cvt_i32_f64: saturating, NaN -> 0
+        c[k] = q < 0 ? 0 : (q > 255 ? 255 : q);
+    }
+    uchar4 o;
+    o.x = (unsigned char)c[0]; o.y = (unsigned char)c[1]; o.z = (unsigned char)c[2]; o.w = 0;
+    reinterpret_cast<uchar4 *>(pbo)[i] = o;
+}
+
+// pool <-> reference AoS (debug / parity export and pt_intersect_once)
+__global__ void k_export_paths(Pool p, TileMap map, uint32_t n_total, uint32_t n_live, int remaining,
+                               pt_path_segment *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    pt_path_segment s;
+    s.ray.origin = {p.ox[i], p.oy[i], p.oz[i]};
+    s.ray.direction = {p.dx[i], p.dy[i], p.dz[i]};
+    s.color = {p.cr[i], p.cg[i], p.cb[i]};
+    const uint32_t pid = p.pid[i];
+    if (pid == DEAD_PID) { s.pixelIndex = -1; s.remainingBounces = 0; }
+    else {
+        const uint32_t sm = pid / (uint32_t)map.tile_pixels;
+        s.pixelIndex = local_to_pixel(map, (int)(pid - sm * (uint32_t)map.tile_pixels));
+        s.remainingBounces = i < n_live ? remaining : 0;
+    }
+    out[i] = s;
+}
+
+__global__ void k_import_paths(Pool p, const pt_path_segment *in, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const pt_path_segment s = in[i];
+    p.ox[i] = s.ray.origin.x; p.oy[i] = s.ray.origin.y; p.oz[i] = s.ray.origin.z;
+    p.dx[i] = s.ray.direction.x; p.dy[i] = s.ray.direction.y; p.dz[i] = s.ray.direction.z;
+    p.cr[i] = s.color.x; p.cg[i] = s.color.y; p.cb[i] = s.color.z;
+    p.pid[i] = i;
+}
+
+__global__ void k_export_isects(Isect is, uint32_t n, pt_shadeable_intersection *out, uint8_t *outside) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pt_shadeable_intersection s;
+    const int m = is.mat[i];
+    s.t = is.t[i];
+    if (s.t > 0.0f) { s.surfaceNormal = {is.nx[i], is.ny[i], is.nz[i]}; s.materialId = m & 0x7fffffff; }
+    else { s.surfaceNormal = {0, 0, 0}; s.materialId = 0; }      // memset(0) + t = -1 only
+    out[i] = s;
+    if (outside) outside[i] = (m < 0) ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(PT_ERR_DEVICE, "HIP error (%s:%d): %s: %s", "ptmi355.hip", __LINE__, #expr, \
+                        hipGetErrorString(e_));                                                 \
+    } while (0)
+
+struct Renderer {
+    bool live = false;
+    pt_scene_desc desc{};
+    pt_camera cam{};
+    int trace_depth = 0;
+    uint32_t flags = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    TileMap map{};
+    int npix = 0;                 // full frame
+    uint32_t cap = 0;             // pool capacity = max_batch * tile_pixels
+    int max_batch = 1;
+    float *pool_mem[2] = {nullptr, nullptr};
+    Pool pool[2]{};
+    int cur = 0;                  // pool holding the current live prefix
+    float *isect_mem = nullptr;
+    Isect isect{};
+    float *final_mem = nullptr;   // 3 planes of cap floats
+    float *image = nullptr;
+    bool own_image = false;
+    float *d_geoms = nullptr, *d_mats = nullptr, *d_tris = nullptr;
+    SceneDev scene{};
+    size_t lds_bytes = 0;
+    Control *ctl = nullptr;
+    Persist *persist = nullptr;
+    uint64_t *status = nullptr;   // MAX tiles * trace_depth words
+    uint32_t max_tiles = 0;
+    size_t ctl_bytes = 0;         // Control + status, zeroed per batch
+    int grid = 0;                 // persistent grid size
+    void *scratch = nullptr;      // export / import staging
+    size_t scratch_bytes = 0;
+    // stepping state
+    int step_iter0 = 0, step_count = 0, step_depth = 0;
+    bool in_step = false;
+    pt_stats stats{};
+    // optional per-kernel HIP-event timing
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;       // pairs (start, stop)
+    std::vector<int> ev_stage;        // stage of each recorded pair
+    size_t ev_used = 0;               // pairs recorded since the last drain
+    pt_profile prof{};
+} R;
+
+constexpr size_t EV_PAIRS = 2048;
+
+int drain_events(void) {
+    if (R.ev_used == 0) return PT_OK;
+    HIPCHK(hipStreamSynchronize(R.stream));
+    for (size_t k = 0; k < R.ev_used; ++k) {
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, R.ev[2 * k], R.ev[2 * k + 1]));
+        R.prof.ms[R.ev_stage[k]] += (double)ms;
+        R.prof.launches[R.ev_stage[k]] += 1;
+    }
+    R.ev_used = 0;
+    return PT_OK;
+}
+
+struct StageTimer {                  // brackets one launch when profiling is on
+    bool on;
+    size_t k;
+    StageTimer(int stage) : on(false), k(0) {
+        if (!R.profiling) return;
+        if (R.ev_used >= EV_PAIRS && drain_events() != PT_OK) return;
+        k = R.ev_used++;
+        R.ev_stage[k] = stage;
+        on = hipEventRecord(R.ev[2 * k], R.stream) == hipSuccess;
+    }
+    ~StageTimer() { if (on) (void)hipEventRecord(R.ev[2 * k + 1], R.stream); }
+};
+
+Pool carve_pool(float *mem, uint32_t cap) {
+    Pool p;
+    p.ox = mem + 0 * (size_t)cap; p.oy = mem + 1 * (size_t)cap; p.oz = mem + 2 * (size_t)cap;
+    p.dx = mem + 3 * (size_t)cap; p.dy = mem + 4 * (size_t)cap; p.dz = mem + 5 * (size_t)cap;
+    p.cr = mem + 6 * (size_t)cap; p.cg = mem + 7 * (size_t)cap; p.cb = mem + 8 * (size_t)cap;
+    p.pid = reinterpret_cast<uint32_t *>(mem + 9 * (size_t)cap);
+    return p;
+}
+
+int tile_rows(int tile_index, int tile_count, int strip_rows, int H) {
+    if (tile_count <= 1) return H;
+    int rows = 0;
+    for (int y = 0; y < H; ++y)
+        if ((y / strip_rows) % tile_count == tile_index) rows++;
+    return rows;
+}
+
+int ensure_scratch(size_t bytes) {
+    if (bytes <= R.scratch_bytes) return PT_OK;
+    if (R.scratch) (void)hipFree(R.scratch);
+    R.scratch = nullptr; R.scratch_bytes = 0;
+    HIPCHK(hipMalloc(&R.scratch, bytes));
+    R.scratch_bytes = bytes;
+    return PT_OK;
+}
+
+BounceArgs bounce_args(int depth) {
+    BounceArgs a{};
+    a.in = R.pool[R.cur];
+    a.out = (R.flags & PT_COMPACT) ? R.pool[R.cur ^ 1] : R.pool[R.cur];
+    a.isect = R.isect;
+    a.scene = R.scene;
+    a.map = R.map;
+    a.ctl = R.ctl;
+    a.status = R.status + (size_t)depth * R.max_tiles;
+    a.fin_r = R.final_mem; a.fin_g = R.final_mem + (size_t)R.cap; a.fin_b = R.final_mem + 2 * (size_t)R.cap;
+    a.perm = nullptr;
+    a.depth = depth; a.trace_depth = R.trace_depth; a.iter0 = R.step_iter0;
+    a.pool_n = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
+    return a;
+}
+
+int enqueue_begin(int iter0, int count) {
+    if (count < 1 || count > R.max_batch)
+        return fail(PT_ERR_INVALID, "batch count %d outside [1, max_batch=%d]", count, R.max_batch);
+    if (iter0 < 1 || (int64_t)iter0 + count - 1 >= (1 << 22))
+        return fail(PT_ERR_INVALID, "iteration %d outside [1, 2^22): makeSeededRandomEngine packs iter in 22 bits", iter0);
+    R.step_iter0 = iter0; R.step_count = count; R.step_depth = 0; R.cur = 0;
+    HIPCHK(hipMemsetAsync(R.ctl, 0, R.ctl_bytes, R.stream));
+    const uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)count;
+    StageTimer tm(PT_STAGE_RAYGEN);
+    hipLaunchKernelGGL(k_raygen, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.pool[0], R.cam,
+                       R.map, count, R.ctl);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
+int enqueue_bounce(int depth) {
+    BounceArgs a = bounce_args(depth);
+    const bool compact = (R.flags & PT_COMPACT) != 0;
+    const bool unfused = (R.flags & (PT_UNFUSED | PT_SORT_MATERIAL)) != 0;
+    if (unfused) {
+        StageTimer tm(PT_STAGE_INTERSECT);
+        hipLaunchKernelGGL(k_intersect, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a.in, R.isect, R.scene,
+                           compact ? &R.ctl->nlive[depth] : (const uint32_t *)nullptr, a.pool_n);
+        HIPCHK(hipGetLastError());
+    }
+    StageTimer tm(PT_STAGE_BOUNCE);
+    if (unfused) {
+        if (compact) hipLaunchKernelGGL((k_bounce<MODE_ISECT, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        else hipLaunchKernelGGL((k_bounce<MODE_ISECT, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+    } else {
+        if (compact) hipLaunchKernelGGL((k_bounce<MODE_FUSED, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        else hipLaunchKernelGGL((k_bounce<MODE_FUSED, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    if (compact) R.cur ^= 1;
+    R.step_depth = depth + 1;
+    return PT_OK;
+}
+
+int enqueue_fake(void) {
+    // the reference as shipped (pathtrace.cu:339-377): one bounce, fake shader
+    const uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
+    hipLaunchKernelGGL(k_intersect, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, R.pool[R.cur], R.isect,
+                       R.scene, (const uint32_t *)nullptr, total);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_shade_fake, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.pool[R.cur],
+                       R.isect, R.scene.mats, R.map, R.step_iter0, total, R.final_mem, R.final_mem + (size_t)R.cap,
+                       R.final_mem + 2 * (size_t)R.cap);
+    HIPCHK(hipGetLastError());
+    R.step_depth = 1;
+    return PT_OK;
+}
+
+int enqueue_end(void) {
+    StageTimer tm(PT_STAGE_GATHER);
+    hipLaunchKernelGGL(k_gather, dim3((R.map.tile_pixels + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.image,
+                       R.final_mem, R.final_mem + (size_t)R.cap, R.final_mem + 2 * (size_t)R.cap, R.map,
+                       R.step_count, R.ctl, R.persist, (R.flags & PT_FAKE_SHADER) ? 0 : R.trace_depth,
+                       (R.flags & PT_FAKE_SHADER) ? (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count : 0u);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
+int enqueue_batch(int iter0, int count) {
+    int rc = enqueue_begin(iter0, count);
+    if (rc) return rc;
+    if (R.flags & PT_FAKE_SHADER) {
+        rc = enqueue_fake();
+        if (rc) return rc;
+    } else {
+        for (int d = 0; d < R.trace_depth; ++d) {
+            rc = enqueue_bounce(d);
+            if (rc) return rc;
+        }
+    }
+    return enqueue_end();
+}
+
+// reads the control block back (after a sync) and folds it into the stats
+int collect_stats(void) {
+    Control c;
+    HIPCHK(hipMemcpyAsync(&c, R.ctl, sizeof(Control), hipMemcpyDeviceToHost, R.stream));
+    HIPCHK(hipStreamSynchronize(R.stream));
+    if (c.error) return fail(PT_ERR_INTERNAL, "look-back watchdog tripped (control.error=%u)", c.error);
+    R.stats.bounces = 0; R.stats.rays = 0;
+    memset(R.stats.live, 0, sizeof R.stats.live);
+    if (R.flags & PT_FAKE_SHADER) {
+        R.stats.live[0] = R.map.tile_pixels * R.step_count; R.stats.rays = R.stats.live[0]; R.stats.bounces = 1;
+    } else {
+        for (int d = 0; d < R.trace_depth && d < 64; ++d) {
+            R.stats.live[d] = (int32_t)c.alive[d];
+            R.stats.rays += c.alive[d];
+            if (c.alive[d]) R.stats.bounces = d + 1;
+        }
+    }
+    R.stats.total_rays += R.stats.rays;
+    R.stats.total_iterations += R.step_count;
+    return PT_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+extern "C" {
+
+const char *pt_last_error(void) { return g_err; }
+const char *pt_version(void) { return "ptmi355 0.1 (gfx950, fp32 no-contract, wave64)"; }
+
+void pt_free(void) {
+    if (!R.live && !R.scratch) return;
+    if (R.stream) (void)hipStreamSynchronize(R.stream);
+    for (int k = 0; k < 2; ++k) if (R.pool_mem[k]) (void)hipFree(R.pool_mem[k]);
+    if (R.isect_mem) (void)hipFree(R.isect_mem);
+    if (R.final_mem) (void)hipFree(R.final_mem);
+    if (R.image && R.own_image) (void)hipFree(R.image);
+    if (R.d_geoms) (void)hipFree(R.d_geoms);
+    if (R.d_mats) (void)hipFree(R.d_mats);
+    if (R.d_tris) (void)hipFree(R.d_tris);
+    if (R.ctl) (void)hipFree(R.ctl);
+    if (R.persist) (void)hipFree(R.persist);
+    if (R.scratch) (void)hipFree(R.scratch);
+    for (hipEvent_t e : R.ev) (void)hipEventDestroy(e);
+    if (R.stream && R.own_stream) (void)hipStreamDestroy(R.stream);
+    R = Renderer{};
+}
+
+static int init_impl(const pt_scene_desc *d);
+
+int pt_init(const pt_scene_desc *d) {
+    if (!d) return fail(PT_ERR_INVALID, "pt_init: null descriptor");
+    if (R.live) pt_free();
+    const int rc = init_impl(d);
+    if (rc != PT_OK) {                 // release whatever was allocated; keep the message
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        R.live = true;
+        pt_free();
+        memcpy(g_err, keep, sizeof keep);
+    }
+    return rc;
+}
+
+static int init_impl(const pt_scene_desc *d) {
+    const int W = d->camera.resolution[0], H = d->camera.resolution[1];
+    if (W <= 0 || H <= 0 || (int64_t)W * H > (1 << 28)) return fail(PT_ERR_INVALID, "pt_init: bad resolution %dx%d", W, H);
+    if (d->num_geoms < 0 || d->num_materials <= 0 || (d->num_geoms > 0 && !d->geoms) || !d->materials)
+        return fail(PT_ERR_INVALID, "pt_init: geoms/materials missing");
+    if (d->trace_depth < 1 || d->trace_depth > MAX_DEPTH) return fail(PT_ERR_INVALID, "pt_init: trace_depth %d outside [1,%d]", d->trace_depth, MAX_DEPTH);
+    const int tile_count = d->tile_count <= 0 ? 1 : d->tile_count;
+    if (d->tile_index < 0 || d->tile_index >= tile_count) return fail(PT_ERR_INVALID, "pt_init: tile_index %d / tile_count %d", d->tile_index, tile_count);
+    if (tile_count > 1 && d->strip_rows <= 0) return fail(PT_ERR_INVALID, "pt_init: strip_rows must be > 0 when tiling");
+    for (int i = 0; i < d->num_geoms; ++i) {
+        const pt_geom &g = d->geoms[i];
+        if (g.type < PT_SPHERE || g.type > PT_TRIANGLE_MESH) return fail(PT_ERR_INVALID, "pt_init: geom %d has type %d", i, g.type);
+        if (g.materialid < 0 || g.materialid >= d->num_materials) return fail(PT_ERR_INVALID, "pt_init: geom %d materialid %d out of range", i, g.materialid);
+    }
+    for (int k = 0; k < d->num_meshes; ++k) {
+        const pt_mesh &m = d->meshes[k];
+        if (m.geom_index < 0 || m.geom_index >= d->num_geoms || d->geoms[m.geom_index].type != PT_TRIANGLE_MESH ||
+            m.first_triangle < 0 || m.triangle_count < 0 || m.first_triangle + m.triangle_count > d->num_triangles)
+            return fail(PT_ERR_INVALID, "pt_init: mesh %d is inconsistent", k);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PT_ERR_DEVICE, "pt_init: no HIP device (this library has no CPU fallback)");
+    if (d->device < 0 || d->device >= ndev) return fail(PT_ERR_INVALID, "pt_init: device %d of %d", d->device, ndev);
+    HIPCHK(hipSetDevice(d->device));
+
+    R = Renderer{};
+    R.desc = *d; R.cam = d->camera; R.trace_depth = d->trace_depth; R.flags = d->flags; R.device = d->device;
+    R.npix = W * H;
+    R.map.W = W; R.map.H = H; R.map.tile_index = d->tile_index; R.map.tile_count = tile_count;
+    R.map.strip_rows = tile_count > 1 ? d->strip_rows : H;
+    R.map.tile_pixels = tile_rows(d->tile_index, tile_count, R.map.strip_rows, H) * W;
+    if (R.map.tile_pixels <= 0) return fail(PT_ERR_INVALID, "pt_init: tile owns no rows");
+    R.max_batch = d->max_batch < 1 ? 1 : d->max_batch;
+    if ((int64_t)R.max_batch * R.map.tile_pixels >= (int64_t)0xfffffff0u)
+        return fail(PT_ERR_INVALID, "pt_init: max_batch * tile pixels overflows the 32-bit path id");
+    R.cap = (uint32_t)R.max_batch * (uint32_t)R.map.tile_pixels;
+    if (d->stream) { R.stream = (hipStream_t)d->stream; R.own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking)); R.own_stream = true; }
+    R.live = true;
+
+    // scene -> device records
+    std::vector<float> grec((size_t)std::max(1, d->num_geoms) * ptd::GEOM_WORDS, 0.0f);
+    for (int i = 0; i < d->num_geoms; ++i) {
+        const pt_geom &g = d->geoms[i];
+        float *r = grec.data() + (size_t)i * ptd::GEOM_WORDS;
+        int first = 0, count = 0;
+        for (int k = 0; k < d->num_meshes; ++k)
+            if (d->meshes[k].geom_index == i) { first = d->meshes[k].first_triangle; count = d->meshes[k].triangle_count; break; }
+        memcpy(&r[0], &g.type, 4); memcpy(&r[1], &g.materialid, 4); memcpy(&r[2], &first, 4); memcpy(&r[3], &count, 4);
+        const pt_mat4 *ms[3] = {&g.inverseTransform, &g.transform, &g.invTranspose};
+        const int offs[3] = {ptd::G_INV, ptd::G_FWD, ptd::G_INVT};
+        for (int m = 0; m < 3; ++m)
+            for (int c = 0; c < 4; ++c)
+                for (int rr = 0; rr < 3; ++rr) r[offs[m] + c * 3 + rr] = ms[m]->m[c][rr];
+    }
+    std::vector<float> mrec((size_t)d->num_materials * ptd::MAT_WORDS, 0.0f);
+    for (int i = 0; i < d->num_materials; ++i) {
+        const pt_material &m = d->materials[i];
+        float *r = mrec.data() + (size_t)i * ptd::MAT_WORDS;
+        r[0] = m.color.x; r[1] = m.color.y; r[2] = m.color.z;
+        r[3] = m.specular.color.x; r[4] = m.specular.color.y; r[5] = m.specular.color.z;
+        r[6] = m.hasReflective; r[7] = m.hasRefractive; r[8] = m.indexOfRefraction; r[9] = m.emittance;
+    }
+    std::vector<float> trec((size_t)std::max(1, d->num_triangles) * 9, 0.0f);
+    for (int i = 0; i < d->num_triangles; ++i) {
+        const pt_triangle &t = d->triangles[i];
+        float *r = trec.data() + (size_t)i * 9;
+        r[0] = t.v0.x; r[1] = t.v0.y; r[2] = t.v0.z;
+        // e1 = v1 - v0, e2 = v2 - v0: the first two statements of glm::intersectRayTriangle, hoisted
+        r[3] = t.v1.x - t.v0.x; r[4] = t.v1.y - t.v0.y; r[5] = t.v1.z - t.v0.z;
+        r[6] = t.v2.x - t.v0.x; r[7] = t.v2.y - t.v0.y; r[8] = t.v2.z - t.v0.z;
+    }
+    HIPCHK(hipMalloc(&R.d_geoms, grec.size() * 4));
+    HIPCHK(hipMalloc(&R.d_mats, mrec.size() * 4));
+    HIPCHK(hipMalloc(&R.d_tris, trec.size() * 4));
+    HIPCHK(hipMemcpy(R.d_geoms, grec.data(), grec.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(R.d_mats, mrec.data(), mrec.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(R.d_tris, trec.data(), trec.size() * 4, hipMemcpyHostToDevice));
+    R.scene.geoms = R.d_geoms; R.scene.ngeoms = d->num_geoms;
+    R.scene.mats = R.d_mats; R.scene.nmats = d->num_materials;
+    R.scene.tris = R.d_tris; R.scene.ntris = d->num_triangles;
+    R.lds_bytes = ((size_t)LDS_CTL_WORDS + (size_t)d->num_geoms * ptd::GEOM_WORDS + (size_t)d->num_materials * ptd::MAT_WORDS) * 4;
+    R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
+    if (d->num_triangles > 0) R.lds_bytes += (size_t)TRI_TILE * 9 * 4;
+    if (R.lds_bytes > 150 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene records need %zu B of LDS (> 150 KiB)", R.lds_bytes);
+    if (R.lds_bytes > 64 * 1024) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_intersect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds_bytes));
+        HIPCHK(hipFuncSetAttribute((const void *)k_bounce<MODE_FUSED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds_bytes));
+        HIPCHK(hipFuncSetAttribute((const void *)k_bounce<MODE_FUSED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds_bytes));
+        HIPCHK(hipFuncSetAttribute((const void *)k_bounce<MODE_ISECT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds_bytes));
+        HIPCHK(hipFuncSetAttribute((const void *)k_bounce<MODE_ISECT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds_bytes));
+    }
+
+    // pools, intersections, final colours, image, control
+    const size_t capz = R.cap;
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipMalloc(&R.pool_mem[k], capz * 10 * 4));
+        R.pool[k] = carve_pool(R.pool_mem[k], R.cap);
+    }
+    HIPCHK(hipMalloc(&R.isect_mem, capz * 5 * 4));
+    R.isect.t = R.isect_mem; R.isect.nx = R.isect_mem + capz; R.isect.ny = R.isect_mem + 2 * capz;
+    R.isect.nz = R.isect_mem + 3 * capz; R.isect.mat = reinterpret_cast<int *>(R.isect_mem + 4 * capz);
+    HIPCHK(hipMalloc(&R.final_mem, capz * 3 * 4));
+    if (d->device_image) { R.image = d->device_image; R.own_image = false; }
+    else {
+        HIPCHK(hipMalloc(&R.image, (size_t)R.npix * 3 * 4));
+        R.own_image = true;
+        HIPCHK(hipMemsetAsync(R.image, 0, (size_t)R.npix * 3 * 4, R.stream));      // pathtrace.cu:85
+    }
+    R.max_tiles = (R.cap + BLOCK - 1) / BLOCK;
+    R.ctl_bytes = sizeof(Control) + (size_t)R.max_tiles * R.trace_depth * sizeof(uint64_t);
+    R.ctl_bytes = (R.ctl_bytes + 15) & ~(size_t)15;
+    HIPCHK(hipMalloc((void **)&R.ctl, R.ctl_bytes));
+    R.status = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(R.ctl) + sizeof(Control));
+    HIPCHK(hipMalloc((void **)&R.persist, sizeof(Persist)));
+    HIPCHK(hipMemsetAsync(R.persist, 0, sizeof(Persist), R.stream));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, d->device));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    R.grid = (int)std::min<uint32_t>(R.max_tiles, (uint32_t)cus * 8u);
+    if (R.grid < 1) R.grid = 1;
+    HIPCHK(hipStreamSynchronize(R.stream));
+    g_err[0] = 0;
+    return PT_OK;
+}
+
+int pt_set_camera(const pt_camera *camera, int trace_depth) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_set_camera: not initialised");
+    if (!camera) return fail(PT_ERR_INVALID, "pt_set_camera: null camera");
+    if (camera->resolution[0] != R.map.W || camera->resolution[1] != R.map.H)
+        return fail(PT_ERR_INVALID, "pt_set_camera: resolution changed (%dx%d -> %dx%d); re-init instead",
+                    R.map.W, R.map.H, camera->resolution[0], camera->resolution[1]);
+    if (trace_depth < 1 || trace_depth > R.desc.trace_depth)
+        return fail(PT_ERR_INVALID, "pt_set_camera: trace_depth %d outside [1, %d]", trace_depth, R.desc.trace_depth);
+    R.cam = *camera;
+    R.trace_depth = trace_depth;
+    return PT_OK;
+}
+
+int pt_synchronize(void) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_synchronize: not initialised");
+    HIPCHK(hipStreamSynchronize(R.stream));
+    return PT_OK;
+}
+
+int pt_trace_batch_async(int iter0, int count) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_batch_async: not initialised");
+    R.in_step = false;
+    return enqueue_batch(iter0, count);
+}
+
+int pt_trace_batch(int iter0, int count, float *host_image_sum) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_batch: not initialised");
+    R.in_step = false;
+    int rc = enqueue_batch(iter0, count);
+    if (rc) return rc;
+    rc = collect_stats();
+    if (rc) return rc;
+    if (host_image_sum) HIPCHK(hipMemcpy(host_image_sum, R.image, (size_t)R.npix * 12, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
+    (void)frame;                                          // unused in the reference too (main.cpp:136)
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_trace: not initialised");
+    R.in_step = false;
+    int rc = enqueue_batch(iter, 1);
+    if (rc) return rc;
+    if (pbo_rgba) {
+        hipLaunchKernelGGL(k_tonemap, dim3((R.npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, pbo_rgba,
+                           R.image, R.npix, iter);
+        HIPCHK(hipGetLastError());
+    }
+    rc = collect_stats();
+    if (rc) return rc;
+    if (host_image_sum) HIPCHK(hipMemcpy(host_image_sum, R.image, (size_t)R.npix * 12, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_trace_begin(int iter0, int count) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_begin: not initialised");
+    int rc = enqueue_begin(iter0, count);
+    if (rc) return rc;
+    R.in_step = true;
+    HIPCHK(hipStreamSynchronize(R.stream));
+    return PT_OK;
+}
+
+int pt_trace_bounce(int depth, int *n_live_after) {
+    if (!R.live || !R.in_step) return fail(PT_ERR_INVALID, "pt_trace_bounce: call pt_trace_begin first");
+    if (depth != R.step_depth || depth >= R.trace_depth)
+        return fail(PT_ERR_INVALID, "pt_trace_bounce: depth %d, expected %d (< %d)", depth, R.step_depth, R.trace_depth);
+    int rc = (R.flags & PT_FAKE_SHADER) ? enqueue_fake() : enqueue_bounce(depth);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(R.stream));
+    if (n_live_after) {
+        uint32_t n = 0;
+        if ((R.flags & PT_COMPACT) && !(R.flags & PT_FAKE_SHADER))
+            HIPCHK(hipMemcpy(&n, &R.ctl->nlive[depth + 1], 4, hipMemcpyDeviceToHost));
+        else n = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
+        *n_live_after = (int)n;
+    }
+    return PT_OK;
+}
+
+int pt_trace_end(void) {
+    if (!R.live || !R.in_step) return fail(PT_ERR_INVALID, "pt_trace_end: call pt_trace_begin first");
+    int rc = enqueue_end();
+    if (rc) return rc;
+    R.in_step = false;
+    return collect_stats();
+}
+
+int pt_export_paths(pt_path_segment *host_paths, int capacity, int *n_live) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_export_paths: not initialised");
+    uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)std::max(1, R.step_count);
+    uint32_t live = total;
+    HIPCHK(hipStreamSynchronize(R.stream));
+    if ((R.flags & PT_COMPACT) && !(R.flags & PT_FAKE_SHADER))
+        HIPCHK(hipMemcpy(&live, &R.ctl->nlive[R.step_depth], 4, hipMemcpyDeviceToHost));
+    const uint32_t n = (R.flags & PT_COMPACT) ? live : total;     // only the live prefix is meaningful after compaction
+    if ((uint32_t)capacity < n) return fail(PT_ERR_INVALID, "pt_export_paths: capacity %d < %u", capacity, n);
+    int rc = ensure_scratch((size_t)n * sizeof(pt_path_segment));
+    if (rc) return rc;
+    if (n) {
+        hipLaunchKernelGGL(k_export_paths, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.pool[R.cur], R.map, n,
+                           live, R.trace_depth - R.step_depth, (pt_path_segment *)R.scratch);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(host_paths, R.scratch, (size_t)n * sizeof(pt_path_segment), hipMemcpyDeviceToHost, R.stream));
+        HIPCHK(hipStreamSynchronize(R.stream));
+    }
+    if (n_live) *n_live = (int)live;
+    return (int)n;
+}
+
+int pt_export_intersections(pt_shadeable_intersection *host_isects, uint8_t *host_outside, int capacity) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_export_intersections: not initialised");
+    if (!(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER)))
+        return fail(PT_ERR_INVALID, "pt_export_intersections: intersections are only materialised with PT_UNFUSED, PT_SORT_MATERIAL or PT_FAKE_SHADER");
+    if (R.step_depth < 1) return fail(PT_ERR_INVALID, "pt_export_intersections: no bounce has run");
+    uint32_t n = (uint32_t)R.map.tile_pixels * (uint32_t)std::max(1, R.step_count);
+    HIPCHK(hipStreamSynchronize(R.stream));
+    if ((R.flags & PT_COMPACT) && !(R.flags & PT_FAKE_SHADER))
+        HIPCHK(hipMemcpy(&n, &R.ctl->nlive[R.step_depth - 1], 4, hipMemcpyDeviceToHost));
+    if ((uint32_t)capacity < n) return fail(PT_ERR_INVALID, "pt_export_intersections: capacity %d < %u", capacity, n);
+    int rc = ensure_scratch((size_t)n * (sizeof(pt_shadeable_intersection) + 1) + 64);
+    if (rc) return rc;
+    uint8_t *d_out = (uint8_t *)R.scratch + (size_t)n * sizeof(pt_shadeable_intersection);
+    if (n) {
+        hipLaunchKernelGGL(k_export_isects, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.isect, n,
+                           (pt_shadeable_intersection *)R.scratch, host_outside ? d_out : (uint8_t *)nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(host_isects, R.scratch, (size_t)n * sizeof(pt_shadeable_intersection), hipMemcpyDeviceToHost, R.stream));
+        if (host_outside) HIPCHK(hipMemcpyAsync(host_outside, d_out, n, hipMemcpyDeviceToHost, R.stream));
+        HIPCHK(hipStreamSynchronize(R.stream));
+    }
+    return (int)n;
+}
+
+int pt_intersect_once(const pt_path_segment *host_paths, int n, pt_shadeable_intersection *host_isects,
+                      uint8_t *host_outside) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_intersect_once: not initialised");
+    if (n < 0 || (uint32_t)n > R.cap) return fail(PT_ERR_INVALID, "pt_intersect_once: n=%d exceeds the pool capacity %u", n, R.cap);
+    if (n == 0) return PT_OK;
+    if (!host_paths || !host_isects) return fail(PT_ERR_INVALID, "pt_intersect_once: null buffer");
+    int rc = ensure_scratch((size_t)n * (sizeof(pt_path_segment) + 1) + 64);
+    if (rc) return rc;
+    R.in_step = false;
+    HIPCHK(hipMemcpyAsync(R.scratch, host_paths, (size_t)n * sizeof(pt_path_segment), hipMemcpyHostToDevice, R.stream));
+    hipLaunchKernelGGL(k_import_paths, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.pool[0],
+                       (const pt_path_segment *)R.scratch, (uint32_t)n);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_intersect, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, R.pool[0], R.isect, R.scene,
+                       (const uint32_t *)nullptr, (uint32_t)n);
+    HIPCHK(hipGetLastError());
+    uint8_t *d_out = (uint8_t *)R.scratch + (size_t)n * sizeof(pt_shadeable_intersection);
+    hipLaunchKernelGGL(k_export_isects, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.isect, (uint32_t)n,
+                       (pt_shadeable_intersection *)R.scratch, host_outside ? d_out : (uint8_t *)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_isects, R.scratch, (size_t)n * sizeof(pt_shadeable_intersection), hipMemcpyDeviceToHost, R.stream));
+    if (host_outside) HIPCHK(hipMemcpyAsync(host_outside, d_out, n, hipMemcpyDeviceToHost, R.stream));
+    HIPCHK(hipStreamSynchronize(R.stream));
+    return PT_OK;
+}
+
+int pt_get_image(float *host_image_sum) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_get_image: not initialised");
+    if (!host_image_sum) return fail(PT_ERR_INVALID, "pt_get_image: null buffer");
+    HIPCHK(hipStreamSynchronize(R.stream));
+    HIPCHK(hipMemcpy(host_image_sum, R.image, (size_t)R.npix * 12, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_tonemap(uint8_t *host_rgba, int iter) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_tonemap: not initialised");
+    if (!host_rgba || iter < 1) return fail(PT_ERR_INVALID, "pt_tonemap: bad argument");
+    int rc = ensure_scratch((size_t)R.npix * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tonemap, dim3((R.npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, (uint8_t *)R.scratch,
+                       R.image, R.npix, iter);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_rgba, R.scratch, (size_t)R.npix * 4, hipMemcpyDeviceToHost, R.stream));
+    HIPCHK(hipStreamSynchronize(R.stream));
+    return PT_OK;
+}
+
+int pt_clear_image(void) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_clear_image: not initialised");
+    HIPCHK(hipMemsetAsync(R.image, 0, (size_t)R.npix * 12, R.stream));
+    HIPCHK(hipStreamSynchronize(R.stream));
+    return PT_OK;
+}
+
+float *pt_device_image(void) { return R.live ? R.image : nullptr; }
+
+long long pt_total_rays(void) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_total_rays: not initialised");
+    Persist p;
+    if (hipMemcpyAsync(&p, R.persist, sizeof p, hipMemcpyDeviceToHost, R.stream) != hipSuccess ||
+        hipStreamSynchronize(R.stream) != hipSuccess)
+        return fail(PT_ERR_DEVICE, "pt_total_rays: device read failed");
+    return (long long)p.rays;
+}
+
+int pt_get_counters(int64_t *rays, int64_t *first_bounce_rays, int64_t *iterations) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_get_counters: not initialised");
+    Persist p;
+    HIPCHK(hipMemcpyAsync(&p, R.persist, sizeof p, hipMemcpyDeviceToHost, R.stream));
+    HIPCHK(hipStreamSynchronize(R.stream));
+    if (rays) *rays = (int64_t)p.rays;
+    if (first_bounce_rays) *first_bounce_rays = (int64_t)p.first_rays;
+    if (iterations) *iterations = (int64_t)p.iterations;
+    return PT_OK;
+}
+
+int pt_set_profiling(int enable) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_set_profiling: not initialised");
+    int rc = drain_events();
+    if (rc) return rc;
+    if (enable && R.ev.empty()) {
+        R.ev.resize(2 * EV_PAIRS);
+        R.ev_stage.assign(EV_PAIRS, 0);
+        for (auto &e : R.ev) HIPCHK(hipEventCreate(&e));
+    }
+    R.profiling = enable != 0;
+    R.prof = pt_profile{};
+    return PT_OK;
+}
+
+int pt_get_profile(pt_profile *out) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_get_profile: not initialised");
+    if (!out) return fail(PT_ERR_INVALID, "pt_get_profile: null");
+    int rc = drain_events();
+    if (rc) return rc;
+    *out = R.prof;
+    return PT_OK;
+}
+
+int pt_get_stats(pt_stats *stats) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_get_stats: not initialised");
+    if (!stats) return fail(PT_ERR_INVALID, "pt_get_stats: null");
+    *stats = R.stats;
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950,
+loads, exports every symbol include/ptmi355.h declares, and fails loudly (no CPU
+fallback) when there is no GPU.  No compute is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pt():
+    ge.load_package().build()
+    return ge.load_package()
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "ptmi355.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(pt):
+    L = pt.library()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), "libptmi355.so does not export %s" % s
+
+
+def test_struct_sizes_match_reference_abi(pt, golden):
+    abi = golden["abi"]["abi"]
+    assert pt.GEOM_DT.itemsize == abi[0] and pt.MATERIAL_DT.itemsize == abi[4]
+    assert pt.CAMERA_DT.itemsize == abi[8] and pt.PATH_DT.itemsize == abi[13] and pt.ISECT_DT.itemsize == abi[17]
+    assert pt.GEOM_DT.fields["transform"][1] == abi[1] and pt.GEOM_DT.fields["inverseTransform"][1] == abi[2]
+    assert pt.GEOM_DT.fields["invTranspose"][1] == abi[3]
+    assert pt.MATERIAL_DT.fields["hasReflective"][1] == abi[6] and pt.MATERIAL_DT.fields["emittance"][1] == abi[7]
+    assert pt.CAMERA_DT.fields["view"][1] == abi[10] and pt.CAMERA_DT.fields["pixelLength"][1] == abi[12]
+    assert pt.PATH_DT.fields["pixelIndex"][1] == abi[15] and pt.ISECT_DT.fields["materialId"][1] == abi[18]
+
+
+def test_free_before_init_is_safe(pt):
+    # main.cpp:126 calls pathtraceFree() before the first pathtraceInit()
+    pt.pathtraceFree()
+    pt.pathtraceFree()
+
+
+def test_calls_before_init_fail_cleanly(pt):
+    L = pt.library()
+    assert L.pt_trace(None, 0, 1, None) < 0
+    assert b"not initialised" in L.pt_last_error()
+    assert L.pt_synchronize() < 0
+    assert L.pt_device_image() is None
+
+
+def test_no_cpu_fallback(pt, scenes):
+    """Without a GPU pt_init must fail (PT_ERR_DEVICE); with one this test is skipped."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    with pytest.raises(pt.PtError) as e:
+        pt.pathtraceInit(scene)
+    assert "no HIP device" in str(e.value) or "HIP error" in str(e.value)
+    with pytest.raises(pt.PtError):
+        pt.pathtrace(None, 0, 1)
+
+
+def test_init_validates_arguments(pt, scenes):
+    import torch
+    L = pt.library()
+    assert L.pt_init(None) < 0
+    s = scenes["cornell_64"]
+    bad = s["geoms"].copy()
+    bad["materialid"][0] = 99
+    scene = pt.Scene(bad, s["materials"], s["camera"], s["depth"])
+    with pytest.raises(pt.PtError) as e:
+        pt.pathtraceInit(scene)
+    assert "materialid" in str(e.value)
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], 0)
+    with pytest.raises(pt.PtError) as e:
+        pt.pathtraceInit(scene)
+    assert "trace_depth" in str(e.value)
+    del torch

@@ -1,0 +1,282 @@
+"""GPU parity: the HIP path, called through the C-ABI, against the CPU oracle on
+the same inputs.  Everything here is bit-exact (float radiance included: the
+library is built without FMA contraction and shares the oracle's sin/cos
+definition), which is stricter than the north star's 1e-4 relative L2."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pt():
+    p = ge.load_package()
+    p.library()
+    yield p
+    p.pathtraceFree()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def rel_l2(a, b):
+    return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / max(1e-30, np.sqrt((b.astype(np.float64) ** 2).sum())))
+
+
+def assert_paths_equal(got, want, n):
+    for f in ("origin", "direction", "color"):
+        assert (bits(got[f][:n]) == bits(want[f][:n])).all(), f
+    assert (got["pixelIndex"][:n] == want["pixelIndex"][:n]).all()
+    assert (got["remainingBounces"][:n] == want["remainingBounces"][:n]).all()
+
+
+def test_raygen(pt, po, scenes, golden):
+    for name in ("cornell_64", "cornell"):
+        s = scenes[name]
+        scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+        pt.pathtraceInit(scene)
+        pt.trace_begin(1, 1)
+        n = scene.resolution[0] * scene.resolution[1]
+        paths, live = pt.export_paths(n)
+        assert live == n
+        want = po.generate_rays(s["camera"], s["depth"])
+        assert paths.tobytes() == want.tobytes()
+        pt.pathtraceFree()
+    assert hashlib.md5(paths.tobytes()).hexdigest() == str(golden["raygen"]["md5_800"])
+
+
+def test_intersect_kernel_vs_golden_rays(pt, po, scenes, golden):
+    """computeIntersections on the adversarial ray sets of tests/golden/geomtests.npz
+    (inside-origin, grazing, axis-parallel +-inf slabs, un-normalised directions)."""
+    z = golden["geomtests"]
+    s = scenes["cornell"]
+    rays = np.concatenate([z["rays_%d" % i] for i in range(7)])
+    paths = np.zeros(len(rays), dtype=pt.PATH_DT)
+    paths["origin"], paths["direction"] = rays[:, :3], rays[:, 3:]
+    paths["color"] = 1.0
+    paths["pixelIndex"] = np.arange(len(rays))
+    paths["remainingBounces"] = 8
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene)
+    got, got_out = pt.intersect_once(paths)
+    want, want_out = po.compute_intersections(paths.view(po.PATH_DT), s["geoms"])
+    assert (bits(got["t"]) == bits(want["t"])).all()
+    assert (bits(got["normal"]) == bits(want["normal"])).all()
+    assert (got["materialId"] == want["materialId"]).all()
+    hit = want["t"] > 0
+    assert hit.sum() > 1000
+    assert (got_out[hit] == want_out[hit]).all()
+    # each geom alone, including the rotated / non-uniformly scaled extras
+    for i, gi in enumerate(z["geom_index"]):
+        geom = s["geoms"][gi:gi + 1] if gi < 100 else z["extra_geoms"][gi - 100:gi - 99]
+        geom = geom.copy()
+        geom["materialid"] = 0
+        sc1 = pt.Scene(geom, s["materials"], s["camera"], s["depth"])
+        pt.pathtraceInit(sc1)
+        r = z["rays_%d" % i]
+        p = np.zeros(len(r), dtype=pt.PATH_DT)
+        p["origin"], p["direction"] = r[:, :3], r[:, 3:]
+        got, _ = pt.intersect_once(p)
+        ref_t = z["out_%d" % i][:, 0]
+        ref_n = z["out_%d" % i][:, 4:7]
+        hit = ref_t > 0
+        assert (bits(got["t"][hit]) == bits(ref_t[hit])).all(), "geom %d" % gi
+        assert (bits(got["normal"][hit]) == bits(np.ascontiguousarray(ref_n[hit]))).all(), "geom %d" % gi
+        assert (got["t"][~hit] == -1.0).all()
+    pt.pathtraceFree()
+
+
+def test_first_bounce_intersections_c2(pt, po, scenes, golden):
+    """SURVEY section 7 minimum slice: ShadeableIntersection[N] of Cornell 800x800 bounce 0."""
+    s = scenes["cornell"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED)
+    pt.trace_begin(1, 1)
+    pt.trace_bounce(0)
+    isx, _ = pt.export_intersections(640000)
+    assert hashlib.md5(isx.tobytes()).hexdigest() == str(golden["fakeshade"]["md5_isect800"])
+    pt.pathtraceFree()
+
+
+@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact"])
+@pytest.mark.parametrize("scene_name", ["cornell_64", "cornell_glass_64", "cornell_diffuse_64"])
+def test_bounce_by_bounce(pt, po, scenes, scene_name, flags_name):
+    """Every bounce: live count, compacted pixelIndex sequence and full path state bit-exact."""
+    s = scenes[scene_name]
+    flags = {"fused": pt.PT_COMPACT, "unfused": pt.PT_COMPACT | pt.PT_UNFUSED, "nocompact": 0}[flags_name]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+    pt.pathtraceInit(scene, flags=flags)
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"],
+                    flags=po.F_COMPACT if flags & pt.PT_COMPACT else 0, trig=po.TRIG_SHARED)
+    for it in (1, 2, 3):
+        snaps = []
+        st = ref.iterate(it, snapshots=snaps)
+        pt.trace_begin(it, 1)
+        for snap in snaps:
+            d = snap["depth"]
+            n_live = pt.trace_bounce(d)
+            paths, live = pt.export_paths(n)
+            if flags & pt.PT_COMPACT:
+                assert n_live == snap["n_live"] == live
+                want = ref.paths if d == len(snaps) - 1 else None
+                # oracle snapshot is taken after compaction: its live prefix is the pool
+                assert_paths_equal(paths, _after(snaps, d, ref), live)
+            else:
+                alive = paths["pixelIndex"] >= 0
+                wp = _after(snaps, d, ref)
+                walive = wp["remainingBounces"] > 0
+                assert (alive == walive[:len(alive)]).all()
+                assert_paths_equal(paths[alive], wp[:len(alive)][alive], int(alive.sum()))
+        for d in range(len(snaps), s["depth"]):
+            pt.trace_bounce(d)
+        pt.trace_end()
+        gs = pt.get_stats()
+        assert list(gs.live[:s["depth"]]) == list(st.live[:s["depth"]])
+        assert gs.rays == st.rays
+        img = pt.get_image(n)
+        assert img.tobytes() == ref.image.tobytes()
+        assert rel_l2(img, ref.image) <= 1e-4          # the north star's stated tolerance
+    pt.pathtraceFree()
+
+
+def _after(snaps, d, ref):
+    """Oracle path array after bounce d (snapshots hold copies made in the callback,
+    which runs after shade + compaction of that bounce)."""
+    return snaps[d]["paths"]
+
+
+@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact"])
+def test_c2_full_iteration(pt, po, scenes, golden, flags_name):
+    """Config C2 (800x800, depth 8): image, live counts and compaction order vs golden + oracle."""
+    z = golden["completion"]
+    s = scenes["cornell"]
+    flags = {"fused": pt.PT_COMPACT, "unfused": pt.PT_COMPACT | pt.PT_UNFUSED, "nocompact": 0}[flags_name]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene, flags=flags)
+    for it in (1, 2):
+        img = pt.pathtrace(None, 0, it)
+        gs = pt.get_stats()
+        assert (np.array(gs.live[:8]) == z["shared__cornell__live"][it - 1]).all()
+        assert gs.rays == z["shared__cornell__rays"][it - 1]
+        assert hashlib.md5(img.tobytes()).hexdigest() == str(z["shared__cornell__img_md5"][it - 1])
+    pt.pathtraceFree()
+
+
+def test_c2_compaction_order_hash(pt, po, scenes, golden):
+    z = golden["completion"]
+    s = scenes["cornell"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
+    pt.trace_begin(1, 1)
+    for d in range(8):
+        live = pt.trace_bounce(d)
+        paths, n_live = pt.export_paths(640000)
+        assert n_live == live
+        h = po.lib().pto_fnv1a_i32(paths["pixelIndex"].copy().ctypes.data, 4, live)
+        assert h == int(z["shared__cornell__seq_hash"][0][d]), "bounce %d" % d
+    pt.trace_end()
+    pt.pathtraceFree()
+
+
+def test_batch_equals_sequential(pt, scenes):
+    """pt_trace_batch(iter0, count) == count sequential pathtrace calls, bit for bit."""
+    s = scenes["cornell_glass_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=1)
+    for it in range(1, 8):
+        seq = pt.pathtrace(None, 0, it).copy()
+    rays_seq = pt.get_stats().total_rays
+    pt.pathtraceFree()
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=4)
+    img = np.zeros((n, 3), dtype=np.float32)
+    pt.trace_batch(1, 4, img)
+    pt.trace_batch(5, 3, img)
+    assert pt.get_stats().total_rays == rays_seq
+    assert img.tobytes() == seq.tobytes()
+    pt.pathtraceFree()
+
+
+def test_tiles_equal_whole_frame(pt, scenes):
+    """Interleaved row-strip tiles (multi-GPU sharding) reproduce the 1-tile image exactly:
+    the RNG is keyed by the global pixelIndex."""
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+    pt.pathtraceInit(scene)
+    for it in (1, 2):
+        whole = pt.pathtrace(None, 0, it).copy()
+    pt.pathtraceFree()
+    for tiles, strip in ((2, 8), (3, 5), (8, 4)):
+        acc = np.zeros((n, 3), dtype=np.float32)
+        for k in range(tiles):
+            pt.pathtraceInit(scene, tile=(k, tiles, strip))
+            for it in (1, 2):
+                img = pt.pathtrace(None, 0, it)
+            # tiles own disjoint pixels: summing zero-padded frames == RCCL reduce(SUM), exact
+            assert ((acc != 0) & (img != 0)).sum() == 0
+            acc += img
+            pt.pathtraceFree()
+        assert acc.tobytes() == whole.tobytes(), (tiles, strip)
+
+
+def test_fake_shader_as_is(pt, scenes, golden):
+    """The reference exactly as shipped: one bounce + shadeFakeMaterial + sendImageToPBO."""
+    z = golden["fakeshade"]
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene, flags=pt.PT_FAKE_SHADER)
+    for it in (1, 2, 3):
+        img = pt.pathtrace(None, 0, it)
+    assert img.tobytes() == z["img64"].tobytes()
+    assert pt.tonemap(64 * 64, 3).tobytes() == z["pbo64"].tobytes()
+    pt.pathtraceFree()
+    s = scenes["cornell"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene, flags=pt.PT_FAKE_SHADER)
+    for it in (1, 2):
+        img = pt.pathtrace(None, 0, it)
+    assert hashlib.md5(img.tobytes()).hexdigest() == str(z["md5_img800"])
+    assert hashlib.md5(pt.tonemap(640000, 2).tobytes()).hexdigest() == str(z["md5_pbo800"])
+    pt.pathtraceFree()
+
+
+def test_lifecycle_and_errors(pt, scenes):
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceFree()                       # before init (main.cpp:126)
+    pt.pathtraceInit(scene)
+    pt.pathtraceInit(scene)                  # re-init on camera move (main.cpp:125-128)
+    a = pt.pathtrace(None, 0, 1).copy()
+    pt.pathtraceFree()
+    pt.pathtraceFree()
+    pt.pathtraceInit(scene)
+    b = pt.pathtrace(None, 0, 1).copy()
+    assert a.tobytes() == b.tobytes()
+    with pytest.raises(pt.PtError):
+        pt.trace_batch(1, 2)                 # count > max_batch
+    with pytest.raises(pt.PtError):
+        pt.trace_bounce(0)                   # stepping without begin
+    with pytest.raises(pt.PtError):
+        pt.export_intersections(10)          # not materialised in fused mode
+    pt.pathtraceFree()
+
+
+def test_pbo_device_pointer(pt, scenes, golden):
+    """pathtrace() writes the tonemapped RGBA8 into a device buffer (the mapped PBO)."""
+    import torch
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene, flags=pt.PT_FAKE_SHADER)
+    pbo = torch.zeros(64 * 64 * 4, dtype=torch.uint8, device="cuda:0")
+    for it in (1, 2, 3):
+        pt.pathtrace(pbo.data_ptr(), 0, it)
+    torch.cuda.synchronize()
+    assert pbo.cpu().numpy().tobytes() == golden["fakeshade"]["pbo64"].tobytes()
+    pt.pathtraceFree()
