@@ -100,6 +100,13 @@ def library():
         if not os.path.exists(path):
             raise PtError("libptmi355.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
+        # torch is the plumbing for streams / device buffers / RCCL.  Import it first so the HIP
+        # runtime it bundles is the one (and only one) resident in the process: loading the
+        # system libamdhip64 first and torch's copy second leaves torch without devices.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         L.pt_last_error.restype = C.c_char_p
         L.pt_version.restype = C.c_char_p

@@ -178,7 +178,8 @@ def test_c2_compaction_order_hash(pt, po, scenes, golden):
         live = pt.trace_bounce(d)
         paths, n_live = pt.export_paths(640000)
         assert n_live == live
-        h = po.lib().pto_fnv1a_i32(paths["pixelIndex"].copy().ctypes.data, 4, live)
+        seq = np.ascontiguousarray(paths["pixelIndex"])       # keep alive across the C call
+        h = po.lib().pto_fnv1a_i32(seq.ctypes.data, 4, live)
         assert h == int(z["shared__cornell__seq_hash"][0][d]), "bounce %d" % d
     pt.trace_end()
     pt.pathtraceFree()
