@@ -6,10 +6,16 @@
 //   * path state lives in SoA planes (ox..oz, dx..dz, cr..cb, pid) of a pool
 //     that holds `batch` iterations of the tile's pixels; two pools ping-pong;
 //   * one fused kernel per bounce: intersect (scene records broadcast from
-//     LDS) -> shade/scatter -> stable compaction (wave64 ballot + rank, block
-//     scan in LDS, decoupled look-back across workgroups) -> write survivors;
-//   * workgroups pull 256-path tiles from an atomic ticket, so tile order ==
-//     ticket order and the look-back can never wait on an unscheduled tile;
+//     LDS) -> shade/scatter -> stable compaction -> write survivors;
+//   * compaction is tile-local and wait-free: a 256-path tile packs its
+//     survivors (wave64 ballot + popcount rank, 4 wave counts through LDS) to
+//     the front of its own 256-slot span and publishes its count; the last
+//     workgroup to finish the launch (one agent-scope atomic per workgroup)
+//     scans the tile counts into tile bases; the next bounce reads logical
+//     path i through those bases (64-entry window in LDS + binary search), so
+//     the logical order is exactly the stable partition's while no workgroup
+//     ever waits on another (round-1 look-back version: 81 % of wave time
+//     parked, profiles/r01a);
 //   * the live count stays on the device: the next bounce reads it from HBM,
 //     no host round trip inside an iteration;
 //   * terminated paths drop their final colour into final[sample][pixel];
@@ -72,12 +78,19 @@ struct TileMap {         // local pixel index -> global pixelIndex (x + y*W)
     int tile_pixels;     // pixels owned by this tile
 };
 
-struct Control {         // zeroed by one hipMemsetAsync per batch
-    uint32_t ticket[MAX_DEPTH];     // tile tickets, one counter per bounce
+struct Control {         // zeroed by one hipMemsetAsync per batch (1 KiB)
     uint32_t nlive[MAX_DEPTH + 1];  // nlive[d] = paths entering bounce d (compaction on)
     uint32_t alive[MAX_DEPTH + 1];  // paths actually traced at bounce d
-    uint32_t error;                 // watchdog flag
+    uint32_t done[MAX_DEPTH];       // workgroups that finished bounce d (last-one-out election)
+    uint32_t error;
     uint32_t pad[61];
+};
+
+// Tile directory of one bounce's OUTPUT pool: tile k's survivors sit in slots
+// [256k, 256k + count[k]); base[] is the exclusive scan of count[] (T+1 entries) and
+// start[j] is the tile that holds logical path 256j.
+struct TileDir {
+    uint32_t *count, *base, *start;
 };
 
 struct Persist {         // survives the per-batch memset
@@ -98,9 +111,9 @@ struct BounceArgs {
     SceneDev scene;
     TileMap map;
     Control *ctl;
-    uint64_t *status;      // look-back words for this bounce: (flag << 32) | value
+    TileDir dir_in;        // directory of the pool being read (base == nullptr: dense)
+    TileDir dir_out;       // directory this launch produces
     float *fin_r, *fin_g, *fin_b;   // final colour planes, index = pid
-    const uint32_t *perm;  // optional sort permutation (material sort)
     int depth, trace_depth, iter0;
     uint32_t pool_n;       // paths in the pool when compaction is off
 };
@@ -143,8 +156,9 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, TileMap
 // scene staging + intersection (computeIntersections, pathtrace.cu:149-213)
 // ---------------------------------------------------------------------------
 // Dynamic LDS carve (no static __shared__: the dynamic base stays 16-B aligned, guide G17):
-// [ctl: 8 dwords][geoms: ngeoms*40 dwords][mats: nmats*12 dwords][tri tile: TRI_TILE*9 dwords (if any)]
-constexpr int LDS_CTL_WORDS = 8;     // [0] tile ticket  [1] tile base  [2..5] per-wave live counts
+// [ctl: 80 dwords][geoms: ngeoms*40 dwords][mats: nmats*12 dwords][tri tile: TRI_TILE*9 dwords (if any)]
+constexpr int LDS_WIN = 8;           // [0] last-block flag  [2..5] per-wave counts  [8..72] tile-base window
+constexpr int LDS_CTL_WORDS = 80;    // control words in front of the scene records (320 B, keeps 16-B alignment)
 __device__ __forceinline__ void stage_scene(float *lds, const SceneDev &sc) {
     const int gw = sc.ngeoms * ptd::GEOM_WORDS;
     const int mw = sc.nmats * ptd::MAT_WORDS;
@@ -222,22 +236,54 @@ __device__ __forceinline__ void resolve_hit(const float *lds, const SceneDev &sc
     }
 }
 
+// Logical path index -> physical slot of a tile-packed pool.  Block-cooperative: every
+// thread of the block calls it (barriers inside).  `k` is the block's logical tile.
+__device__ __forceinline__ uint32_t resolve_src(const TileDir &dir, uint32_t tiles_prev, uint32_t k, uint32_t p,
+                                                bool active, uint32_t *win) {
+    if (!dir.base) return p;                        // dense pool (ray generation / sorted / imported)
+    uint32_t s = dir.start[k];
+    bool resolved = !active;
+    uint32_t src = 0;
+    while (true) {
+        if (threadIdx.x < 65) {
+            const uint32_t t = s + threadIdx.x;
+            win[threadIdx.x] = t <= tiles_prev ? dir.base[t] : 0xffffffffu;
+        }
+        __syncthreads();
+        if (!resolved) {
+            int lo = 0, hi = 64;                    // win[0] <= p always holds
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (win[mid] <= p) lo = mid; else hi = mid - 1;
+            }
+            if (lo < 64) { resolved = true; src = (s + (uint32_t)lo) * BLOCK + (p - win[lo]); }
+        }
+        if (!__syncthreads_or(!resolved)) break;    // also fences `win` for the next window
+        s += 64;
+    }
+    return src;
+}
+
 // standalone computeIntersections: materialises the ShadeableIntersection planes
+// (indexed by LOGICAL path index)
 __global__ __launch_bounds__(BLOCK) void k_intersect(Pool in, Isect out, SceneDev sc, const uint32_t *n_ptr,
-                                                     uint32_t n_fixed) {
+                                                     uint32_t n_fixed, TileDir dir_in, const uint32_t *nprev_ptr) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    uint32_t *win = reinterpret_cast<uint32_t *>(lds_raw) + LDS_WIN;
     float *lds = lds_raw + LDS_CTL_WORDS;
     stage_scene(lds, sc);
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     const uint32_t tiles = (n + BLOCK - 1) / BLOCK;
+    const uint32_t tiles_prev = (dir_in.base && nprev_ptr) ? (*nprev_ptr + BLOCK - 1) / BLOCK : 0;
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const uint32_t i = tile * BLOCK + threadIdx.x;
         bool active = i < n;
+        const uint32_t src = resolve_src(dir_in, tiles_prev, tile, i, active, win);
         f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
         if (active) {
-            if (in.pid[i] == DEAD_PID) active = false;
-            ro = ptd::mk(in.ox[i], in.oy[i], in.oz[i]);
-            rd = ptd::mk(in.dx[i], in.dy[i], in.dz[i]);
+            if (in.pid[src] == DEAD_PID) active = false;
+            ro = ptd::mk(in.ox[src], in.oy[src], in.oz[src]);
+            rd = ptd::mk(in.dx[src], in.dy[src], in.dz[src]);
         }
         ptd::Hit h;
         intersect_scene(lds, sc, active, ro, rd, h);
@@ -252,60 +298,42 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(Pool in, Isect out, SceneDe
 }
 
 // ---------------------------------------------------------------------------
-// stable compaction across workgroups: decoupled look-back on 64-bit words
+// stable compaction: tile counts -> tile bases, by the last workgroup out
 // ---------------------------------------------------------------------------
-constexpr uint64_t ST_AGG = 1ull << 32, ST_PREFIX = 2ull << 32;
-
-__device__ __forceinline__ uint64_t st_load(uint64_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_store(uint64_t *p, uint64_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Called by wave 0 of the block (all 64 lanes).  Returns the exclusive prefix
-// of `agg` over all earlier tiles and publishes this tile's inclusive prefix.
-__device__ __forceinline__ uint32_t lookback_exclusive(uint64_t *status, uint32_t tile, uint32_t agg,
-                                                       Control *ctl) {
-    const int lane = threadIdx.x & 63;
-    if (tile == 0) {
-        if (lane == 0) st_store(&status[0], ST_PREFIX | agg);
-        return 0;
+// Hand-off (guide G16): each workgroup's thread 0 stores its tile counts with agent-scope
+// atomic (write-through) stores, drains them (s_waitcnt vmcnt(0)) and then adds 1 to
+// done[depth]; the workgroup whose add returns grid-1 is last, acquires once (agent
+// scope) and reads every count.  Nothing spins; nothing depends on dispatch order.
+__device__ __forceinline__ void scan_tile_counts(const TileDir &dir, uint32_t tiles, uint32_t *n_out,
+                                                 uint32_t *lds_scan /* >= 8 words */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t per = (tiles + BLOCK - 1) / BLOCK;          // contiguous entries per thread
+    const uint32_t lo = min(tiles, threadIdx.x * per), hi = min(tiles, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t t = lo; t < hi; ++t) sum += dir.count[t];
+    uint32_t incl = sum;                                        // wave inclusive scan
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
     }
-    if (lane == 0) st_store(&status[tile], ST_AGG | agg);
-    uint32_t running = 0;
-    int look = (int)tile - 1;
-    uint32_t spins = 0;
-    while (true) {
-        const int idx = look - lane;
-        uint64_t s = idx >= 0 ? st_load(&status[idx]) : ST_PREFIX;
-        const uint32_t flag = (uint32_t)(s >> 32);
-        const uint64_t invalid = __ballot(flag == 0);
-        const uint64_t prefix = __ballot(flag == 2);
-        if (prefix) {
-            const int p = __ffsll((unsigned long long)prefix) - 1;          // nearest tile with a full prefix
-            const uint64_t below = (p == 63) ? ~0ull : ((1ull << (p + 1)) - 1);
-            if ((invalid & below) == 0) {
-                uint32_t v = (lane <= p) ? (uint32_t)s : 0u;
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                running += v;
-                break;
-            }
-        } else if (invalid == 0) {
-            uint32_t v = (uint32_t)s;
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            running += v;
-            look -= 64;
-            continue;
-        }
-        if (++spins > (1u << 24)) {             // watchdog: every wave reaches an exit
-            if (lane == 0) atomicOr(&ctl->error, 1u);
-            break;
-        }
-        __builtin_amdgcn_s_sleep(1);
+    if (lane == 63) lds_scan[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = lds_scan[w];
+        if (w < wave) wave_off += c;
+        total += c;
     }
-    if (lane == 0) st_store(&status[tile], ST_PREFIX | (uint64_t)(running + agg));
-    return running;
+    uint32_t run = wave_off + incl - sum;                       // exclusive prefix of this thread's range
+    for (uint32_t t = lo; t < hi; ++t) {
+        const uint32_t c = dir.count[t];
+        dir.base[t] = run;
+        const uint32_t j = (run + BLOCK - 1) / BLOCK;           // the one multiple of 256 the span can hold
+        if (c && j * BLOCK < run + c) dir.start[j] = t;
+        run += c;
+    }
+    if (threadIdx.x == 0) { dir.base[tiles] = total; *n_out = total; }
 }
 
 // ---------------------------------------------------------------------------
@@ -319,22 +347,21 @@ template <int MODE, bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);      // barriers order every access below
+    uint32_t *win = sctl + LDS_WIN;
     float *lds = lds_raw + LDS_CTL_WORDS;
     stage_scene(lds, a.scene);
     const float *mats = lds + a.scene.ngeoms * ptd::GEOM_WORDS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = COMPACT ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + BLOCK - 1) / BLOCK;
+    const uint32_t tiles_prev = (COMPACT && a.dir_in.base) ? (a.ctl->nlive[a.depth - 1] + BLOCK - 1) / BLOCK : 0;
     const bool last_bounce = (a.depth == a.trace_depth - 1);
+    uint32_t traced = 0;
 
-    while (true) {
-        if (threadIdx.x == 0) sctl[0] = atomicAdd(&a.ctl->ticket[a.depth], 1u);
-        __syncthreads();
-        const uint32_t tile = sctl[0];
-        if (tile >= tiles) break;                       // uniform exit
-        const uint32_t i = tile * BLOCK + threadIdx.x;
-        const uint32_t src = (MODE == MODE_ISECT && a.perm && i < n) ? a.perm[i] : i;
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t i = tile * BLOCK + threadIdx.x;            // logical path index
         bool active = i < n;
+        const uint32_t src = COMPACT ? resolve_src(a.dir_in, tiles_prev, tile, i, active, win) : i;
         uint32_t pid = DEAD_PID;
         ptd::PathState ps;
         ps.o = ptd::mk(0, 0, 0); ps.d = ptd::mk(0, 0, 1); ps.c = ptd::mk(0, 0, 0);
@@ -353,8 +380,8 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs a) {
             intersect_scene(lds, a.scene, active, ps.o, ps.d, h);
             if (active) { resolve_hit(lds, a.scene, h, t, nrm, mat); outside = h.outside; }
         } else if (active) {
-            t = a.isect.t[src]; nrm = ptd::mk(a.isect.nx[src], a.isect.ny[src], a.isect.nz[src]);
-            const int m = a.isect.mat[src];
+            t = a.isect.t[i]; nrm = ptd::mk(a.isect.nx[i], a.isect.ny[i], a.isect.nz[i]);
+            const int m = a.isect.mat[i];
             mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
         }
         bool alive = false;
@@ -366,14 +393,14 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs a) {
                                        last_bounce);
             if (!alive) { a.fin_r[pid] = ps.c.x; a.fin_g[pid] = ps.c.y; a.fin_b[pid] = ps.c.z; }
         }
-        // ---- where does the survivor go? ----
+        // ---- survivors pack to the front of this tile's own 256-slot span ----
         uint32_t dst = i;
         const uint64_t bal = __ballot(alive);
-        const uint32_t wave_cnt = (uint32_t)__popcll((unsigned long long)bal);
         const uint64_t act = __ballot(active);
+        if (lane == 0) traced += (uint32_t)__popcll((unsigned long long)act);
         if (COMPACT) {
             const uint32_t rank = (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
-            if (lane == 0) sctl[2 + wave] = wave_cnt;
+            if (lane == 0) sctl[2 + wave] = (uint32_t)__popcll((unsigned long long)bal);
             __syncthreads();
             uint32_t wave_off = 0, agg = 0;
 #pragma unroll
@@ -382,19 +409,9 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs a) {
                 if (w < wave) wave_off += c;
                 agg += c;
             }
-            if (wave == 0) {
-                const uint32_t excl = lookback_exclusive(a.status, tile, agg, a.ctl);
-                if (lane == 0) {
-                    sctl[1] = excl;
-                    if (tile == tiles - 1) a.ctl->nlive[a.depth + 1] = excl + agg;
-                }
-            }
-            __syncthreads();
-            dst = sctl[1] + wave_off + rank;
-        }
-        if (lane == 0) {
-            const uint32_t na = (uint32_t)__popcll((unsigned long long)act);
-            if (na) atomicAdd(&a.ctl->alive[a.depth], na);
+            dst = tile * BLOCK + wave_off + rank;
+            if (threadIdx.x == 0)
+                __hip_atomic_store(&a.dir_out.count[tile], agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (alive) {
             a.out.ox[dst] = ps.o.x; a.out.oy[dst] = ps.o.y; a.out.oz[dst] = ps.o.z;
@@ -404,10 +421,26 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs a) {
         } else if (!COMPACT && i < n) {
             a.out.pid[dst] = DEAD_PID;
         }
-        // COMPACT: s_tile / s_wave_cnt / s_base are next rewritten behind barriers that every
-        // thread reaches only after its reads above.  Without compaction there is no barrier
-        // after the ticket read, so fence the ticket word before thread 0 pulls the next one.
-        if (!COMPACT) __syncthreads();
+        __syncthreads();       // sctl[2..5] / win are rewritten by the next tile
+    }
+    if (lane == 0 && traced) atomicAdd(&a.ctl->alive[a.depth], traced);
+
+    if (COMPACT) {
+        // last workgroup out turns the tile counts into the next bounce's directory
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread stored every count of the block
+            const uint32_t old = __hip_atomic_fetch_add(&a.ctl->done[a.depth], 1u, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = (old == gridDim.x - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            sctl[0] = last ? 1u : 0u;
+        }
+        __syncthreads();
+        if (sctl[0]) scan_tile_counts(a.dir_out, tiles, &a.ctl->nlive[a.depth + 1], sctl + 2);
     }
 }
 
@@ -483,14 +516,23 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap(uint8_t *pbo, const float *im
 
 // pool <-> reference AoS (debug / parity export and pt_intersect_once)
 __global__ void k_export_paths(Pool p, TileMap map, uint32_t n_total, uint32_t n_live, int remaining,
-                               pt_path_segment *out) {
+                               pt_path_segment *out, TileDir dir, uint32_t tiles_prev) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
+    uint32_t src = i;
+    if (dir.base) {                       // logical -> physical: largest t with base[t] <= i
+        uint32_t lo = 0, hi = tiles_prev;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (dir.base[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        src = lo * BLOCK + (i - dir.base[lo]);
+    }
     pt_path_segment s;
-    s.ray.origin = {p.ox[i], p.oy[i], p.oz[i]};
-    s.ray.direction = {p.dx[i], p.dy[i], p.dz[i]};
-    s.color = {p.cr[i], p.cg[i], p.cb[i]};
-    const uint32_t pid = p.pid[i];
+    s.ray.origin = {p.ox[src], p.oy[src], p.oz[src]};
+    s.ray.direction = {p.dx[src], p.dy[src], p.dz[src]};
+    s.color = {p.cr[src], p.cg[src], p.cb[src]};
+    const uint32_t pid = p.pid[src];
     if (pid == DEAD_PID) { s.pixelIndex = -1; s.remainingBounces = 0; }
     else {
         const uint32_t sm = pid / (uint32_t)map.tile_pixels;
@@ -569,9 +611,10 @@ struct Renderer {
     size_t lds_bytes = 0;
     Control *ctl = nullptr;
     Persist *persist = nullptr;
-    uint64_t *status = nullptr;   // MAX tiles * trace_depth words
+    uint32_t *dir_mem = nullptr;  // per bounce: count[T], base[T+1], start[T+1]
+    int cur_dir = -1;             // bounce whose directory describes pool[cur] (-1: dense)
     uint32_t max_tiles = 0;
-    size_t ctl_bytes = 0;         // Control + status, zeroed per batch
+    size_t ctl_bytes = 0;         // Control, zeroed per batch
     int grid = 0;                 // persistent grid size
     void *scratch = nullptr;      // export / import staging
     size_t scratch_bytes = 0;
@@ -641,6 +684,14 @@ int ensure_scratch(size_t bytes) {
     return PT_OK;
 }
 
+TileDir tile_dir(int depth) {
+    TileDir d{nullptr, nullptr, nullptr};
+    if (depth < 0) return d;
+    uint32_t *m = R.dir_mem + (size_t)depth * (3 * (size_t)R.max_tiles + 2);
+    d.count = m; d.base = m + R.max_tiles; d.start = d.base + R.max_tiles + 1;
+    return d;
+}
+
 BounceArgs bounce_args(int depth) {
     BounceArgs a{};
     a.in = R.pool[R.cur];
@@ -649,9 +700,9 @@ BounceArgs bounce_args(int depth) {
     a.scene = R.scene;
     a.map = R.map;
     a.ctl = R.ctl;
-    a.status = R.status + (size_t)depth * R.max_tiles;
+    a.dir_in = tile_dir((R.flags & PT_COMPACT) ? R.cur_dir : -1);
+    a.dir_out = tile_dir(depth);
     a.fin_r = R.final_mem; a.fin_g = R.final_mem + (size_t)R.cap; a.fin_b = R.final_mem + 2 * (size_t)R.cap;
-    a.perm = nullptr;
     a.depth = depth; a.trace_depth = R.trace_depth; a.iter0 = R.step_iter0;
     a.pool_n = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
     return a;
@@ -662,7 +713,7 @@ int enqueue_begin(int iter0, int count) {
         return fail(PT_ERR_INVALID, "batch count %d outside [1, max_batch=%d]", count, R.max_batch);
     if (iter0 < 1 || (int64_t)iter0 + count - 1 >= (1 << 22))
         return fail(PT_ERR_INVALID, "iteration %d outside [1, 2^22): makeSeededRandomEngine packs iter in 22 bits", iter0);
-    R.step_iter0 = iter0; R.step_count = count; R.step_depth = 0; R.cur = 0;
+    R.step_iter0 = iter0; R.step_count = count; R.step_depth = 0; R.cur = 0; R.cur_dir = -1;
     HIPCHK(hipMemsetAsync(R.ctl, 0, R.ctl_bytes, R.stream));
     const uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)count;
     StageTimer tm(PT_STAGE_RAYGEN);
@@ -679,7 +730,8 @@ int enqueue_bounce(int depth) {
     if (unfused) {
         StageTimer tm(PT_STAGE_INTERSECT);
         hipLaunchKernelGGL(k_intersect, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a.in, R.isect, R.scene,
-                           compact ? &R.ctl->nlive[depth] : (const uint32_t *)nullptr, a.pool_n);
+                           compact ? &R.ctl->nlive[depth] : (const uint32_t *)nullptr, a.pool_n, a.dir_in,
+                           (compact && depth > 0) ? &R.ctl->nlive[depth - 1] : (const uint32_t *)nullptr);
         HIPCHK(hipGetLastError());
     }
     StageTimer tm(PT_STAGE_BOUNCE);
@@ -691,7 +743,7 @@ int enqueue_bounce(int depth) {
         else hipLaunchKernelGGL((k_bounce<MODE_FUSED, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
     }
     HIPCHK(hipGetLastError());
-    if (compact) R.cur ^= 1;
+    if (compact) { R.cur ^= 1; R.cur_dir = depth; }
     R.step_depth = depth + 1;
     return PT_OK;
 }
@@ -700,7 +752,7 @@ int enqueue_fake(void) {
     // the reference as shipped (pathtrace.cu:339-377): one bounce, fake shader
     const uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
     hipLaunchKernelGGL(k_intersect, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, R.pool[R.cur], R.isect,
-                       R.scene, (const uint32_t *)nullptr, total);
+                       R.scene, (const uint32_t *)nullptr, total, tile_dir(-1), (const uint32_t *)nullptr);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_shade_fake, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.pool[R.cur],
                        R.isect, R.scene.mats, R.map, R.step_iter0, total, R.final_mem, R.final_mem + (size_t)R.cap,
@@ -778,6 +830,7 @@ void pt_free(void) {
     if (R.d_mats) (void)hipFree(R.d_mats);
     if (R.d_tris) (void)hipFree(R.d_tris);
     if (R.ctl) (void)hipFree(R.ctl);
+    if (R.dir_mem) (void)hipFree(R.dir_mem);
     if (R.persist) (void)hipFree(R.persist);
     if (R.scratch) (void)hipFree(R.scratch);
     for (hipEvent_t e : R.ev) (void)hipEventDestroy(e);
@@ -912,16 +965,23 @@ static int init_impl(const pt_scene_desc *d) {
         HIPCHK(hipMemsetAsync(R.image, 0, (size_t)R.npix * 3 * 4, R.stream));      // pathtrace.cu:85
     }
     R.max_tiles = (R.cap + BLOCK - 1) / BLOCK;
-    R.ctl_bytes = sizeof(Control) + (size_t)R.max_tiles * R.trace_depth * sizeof(uint64_t);
-    R.ctl_bytes = (R.ctl_bytes + 15) & ~(size_t)15;
+    R.ctl_bytes = sizeof(Control);
+    static_assert(sizeof(Control) % 16 == 0, "memset block is a multiple of 16 B");
     HIPCHK(hipMalloc((void **)&R.ctl, R.ctl_bytes));
-    R.status = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(R.ctl) + sizeof(Control));
+    HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)R.trace_depth * (3 * (size_t)R.max_tiles + 2) * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&R.persist, sizeof(Persist)));
     HIPCHK(hipMemsetAsync(R.persist, 0, sizeof(Persist), R.stream));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, d->device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    R.grid = (int)std::min<uint32_t>(R.max_tiles, (uint32_t)cus * 8u);
+    // persistent grid: as many workgroups as are co-resident for the fused kernel (tiles are
+    // dealt round-robin, so more workgroups than that only re-stage the scene)
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bounce<MODE_FUSED, true>, BLOCK,
+                                                        R.lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    R.grid = (int)std::min<uint32_t>(R.max_tiles, (uint32_t)cus * (uint32_t)per_cu);
     if (R.grid < 1) R.grid = 1;
     HIPCHK(hipStreamSynchronize(R.stream));
     g_err[0] = 0;
@@ -1027,8 +1087,12 @@ int pt_export_paths(pt_path_segment *host_paths, int capacity, int *n_live) {
     int rc = ensure_scratch((size_t)n * sizeof(pt_path_segment));
     if (rc) return rc;
     if (n) {
+        uint32_t nprev = 0;
+        const bool packed = (R.flags & PT_COMPACT) && R.cur_dir >= 0;
+        if (packed) HIPCHK(hipMemcpy(&nprev, &R.ctl->nlive[R.cur_dir], 4, hipMemcpyDeviceToHost));
         hipLaunchKernelGGL(k_export_paths, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.pool[R.cur], R.map, n,
-                           live, R.trace_depth - R.step_depth, (pt_path_segment *)R.scratch);
+                           live, R.trace_depth - R.step_depth, (pt_path_segment *)R.scratch,
+                           tile_dir(packed ? R.cur_dir : -1), (nprev + BLOCK - 1) / BLOCK);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(host_paths, R.scratch, (size_t)n * sizeof(pt_path_segment), hipMemcpyDeviceToHost, R.stream));
         HIPCHK(hipStreamSynchronize(R.stream));
@@ -1075,7 +1139,7 @@ int pt_intersect_once(const pt_path_segment *host_paths, int n, pt_shadeable_int
                        (const pt_path_segment *)R.scratch, (uint32_t)n);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_intersect, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, R.pool[0], R.isect, R.scene,
-                       (const uint32_t *)nullptr, (uint32_t)n);
+                       (const uint32_t *)nullptr, (uint32_t)n, tile_dir(-1), (const uint32_t *)nullptr);
     HIPCHK(hipGetLastError());
     uint8_t *d_out = (uint8_t *)R.scratch + (size_t)n * sizeof(pt_shadeable_intersection);
     hipLaunchKernelGGL(k_export_isects, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.isect, (uint32_t)n,
