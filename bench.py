@@ -84,7 +84,7 @@ def main():
     flags = 0
     for f in args.flags.split(","):
         flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED, "": 0}[f]
-    per_step_iters = args.batch * world          # iterations of this rank's tile per step
+    per_step_iters = pt.sharding.step_iterations(0, args.batch, world)[1]     # = batch * world
 
     stream = torch.cuda.current_stream()
     image = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")     # accumulation buffer (torch-owned)
@@ -94,10 +94,10 @@ def main():
                      device_image=image.data_ptr())
 
     def step(i):
-        pt.trace_batch_async(1 + i * per_step_iters, per_step_iters)
+        iter0, count = pt.sharding.step_iterations(i, args.batch, world)
+        pt.trace_batch_async(iter0, count)
         if world > 1:
-            frame.copy_(image)
-            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)      # RCCL over xGMI, once per step
+            pt.sharding.reduce_frame(dist, image, frame, dst=0)  # RCCL reduce(SUM) over xGMI, once per step
 
     def barrier():
         if world > 1:

@@ -11,3 +11,4 @@ from .binding import (  # noqa: F401
     trace_end, clear_image, version, set_profiling, get_profile, STAGES, total_rays, counters,
 )
 from .build import build  # noqa: F401
+from . import sharding  # noqa: F401,E402

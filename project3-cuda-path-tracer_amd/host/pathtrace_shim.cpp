@@ -1,0 +1,68 @@
+// pathtrace_shim.cpp -- the reference-side binding.
+//
+// Drop this file into the reference tree IN PLACE OF src/pathtrace.cu and link
+// libptmi355.so: it provides the three functions declared in src/pathtrace.h:6-8
+// with their exact signatures and forwards them to the C-ABI of
+// include/ptmi355.h.  It is compiled against the reference's own headers
+// (scene.h, sceneStructs.h), so it is not built as part of this repository's
+// library; tests/test_shim_compiles.py compile-checks it when /root/reference
+// is present.
+//
+// Behaviour kept from src/pathtrace.cu:
+//   * pathtraceInit copies geoms/materials and keeps the Scene* (:79-98);
+//   * pathtrace re-reads camera + traceDepth from the Scene on every call
+//     (:285-286), writes the tonemapped RGBA8 into `pbo` when it is non-NULL
+//     (:386) and refreshes scene->state.image with the running sum (:389-390);
+//   * pathtraceFree is safe before the first init (main.cpp:126);
+//   * errors print "CUDA error (file:line): msg: detail" to stderr and
+//     exit(EXIT_FAILURE), as checkCUDAError does (:21-39).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "pathtrace.h"      // reference: pulls scene.h / sceneStructs.h / uchar4
+#include "ptmi355.h"
+
+static_assert(sizeof(Geom) == sizeof(pt_geom) && sizeof(Material) == sizeof(pt_material) &&
+              sizeof(Camera) == sizeof(pt_camera) && sizeof(glm::vec3) == sizeof(pt_vec3),
+              "reference structs and the C-ABI mirrors must be byte-identical");
+
+static Scene *hst_scene = NULL;
+
+static void check(int rc, const char *msg, int line) {
+    if (rc >= 0) return;
+    fprintf(stderr, "CUDA error (pathtrace_shim.cpp:%d): %s: %s\n", line, msg, pt_last_error());
+    exit(EXIT_FAILURE);
+}
+#define CHECK(rc, msg) check((rc), (msg), __LINE__)
+
+void pathtraceInit(Scene *scene) {
+    hst_scene = scene;
+    pt_scene_desc d;
+    memset(&d, 0, sizeof d);
+    d.geoms = reinterpret_cast<const pt_geom *>(scene->geoms.data());
+    d.num_geoms = (int32_t)scene->geoms.size();
+    d.materials = reinterpret_cast<const pt_material *>(scene->materials.data());
+    d.num_materials = (int32_t)scene->materials.size();
+    memcpy(&d.camera, &scene->state.camera, sizeof d.camera);
+    d.trace_depth = scene->state.traceDepth;
+    d.flags = PT_COMPACT;            // the toggles the assignment asks for: PT_SORT_MATERIAL, PT_CACHE_FIRST
+    d.device = 0;                    // cudaGLSetGLDevice(0), preview.cpp:107
+    d.tile_index = 0; d.tile_count = 1; d.strip_rows = 8;
+    d.max_batch = 1;
+    CHECK(pt_init(&d), "pathtraceInit");
+}
+
+void pathtraceFree() {
+    pt_free();                       // no-op when nothing is allocated
+    hst_scene = NULL;
+}
+
+void pathtrace(uchar4 *pbo, int frame, int iter) {
+    const Camera &cam = hst_scene->state.camera;
+    CHECK(pt_set_camera(reinterpret_cast<const pt_camera *>(&cam), hst_scene->state.traceDepth),
+          "pathtrace (camera)");
+    CHECK(pt_trace(reinterpret_cast<uint8_t *>(pbo), frame, iter,
+                   reinterpret_cast<float *>(hst_scene->state.image.data())),
+          "pathtrace");
+}

@@ -281,3 +281,17 @@ def test_pbo_device_pointer(pt, scenes, golden):
     torch.cuda.synchronize()
     assert pbo.cpu().numpy().tobytes() == golden["fakeshade"]["pbo64"].tobytes()
     pt.pathtraceFree()
+
+
+def test_tile_order_matches_host_sharding(pt, scenes):
+    """csrc local_to_pixel == sharding.tile_pixel_indices (what bench.py / RCCL plumbing assume)."""
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    for rank, world, strip in ((1, 3, 5), (7, 8, 4), (0, 2, 8)):
+        pt.pathtraceInit(scene, tile=(rank, world, strip))
+        pt.trace_begin(1, 1)
+        want = pt.sharding.tile_pixel_indices(rank, world, strip, 64, 64)
+        paths, live = pt.export_paths(len(want))
+        assert live == len(want)
+        assert (paths["pixelIndex"] == want).all()
+        pt.pathtraceFree()
