@@ -164,8 +164,21 @@ struct Hit {
                     // mesh: (bits of) the winning triangle index in aux.x
 };
 
-// boxIntersectionTest (intersections.h:48-90) without the normal (deferred).
-PTD float box_test(const float *g, f3 ro, f3 rd, f3 &face_n, int &outside) {
+// A primitive whose object-space test succeeded but whose world-space distance has not been
+// evaluated yet.  Both reference tests end the same way -- objP = getPointOnRay(q, t_obj);
+// worldP = transform * objP; t = length(r.origin - worldP) (intersections.h:85-87,136-143) --
+// so that tail is shared and, because incoherent waves have different lanes hitting different
+// primitives, run once per *pending slot* instead of once per primitive (intersect_scene).
+struct Candidate {
+    f3 qo, qd;      // object-space ray (qd normalised)
+    float t_obj;    // object-space parameter chosen by the test
+    f3 face_n;      // cube only: tmin_n
+    int geom;       // -1 = empty
+    int outside;
+};
+
+// boxIntersectionTest, object-space part (intersections.h:48-84)
+PTD bool box_candidate(const float *g, f3 ro, f3 rd, Candidate &c) {
     f3 qo = mv_point(g + G_INV, ro);
     f3 qd = normalize(mv_dir(g + G_INV, rd));
     float tmin = -1e38f, tmax = 1e38f;
@@ -185,39 +198,43 @@ PTD float box_test(const float *g, f3 ro, f3 rd, f3 &face_n, int &outside) {
     PTD_SLAB(qo.z, qd.z, 0.0f, 0.0f, sgn)
 #undef PTD_SLAB
     if (tmax >= tmin && tmax > 0) {
-        outside = 1;
-        if (tmin <= 0) { tmin = tmax; tmin_n = tmax_n; outside = 0; }
-        f3 p = mv_point(g + G_FWD, point_on_ray(qo, qd, tmin));
-        face_n = tmin_n;
-        return length(sub(ro, p));
+        c.outside = 1;
+        if (tmin <= 0) { tmin = tmax; tmin_n = tmax_n; c.outside = 0; }
+        c.qo = qo; c.qd = qd; c.t_obj = tmin; c.face_n = tmin_n;
+        return true;
     }
-    return -1.0f;
+    return false;
 }
 
-// sphereIntersectionTest (intersections.h:102-144) without the normal (deferred).
-PTD float sphere_test(const float *g, f3 ro, f3 rd, f3 &obj_p, int &outside) {
+// sphereIntersectionTest, object-space part (intersections.h:102-134)
+PTD bool sphere_candidate(const float *g, f3 ro, f3 rd, Candidate &c) {
     f3 o = mv_point(g + G_INV, ro);
     f3 d = normalize(mv_dir(g + G_INV, rd));
     float vDotDirection = dot(o, d);
     float radicand = vDotDirection * vDotDirection - (dot(o, o) - (0.5f * 0.5f));
-    if (radicand < 0) return -1.0f;
+    if (radicand < 0) return false;
     float squareRoot = __builtin_sqrtf(radicand);
     float firstTerm = -vDotDirection;
     float t1 = firstTerm + squareRoot;
     float t2 = firstTerm - squareRoot;
     float t;
     if (t1 < 0 && t2 < 0) {
-        return -1.0f;
+        return false;
     } else if (t1 > 0 && t2 > 0) {
         t = (t2 < t1) ? t2 : t1;      // std::min(t1, t2)
-        outside = 1;
+        c.outside = 1;
     } else {
         t = (t1 < t2) ? t2 : t1;      // std::max(t1, t2)
-        outside = 0;
+        c.outside = 0;
     }
-    f3 op = point_on_ray(o, d, t);
-    f3 p = mv_point(g + G_FWD, op);
-    obj_p = op;
+    c.qo = o; c.qd = d; c.t_obj = t; c.face_n = mk(0, 0, 0);
+    return true;
+}
+
+// shared tail of both tests: world distance of a candidate; objP is returned for the sphere normal
+PTD float candidate_distance(const float *g, f3 ro, const Candidate &c, f3 &obj_p) {
+    obj_p = point_on_ray(c.qo, c.qd, c.t_obj);
+    f3 p = mv_point(g + G_FWD, obj_p);
     return length(sub(ro, p));
 }
 

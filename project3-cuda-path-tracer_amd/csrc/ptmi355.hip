@@ -53,6 +53,12 @@ using ptd::f3;
 
 namespace {
 
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 4                     // waves per SIMD the bounce kernels are register-budgeted for
+#endif
+#ifndef PT_DEFER
+#define PT_DEFER 1                         // share the world-distance tail of the box/sphere tests across geoms
+#endif
 constexpr int BLOCK = 256;                 // 4 waves of 64
 constexpr int WAVES = BLOCK / 64;
 constexpr int TRI_TILE = 1024;             // triangles staged in LDS per pass (36 KiB)
@@ -174,17 +180,29 @@ __device__ __forceinline__ void intersect_scene(const float *lds, const SceneDev
                                                 f3 rd, ptd::Hit &h) {
     h.t = FLT_MAX; h.geom = -1; h.outside = 1; h.aux = ptd::mk(0, 0, 0);
     float *tri_lds = const_cast<float *>(lds) + sc.ngeoms * ptd::GEOM_WORDS + sc.nmats * ptd::MAT_WORDS;
-    int outside = 1;                                    // shared across tests, pathtrace.cu:169
+    ptd::Candidate pend;
+    pend.geom = -1; pend.outside = 1; pend.t_obj = 0.0f;
+    pend.qo = ptd::mk(0, 0, 0); pend.qd = ptd::mk(0, 0, 1); pend.face_n = ptd::mk(0, 0, 0);
+    // Evaluate the pending candidates' world distance and fold them into the running minimum.
+    // Candidates are folded in geom order per lane, so `t_min > t` keeps the reference's
+    // first-geom-wins tie rule (pathtrace.cu:192).
+    auto flush = [&]() {
+        if (pend.geom >= 0) {
+            const float *rec = lds + pend.geom * ptd::GEOM_WORDS;      // per-lane record (LDS gather)
+            f3 obj_p;
+            const float t = ptd::candidate_distance(rec, ro, pend, obj_p);
+            if (t > 0.0f && h.t > t) {
+                h.t = t; h.geom = pend.geom; h.outside = pend.outside;
+                h.aux = (__float_as_int(rec[0]) == PT_CUBE) ? pend.face_n : obj_p;
+            }
+            pend.geom = -1;
+        }
+    };
     for (int g = 0; g < sc.ngeoms; ++g) {
         const float *rec = lds + g * ptd::GEOM_WORDS;
         const int type = __builtin_amdgcn_readfirstlane(__float_as_int(rec[0]));
-        float t = -1.0f;
-        f3 aux = ptd::mk(0, 0, 0);
-        if (type == PT_CUBE) {
-            if (active) t = ptd::box_test(rec, ro, rd, aux, outside);
-        } else if (type == PT_SPHERE) {
-            if (active) t = ptd::sphere_test(rec, ro, rd, aux, outside);
-        } else if (type == PT_TRIANGLE_MESH) {
+        if (type == PT_TRIANGLE_MESH) {
+            if (__ballot(pend.geom >= 0)) flush();          // keep geom order
             // completion spec 8.0: nearest triangle by strictly smaller bary.z, first wins ties
             const int first = __builtin_amdgcn_readfirstlane(__float_as_int(rec[2]));
             const int count = __builtin_amdgcn_readfirstlane(__float_as_int(rec[3]));
@@ -208,16 +226,31 @@ __device__ __forceinline__ void intersect_scene(const float *lds, const SceneDev
                 }
             }
             if (active && best_i >= 0) {
-                outside = 1;
                 f3 p = ptd::add(ro, ptd::scale(rd, best));
-                t = ptd::length(ptd::sub(ro, p));
-                aux.x = __int_as_float(best_i);
+                const float t = ptd::length(ptd::sub(ro, p));
+                if (t > 0.0f && h.t > t) {
+                    h.t = t; h.geom = g; h.outside = 1;
+                    h.aux = ptd::mk(__int_as_float(best_i), 0.0f, 0.0f);
+                }
             }
+            continue;
         }
-        if (t > 0.0f && h.t > t) {                      // pathtrace.cu:192 (first geom wins ties)
-            h.t = t; h.geom = g; h.outside = outside; h.aux = aux;
+        ptd::Candidate c;
+        bool hit = false;
+        if (active) {
+            if (type == PT_CUBE) hit = ptd::box_candidate(rec, ro, rd, c);
+            else if (type == PT_SPHERE) hit = ptd::sphere_candidate(rec, ro, rd, c);
         }
+#if PT_DEFER
+        // a lane that already holds a candidate and found another forces the shared tail now
+        if (__ballot(hit && pend.geom >= 0)) flush();
+        if (hit) { pend = c; pend.geom = g; }
+#else
+        if (hit) { pend = c; pend.geom = g; }
+        flush();
+#endif
     }
+    if (__ballot(pend.geom >= 0)) flush();
 }
 
 // normal + materialId of the winning primitive
@@ -266,7 +299,7 @@ __device__ __forceinline__ uint32_t resolve_src(const TileDir &dir, uint32_t til
 
 // standalone computeIntersections: materialises the ShadeableIntersection planes
 // (indexed by LOGICAL path index)
-__global__ __launch_bounds__(BLOCK) void k_intersect(Pool in, Isect out, SceneDev sc, const uint32_t *n_ptr,
+__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc, const uint32_t *n_ptr,
                                                      uint32_t n_fixed, TileDir dir_in, const uint32_t *nprev_ptr) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *win = reinterpret_cast<uint32_t *>(lds_raw) + LDS_WIN;
@@ -344,7 +377,7 @@ __device__ __forceinline__ void scan_tile_counts(const TileDir &dir, uint32_t ti
 enum { MODE_FUSED = 0, MODE_ISECT = 1 };
 
 template <int MODE, bool COMPACT>
-__global__ __launch_bounds__(BLOCK) void k_bounce(BounceArgs a) {
+__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);      // barriers order every access below
     uint32_t *win = sctl + LDS_WIN;
