@@ -137,7 +137,7 @@ constexpr int G_INV = 4, G_FWD = 16, G_INVT = 28;
 constexpr int MAT_WORDS = 12;
 
 // vec3(m * vec4(v, 1)): (m0*v.x + m1*v.y) + (m2*v.z + m3*1)   (type_mat4x4.inl:617-628)
-PTD f3 mv_point(const float *m, f3 v) {
+template <typename P> PTD f3 mv_point(P m, f3 v) {
     f3 r;
     r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9]);
     r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10]);
@@ -145,7 +145,7 @@ PTD f3 mv_point(const float *m, f3 v) {
     return r;
 }
 // vec3(m * vec4(v, 0)): the m3 * 0.0f product is kept (it is +-0, or NaN for a non-finite matrix)
-PTD f3 mv_dir(const float *m, f3 v) {
+template <typename P> PTD f3 mv_dir(P m, f3 v) {
     f3 r;
     r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9] * 0.0f);
     r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10] * 0.0f);
@@ -178,7 +178,7 @@ struct Candidate {
 };
 
 // boxIntersectionTest, object-space part (intersections.h:48-84)
-PTD bool box_candidate(const float *g, f3 ro, f3 rd, Candidate &c) {
+template <typename P> PTD bool box_candidate(P g, f3 ro, f3 rd, Candidate &c) {
     f3 qo = mv_point(g + G_INV, ro);
     f3 qd = normalize(mv_dir(g + G_INV, rd));
     float tmin = -1e38f, tmax = 1e38f;
@@ -207,7 +207,7 @@ PTD bool box_candidate(const float *g, f3 ro, f3 rd, Candidate &c) {
 }
 
 // sphereIntersectionTest, object-space part (intersections.h:102-134)
-PTD bool sphere_candidate(const float *g, f3 ro, f3 rd, Candidate &c) {
+template <typename P> PTD bool sphere_candidate(P g, f3 ro, f3 rd, Candidate &c) {
     f3 o = mv_point(g + G_INV, ro);
     f3 d = normalize(mv_dir(g + G_INV, rd));
     float vDotDirection = dot(o, d);
@@ -232,7 +232,7 @@ PTD bool sphere_candidate(const float *g, f3 ro, f3 rd, Candidate &c) {
 }
 
 // shared tail of both tests: world distance of a candidate; objP is returned for the sphere normal
-PTD float candidate_distance(const float *g, f3 ro, const Candidate &c, f3 &obj_p) {
+template <typename P> PTD float candidate_distance(P g, f3 ro, const Candidate &c, f3 &obj_p) {
     obj_p = point_on_ray(c.qo, c.qd, c.t_obj);
     f3 p = mv_point(g + G_FWD, obj_p);
     return length(sub(ro, p));

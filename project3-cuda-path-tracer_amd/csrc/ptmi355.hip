@@ -57,25 +57,31 @@ namespace {
 #define PT_MIN_WAVES 4                     // waves per SIMD the bounce kernels are register-budgeted for
 #endif
 #ifndef PT_DEFER
-#define PT_DEFER 1                         // share the world-distance tail of the box/sphere tests across geoms
+#define PT_DEFER 0                         // share the world-distance tail of the box/sphere tests across geoms
 #endif
 constexpr int BLOCK = 256;                 // 4 waves of 64
 constexpr int WAVES = BLOCK / 64;
+constexpr int TILE = 64;                   // paths per tile = one wave64
 constexpr int TRI_TILE = 1024;             // triangles staged in LDS per pass (36 KiB)
 constexpr int MAX_DEPTH = 64;
 constexpr uint32_t DEAD_PID = 0xffffffffu;
 
 // ---------------------------------------------------------------------------
-// device-side parameter blocks
+// device-side parameter blocks (few pointers: every extra pointer pair costs
+// 2 SGPRs per wave for the whole kernel)
 // ---------------------------------------------------------------------------
-struct Pool {            // SoA planes, each `cap` elements
-    float *ox, *oy, *oz, *dx, *dy, *dz, *cr, *cg, *cb;
-    uint32_t *pid;       // sample_local * tile_pixels + local_pixel ; DEAD_PID = terminated (no-compaction mode)
+struct Pool {            // SoA planes of `cap` elements: ox oy oz dx dy dz cr cg cb pid
+    float *base;
+    uint32_t cap;
+    __device__ __forceinline__ float *plane(int k) const { return base + (size_t)k * cap; }
+    __device__ __forceinline__ uint32_t *pid() const { return reinterpret_cast<uint32_t *>(base + (size_t)9 * cap); }
 };
 
-struct Isect {           // ShadeableIntersection planes (unfused / sort / fake-shader modes)
-    float *t, *nx, *ny, *nz;
-    int *mat;            // bit 31 carries the winning test's !outside
+struct Isect {           // ShadeableIntersection planes t nx ny nz mat (unfused / sort / fake-shader modes)
+    float *base;         // mat: bit 31 carries the winning test's !outside
+    uint32_t cap;
+    __device__ __forceinline__ float *plane(int k) const { return base + (size_t)k * cap; }
+    __device__ __forceinline__ int *mat() const { return reinterpret_cast<int *>(base + (size_t)4 * cap); }
 };
 
 struct TileMap {         // local pixel index -> global pixelIndex (x + y*W)
@@ -93,10 +99,14 @@ struct Control {         // zeroed by one hipMemsetAsync per batch (1 KiB)
 };
 
 // Tile directory of one bounce's OUTPUT pool: tile k's survivors sit in slots
-// [256k, 256k + count[k]); base[] is the exclusive scan of count[] (T+1 entries) and
-// start[j] is the tile that holds logical path 256j.
+// [64k, 64k + count[k]); base[] is the exclusive scan of count[] (T+1 entries) and
+// start[j] is the tile that holds logical path 64j.
 struct TileDir {
-    uint32_t *count, *base, *start;
+    uint32_t *mem;       // count[T] | base[T+1] | start[T+1]; nullptr = dense pool
+    uint32_t T;          // capacity in tiles
+    __device__ __forceinline__ uint32_t *count() const { return mem; }
+    __device__ __forceinline__ uint32_t *base() const { return mem + T; }
+    __device__ __forceinline__ uint32_t *start() const { return mem + 2 * (size_t)T + 1; }
 };
 
 struct Persist {         // survives the per-batch memset
@@ -117,11 +127,13 @@ struct BounceArgs {
     SceneDev scene;
     TileMap map;
     Control *ctl;
-    TileDir dir_in;        // directory of the pool being read (base == nullptr: dense)
+    TileDir dir_in;        // directory of the pool being read (mem == nullptr: dense)
     TileDir dir_out;       // directory this launch produces
-    float *fin_r, *fin_g, *fin_b;   // final colour planes, index = pid
+    float *fin;            // final colour planes r g b (stride in.cap), index = pid
+    pt_camera cam;         // used when gen_rays != 0
     int depth, trace_depth, iter0;
-    uint32_t pool_n;       // paths in the pool when compaction is off
+    uint32_t pool_n;       // paths in the pool when compaction is off / at bounce 0
+    int gen_rays;          // bounce 0 generates the camera ray instead of loading it
 };
 
 __device__ __forceinline__ int local_to_pixel(const TileMap &m, int j) {
@@ -133,8 +145,21 @@ __device__ __forceinline__ int local_to_pixel(const TileMap &m, int j) {
     return x + y * m.W;
 }
 
+// generateRayFromCamera (pathtrace.cu:122-143) for one pixel
+__device__ __forceinline__ f3 camera_dir(const pt_camera &cam, int pix, int W) {
+    const int y = pix / W;
+    const int x = pix - y * W;
+    f3 view = ptd::mk(cam.view.x, cam.view.y, cam.view.z);
+    f3 right = ptd::mk(cam.right.x, cam.right.y, cam.right.z);
+    f3 up = ptd::mk(cam.up.x, cam.up.y, cam.up.z);
+    f3 a = ptd::scale(ptd::scale(right, cam.pixelLength[0]), ((float)x - (float)cam.resolution[0] * 0.5f));
+    f3 b = ptd::scale(ptd::scale(up, cam.pixelLength[1]), ((float)y - (float)cam.resolution[1] * 0.5f));
+    return ptd::normalize(ptd::sub(ptd::sub(view, a), b));
+}
+
 // ---------------------------------------------------------------------------
-// generateRayFromCamera (pathtrace.cu:122-143) -> SoA pool, `count` samples
+// generateRayFromCamera -> SoA pool, `count` samples (stepping interface; the
+// batch path generates rays inside bounce 0)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, TileMap map, int count,
                                                   Control *ctl) {
@@ -143,52 +168,50 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, TileMap
     if (i == 0) { ctl->nlive[0] = total; }
     if (i >= total) return;
     uint32_t j = i % (uint32_t)map.tile_pixels;
-    int pix = local_to_pixel(map, (int)j);
-    int y = pix / map.W;
-    int x = pix - y * map.W;
-    f3 view = ptd::mk(cam.view.x, cam.view.y, cam.view.z);
-    f3 right = ptd::mk(cam.right.x, cam.right.y, cam.right.z);
-    f3 up = ptd::mk(cam.up.x, cam.up.y, cam.up.z);
-    f3 a = ptd::scale(ptd::scale(right, cam.pixelLength[0]), ((float)x - (float)cam.resolution[0] * 0.5f));
-    f3 b = ptd::scale(ptd::scale(up, cam.pixelLength[1]), ((float)y - (float)cam.resolution[1] * 0.5f));
-    f3 d = ptd::normalize(ptd::sub(ptd::sub(view, a), b));
-    p.ox[i] = cam.position.x; p.oy[i] = cam.position.y; p.oz[i] = cam.position.z;
-    p.dx[i] = d.x; p.dy[i] = d.y; p.dz[i] = d.z;
-    p.cr[i] = 1.0f; p.cg[i] = 1.0f; p.cb[i] = 1.0f;
-    p.pid[i] = i;
+    f3 d = camera_dir(cam, local_to_pixel(map, (int)j), map.W);
+    p.plane(0)[i] = cam.position.x; p.plane(1)[i] = cam.position.y; p.plane(2)[i] = cam.position.z;
+    p.plane(3)[i] = d.x; p.plane(4)[i] = d.y; p.plane(5)[i] = d.z;
+    p.plane(6)[i] = 1.0f; p.plane(7)[i] = 1.0f; p.plane(8)[i] = 1.0f;
+    p.pid()[i] = i;
 }
 
 // ---------------------------------------------------------------------------
 // scene staging + intersection (computeIntersections, pathtrace.cu:149-213)
 // ---------------------------------------------------------------------------
 // Dynamic LDS carve (no static __shared__: the dynamic base stays 16-B aligned, guide G17):
-// [ctl: 80 dwords][geoms: ngeoms*40 dwords][mats: nmats*12 dwords][tri tile: TRI_TILE*9 dwords (if any)]
-constexpr int LDS_WIN = 8;           // [0] last-block flag  [2..5] per-wave counts  [8..72] tile-base window
-constexpr int LDS_CTL_WORDS = 80;    // control words in front of the scene records (320 B, keeps 16-B alignment)
-__device__ __forceinline__ void stage_scene(float *lds, const SceneDev &sc) {
-    const int gw = sc.ngeoms * ptd::GEOM_WORDS;
+// [ctl: 16 dwords][mats: nmats*12 dwords][tri tile: TRI_TILE*9 dwords (if any)]
+// Geom records are NOT staged: every lane of every wave reads the same record, so they are
+// fetched with wave-uniform (scalar, SGPR) loads straight from the 1-KB record array, which
+// costs no VGPRs and no LDS bandwidth; materials are per-lane gathers and live in LDS.
+constexpr int LDS_CTL_WORDS = 16;    // [0] last-block flag, [2..5] scan scratch
+__device__ __forceinline__ void stage_scene(float *lds_mats, const SceneDev &sc) {
     const int mw = sc.nmats * ptd::MAT_WORDS;
-    for (int k = threadIdx.x; k < gw; k += BLOCK) lds[k] = sc.geoms[k];
-    for (int k = threadIdx.x; k < mw; k += BLOCK) lds[gw + k] = sc.mats[k];
+    for (int k = threadIdx.x; k < mw; k += BLOCK) lds_mats[k] = sc.mats[k];
     __syncthreads();
 }
 
-// All 256 threads of the block must call this together (mesh geoms stage
-// triangle tiles through LDS with block-wide barriers); `active` masks lanes
-// beyond the end of the pool.
-__device__ __forceinline__ void intersect_scene(const float *lds, const SceneDev &sc, bool active, f3 ro,
-                                                f3 rd, ptd::Hit &h) {
+// `uniform_trips` != 0: every wave of the block executes the same geom sequence (needed when
+// meshes stage triangle tiles through LDS with block barriers); `active` masks idle lanes.
+// Geom records are read through the CONSTANT address space: the array is immutable for the
+// lifetime of the launch and the address is wave-uniform, so the loads become s_load_dwordxN
+// (scalar cache -> SGPRs) instead of per-lane vector loads.
+typedef const __attribute__((address_space(4))) float cfloat;
+__device__ __forceinline__ cfloat *as_const(const float *p) {
+    return (cfloat *)(unsigned long long)p;
+}
+
+template <bool HAS_MESH>
+__device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms, int ngeoms,
+                                                const float *__restrict__ tris, float *tri_lds, bool active,
+                                                f3 ro, f3 rd, ptd::Hit &h) {
     h.t = FLT_MAX; h.geom = -1; h.outside = 1; h.aux = ptd::mk(0, 0, 0);
-    float *tri_lds = const_cast<float *>(lds) + sc.ngeoms * ptd::GEOM_WORDS + sc.nmats * ptd::MAT_WORDS;
+#if PT_DEFER
     ptd::Candidate pend;
     pend.geom = -1; pend.outside = 1; pend.t_obj = 0.0f;
     pend.qo = ptd::mk(0, 0, 0); pend.qd = ptd::mk(0, 0, 1); pend.face_n = ptd::mk(0, 0, 0);
-    // Evaluate the pending candidates' world distance and fold them into the running minimum.
-    // Candidates are folded in geom order per lane, so `t_min > t` keeps the reference's
-    // first-geom-wins tie rule (pathtrace.cu:192).
     auto flush = [&]() {
         if (pend.geom >= 0) {
-            const float *rec = lds + pend.geom * ptd::GEOM_WORDS;      // per-lane record (LDS gather)
+            const float *rec = geoms + pend.geom * ptd::GEOM_WORDS;    // per-lane record (cached gather)
             f3 obj_p;
             const float t = ptd::candidate_distance(rec, ro, pend, obj_p);
             if (t > 0.0f && h.t > t) {
@@ -198,20 +221,23 @@ __device__ __forceinline__ void intersect_scene(const float *lds, const SceneDev
             pend.geom = -1;
         }
     };
-    for (int g = 0; g < sc.ngeoms; ++g) {
-        const float *rec = lds + g * ptd::GEOM_WORDS;
-        const int type = __builtin_amdgcn_readfirstlane(__float_as_int(rec[0]));
-        if (type == PT_TRIANGLE_MESH) {
+#endif
+    for (int g = 0; g < ngeoms; ++g) {
+        cfloat *rec = as_const(geoms) + g * ptd::GEOM_WORDS;           // wave-uniform address -> s_load
+        const int type = __float_as_int(rec[0]);
+        if (HAS_MESH && type == PT_TRIANGLE_MESH) {
+#if PT_DEFER
             if (__ballot(pend.geom >= 0)) flush();          // keep geom order
+#endif
             // completion spec 8.0: nearest triangle by strictly smaller bary.z, first wins ties
-            const int first = __builtin_amdgcn_readfirstlane(__float_as_int(rec[2]));
-            const int count = __builtin_amdgcn_readfirstlane(__float_as_int(rec[3]));
+            const int first = __float_as_int(rec[2]);
+            const int count = __float_as_int(rec[3]);
             float best = FLT_MAX;
             int best_i = -1;
             for (int base = 0; base < count; base += TRI_TILE) {
                 const int nt = min(TRI_TILE, count - base);
                 __syncthreads();
-                const float *src = sc.tris + (size_t)(first + base) * 9;
+                const float *src = tris + (size_t)(first + base) * 9;
                 for (int k = threadIdx.x; k < nt * 9; k += BLOCK) tri_lds[k] = src[k];
                 __syncthreads();
                 if (active) {
@@ -235,97 +261,116 @@ __device__ __forceinline__ void intersect_scene(const float *lds, const SceneDev
             }
             continue;
         }
+        if (!active) continue;
         ptd::Candidate c;
         bool hit = false;
-        if (active) {
-            if (type == PT_CUBE) hit = ptd::box_candidate(rec, ro, rd, c);
-            else if (type == PT_SPHERE) hit = ptd::sphere_candidate(rec, ro, rd, c);
-        }
+        if (type == PT_CUBE) hit = ptd::box_candidate(rec, ro, rd, c);
+        else if (type == PT_SPHERE) hit = ptd::sphere_candidate(rec, ro, rd, c);
 #if PT_DEFER
-        // a lane that already holds a candidate and found another forces the shared tail now
         if (__ballot(hit && pend.geom >= 0)) flush();
         if (hit) { pend = c; pend.geom = g; }
 #else
-        if (hit) { pend = c; pend.geom = g; }
-        flush();
+        if (hit) {
+            f3 obj_p;
+            const float t = ptd::candidate_distance(rec, ro, c, obj_p);
+            if (t > 0.0f && h.t > t) {                  // pathtrace.cu:192 (first geom wins ties)
+                h.t = t; h.geom = g; h.outside = c.outside;
+                h.aux = (type == PT_CUBE) ? c.face_n : obj_p;
+            }
+        }
 #endif
     }
+#if PT_DEFER
     if (__ballot(pend.geom >= 0)) flush();
+#endif
 }
 
-// normal + materialId of the winning primitive
-__device__ __forceinline__ void resolve_hit(const float *lds, const SceneDev &sc, const ptd::Hit &h, float &t,
-                                            f3 &n, int &mat) {
+// normal + materialId of the winning primitive (per-lane record: cached gather from the
+// 1-KB record array)
+__device__ __forceinline__ void resolve_hit(const float *__restrict__ geoms, const float *__restrict__ tris,
+                                            const ptd::Hit &h, float &t, f3 &n, int &mat) {
     if (h.geom < 0) { t = -1.0f; n = ptd::mk(0, 0, 0); mat = 0; return; }
-    const float *rec = lds + h.geom * ptd::GEOM_WORDS;
+    const float *rec = geoms + h.geom * ptd::GEOM_WORDS;
     const int type = __float_as_int(rec[0]);
     t = h.t;
     mat = __float_as_int(rec[1]);
     if (type == PT_CUBE) n = ptd::cube_normal(rec, h.aux);
     else if (type == PT_SPHERE) n = ptd::sphere_normal(rec, h.aux, h.outside);
     else {
-        const float *tv = sc.tris + (size_t)__float_as_int(h.aux.x) * 9;
+        const float *tv = tris + (size_t)__float_as_int(h.aux.x) * 9;
         n = ptd::normalize(ptd::cross(ptd::mk(tv[3], tv[4], tv[5]), ptd::mk(tv[6], tv[7], tv[8])));
     }
 }
 
-// Logical path index -> physical slot of a tile-packed pool.  Block-cooperative: every
-// thread of the block calls it (barriers inside).  `k` is the block's logical tile.
+// Logical path index -> physical slot of a tile-packed pool, one wave at a time and without
+// LDS: lane l holds base[s + l]; a 6-step binary search reads other lanes' values with
+// ds_bpermute (__shfl).  `k` is the wave's logical tile (wave-uniform).
 __device__ __forceinline__ uint32_t resolve_src(const TileDir &dir, uint32_t tiles_prev, uint32_t k, uint32_t p,
-                                                bool active, uint32_t *win) {
-    if (!dir.base) return p;                        // dense pool (ray generation / sorted / imported)
-    uint32_t s = dir.start[k];
+                                                bool active, Control *ctl) {
+    if (!dir.mem) return p;                         // dense pool (ray generation / sorted / imported)
+    const int lane = threadIdx.x & 63;
+    uint32_t s = dir.start()[k];
+    const uint32_t *base = dir.base();
     bool resolved = !active;
     uint32_t src = 0;
-    while (true) {
-        if (threadIdx.x < 65) {
-            const uint32_t t = s + threadIdx.x;
-            win[threadIdx.x] = t <= tiles_prev ? dir.base[t] : 0xffffffffu;
+    // bounded: a sane directory resolves within tiles_prev/63 + 1 windows; every wave reaches the exit
+    for (uint32_t guard = 0;; ++guard) {
+        if (guard > tiles_prev / 63 + 1) {
+            if (lane == 0) atomicOr(&ctl->error, 2u);
+            break;
         }
-        __syncthreads();
-        if (!resolved) {
-            int lo = 0, hi = 64;                    // win[0] <= p always holds
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (win[mid] <= p) lo = mid; else hi = mid - 1;
-            }
-            if (lo < 64) { resolved = true; src = (s + (uint32_t)lo) * BLOCK + (p - win[lo]); }
+        const uint32_t t = s + (uint32_t)lane;
+        const uint32_t w = t <= tiles_prev ? base[t] : 0xffffffffu;
+        int lo = 0, hi = 63;                        // w(lane 0) <= p always holds for unresolved lanes
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const int mid = (lo + hi + 1) >> 1;
+            const uint32_t wm = (uint32_t)__shfl((int)w, mid);
+            if (wm <= p) lo = mid; else hi = mid - 1;
         }
-        if (!__syncthreads_or(!resolved)) break;    // also fences `win` for the next window
-        s += 64;
+        const uint32_t wl = (uint32_t)__shfl((int)w, lo);
+        if (!resolved && lo < 63) { resolved = true; src = (s + (uint32_t)lo) * TILE + (p - wl); }
+        if (!__any(!resolved)) break;
+        s += 63;
     }
     return src;
 }
 
 // standalone computeIntersections: materialises the ShadeableIntersection planes
 // (indexed by LOGICAL path index)
-__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc, const uint32_t *n_ptr,
-                                                     uint32_t n_fixed, TileDir dir_in, const uint32_t *nprev_ptr) {
+template <bool HAS_MESH>
+__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc,
+                                                                    const uint32_t *n_ptr, uint32_t n_fixed,
+                                                                    TileDir dir_in, const uint32_t *nprev_ptr,
+                                                                    Control *ctl) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    uint32_t *win = reinterpret_cast<uint32_t *>(lds_raw) + LDS_WIN;
-    float *lds = lds_raw + LDS_CTL_WORDS;
-    stage_scene(lds, sc);
+    float *tri_lds = lds_raw + LDS_CTL_WORDS + sc.nmats * ptd::MAT_WORDS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    const uint32_t tiles = (n + BLOCK - 1) / BLOCK;
-    const uint32_t tiles_prev = (dir_in.base && nprev_ptr) ? (*nprev_ptr + BLOCK - 1) / BLOCK : 0;
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint32_t i = tile * BLOCK + threadIdx.x;
-        bool active = i < n;
-        const uint32_t src = resolve_src(dir_in, tiles_prev, tile, i, active, win);
+    const uint32_t tiles = (n + TILE - 1) / TILE;
+    const uint32_t tiles_prev = (dir_in.mem && nprev_ptr) ? (*nprev_ptr + TILE - 1) / TILE : 0;
+    const uint32_t wstride = gridDim.x * WAVES;
+    const uint32_t rounds = (tiles + wstride - 1) / wstride;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t tile = __builtin_amdgcn_readfirstlane(r * wstride + blockIdx.x * WAVES + wave);
+        if (!HAS_MESH && tile >= tiles) break;
+        const uint32_t i = tile * TILE + lane;
+        bool active = tile < tiles && i < n;
+        const uint32_t src = (tile < tiles) ? resolve_src(dir_in, tiles_prev, tile, i, active, ctl) : 0;
         f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
         if (active) {
-            if (in.pid[src] == DEAD_PID) active = false;
-            ro = ptd::mk(in.ox[src], in.oy[src], in.oz[src]);
-            rd = ptd::mk(in.dx[src], in.dy[src], in.dz[src]);
+            if (in.pid()[src] == DEAD_PID) active = false;
+            ro = ptd::mk(in.plane(0)[src], in.plane(1)[src], in.plane(2)[src]);
+            rd = ptd::mk(in.plane(3)[src], in.plane(4)[src], in.plane(5)[src]);
         }
         ptd::Hit h;
-        intersect_scene(lds, sc, active, ro, rd, h);
-        if (i < n) {
+        intersect_scene<HAS_MESH>(sc.geoms, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h);
+        if (tile < tiles && i < n) {
             float t; f3 nrm; int mat;
-            resolve_hit(lds, sc, h, t, nrm, mat);
+            resolve_hit(sc.geoms, sc.tris, h, t, nrm, mat);
             // a miss writes only t; the other fields read as the zeros of pathtrace.cu:343's memset
-            out.t[i] = t; out.nx[i] = nrm.x; out.ny[i] = nrm.y; out.nz[i] = nrm.z;
-            out.mat[i] = mat | (h.outside ? 0 : (int)0x80000000u);
+            out.plane(0)[i] = t; out.plane(1)[i] = nrm.x; out.plane(2)[i] = nrm.y; out.plane(3)[i] = nrm.z;
+            out.mat()[i] = mat | (h.outside ? 0 : (int)0x80000000u);
         }
     }
 }
@@ -333,17 +378,19 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
 // ---------------------------------------------------------------------------
 // stable compaction: tile counts -> tile bases, by the last workgroup out
 // ---------------------------------------------------------------------------
-// Hand-off (guide G16): each workgroup's thread 0 stores its tile counts with agent-scope
-// atomic (write-through) stores, drains them (s_waitcnt vmcnt(0)) and then adds 1 to
-// done[depth]; the workgroup whose add returns grid-1 is last, acquires once (agent
-// scope) and reads every count.  Nothing spins; nothing depends on dispatch order.
+// Hand-off (guide G16): each wave stores its tile counts with agent-scope atomic
+// (write-through) stores and drains them (s_waitcnt vmcnt(0)); after the workgroup's barrier
+// one lane adds 1 to done[depth]; the workgroup whose add returns grid-1 is last, acquires
+// once (agent scope) and reads every count.  Nothing spins; nothing depends on dispatch order.
 __device__ __forceinline__ void scan_tile_counts(const TileDir &dir, uint32_t tiles, uint32_t *n_out,
                                                  uint32_t *lds_scan /* >= 8 words */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t *count = dir.count();
+    uint32_t *base = dir.base(), *start = dir.start();
     const uint32_t per = (tiles + BLOCK - 1) / BLOCK;          // contiguous entries per thread
     const uint32_t lo = min(tiles, threadIdx.x * per), hi = min(tiles, lo + per);
     uint32_t sum = 0;
-    for (uint32_t t = lo; t < hi; ++t) sum += dir.count[t];
+    for (uint32_t t = lo; t < hi; ++t) sum += count[t];
     uint32_t incl = sum;                                        // wave inclusive scan
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t v = __shfl_up(incl, off);
@@ -360,13 +407,13 @@ __device__ __forceinline__ void scan_tile_counts(const TileDir &dir, uint32_t ti
     }
     uint32_t run = wave_off + incl - sum;                       // exclusive prefix of this thread's range
     for (uint32_t t = lo; t < hi; ++t) {
-        const uint32_t c = dir.count[t];
-        dir.base[t] = run;
-        const uint32_t j = (run + BLOCK - 1) / BLOCK;           // the one multiple of 256 the span can hold
-        if (c && j * BLOCK < run + c) dir.start[j] = t;
+        const uint32_t c = count[t];
+        base[t] = run;
+        const uint32_t j = (run + TILE - 1) / TILE;             // the one multiple of 64 the span can hold
+        if (c && j * TILE < run + c) start[j] = t;
         run += c;
     }
-    if (threadIdx.x == 0) { dir.base[tiles] = total; *n_out = total; }
+    if (threadIdx.x == 0) { base[tiles] = total; *n_out = total; }
 }
 
 // ---------------------------------------------------------------------------
@@ -376,93 +423,105 @@ __device__ __forceinline__ void scan_tile_counts(const TileDir &dir, uint32_t ti
 // MODE_ISECT   : read the materialised planes written by k_intersect (PT_UNFUSED / sort)
 enum { MODE_FUSED = 0, MODE_ISECT = 1 };
 
-template <int MODE, bool COMPACT>
+template <int MODE, bool COMPACT, bool HAS_MESH>
 __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);      // barriers order every access below
-    uint32_t *win = sctl + LDS_WIN;
-    float *lds = lds_raw + LDS_CTL_WORDS;
-    stage_scene(lds, a.scene);
-    const float *mats = lds + a.scene.ngeoms * ptd::GEOM_WORDS;
+    uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
+    float *mats = lds_raw + LDS_CTL_WORDS;
+    float *tri_lds = mats + a.scene.nmats * ptd::MAT_WORDS;
+    stage_scene(mats, a.scene);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t n = COMPACT ? a.ctl->nlive[a.depth] : a.pool_n;
-    const uint32_t tiles = (n + BLOCK - 1) / BLOCK;
-    const uint32_t tiles_prev = (COMPACT && a.dir_in.base) ? (a.ctl->nlive[a.depth - 1] + BLOCK - 1) / BLOCK : 0;
+    const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
+    const uint32_t tiles = (n + TILE - 1) / TILE;
+    const uint32_t tiles_prev = (COMPACT && a.dir_in.mem) ? (a.ctl->nlive[a.depth - 1] + TILE - 1) / TILE : 0;
     const bool last_bounce = (a.depth == a.trace_depth - 1);
+    const uint32_t wstride = gridDim.x * WAVES;
+    const uint32_t rounds = (tiles + wstride - 1) / wstride;
     uint32_t traced = 0;
+    if (a.gen_rays && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = a.pool_n;   // k_raygen's job otherwise
 
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint32_t i = tile * BLOCK + threadIdx.x;            // logical path index
-        bool active = i < n;
-        const uint32_t src = COMPACT ? resolve_src(a.dir_in, tiles_prev, tile, i, active, win) : i;
+    // every wave walks its own 64-path tiles; no workgroup barrier inside the loop unless a
+    // mesh needs block-wide triangle staging (then all waves run `rounds` iterations)
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t tile = __builtin_amdgcn_readfirstlane(r * wstride + blockIdx.x * WAVES + wave);
+        if (!HAS_MESH && tile >= tiles) break;
+        const bool have = tile < tiles;
+        const uint32_t i = tile * TILE + lane;                    // logical path index
+        bool active = have && i < n;
+        uint32_t src = i;
+        if (COMPACT && have) src = resolve_src(a.dir_in, tiles_prev, tile, i, active, a.ctl);
         uint32_t pid = DEAD_PID;
-        ptd::PathState ps;
-        ps.o = ptd::mk(0, 0, 0); ps.d = ptd::mk(0, 0, 1); ps.c = ptd::mk(0, 0, 0);
+        f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
         if (active) {
-            pid = a.in.pid[src];
-            if (pid == DEAD_PID) active = false;
+            if (a.gen_rays) {
+                pid = i;
+            } else {
+                pid = a.in.pid()[src];
+                if (pid == DEAD_PID) active = false;
+            }
         }
+        uint32_t smp = 0;
+        int pixel = 0;
         if (active) {
-            ps.o = ptd::mk(a.in.ox[src], a.in.oy[src], a.in.oz[src]);
-            ps.d = ptd::mk(a.in.dx[src], a.in.dy[src], a.in.dz[src]);
-            ps.c = ptd::mk(a.in.cr[src], a.in.cg[src], a.in.cb[src]);
+            smp = pid / (uint32_t)a.map.tile_pixels;
+            pixel = local_to_pixel(a.map, (int)(pid - smp * (uint32_t)a.map.tile_pixels));
+            if (a.gen_rays) {
+                ro = ptd::mk(a.cam.position.x, a.cam.position.y, a.cam.position.z);
+                rd = camera_dir(a.cam, pixel, a.map.W);
+            } else {
+                ro = ptd::mk(a.in.plane(0)[src], a.in.plane(1)[src], a.in.plane(2)[src]);
+                rd = ptd::mk(a.in.plane(3)[src], a.in.plane(4)[src], a.in.plane(5)[src]);
+            }
         }
         float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
         if (MODE == MODE_FUSED) {
             ptd::Hit h;
-            intersect_scene(lds, a.scene, active, ps.o, ps.d, h);
-            if (active) { resolve_hit(lds, a.scene, h, t, nrm, mat); outside = h.outside; }
+            intersect_scene<HAS_MESH>(a.scene.geoms, a.scene.ngeoms, a.scene.tris, tri_lds, active, ro, rd, h);
+            if (active) { resolve_hit(a.scene.geoms, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
         } else if (active) {
-            t = a.isect.t[i]; nrm = ptd::mk(a.isect.nx[i], a.isect.ny[i], a.isect.nz[i]);
-            const int m = a.isect.mat[i];
+            t = a.isect.plane(0)[i];
+            nrm = ptd::mk(a.isect.plane(1)[i], a.isect.plane(2)[i], a.isect.plane(3)[i]);
+            const int m = a.isect.mat()[i];
             mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
         }
         bool alive = false;
+        ptd::PathState ps;
+        ps.o = ro; ps.d = rd; ps.c = ptd::mk(1.0f, 1.0f, 1.0f);
         if (active) {
-            const uint32_t s = pid / (uint32_t)a.map.tile_pixels;
-            const uint32_t j = pid - s * (uint32_t)a.map.tile_pixels;
-            const int pixel = local_to_pixel(a.map, (int)j);
-            alive = ptd::shade_scatter(ps, t, nrm, mat, outside, mats, a.iter0 + (int)s, pixel, a.depth,
+            if (!a.gen_rays) ps.c = ptd::mk(a.in.plane(6)[src], a.in.plane(7)[src], a.in.plane(8)[src]);
+            alive = ptd::shade_scatter(ps, t, nrm, mat, outside, mats, a.iter0 + (int)smp, pixel, a.depth,
                                        last_bounce);
-            if (!alive) { a.fin_r[pid] = ps.c.x; a.fin_g[pid] = ps.c.y; a.fin_b[pid] = ps.c.z; }
+            if (!alive) {
+                a.fin[pid] = ps.c.x; a.fin[(size_t)a.in.cap + pid] = ps.c.y; a.fin[2 * (size_t)a.in.cap + pid] = ps.c.z;
+            }
         }
-        // ---- survivors pack to the front of this tile's own 256-slot span ----
-        uint32_t dst = i;
+        // ---- survivors pack to the front of this wave's own 64-slot span ----
         const uint64_t bal = __ballot(alive);
         const uint64_t act = __ballot(active);
-        if (lane == 0) traced += (uint32_t)__popcll((unsigned long long)act);
-        if (COMPACT) {
-            const uint32_t rank = (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
-            if (lane == 0) sctl[2 + wave] = (uint32_t)__popcll((unsigned long long)bal);
-            __syncthreads();
-            uint32_t wave_off = 0, agg = 0;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                const uint32_t c = sctl[2 + w];
-                if (w < wave) wave_off += c;
-                agg += c;
-            }
-            dst = tile * BLOCK + wave_off + rank;
-            if (threadIdx.x == 0)
-                __hip_atomic_store(&a.dir_out.count[tile], agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        traced += (uint32_t)__popcll((unsigned long long)act);
+        uint32_t dst = i;
+        if (COMPACT && have) {
+            dst = tile * TILE + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
+            if (lane == 0)
+                __hip_atomic_store(&a.dir_out.count()[tile], (uint32_t)__popcll((unsigned long long)bal),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (alive) {
-            a.out.ox[dst] = ps.o.x; a.out.oy[dst] = ps.o.y; a.out.oz[dst] = ps.o.z;
-            a.out.dx[dst] = ps.d.x; a.out.dy[dst] = ps.d.y; a.out.dz[dst] = ps.d.z;
-            a.out.cr[dst] = ps.c.x; a.out.cg[dst] = ps.c.y; a.out.cb[dst] = ps.c.z;
-            a.out.pid[dst] = pid;
-        } else if (!COMPACT && i < n) {
-            a.out.pid[dst] = DEAD_PID;
+            a.out.plane(0)[dst] = ps.o.x; a.out.plane(1)[dst] = ps.o.y; a.out.plane(2)[dst] = ps.o.z;
+            a.out.plane(3)[dst] = ps.d.x; a.out.plane(4)[dst] = ps.d.y; a.out.plane(5)[dst] = ps.d.z;
+            a.out.plane(6)[dst] = ps.c.x; a.out.plane(7)[dst] = ps.c.y; a.out.plane(8)[dst] = ps.c.z;
+            a.out.pid()[dst] = pid;
+        } else if (!COMPACT && have && i < n) {
+            a.out.pid()[dst] = DEAD_PID;
         }
-        __syncthreads();       // sctl[2..5] / win are rewritten by the next tile
     }
     if (lane == 0 && traced) atomicAdd(&a.ctl->alive[a.depth], traced);
 
     if (COMPACT) {
         // last workgroup out turns the tile counts into the next bounce's directory
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's count stores have left
         __syncthreads();
         if (threadIdx.x == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread stored every count of the block
             const uint32_t old = __hip_atomic_fetch_add(&a.ctl->done[a.depth], 1u, __ATOMIC_RELAXED,
                                                         __HIP_MEMORY_SCOPE_AGENT);
             const bool last = (old == gridDim.x - 1);
@@ -479,22 +538,22 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 
 // shadeFakeMaterial (pathtrace.cu:224-266): one bounce, never spawns a ray
 __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const float *mats_g, TileMap map,
-                                                      int iter0, uint32_t n, float *fr, float *fg, float *fb) {
+                                                      int iter0, uint32_t n, float *fin) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const uint32_t pid = p.pid[i];
+    const uint32_t pid = p.pid()[i];
     const uint32_t s = pid / (uint32_t)map.tile_pixels;
     const int idx = local_to_pixel(map, (int)(pid - s * (uint32_t)map.tile_pixels));
-    f3 c = ptd::mk(p.cr[i], p.cg[i], p.cb[i]);
-    const float t = is.t[i];
+    f3 c = ptd::mk(p.plane(6)[i], p.plane(7)[i], p.plane(8)[i]);
+    const float t = is.plane(0)[i];
     if (t > 0.0f) {
         uint32_t rng = ptd::seeded_engine(iter0 + (int)s, idx, 0);
-        const float *m = mats_g + (is.mat[i] & 0x7fffffff) * ptd::MAT_WORDS;
+        const float *m = mats_g + (is.mat()[i] & 0x7fffffff) * ptd::MAT_WORDS;
         f3 mc = ptd::mk(m[0], m[1], m[2]);
         if (m[9] > 0.0f) {
             c = ptd::mul(c, ptd::scale(mc, m[9]));
         } else {
-            f3 nrm = ptd::mk(is.nx[i], is.ny[i], is.nz[i]);
+            f3 nrm = ptd::mk(is.plane(1)[i], is.plane(2)[i], is.plane(3)[i]);
             float lightTerm = ptd::dot(nrm, ptd::mk(0.0f, 1.0f, 0.0f));
             f3 x = ptd::scale(ptd::scale(mc, lightTerm), 0.3f);
             f3 y = ptd::scale(ptd::scale(mc, (1.0f - t * 0.02f)), 0.7f);
@@ -504,15 +563,15 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const fl
     } else {
         c = ptd::mk(0.0f, 0.0f, 0.0f);
     }
-    p.cr[i] = c.x; p.cg[i] = c.y; p.cb[i] = c.z;
-    fr[pid] = c.x; fg[pid] = c.y; fb[pid] = c.z;
+    p.plane(6)[i] = c.x; p.plane(7)[i] = c.y; p.plane(8)[i] = c.z;
+    fin[pid] = c.x; fin[(size_t)p.cap + pid] = c.y; fin[2 * (size_t)p.cap + pid] = c.z;
 }
 
 // finalGather (pathtrace.cu:269-278): image[pixelIndex] += colour, one add per
 // pixel per iteration, samples added in iteration order
-__global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fr, const float *fg,
-                                                  const float *fb, TileMap map, int count, const Control *ctl,
-                                                  Persist *per, int depths, uint32_t fake_rays) {
+__global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin, uint32_t cap, TileMap map,
+                                                  int count, const Control *ctl, Persist *per, int depths,
+                                                  uint32_t fake_rays) {
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
     if (j == 0) {                    // fold this batch's ray count into the persistent counter
         unsigned long long r = fake_rays;
@@ -526,7 +585,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fr,
     float r = image[3 * pix + 0], g = image[3 * pix + 1], b = image[3 * pix + 2];
     for (int s = 0; s < count; ++s) {
         const size_t k = (size_t)s * map.tile_pixels + j;
-        r += fr[k]; g += fg[k]; b += fb[k];
+        r += fin[k]; g += fin[(size_t)cap + k]; b += fin[2 * (size_t)cap + k];
     }
     image[3 * pix + 0] = r; image[3 * pix + 1] = g; image[3 * pix + 2] = b;
 }
@@ -553,19 +612,20 @@ __global__ void k_export_paths(Pool p, TileMap map, uint32_t n_total, uint32_t n
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
     uint32_t src = i;
-    if (dir.base) {                       // logical -> physical: largest t with base[t] <= i
+    if (dir.mem) {                        // logical -> physical: largest t with base[t] <= i
+        const uint32_t *base = dir.base();
         uint32_t lo = 0, hi = tiles_prev;
         while (lo < hi) {
             const uint32_t mid = (lo + hi + 1) >> 1;
-            if (dir.base[mid] <= i) lo = mid; else hi = mid - 1;
+            if (base[mid] <= i) lo = mid; else hi = mid - 1;
         }
-        src = lo * BLOCK + (i - dir.base[lo]);
+        src = lo * TILE + (i - base[lo]);
     }
     pt_path_segment s;
-    s.ray.origin = {p.ox[src], p.oy[src], p.oz[src]};
-    s.ray.direction = {p.dx[src], p.dy[src], p.dz[src]};
-    s.color = {p.cr[src], p.cg[src], p.cb[src]};
-    const uint32_t pid = p.pid[src];
+    s.ray.origin = {p.plane(0)[src], p.plane(1)[src], p.plane(2)[src]};
+    s.ray.direction = {p.plane(3)[src], p.plane(4)[src], p.plane(5)[src]};
+    s.color = {p.plane(6)[src], p.plane(7)[src], p.plane(8)[src]};
+    const uint32_t pid = p.pid()[src];
     if (pid == DEAD_PID) { s.pixelIndex = -1; s.remainingBounces = 0; }
     else {
         const uint32_t sm = pid / (uint32_t)map.tile_pixels;
@@ -579,19 +639,19 @@ __global__ void k_import_paths(Pool p, const pt_path_segment *in, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const pt_path_segment s = in[i];
-    p.ox[i] = s.ray.origin.x; p.oy[i] = s.ray.origin.y; p.oz[i] = s.ray.origin.z;
-    p.dx[i] = s.ray.direction.x; p.dy[i] = s.ray.direction.y; p.dz[i] = s.ray.direction.z;
-    p.cr[i] = s.color.x; p.cg[i] = s.color.y; p.cb[i] = s.color.z;
-    p.pid[i] = i;
+    p.plane(0)[i] = s.ray.origin.x; p.plane(1)[i] = s.ray.origin.y; p.plane(2)[i] = s.ray.origin.z;
+    p.plane(3)[i] = s.ray.direction.x; p.plane(4)[i] = s.ray.direction.y; p.plane(5)[i] = s.ray.direction.z;
+    p.plane(6)[i] = s.color.x; p.plane(7)[i] = s.color.y; p.plane(8)[i] = s.color.z;
+    p.pid()[i] = i;
 }
 
 __global__ void k_export_isects(Isect is, uint32_t n, pt_shadeable_intersection *out, uint8_t *outside) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     pt_shadeable_intersection s;
-    const int m = is.mat[i];
-    s.t = is.t[i];
-    if (s.t > 0.0f) { s.surfaceNormal = {is.nx[i], is.ny[i], is.nz[i]}; s.materialId = m & 0x7fffffff; }
+    const int m = is.mat()[i];
+    s.t = is.plane(0)[i];
+    if (s.t > 0.0f) { s.surfaceNormal = {is.plane(1)[i], is.plane(2)[i], is.plane(3)[i]}; s.materialId = m & 0x7fffffff; }
     else { s.surfaceNormal = {0, 0, 0}; s.materialId = 0; }      // memset(0) + t = -1 only
     out[i] = s;
     if (outside) outside[i] = (m < 0) ? 0 : 1;
@@ -649,6 +709,8 @@ struct Renderer {
     uint32_t max_tiles = 0;
     size_t ctl_bytes = 0;         // Control, zeroed per batch
     int grid = 0;                 // persistent grid size
+    bool gen_fused = false;       // bounce 0 of the current batch generates its own rays
+    bool has_mesh = false;
     void *scratch = nullptr;      // export / import staging
     size_t scratch_bytes = 0;
     // stepping state
@@ -691,14 +753,7 @@ struct StageTimer {                  // brackets one launch when profiling is on
     ~StageTimer() { if (on) (void)hipEventRecord(R.ev[2 * k + 1], R.stream); }
 };
 
-Pool carve_pool(float *mem, uint32_t cap) {
-    Pool p;
-    p.ox = mem + 0 * (size_t)cap; p.oy = mem + 1 * (size_t)cap; p.oz = mem + 2 * (size_t)cap;
-    p.dx = mem + 3 * (size_t)cap; p.dy = mem + 4 * (size_t)cap; p.dz = mem + 5 * (size_t)cap;
-    p.cr = mem + 6 * (size_t)cap; p.cg = mem + 7 * (size_t)cap; p.cb = mem + 8 * (size_t)cap;
-    p.pid = reinterpret_cast<uint32_t *>(mem + 9 * (size_t)cap);
-    return p;
-}
+Pool carve_pool(float *mem, uint32_t cap) { return Pool{mem, cap}; }
 
 int tile_rows(int tile_index, int tile_count, int strip_rows, int H) {
     if (tile_count <= 1) return H;
@@ -718,11 +773,8 @@ int ensure_scratch(size_t bytes) {
 }
 
 TileDir tile_dir(int depth) {
-    TileDir d{nullptr, nullptr, nullptr};
-    if (depth < 0) return d;
-    uint32_t *m = R.dir_mem + (size_t)depth * (3 * (size_t)R.max_tiles + 2);
-    d.count = m; d.base = m + R.max_tiles; d.start = d.base + R.max_tiles + 1;
-    return d;
+    if (depth < 0) return TileDir{nullptr, 0};
+    return TileDir{R.dir_mem + (size_t)depth * (3 * (size_t)R.max_tiles + 2), R.max_tiles};
 }
 
 BounceArgs bounce_args(int depth) {
@@ -735,19 +787,24 @@ BounceArgs bounce_args(int depth) {
     a.ctl = R.ctl;
     a.dir_in = tile_dir((R.flags & PT_COMPACT) ? R.cur_dir : -1);
     a.dir_out = tile_dir(depth);
-    a.fin_r = R.final_mem; a.fin_g = R.final_mem + (size_t)R.cap; a.fin_b = R.final_mem + 2 * (size_t)R.cap;
+    a.fin = R.final_mem;
+    a.cam = R.cam;
     a.depth = depth; a.trace_depth = R.trace_depth; a.iter0 = R.step_iter0;
     a.pool_n = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
+    a.gen_rays = (depth == 0 && R.gen_fused) ? 1 : 0;
     return a;
 }
 
-int enqueue_begin(int iter0, int count) {
+int enqueue_begin(int iter0, int count, bool stepping) {
     if (count < 1 || count > R.max_batch)
         return fail(PT_ERR_INVALID, "batch count %d outside [1, max_batch=%d]", count, R.max_batch);
     if (iter0 < 1 || (int64_t)iter0 + count - 1 >= (1 << 22))
         return fail(PT_ERR_INVALID, "iteration %d outside [1, 2^22): makeSeededRandomEngine packs iter in 22 bits", iter0);
     R.step_iter0 = iter0; R.step_count = count; R.step_depth = 0; R.cur = 0; R.cur_dir = -1;
     HIPCHK(hipMemsetAsync(R.ctl, 0, R.ctl_bytes, R.stream));
+    // batch path: bounce 0 generates the camera rays itself (no 40 B/path round trip through HBM)
+    R.gen_fused = !stepping && !(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER));
+    if (R.gen_fused) return PT_OK;
     const uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)count;
     StageTimer tm(PT_STAGE_RAYGEN);
     hipLaunchKernelGGL(k_raygen, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.pool[0], R.cam,
@@ -756,24 +813,36 @@ int enqueue_begin(int iter0, int count) {
     return PT_OK;
 }
 
+template <bool HAS_MESH>
+void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, const TileDir &dir,
+                      const uint32_t *nprev) {
+    hipLaunchKernelGGL((k_intersect<HAS_MESH>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, in, R.isect,
+                       R.scene, n_ptr, n_fixed, dir, nprev, R.ctl);
+}
+
+template <int MODE, bool COMPACT>
+void launch_bounce(const BounceArgs &a) {
+    if (R.has_mesh) hipLaunchKernelGGL((k_bounce<MODE, COMPACT, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+    else hipLaunchKernelGGL((k_bounce<MODE, COMPACT, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+}
+
 int enqueue_bounce(int depth) {
     BounceArgs a = bounce_args(depth);
     const bool compact = (R.flags & PT_COMPACT) != 0;
     const bool unfused = (R.flags & (PT_UNFUSED | PT_SORT_MATERIAL)) != 0;
     if (unfused) {
         StageTimer tm(PT_STAGE_INTERSECT);
-        hipLaunchKernelGGL(k_intersect, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a.in, R.isect, R.scene,
-                           compact ? &R.ctl->nlive[depth] : (const uint32_t *)nullptr, a.pool_n, a.dir_in,
-                           (compact && depth > 0) ? &R.ctl->nlive[depth - 1] : (const uint32_t *)nullptr);
+        const uint32_t *n_ptr = compact ? &R.ctl->nlive[depth] : (const uint32_t *)nullptr;
+        const uint32_t *nprev = (compact && depth > 0) ? &R.ctl->nlive[depth - 1] : (const uint32_t *)nullptr;
+        if (R.has_mesh) launch_intersect<true>(a.in, n_ptr, a.pool_n, a.dir_in, nprev);
+        else launch_intersect<false>(a.in, n_ptr, a.pool_n, a.dir_in, nprev);
         HIPCHK(hipGetLastError());
     }
     StageTimer tm(PT_STAGE_BOUNCE);
     if (unfused) {
-        if (compact) hipLaunchKernelGGL((k_bounce<MODE_ISECT, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
-        else hipLaunchKernelGGL((k_bounce<MODE_ISECT, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        if (compact) launch_bounce<MODE_ISECT, true>(a); else launch_bounce<MODE_ISECT, false>(a);
     } else {
-        if (compact) hipLaunchKernelGGL((k_bounce<MODE_FUSED, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
-        else hipLaunchKernelGGL((k_bounce<MODE_FUSED, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        if (compact) launch_bounce<MODE_FUSED, true>(a); else launch_bounce<MODE_FUSED, false>(a);
     }
     HIPCHK(hipGetLastError());
     if (compact) { R.cur ^= 1; R.cur_dir = depth; }
@@ -784,12 +853,11 @@ int enqueue_bounce(int depth) {
 int enqueue_fake(void) {
     // the reference as shipped (pathtrace.cu:339-377): one bounce, fake shader
     const uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
-    hipLaunchKernelGGL(k_intersect, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, R.pool[R.cur], R.isect,
-                       R.scene, (const uint32_t *)nullptr, total, tile_dir(-1), (const uint32_t *)nullptr);
+    if (R.has_mesh) launch_intersect<true>(R.pool[R.cur], nullptr, total, tile_dir(-1), nullptr);
+    else launch_intersect<false>(R.pool[R.cur], nullptr, total, tile_dir(-1), nullptr);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_shade_fake, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.pool[R.cur],
-                       R.isect, R.scene.mats, R.map, R.step_iter0, total, R.final_mem, R.final_mem + (size_t)R.cap,
-                       R.final_mem + 2 * (size_t)R.cap);
+                       R.isect, R.scene.mats, R.map, R.step_iter0, total, R.final_mem);
     HIPCHK(hipGetLastError());
     R.step_depth = 1;
     return PT_OK;
@@ -798,7 +866,7 @@ int enqueue_fake(void) {
 int enqueue_end(void) {
     StageTimer tm(PT_STAGE_GATHER);
     hipLaunchKernelGGL(k_gather, dim3((R.map.tile_pixels + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.image,
-                       R.final_mem, R.final_mem + (size_t)R.cap, R.final_mem + 2 * (size_t)R.cap, R.map,
+                       R.final_mem, R.cap, R.map,
                        R.step_count, R.ctl, R.persist, (R.flags & PT_FAKE_SHADER) ? 0 : R.trace_depth,
                        (R.flags & PT_FAKE_SHADER) ? (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count : 0u);
     HIPCHK(hipGetLastError());
@@ -806,7 +874,7 @@ int enqueue_end(void) {
 }
 
 int enqueue_batch(int iter0, int count) {
-    int rc = enqueue_begin(iter0, count);
+    int rc = enqueue_begin(iter0, count, false);
     if (rc) return rc;
     if (R.flags & PT_FAKE_SHADER) {
         rc = enqueue_fake();
@@ -825,7 +893,7 @@ int collect_stats(void) {
     Control c;
     HIPCHK(hipMemcpyAsync(&c, R.ctl, sizeof(Control), hipMemcpyDeviceToHost, R.stream));
     HIPCHK(hipStreamSynchronize(R.stream));
-    if (c.error) return fail(PT_ERR_INTERNAL, "look-back watchdog tripped (control.error=%u)", c.error);
+    if (c.error) return fail(PT_ERR_INTERNAL, "kernel watchdog tripped: inconsistent tile directory (control.error=%u)", c.error);
     R.stats.bounces = 0; R.stats.rays = 0;
     memset(R.stats.live, 0, sizeof R.stats.live);
     if (R.flags & PT_FAKE_SHADER) {
@@ -969,17 +1037,12 @@ static int init_impl(const pt_scene_desc *d) {
     R.scene.geoms = R.d_geoms; R.scene.ngeoms = d->num_geoms;
     R.scene.mats = R.d_mats; R.scene.nmats = d->num_materials;
     R.scene.tris = R.d_tris; R.scene.ntris = d->num_triangles;
-    R.lds_bytes = ((size_t)LDS_CTL_WORDS + (size_t)d->num_geoms * ptd::GEOM_WORDS + (size_t)d->num_materials * ptd::MAT_WORDS) * 4;
+    R.has_mesh = false;
+    for (int i = 0; i < d->num_geoms; ++i) R.has_mesh |= d->geoms[i].type == PT_TRIANGLE_MESH;
+    R.lds_bytes = ((size_t)LDS_CTL_WORDS + (size_t)d->num_materials * ptd::MAT_WORDS) * 4;
     R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
-    if (d->num_triangles > 0) R.lds_bytes += (size_t)TRI_TILE * 9 * 4;
-    if (R.lds_bytes > 150 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene records need %zu B of LDS (> 150 KiB)", R.lds_bytes);
-    if (R.lds_bytes > 64 * 1024) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_intersect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds_bytes));
-        HIPCHK(hipFuncSetAttribute((const void *)k_bounce<MODE_FUSED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds_bytes));
-        HIPCHK(hipFuncSetAttribute((const void *)k_bounce<MODE_FUSED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds_bytes));
-        HIPCHK(hipFuncSetAttribute((const void *)k_bounce<MODE_ISECT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds_bytes));
-        HIPCHK(hipFuncSetAttribute((const void *)k_bounce<MODE_ISECT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds_bytes));
-    }
+    if (R.has_mesh) R.lds_bytes += (size_t)TRI_TILE * 9 * 4;
+    if (R.lds_bytes > 60 * 1024) return fail(PT_ERR_INVALID, "pt_init: material records need %zu B of LDS (> 60 KiB)", R.lds_bytes);
 
     // pools, intersections, final colours, image, control
     const size_t capz = R.cap;
@@ -988,8 +1051,7 @@ static int init_impl(const pt_scene_desc *d) {
         R.pool[k] = carve_pool(R.pool_mem[k], R.cap);
     }
     HIPCHK(hipMalloc(&R.isect_mem, capz * 5 * 4));
-    R.isect.t = R.isect_mem; R.isect.nx = R.isect_mem + capz; R.isect.ny = R.isect_mem + 2 * capz;
-    R.isect.nz = R.isect_mem + 3 * capz; R.isect.mat = reinterpret_cast<int *>(R.isect_mem + 4 * capz);
+    R.isect = Isect{R.isect_mem, R.cap};
     HIPCHK(hipMalloc(&R.final_mem, capz * 3 * 4));
     if (d->device_image) { R.image = d->device_image; R.own_image = false; }
     else {
@@ -997,7 +1059,7 @@ static int init_impl(const pt_scene_desc *d) {
         R.own_image = true;
         HIPCHK(hipMemsetAsync(R.image, 0, (size_t)R.npix * 3 * 4, R.stream));      // pathtrace.cu:85
     }
-    R.max_tiles = (R.cap + BLOCK - 1) / BLOCK;
+    R.max_tiles = (R.cap + TILE - 1) / TILE;
     R.ctl_bytes = sizeof(Control);
     static_assert(sizeof(Control) % 16 == 0, "memset block is a multiple of 16 B");
     HIPCHK(hipMalloc((void **)&R.ctl, R.ctl_bytes));
@@ -1010,11 +1072,15 @@ static int init_impl(const pt_scene_desc *d) {
     // persistent grid: as many workgroups as are co-resident for the fused kernel (tiles are
     // dealt round-robin, so more workgroups than that only re-stage the scene)
     int per_cu = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bounce<MODE_FUSED, true>, BLOCK,
-                                                        R.lds_bytes));
+    if (R.has_mesh)
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bounce<MODE_FUSED, true, true>,
+                                                            BLOCK, R.lds_bytes));
+    else
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bounce<MODE_FUSED, true, false>,
+                                                            BLOCK, R.lds_bytes));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
-    R.grid = (int)std::min<uint32_t>(R.max_tiles, (uint32_t)cus * (uint32_t)per_cu);
+    R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
     if (R.grid < 1) R.grid = 1;
     HIPCHK(hipStreamSynchronize(R.stream));
     g_err[0] = 0;
@@ -1076,7 +1142,7 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
 
 int pt_trace_begin(int iter0, int count) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_begin: not initialised");
-    int rc = enqueue_begin(iter0, count);
+    int rc = enqueue_begin(iter0, count, true);
     if (rc) return rc;
     R.in_step = true;
     HIPCHK(hipStreamSynchronize(R.stream));
@@ -1125,7 +1191,7 @@ int pt_export_paths(pt_path_segment *host_paths, int capacity, int *n_live) {
         if (packed) HIPCHK(hipMemcpy(&nprev, &R.ctl->nlive[R.cur_dir], 4, hipMemcpyDeviceToHost));
         hipLaunchKernelGGL(k_export_paths, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.pool[R.cur], R.map, n,
                            live, R.trace_depth - R.step_depth, (pt_path_segment *)R.scratch,
-                           tile_dir(packed ? R.cur_dir : -1), (nprev + BLOCK - 1) / BLOCK);
+                           tile_dir(packed ? R.cur_dir : -1), (nprev + TILE - 1) / TILE);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(host_paths, R.scratch, (size_t)n * sizeof(pt_path_segment), hipMemcpyDeviceToHost, R.stream));
         HIPCHK(hipStreamSynchronize(R.stream));
@@ -1171,8 +1237,8 @@ int pt_intersect_once(const pt_path_segment *host_paths, int n, pt_shadeable_int
     hipLaunchKernelGGL(k_import_paths, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.pool[0],
                        (const pt_path_segment *)R.scratch, (uint32_t)n);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_intersect, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, R.pool[0], R.isect, R.scene,
-                       (const uint32_t *)nullptr, (uint32_t)n, tile_dir(-1), (const uint32_t *)nullptr);
+    if (R.has_mesh) launch_intersect<true>(R.pool[0], nullptr, (uint32_t)n, tile_dir(-1), nullptr);
+    else launch_intersect<false>(R.pool[0], nullptr, (uint32_t)n, tile_dir(-1), nullptr);
     HIPCHK(hipGetLastError());
     uint8_t *d_out = (uint8_t *)R.scratch + (size_t)n * sizeof(pt_shadeable_intersection);
     hipLaunchKernelGGL(k_export_isects, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.isect, (uint32_t)n,
