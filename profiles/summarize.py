@@ -29,7 +29,7 @@ def main(d):
         for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
             print("%-34s %8d %12.1f %12.2f %12.2f %12.2f  %5.1f%%" % (k, len(v), sum(v) / 1e3, sum(v) / len(v) / 1e3,
                                                                  min(v) / 1e3, max(v) / 1e3, 100.0 * sum(v) / tot))
-    for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
+    for sub in sorted(glob.glob(os.path.join(d, "p*"))):
         if not os.path.isdir(sub):
             continue
         for f in glob.glob(os.path.join(sub, "**", "*counter_collection.csv"), recursive=True):

@@ -238,10 +238,67 @@ template <typename P> PTD float candidate_distance(P g, f3 ro, const Candidate &
     return length(sub(ro, p));
 }
 
+// boxIntersectionTest (intersections.h:48-90) without the normal (deferred).
+template <typename P> PTD float box_test(P g, f3 ro, f3 rd, f3 &face_n, int &outside) {
+    f3 qo = mv_point(g + G_INV, ro);
+    f3 qd = normalize(mv_dir(g + G_INV, rd));
+    float tmin = -1e38f, tmax = 1e38f;
+    f3 tmin_n = mk(0, 0, 0), tmax_n = mk(0, 0, 0);
+#define PTD_SLAB(QO, QD, NX, NY, NZ)                                      \
+    {                                                                     \
+        float t1 = (-0.5f - (QO)) / (QD);                                 \
+        float t2 = (+0.5f - (QO)) / (QD);                                 \
+        float ta = t1 < t2 ? t1 : t2;                                     \
+        float tb = t1 > t2 ? t1 : t2;                                     \
+        float sgn = t2 < t1 ? 1.0f : -1.0f;                               \
+        if (ta > 0 && ta > tmin) { tmin = ta; tmin_n = mk(NX, NY, NZ); }  \
+        if (tb < tmax) { tmax = tb; tmax_n = mk(NX, NY, NZ); }            \
+    }
+    PTD_SLAB(qo.x, qd.x, sgn, 0.0f, 0.0f)
+    PTD_SLAB(qo.y, qd.y, 0.0f, sgn, 0.0f)
+    PTD_SLAB(qo.z, qd.z, 0.0f, 0.0f, sgn)
+#undef PTD_SLAB
+    if (tmax >= tmin && tmax > 0) {
+        outside = 1;
+        if (tmin <= 0) { tmin = tmax; tmin_n = tmax_n; outside = 0; }
+        f3 p = mv_point(g + G_FWD, point_on_ray(qo, qd, tmin));
+        face_n = tmin_n;
+        return length(sub(ro, p));
+    }
+    return -1.0f;
+}
+
+// sphereIntersectionTest (intersections.h:102-144) without the normal (deferred).
+template <typename P> PTD float sphere_test(P g, f3 ro, f3 rd, f3 &obj_p, int &outside) {
+    f3 o = mv_point(g + G_INV, ro);
+    f3 d = normalize(mv_dir(g + G_INV, rd));
+    float vDotDirection = dot(o, d);
+    float radicand = vDotDirection * vDotDirection - (dot(o, o) - (0.5f * 0.5f));
+    if (radicand < 0) return -1.0f;
+    float squareRoot = __builtin_sqrtf(radicand);
+    float firstTerm = -vDotDirection;
+    float t1 = firstTerm + squareRoot;
+    float t2 = firstTerm - squareRoot;
+    float t;
+    if (t1 < 0 && t2 < 0) {
+        return -1.0f;
+    } else if (t1 > 0 && t2 > 0) {
+        t = (t2 < t1) ? t2 : t1;      // std::min(t1, t2)
+        outside = 1;
+    } else {
+        t = (t1 < t2) ? t2 : t1;      // std::max(t1, t2)
+        outside = 0;
+    }
+    f3 op = point_on_ray(o, d, t);
+    f3 p = mv_point(g + G_FWD, op);
+    obj_p = op;
+    return length(sub(ro, p));
+}
+
 // surface normal of the winning primitive (the part of the two tests above
 // that the reference evaluates for every candidate)
-PTD f3 cube_normal(const float *g, f3 face_n) { return normalize(mv_dir(g + G_FWD, face_n)); }
-PTD f3 sphere_normal(const float *g, f3 obj_p, int outside) {
+template <typename P> PTD f3 cube_normal(P g, f3 face_n) { return normalize(mv_dir(g + G_FWD, face_n)); }
+template <typename P> PTD f3 sphere_normal(P g, f3 obj_p, int outside) {
     f3 n = normalize(mv_dir(g + G_INVT, obj_p));
     return outside ? n : neg(n);
 }

@@ -56,6 +56,9 @@ namespace {
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4                     // waves per SIMD the bounce kernels are register-budgeted for
 #endif
+#ifndef PT_GEOM_LDS
+#define PT_GEOM_LDS 0                      // 1: broadcast geom records from LDS, 0: scalar loads (SGPRs)
+#endif
 #ifndef PT_DEFER
 #define PT_DEFER 0                         // share the world-distance tail of the box/sphere tests across geoms
 #endif
@@ -95,18 +98,20 @@ struct Control {         // zeroed by one hipMemsetAsync per batch (1 KiB)
     uint32_t alive[MAX_DEPTH + 1];  // paths actually traced at bounce d
     uint32_t done[MAX_DEPTH];       // workgroups that finished bounce d (last-one-out election)
     uint32_t error;
-    uint32_t pad[61];
+    uint32_t scan_ticks[MAX_DEPTH];  // 100 MHz ticks the last workgroup spent scanning (diagnostic)
+    uint32_t pad[61 - MAX_DEPTH + 64];
 };
 
 // Tile directory of one bounce's OUTPUT pool: tile k's survivors sit in slots
 // [64k, 64k + count[k]); base[] is the exclusive scan of count[] (T+1 entries) and
 // start[j] is the tile that holds logical path 64j.
 struct TileDir {
-    uint32_t *mem;       // count[T] | base[T+1] | start[T+1]; nullptr = dense pool
-    uint32_t T;          // capacity in tiles
+    uint32_t *mem;       // count[T] | base[T+4] | start[T+4], T a multiple of 4, every section 16-B aligned;
+                         // nullptr = dense pool
+    uint32_t T;          // capacity in tiles (rounded up to a multiple of 4)
     __device__ __forceinline__ uint32_t *count() const { return mem; }
     __device__ __forceinline__ uint32_t *base() const { return mem + T; }
-    __device__ __forceinline__ uint32_t *start() const { return mem + 2 * (size_t)T + 1; }
+    __device__ __forceinline__ uint32_t *start() const { return mem + 2 * (size_t)T + 4; }
 };
 
 struct Persist {         // survives the per-batch memset
@@ -187,6 +192,10 @@ constexpr int LDS_CTL_WORDS = 16;    // [0] last-block flag, [2..5] scan scratch
 __device__ __forceinline__ void stage_scene(float *lds_mats, const SceneDev &sc) {
     const int mw = sc.nmats * ptd::MAT_WORDS;
     for (int k = threadIdx.x; k < mw; k += BLOCK) lds_mats[k] = sc.mats[k];
+#if PT_GEOM_LDS
+    float *lds_geoms = lds_mats + ((mw + 3) & ~3);
+    for (int k = threadIdx.x; k < sc.ngeoms * ptd::GEOM_WORDS; k += BLOCK) lds_geoms[k] = sc.geoms[k];
+#endif
     __syncthreads();
 }
 
@@ -205,6 +214,8 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
                                                 const float *__restrict__ tris, float *tri_lds, bool active,
                                                 f3 ro, f3 rd, ptd::Hit &h) {
     h.t = FLT_MAX; h.geom = -1; h.outside = 1; h.aux = ptd::mk(0, 0, 0);
+    int outside = 1;                                    // shared across tests, pathtrace.cu:169
+    (void)outside;
 #if PT_DEFER
     ptd::Candidate pend;
     pend.geom = -1; pend.outside = 1; pend.t_obj = 0.0f;
@@ -223,8 +234,13 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
     };
 #endif
     for (int g = 0; g < ngeoms; ++g) {
+#if PT_GEOM_LDS
+        const float *rec = geoms + g * ptd::GEOM_WORDS;                // LDS broadcast
+        const int type = __builtin_amdgcn_readfirstlane(__float_as_int(rec[0]));
+#else
         cfloat *rec = as_const(geoms) + g * ptd::GEOM_WORDS;           // wave-uniform address -> s_load
         const int type = __float_as_int(rec[0]);
+#endif
         if (HAS_MESH && type == PT_TRIANGLE_MESH) {
 #if PT_DEFER
             if (__ballot(pend.geom >= 0)) flush();          // keep geom order
@@ -261,6 +277,18 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
             }
             continue;
         }
+#if !PT_DEFER
+        {   // monolithic reference-shaped tests (object-space test + world-distance tail in one body)
+            float t = -1.0f;
+            f3 aux = ptd::mk(0, 0, 0);
+            if (type == PT_CUBE) { if (active) t = ptd::box_test(rec, ro, rd, aux, outside); }
+            else if (type == PT_SPHERE) { if (active) t = ptd::sphere_test(rec, ro, rd, aux, outside); }
+            if (t > 0.0f && h.t > t) {                  // pathtrace.cu:192 (first geom wins ties)
+                h.t = t; h.geom = g; h.outside = outside; h.aux = aux;
+            }
+            continue;
+        }
+#endif
         if (!active) continue;
         ptd::Candidate c;
         bool hit = false;
@@ -344,7 +372,14 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
                                                                     TileDir dir_in, const uint32_t *nprev_ptr,
                                                                     Control *ctl) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    float *tri_lds = lds_raw + LDS_CTL_WORDS + sc.nmats * ptd::MAT_WORDS;
+    float *mats_lds = lds_raw + LDS_CTL_WORDS;
+    float *tri_lds = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_GEOM_LDS * sc.ngeoms * ptd::GEOM_WORDS;
+#if PT_GEOM_LDS
+    stage_scene(mats_lds, sc);
+    const float *gsrc = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
+#else
+    const float *gsrc = sc.geoms;
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     const uint32_t tiles = (n + TILE - 1) / TILE;
@@ -364,10 +399,10 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
             rd = ptd::mk(in.plane(3)[src], in.plane(4)[src], in.plane(5)[src]);
         }
         ptd::Hit h;
-        intersect_scene<HAS_MESH>(sc.geoms, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h);
+        intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h);
         if (tile < tiles && i < n) {
             float t; f3 nrm; int mat;
-            resolve_hit(sc.geoms, sc.tris, h, t, nrm, mat);
+            resolve_hit(gsrc, sc.tris, h, t, nrm, mat);
             // a miss writes only t; the other fields read as the zeros of pathtrace.cu:343's memset
             out.plane(0)[i] = t; out.plane(1)[i] = nrm.x; out.plane(2)[i] = nrm.y; out.plane(3)[i] = nrm.z;
             out.mat()[i] = mat | (h.outside ? 0 : (int)0x80000000u);
@@ -384,36 +419,63 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
 // once (agent scope) and reads every count.  Nothing spins; nothing depends on dispatch order.
 __device__ __forceinline__ void scan_tile_counts(const TileDir &dir, uint32_t tiles, uint32_t *n_out,
                                                  uint32_t *lds_scan /* >= 8 words */) {
+    // Single-workgroup scan, 1024 entries per step: each thread owns 4 consecutive entries (one
+    // 16-B load, one 16-B store), wave scan by shuffles, the 4 wave totals cross through a
+    // double-buffered LDS slot (one barrier per step), loads run two steps ahead.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t *count = dir.count();
-    uint32_t *base = dir.base(), *start = dir.start();
-    const uint32_t per = (tiles + BLOCK - 1) / BLOCK;          // contiguous entries per thread
-    const uint32_t lo = min(tiles, threadIdx.x * per), hi = min(tiles, lo + per);
-    uint32_t sum = 0;
-    for (uint32_t t = lo; t < hi; ++t) sum += count[t];
-    uint32_t incl = sum;                                        // wave inclusive scan
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) lds_scan[wave] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0, total = 0;
+    const uint4 *count4 = reinterpret_cast<const uint4 *>(dir.count());
+    uint4 *base4 = reinterpret_cast<uint4 *>(dir.base());
+    uint32_t *start = dir.start();
+    const uint32_t steps = (tiles + 4 * BLOCK - 1) / (4 * BLOCK);
+    auto fetch = [&](uint32_t step) -> uint4 {
+        const uint32_t e = (step * BLOCK + threadIdx.x) * 4;          // first entry of this thread
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (step < steps && e < tiles) {
+            v = count4[e >> 2];                                          // entries past `tiles` hold junk: mask
+            if (e + 1 >= tiles) v.y = 0;
+            if (e + 2 >= tiles) v.z = 0;
+            if (e + 3 >= tiles) v.w = 0;
+        }
+        return v;
+    };
+    uint32_t carry = 0;
+    uint4 v0 = fetch(0), v1 = fetch(1);
+    for (uint32_t step = 0; step < steps; ++step) {
+        const uint4 v = v0;
+        v0 = v1;
+        v1 = fetch(step + 2);
+        const uint32_t sum = v.x + v.y + v.z + v.w;
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off);
+            if (lane >= off) incl += u;
+        }
+        uint32_t *slot = lds_scan + (step & 1) * WAVES;
+        if (lane == 63) slot[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        const uint32_t c = lds_scan[w];
-        if (w < wave) wave_off += c;
-        total += c;
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c = slot[w];
+            if (w < wave) wave_off += c;
+            total += c;
+        }
+        const uint32_t e = (step * BLOCK + threadIdx.x) * 4;
+        if (e < tiles) {
+            uint4 b;
+            b.x = carry + wave_off + incl - sum;
+            b.y = b.x + v.x; b.z = b.y + v.y; b.w = b.z + v.z;
+            base4[e >> 2] = b;                                           // base[] has 4 spare entries
+            const uint32_t bs[4] = {b.x, b.y, b.z, b.w}, cs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t j = (bs[k] + TILE - 1) / TILE;           // the one multiple of 64 the span can hold
+                if (cs[k] && j * TILE < bs[k] + cs[k]) start[j] = e + k;
+            }
+        }
+        carry += total;
     }
-    uint32_t run = wave_off + incl - sum;                       // exclusive prefix of this thread's range
-    for (uint32_t t = lo; t < hi; ++t) {
-        const uint32_t c = count[t];
-        base[t] = run;
-        const uint32_t j = (run + TILE - 1) / TILE;             // the one multiple of 64 the span can hold
-        if (c && j * TILE < run + c) start[j] = t;
-        run += c;
-    }
-    if (threadIdx.x == 0) { base[tiles] = total; *n_out = total; }
+    if (threadIdx.x == 0) { dir.base()[tiles] = carry; *n_out = carry; }
 }
 
 // ---------------------------------------------------------------------------
@@ -428,7 +490,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
     float *mats = lds_raw + LDS_CTL_WORDS;
-    float *tri_lds = mats + a.scene.nmats * ptd::MAT_WORDS;
+    float *tri_lds = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_GEOM_LDS * a.scene.ngeoms * ptd::GEOM_WORDS;
     stage_scene(mats, a.scene);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
@@ -476,8 +538,13 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
         if (MODE == MODE_FUSED) {
             ptd::Hit h;
-            intersect_scene<HAS_MESH>(a.scene.geoms, a.scene.ngeoms, a.scene.tris, tri_lds, active, ro, rd, h);
-            if (active) { resolve_hit(a.scene.geoms, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
+#if PT_GEOM_LDS
+            const float *gsrc = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
+#else
+            const float *gsrc = a.scene.geoms;
+#endif
+            intersect_scene<HAS_MESH>(gsrc, a.scene.ngeoms, a.scene.tris, tri_lds, active, ro, rd, h);
+            if (active) { resolve_hit(gsrc, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
         } else if (active) {
             t = a.isect.plane(0)[i];
             nrm = ptd::mk(a.isect.plane(1)[i], a.isect.plane(2)[i], a.isect.plane(3)[i]);
@@ -532,7 +599,12 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             sctl[0] = last ? 1u : 0u;
         }
         __syncthreads();
-        if (sctl[0]) scan_tile_counts(a.dir_out, tiles, &a.ctl->nlive[a.depth + 1], sctl + 2);
+        if (sctl[0]) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            scan_tile_counts(a.dir_out, tiles, &a.ctl->nlive[a.depth + 1], sctl + 2);
+            __syncthreads();
+            if (threadIdx.x == 0) a.ctl->scan_ticks[a.depth] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
+        }
     }
 }
 
@@ -774,7 +846,7 @@ int ensure_scratch(size_t bytes) {
 
 TileDir tile_dir(int depth) {
     if (depth < 0) return TileDir{nullptr, 0};
-    return TileDir{R.dir_mem + (size_t)depth * (3 * (size_t)R.max_tiles + 2), R.max_tiles};
+    return TileDir{R.dir_mem + (size_t)depth * (3 * (size_t)R.max_tiles + 8), R.max_tiles};
 }
 
 BounceArgs bounce_args(int depth) {
@@ -904,6 +976,11 @@ int collect_stats(void) {
             R.stats.rays += c.alive[d];
             if (c.alive[d]) R.stats.bounces = d + 1;
         }
+    }
+    if (getenv("PTMI355_DEBUG_SCAN")) {
+        fprintf(stderr, "[ptmi355] scan us per bounce:");
+        for (int d = 0; d < R.trace_depth; ++d) fprintf(stderr, " %.1f", c.scan_ticks[d] / 100.0);
+        fprintf(stderr, "\n");
     }
     R.stats.total_rays += R.stats.rays;
     R.stats.total_iterations += R.step_count;
@@ -1039,8 +1116,10 @@ static int init_impl(const pt_scene_desc *d) {
     R.scene.tris = R.d_tris; R.scene.ntris = d->num_triangles;
     R.has_mesh = false;
     for (int i = 0; i < d->num_geoms; ++i) R.has_mesh |= d->geoms[i].type == PT_TRIANGLE_MESH;
-    R.lds_bytes = ((size_t)LDS_CTL_WORDS + (size_t)d->num_materials * ptd::MAT_WORDS) * 4;
+    R.lds_bytes = ((size_t)LDS_CTL_WORDS + (((size_t)d->num_materials * ptd::MAT_WORDS + 3) & ~(size_t)3) +
+                   (size_t)PT_GEOM_LDS * d->num_geoms * ptd::GEOM_WORDS) * 4;
     R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
+    if (const char *pad = getenv("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
     if (R.has_mesh) R.lds_bytes += (size_t)TRI_TILE * 9 * 4;
     if (R.lds_bytes > 60 * 1024) return fail(PT_ERR_INVALID, "pt_init: material records need %zu B of LDS (> 60 KiB)", R.lds_bytes);
 
@@ -1059,11 +1138,11 @@ static int init_impl(const pt_scene_desc *d) {
         R.own_image = true;
         HIPCHK(hipMemsetAsync(R.image, 0, (size_t)R.npix * 3 * 4, R.stream));      // pathtrace.cu:85
     }
-    R.max_tiles = (R.cap + TILE - 1) / TILE;
+    R.max_tiles = (((R.cap + TILE - 1) / TILE) + 3u) & ~3u;      // multiple of 4: 16-B aligned directory sections
     R.ctl_bytes = sizeof(Control);
     static_assert(sizeof(Control) % 16 == 0, "memset block is a multiple of 16 B");
     HIPCHK(hipMalloc((void **)&R.ctl, R.ctl_bytes));
-    HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)R.trace_depth * (3 * (size_t)R.max_tiles + 2) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)R.trace_depth * (3 * (size_t)R.max_tiles + 8) * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&R.persist, sizeof(Persist)));
     HIPCHK(hipMemsetAsync(R.persist, 0, sizeof(Persist), R.stream));
     hipDeviceProp_t prop;
