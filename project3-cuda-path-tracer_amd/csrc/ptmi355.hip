@@ -102,17 +102,25 @@ struct Control {         // zeroed by one hipMemsetAsync per batch (1 KiB)
     uint32_t pad[61 - MAX_DEPTH + 64];
 };
 
-// Tile directory of one bounce's OUTPUT pool: tile k's survivors sit in slots
-// [64k, 64k + count[k]); base[] is the exclusive scan of count[] (T+1 entries) and
-// start[j] is the tile that holds logical path 64j.
-struct TileDir {
-    uint32_t *mem;       // count[T] | base[T+4] | start[T+4], T a multiple of 4, every section 16-B aligned;
-                         // nullptr = dense pool
-    uint32_t T;          // capacity in tiles (rounded up to a multiple of 4)
+// Range directory of one bounce's OUTPUT pool.  Wave w of the persistent grid owns the
+// contiguous run of `R` logical tiles [wR, (w+1)R) (R = ceil(tiles / W)) and packs every
+// survivor of that run, in order, to the front of the run's own span of R*64 slots; count[w]
+// is how many it packed, base[] the exclusive scan of count[] (W+1 entries).  Logical path i
+// of the output therefore lives in slot r*R*64 + (i - base[r]) for the range r with
+// base[r] <= i < base[r+1] -- the stable partition's order, with no cross-wave communication
+// inside the launch and only W (<= 8192) words to scan at its end.
+struct RangeDir {
+    uint32_t *mem;       // count[Wp] | base[Wp+4]  (Wp = W rounded up to 4); nullptr = dense pool
+    uint32_t W;          // waves in the persistent grid = ranges
     __device__ __forceinline__ uint32_t *count() const { return mem; }
-    __device__ __forceinline__ uint32_t *base() const { return mem + T; }
-    __device__ __forceinline__ uint32_t *start() const { return mem + 2 * (size_t)T + 4; }
+    __device__ __forceinline__ uint32_t *base() const { return mem + ((W + 3u) & ~3u); }
 };
+
+// tiles per range for a pool of n paths split over W waves
+__host__ __device__ __forceinline__ uint32_t range_tiles(uint32_t n, uint32_t W) {
+    const uint32_t tiles = (n + 63u) / 64u;
+    return (tiles + W - 1) / W;
+}
 
 struct Persist {         // survives the per-batch memset
     unsigned long long rays;        // sum over bounces of paths traced since pt_init
@@ -132,8 +140,8 @@ struct BounceArgs {
     SceneDev scene;
     TileMap map;
     Control *ctl;
-    TileDir dir_in;        // directory of the pool being read (mem == nullptr: dense)
-    TileDir dir_out;       // directory this launch produces
+    RangeDir dir_in;       // directory of the pool being read (mem == nullptr: dense)
+    RangeDir dir_out;      // directory this launch produces
     float *fin;            // final colour planes r g b (stride in.cap), index = pid
     pt_camera cam;         // used when gen_rays != 0
     int depth, trace_depth, iter0;
@@ -330,25 +338,43 @@ __device__ __forceinline__ void resolve_hit(const float *__restrict__ geoms, con
     }
 }
 
-// Logical path index -> physical slot of a tile-packed pool, one wave at a time and without
-// LDS: lane l holds base[s + l]; a 6-step binary search reads other lanes' values with
-// ds_bpermute (__shfl).  `k` is the wave's logical tile (wave-uniform).
-__device__ __forceinline__ uint32_t resolve_src(const TileDir &dir, uint32_t tiles_prev, uint32_t k, uint32_t p,
-                                                bool active, Control *ctl) {
-    if (!dir.mem) return p;                         // dense pool (ray generation / sorted / imported)
+// ---- reading a range-packed pool -------------------------------------------------------
+// Wave-cooperative 64-ary search: largest r in [0, W) with base[r] <= P (P < base[W]).
+__device__ __forceinline__ uint32_t find_range(const uint32_t *base, uint32_t W, uint32_t P) {
     const int lane = threadIdx.x & 63;
-    uint32_t s = dir.start()[k];
+    uint32_t lo = 0, hi = W;                        // answer in [lo, hi)
+    for (int guard = 0; guard < 8 && hi - lo > 1; ++guard) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint32_t idx = lo + (uint32_t)lane * step;
+        const uint32_t v = idx < hi ? base[idx] : 0xffffffffu;
+        const uint64_t ok = __ballot(v <= P);       // base[] is non-decreasing: a prefix of the lanes
+        const uint32_t k = (uint32_t)__popcll((unsigned long long)ok);
+        const uint32_t nlo = lo + (k ? k - 1 : 0) * step;
+        hi = min(hi, nlo + step);
+        lo = nlo;
+    }
+    return lo;
+}
+
+// Source slots of the 64 logical paths p = p0 + lane, starting the search at range `cur`
+// (wave-uniform, base[cur] <= p0).  Lane l first holds base[cur + l]; a 6-step binary search
+// reads other lanes' values with ds_bpermute.  Returns the slot; `cur` advances to the range of
+// the tile's last path so the next tile of the run starts where this one ended.
+__device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t span, uint32_t &cur, uint32_t p,
+                                                bool active, Control *ctl) {
+    const int lane = threadIdx.x & 63;
     const uint32_t *base = dir.base();
     bool resolved = !active;
-    uint32_t src = 0;
-    // bounded: a sane directory resolves within tiles_prev/63 + 1 windows; every wave reaches the exit
+    uint32_t src = 0, rng = cur;
+    uint32_t s = cur;
+    // bounded: a sane directory resolves within W/63 + 1 windows; every wave reaches the exit
     for (uint32_t guard = 0;; ++guard) {
-        if (guard > tiles_prev / 63 + 1) {
+        if (guard > dir.W / 63 + 1) {
             if (lane == 0) atomicOr(&ctl->error, 2u);
             break;
         }
         const uint32_t t = s + (uint32_t)lane;
-        const uint32_t w = t <= tiles_prev ? base[t] : 0xffffffffu;
+        const uint32_t w = t <= dir.W ? base[t] : 0xffffffffu;
         int lo = 0, hi = 63;                        // w(lane 0) <= p always holds for unresolved lanes
 #pragma unroll
         for (int step = 0; step < 6; ++step) {
@@ -357,10 +383,13 @@ __device__ __forceinline__ uint32_t resolve_src(const TileDir &dir, uint32_t til
             if (wm <= p) lo = mid; else hi = mid - 1;
         }
         const uint32_t wl = (uint32_t)__shfl((int)w, lo);
-        if (!resolved && lo < 63) { resolved = true; src = (s + (uint32_t)lo) * TILE + (p - wl); }
+        if (!resolved && lo < 63) { resolved = true; rng = s + (uint32_t)lo; src = rng * span + (p - wl); }
         if (!__any(!resolved)) break;
         s += 63;
     }
+    // the highest active lane holds the tile's last path
+    const uint64_t act = __ballot(active);
+    if (act) cur = (uint32_t)__builtin_amdgcn_readlane((int)rng, 63 - __builtin_clzll((unsigned long long)act));
     return src;
 }
 
@@ -369,7 +398,7 @@ __device__ __forceinline__ uint32_t resolve_src(const TileDir &dir, uint32_t til
 template <bool HAS_MESH>
 __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc,
                                                                     const uint32_t *n_ptr, uint32_t n_fixed,
-                                                                    TileDir dir_in, const uint32_t *nprev_ptr,
+                                                                    RangeDir dir_in, const uint32_t *nprev_ptr,
                                                                     Control *ctl) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     float *mats_lds = lds_raw + LDS_CTL_WORDS;
@@ -380,18 +409,24 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
 #else
     const float *gsrc = sc.geoms;
 #endif
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     const uint32_t tiles = (n + TILE - 1) / TILE;
-    const uint32_t tiles_prev = (dir_in.mem && nprev_ptr) ? (*nprev_ptr + TILE - 1) / TILE : 0;
-    const uint32_t wstride = gridDim.x * WAVES;
-    const uint32_t rounds = (tiles + wstride - 1) / wstride;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t tile = __builtin_amdgcn_readfirstlane(r * wstride + blockIdx.x * WAVES + wave);
+    const uint32_t R = range_tiles(n, W);
+    const bool packed = dir_in.mem && nprev_ptr;
+    const uint32_t span = packed ? range_tiles(*nprev_ptr, W) * TILE : 0;
+    uint32_t cur = 0;
+    if (packed && wid * R < tiles) cur = find_range(dir_in.base(), W, wid * R * TILE);
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t tile = wid * R + r;
         if (!HAS_MESH && tile >= tiles) break;
+        const bool have = tile < tiles;
         const uint32_t i = tile * TILE + lane;
-        bool active = tile < tiles && i < n;
-        const uint32_t src = (tile < tiles) ? resolve_src(dir_in, tiles_prev, tile, i, active, ctl) : 0;
+        bool active = have && i < n;
+        uint32_t src = i;
+        if (packed && have) src = resolve_src(dir_in, span, cur, i, active, ctl);
         f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
         if (active) {
             if (in.pid()[src] == DEAD_PID) active = false;
@@ -400,7 +435,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
         }
         ptd::Hit h;
         intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h);
-        if (tile < tiles && i < n) {
+        if (have && i < n) {
             float t; f3 nrm; int mat;
             resolve_hit(gsrc, sc.tris, h, t, nrm, mat);
             // a miss writes only t; the other fields read as the zeros of pathtrace.cu:343's memset
@@ -411,39 +446,30 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
 }
 
 // ---------------------------------------------------------------------------
-// stable compaction: tile counts -> tile bases, by the last workgroup out
+// stable compaction: range counts -> range bases, by the last workgroup out
 // ---------------------------------------------------------------------------
-// Hand-off (guide G16): each wave stores its tile counts with agent-scope atomic
-// (write-through) stores and drains them (s_waitcnt vmcnt(0)); after the workgroup's barrier
-// one lane adds 1 to done[depth]; the workgroup whose add returns grid-1 is last, acquires
-// once (agent scope) and reads every count.  Nothing spins; nothing depends on dispatch order.
-__device__ __forceinline__ void scan_tile_counts(const TileDir &dir, uint32_t tiles, uint32_t *n_out,
-                                                 uint32_t *lds_scan /* >= 8 words */) {
-    // Single-workgroup scan, 1024 entries per step: each thread owns 4 consecutive entries (one
-    // 16-B load, one 16-B store), wave scan by shuffles, the 4 wave totals cross through a
-    // double-buffered LDS slot (one barrier per step), loads run two steps ahead.
+// Hand-off (guide G16): each wave stores its range count with an agent-scope atomic
+// (write-through) store and drains it (s_waitcnt vmcnt(0)); after the workgroup's barrier one
+// lane adds 1 to done[depth]; the workgroup whose add returns grid-1 is last, acquires once
+// (agent scope) and scans the W counts (<= 8 steps of 1024).  Nothing spins; nothing depends
+// on dispatch order.
+__device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t *n_out,
+                                                  uint32_t *lds_scan /* >= 8 words */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t W = dir.W;
     const uint4 *count4 = reinterpret_cast<const uint4 *>(dir.count());
     uint4 *base4 = reinterpret_cast<uint4 *>(dir.base());
-    uint32_t *start = dir.start();
-    const uint32_t steps = (tiles + 4 * BLOCK - 1) / (4 * BLOCK);
-    auto fetch = [&](uint32_t step) -> uint4 {
+    const uint32_t steps = (W + 4 * BLOCK - 1) / (4 * BLOCK);
+    uint32_t carry = 0;
+    for (uint32_t step = 0; step < steps; ++step) {
         const uint32_t e = (step * BLOCK + threadIdx.x) * 4;          // first entry of this thread
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (step < steps && e < tiles) {
-            v = count4[e >> 2];                                          // entries past `tiles` hold junk: mask
-            if (e + 1 >= tiles) v.y = 0;
-            if (e + 2 >= tiles) v.z = 0;
-            if (e + 3 >= tiles) v.w = 0;
+        if (e < W) {
+            v = count4[e >> 2];
+            if (e + 1 >= W) v.y = 0;
+            if (e + 2 >= W) v.z = 0;
+            if (e + 3 >= W) v.w = 0;
         }
-        return v;
-    };
-    uint32_t carry = 0;
-    uint4 v0 = fetch(0), v1 = fetch(1);
-    for (uint32_t step = 0; step < steps; ++step) {
-        const uint4 v = v0;
-        v0 = v1;
-        v1 = fetch(step + 2);
         const uint32_t sum = v.x + v.y + v.z + v.w;
         uint32_t incl = sum;
         for (int off = 1; off < 64; off <<= 1) {
@@ -460,22 +486,16 @@ __device__ __forceinline__ void scan_tile_counts(const TileDir &dir, uint32_t ti
             if (w < wave) wave_off += c;
             total += c;
         }
-        const uint32_t e = (step * BLOCK + threadIdx.x) * 4;
-        if (e < tiles) {
+        if (e < W) {
             uint4 b;
             b.x = carry + wave_off + incl - sum;
             b.y = b.x + v.x; b.z = b.y + v.y; b.w = b.z + v.z;
             base4[e >> 2] = b;                                           // base[] has 4 spare entries
-            const uint32_t bs[4] = {b.x, b.y, b.z, b.w}, cs[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t j = (bs[k] + TILE - 1) / TILE;           // the one multiple of 64 the span can hold
-                if (cs[k] && j * TILE < bs[k] + cs[k]) start[j] = e + k;
-            }
         }
         carry += total;
     }
-    if (threadIdx.x == 0) { dir.base()[tiles] = carry; *n_out = carry; }
+    __syncthreads();
+    if (threadIdx.x == 0) { dir.base()[W] = carry; *n_out = carry; }
 }
 
 // ---------------------------------------------------------------------------
@@ -492,26 +512,31 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     float *mats = lds_raw + LDS_CTL_WORDS;
     float *tri_lds = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_GEOM_LDS * a.scene.ngeoms * ptd::GEOM_WORDS;
     stage_scene(mats, a.scene);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
     const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
-    const uint32_t tiles_prev = (COMPACT && a.dir_in.mem) ? (a.ctl->nlive[a.depth - 1] + TILE - 1) / TILE : 0;
+    const uint32_t R = range_tiles(n, W);                        // logical tiles per wave (one contiguous run)
+    const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
+    const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
     const bool last_bounce = (a.depth == a.trace_depth - 1);
-    const uint32_t wstride = gridDim.x * WAVES;
-    const uint32_t rounds = (tiles + wstride - 1) / wstride;
     uint32_t traced = 0;
+    uint32_t packed = 0;                                         // survivors this wave has written (wave-uniform)
+    uint32_t cur = 0;                                            // source range of the run's current position
     if (a.gen_rays && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = a.pool_n;   // k_raygen's job otherwise
+    if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), W, wid * R * TILE);
 
-    // every wave walks its own 64-path tiles; no workgroup barrier inside the loop unless a
-    // mesh needs block-wide triangle staging (then all waves run `rounds` iterations)
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t tile = __builtin_amdgcn_readfirstlane(r * wstride + blockIdx.x * WAVES + wave);
+    // every wave walks its own run of R consecutive 64-path tiles; no workgroup barrier inside
+    // the loop unless a mesh needs block-wide triangle staging (then all waves run R iterations)
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t tile = wid * R + r;
         if (!HAS_MESH && tile >= tiles) break;
         const bool have = tile < tiles;
         const uint32_t i = tile * TILE + lane;                    // logical path index
         bool active = have && i < n;
         uint32_t src = i;
-        if (COMPACT && have) src = resolve_src(a.dir_in, tiles_prev, tile, i, active, a.ctl);
+        if (packed_in && have) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
         uint32_t pid = DEAD_PID;
         f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
         if (active) {
@@ -562,16 +587,14 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
                 a.fin[pid] = ps.c.x; a.fin[(size_t)a.in.cap + pid] = ps.c.y; a.fin[2 * (size_t)a.in.cap + pid] = ps.c.z;
             }
         }
-        // ---- survivors pack to the front of this wave's own 64-slot span ----
+        // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
         const uint64_t bal = __ballot(alive);
         const uint64_t act = __ballot(active);
         traced += (uint32_t)__popcll((unsigned long long)act);
         uint32_t dst = i;
-        if (COMPACT && have) {
-            dst = tile * TILE + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
-            if (lane == 0)
-                __hip_atomic_store(&a.dir_out.count()[tile], (uint32_t)__popcll((unsigned long long)bal),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (COMPACT) {
+            dst = wid * R * TILE + packed + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
+            packed += (uint32_t)__popcll((unsigned long long)bal);
         }
         if (alive) {
             a.out.plane(0)[dst] = ps.o.x; a.out.plane(1)[dst] = ps.o.y; a.out.plane(2)[dst] = ps.o.z;
@@ -585,8 +608,10 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     if (lane == 0 && traced) atomicAdd(&a.ctl->alive[a.depth], traced);
 
     if (COMPACT) {
-        // last workgroup out turns the tile counts into the next bounce's directory
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's count stores have left
+        // every wave publishes its range count; the last workgroup out scans them
+        if (lane == 0)
+            __hip_atomic_store(&a.dir_out.count()[wid], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's count store has left
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint32_t old = __hip_atomic_fetch_add(&a.ctl->done[a.depth], 1u, __ATOMIC_RELAXED,
@@ -601,8 +626,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         __syncthreads();
         if (sctl[0]) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            scan_tile_counts(a.dir_out, tiles, &a.ctl->nlive[a.depth + 1], sctl + 2);
-            __syncthreads();
+            scan_range_counts(a.dir_out, &a.ctl->nlive[a.depth + 1], sctl + 2);
             if (threadIdx.x == 0) a.ctl->scan_ticks[a.depth] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
         }
     }
@@ -680,18 +704,18 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap(uint8_t *pbo, const float *im
 
 // pool <-> reference AoS (debug / parity export and pt_intersect_once)
 __global__ void k_export_paths(Pool p, TileMap map, uint32_t n_total, uint32_t n_live, int remaining,
-                               pt_path_segment *out, TileDir dir, uint32_t tiles_prev) {
+                               pt_path_segment *out, RangeDir dir, uint32_t span) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
     uint32_t src = i;
-    if (dir.mem) {                        // logical -> physical: largest t with base[t] <= i
+    if (dir.mem) {                        // logical -> physical: largest r with base[r] <= i
         const uint32_t *base = dir.base();
-        uint32_t lo = 0, hi = tiles_prev;
+        uint32_t lo = 0, hi = dir.W - 1;
         while (lo < hi) {
             const uint32_t mid = (lo + hi + 1) >> 1;
             if (base[mid] <= i) lo = mid; else hi = mid - 1;
         }
-        src = lo * TILE + (i - base[lo]);
+        src = lo * span + (i - base[lo]);
     }
     pt_path_segment s;
     s.ray.origin = {p.plane(0)[src], p.plane(1)[src], p.plane(2)[src]};
@@ -776,7 +800,8 @@ struct Renderer {
     size_t lds_bytes = 0;
     Control *ctl = nullptr;
     Persist *persist = nullptr;
-    uint32_t *dir_mem = nullptr;  // per bounce: count[T], base[T+1], start[T+1]
+    uint32_t *dir_mem = nullptr;  // per bounce: count[Wp], base[Wp+4]
+    size_t dir_stride = 0;        // words per bounce
     int cur_dir = -1;             // bounce whose directory describes pool[cur] (-1: dense)
     uint32_t max_tiles = 0;
     size_t ctl_bytes = 0;         // Control, zeroed per batch
@@ -844,9 +869,10 @@ int ensure_scratch(size_t bytes) {
     return PT_OK;
 }
 
-TileDir tile_dir(int depth) {
-    if (depth < 0) return TileDir{nullptr, 0};
-    return TileDir{R.dir_mem + (size_t)depth * (3 * (size_t)R.max_tiles + 8), R.max_tiles};
+RangeDir tile_dir(int depth) {
+    const uint32_t W = (uint32_t)R.grid * WAVES;
+    if (depth < 0) return RangeDir{nullptr, W};
+    return RangeDir{R.dir_mem + (size_t)depth * R.dir_stride, W};
 }
 
 BounceArgs bounce_args(int depth) {
@@ -886,7 +912,7 @@ int enqueue_begin(int iter0, int count, bool stepping) {
 }
 
 template <bool HAS_MESH>
-void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, const TileDir &dir,
+void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, const RangeDir &dir,
                       const uint32_t *nprev) {
     hipLaunchKernelGGL((k_intersect<HAS_MESH>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, in, R.isect,
                        R.scene, n_ptr, n_fixed, dir, nprev, R.ctl);
@@ -1138,11 +1164,11 @@ static int init_impl(const pt_scene_desc *d) {
         R.own_image = true;
         HIPCHK(hipMemsetAsync(R.image, 0, (size_t)R.npix * 3 * 4, R.stream));      // pathtrace.cu:85
     }
-    R.max_tiles = (((R.cap + TILE - 1) / TILE) + 3u) & ~3u;      // multiple of 4: 16-B aligned directory sections
+    R.max_tiles = (R.cap + TILE - 1) / TILE;
     R.ctl_bytes = sizeof(Control);
     static_assert(sizeof(Control) % 16 == 0, "memset block is a multiple of 16 B");
     HIPCHK(hipMalloc((void **)&R.ctl, R.ctl_bytes));
-    HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)R.trace_depth * (3 * (size_t)R.max_tiles + 8) * sizeof(uint32_t)));
+
     HIPCHK(hipMalloc((void **)&R.persist, sizeof(Persist)));
     HIPCHK(hipMemsetAsync(R.persist, 0, sizeof(Persist), R.stream));
     hipDeviceProp_t prop;
@@ -1161,6 +1187,11 @@ static int init_impl(const pt_scene_desc *d) {
     if (per_cu > 8) per_cu = 8;
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
     if (R.grid < 1) R.grid = 1;
+    {   // range directory: one count + one base per wave of the persistent grid, per bounce
+        const size_t Wp = ((size_t)R.grid * WAVES + 3) & ~(size_t)3;
+        R.dir_stride = 2 * Wp + 8;
+        HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)R.trace_depth * R.dir_stride * sizeof(uint32_t)));
+    }
     HIPCHK(hipStreamSynchronize(R.stream));
     g_err[0] = 0;
     return PT_OK;
@@ -1270,7 +1301,7 @@ int pt_export_paths(pt_path_segment *host_paths, int capacity, int *n_live) {
         if (packed) HIPCHK(hipMemcpy(&nprev, &R.ctl->nlive[R.cur_dir], 4, hipMemcpyDeviceToHost));
         hipLaunchKernelGGL(k_export_paths, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.pool[R.cur], R.map, n,
                            live, R.trace_depth - R.step_depth, (pt_path_segment *)R.scratch,
-                           tile_dir(packed ? R.cur_dir : -1), (nprev + TILE - 1) / TILE);
+                           tile_dir(packed ? R.cur_dir : -1), range_tiles(nprev, (uint32_t)R.grid * WAVES) * TILE);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(host_paths, R.scratch, (size_t)n * sizeof(pt_path_segment), hipMemcpyDeviceToHost, R.stream));
         HIPCHK(hipStreamSynchronize(R.stream));
