@@ -97,9 +97,10 @@ struct Control {         // zeroed by one hipMemsetAsync per batch (1 KiB)
     uint32_t nlive[MAX_DEPTH + 1];  // nlive[d] = paths entering bounce d (compaction on)
     uint32_t alive[MAX_DEPTH + 1];  // paths actually traced at bounce d
     uint32_t done[MAX_DEPTH];       // workgroups that finished bounce d (last-one-out election)
+    uint32_t done_sort[MAX_DEPTH];  // same for the material-sort histogram of bounce d
     uint32_t error;
     uint32_t scan_ticks[MAX_DEPTH];  // 100 MHz ticks the last workgroup spent scanning (diagnostic)
-    uint32_t pad[61 - MAX_DEPTH + 64];
+    uint32_t pad[61 - MAX_DEPTH + 64 - MAX_DEPTH + 64];
 };
 
 // Range directory of one bounce's OUTPUT pool.  Wave w of the persistent grid owns the
@@ -499,6 +500,161 @@ __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t 
 }
 
 // ---------------------------------------------------------------------------
+// material sort (INSTRUCTION.md:78-86; spec 8.0): stable counting sort of the live paths and
+// their intersections by key = materialId (misses last), before shading
+// ---------------------------------------------------------------------------
+// Pass 1 (k_sort_hist): every wave histograms the keys of its run of R tiles (wave64
+// match-ballot, per-wave bins in LDS) into table[bin][wave]; the last workgroup out scans the
+// bin-major table (nbins * W words) in place into start offsets.  Pass 2 (k_sort_scatter):
+// every wave walks its run again and moves path state + intersection to
+// offset[key][wave] + (same-key paths already seen in the run) + (same-key lanes below it),
+// which is the stable order.  The sorted pool is dense.
+constexpr int SORT_MAX_BINS = 256;
+
+struct SortArgs {
+    Pool in, out;            // out: dense, sorted
+    Isect isect, isect_out;  // logical order in, sorted order out
+    RangeDir dir_in;
+    Control *ctl;
+    uint32_t *table;         // nbins * W words
+    int depth, nbins;        // nbins = nmats + 1 (misses)
+    uint32_t pool_n;
+    int compact;
+};
+
+__device__ __forceinline__ uint32_t sort_key(const Isect &is, uint32_t i, int nbins) {
+    const float t = is.plane(0)[i];
+    const int m = is.mat()[i] & 0x7fffffff;
+    return t > 0.0f ? (uint32_t)m : (uint32_t)(nbins - 1);
+}
+
+// in-place exclusive scan of `total` words by one workgroup (1024 words per step)
+__device__ __forceinline__ void scan_words_inplace(uint32_t *w, uint32_t total, uint32_t *lds_scan) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t steps = (total + 4 * BLOCK - 1) / (4 * BLOCK);
+    uint32_t carry = 0;
+    for (uint32_t step = 0; step < steps; ++step) {
+        const uint32_t e = (step * BLOCK + threadIdx.x) * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (e + k < total) ? w[e + k] : 0u;
+        const uint32_t sum = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off);
+            if (lane >= off) incl += u;
+        }
+        uint32_t *slot = lds_scan + (step & 1) * WAVES;
+        if (lane == 63) slot[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) {
+            const uint32_t c = slot[k];
+            if (k < wave) wave_off += c;
+            tot += c;
+        }
+        uint32_t run = carry + wave_off + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (e + k < total) w[e + k] = run;
+            run += v[k];
+        }
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_sort_hist(SortArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
+    uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * SORT_MAX_BINS;   // per-wave bins
+    const int lane = threadIdx.x & 63;
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    const uint32_t n = a.compact ? a.ctl->nlive[a.depth] : a.pool_n;
+    const uint32_t tiles = (n + TILE - 1) / TILE;
+    const uint32_t R = range_tiles(n, W);
+    for (int b = lane; b < a.nbins; b += 64) bins[b] = 0;
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t tile = wid * R + r;
+        if (tile >= tiles) break;
+        const uint32_t i = tile * TILE + lane;
+        const bool valid = i < n;
+        const uint32_t key = valid ? sort_key(a.isect, i, a.nbins) : 0u;
+        uint64_t rem = __ballot(valid);
+        while (rem) {                                           // one round per distinct key in the tile
+            const int l = __ffsll((unsigned long long)rem) - 1;
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
+            const uint64_t m = __ballot(valid && key == k);
+            if (lane == 0) bins[k] += (uint32_t)__popcll((unsigned long long)m);
+            rem &= ~m;
+        }
+    }
+    // publish table[bin][wave] (write-through), then elect the last workgroup to scan it
+    for (int b = lane; b < a.nbins; b += 64)
+        __hip_atomic_store(&a.table[(size_t)b * W + wid], bins[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(&a.ctl->done_sort[a.depth], 1u, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = (old == gridDim.x - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        sctl[0] = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (sctl[0]) scan_words_inplace(a.table, (uint32_t)a.nbins * W, sctl + 2);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
+    uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * SORT_MAX_BINS;   // per-wave running offsets
+    const int lane = threadIdx.x & 63;
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    const uint32_t n = a.compact ? a.ctl->nlive[a.depth] : a.pool_n;
+    const uint32_t tiles = (n + TILE - 1) / TILE;
+    const uint32_t R = range_tiles(n, W);
+    const bool packed = a.compact && a.dir_in.mem != nullptr;
+    const uint32_t span = packed ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
+    uint32_t cur = 0;
+    if (packed && wid * R < tiles) cur = find_range(a.dir_in.base(), W, wid * R * TILE);
+    for (int b = lane; b < a.nbins; b += 64) bins[b] = a.table[(size_t)b * W + wid];
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t tile = wid * R + r;
+        if (tile >= tiles) break;
+        const uint32_t i = tile * TILE + lane;
+        const bool valid = i < n;
+        uint32_t src = i;
+        if (packed) src = resolve_src(a.dir_in, span, cur, i, valid, a.ctl);
+        const uint32_t key = valid ? sort_key(a.isect, i, a.nbins) : 0u;
+        uint32_t dst = 0;
+        uint64_t rem = __ballot(valid);
+        while (rem) {
+            const int l = __ffsll((unsigned long long)rem) - 1;
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
+            const uint64_t m = __ballot(valid && key == k);
+            const uint32_t base = bins[k];                          // same address for the whole wave
+            if (valid && key == k) dst = base + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)));
+            if (lane == 0) bins[k] = base + (uint32_t)__popcll((unsigned long long)m);
+            rem &= ~m;
+        }
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a.out.plane(k)[dst] = a.in.plane(k)[src];
+            a.out.pid()[dst] = a.in.pid()[src];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.isect_out.plane(k)[dst] = a.isect.plane(k)[i];
+            a.isect_out.mat()[dst] = a.isect.mat()[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // the fused bounce kernel
 // ---------------------------------------------------------------------------
 // MODE_FUSED   : intersect inline (ShadeableIntersection never touches HBM)
@@ -791,6 +947,8 @@ struct Renderer {
     Pool pool[2]{};
     int cur = 0;                  // pool holding the current live prefix
     float *isect_mem = nullptr;
+    float *isect2_mem = nullptr;  // sorted intersections (PT_SORT_MATERIAL)
+    uint32_t *sort_table = nullptr;
     Isect isect{};
     float *final_mem = nullptr;   // 3 planes of cap floats
     float *image = nullptr;
@@ -806,6 +964,7 @@ struct Renderer {
     uint32_t max_tiles = 0;
     size_t ctl_bytes = 0;         // Control, zeroed per batch
     int grid = 0;                 // persistent grid size
+    bool sorted_isects = false;   // the last bounce's intersections live in isect2 (sorted order)
     bool gen_fused = false;       // bounce 0 of the current batch generates its own rays
     bool has_mesh = false;
     void *scratch = nullptr;      // export / import staging
@@ -899,6 +1058,7 @@ int enqueue_begin(int iter0, int count, bool stepping) {
     if (iter0 < 1 || (int64_t)iter0 + count - 1 >= (1 << 22))
         return fail(PT_ERR_INVALID, "iteration %d outside [1, 2^22): makeSeededRandomEngine packs iter in 22 bits", iter0);
     R.step_iter0 = iter0; R.step_count = count; R.step_depth = 0; R.cur = 0; R.cur_dir = -1;
+    R.sorted_isects = false;
     HIPCHK(hipMemsetAsync(R.ctl, 0, R.ctl_bytes, R.stream));
     // batch path: bounce 0 generates the camera rays itself (no 40 B/path round trip through HBM)
     R.gen_fused = !stepping && !(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER));
@@ -936,6 +1096,24 @@ int enqueue_bounce(int depth) {
         else launch_intersect<false>(a.in, n_ptr, a.pool_n, a.dir_in, nprev);
         HIPCHK(hipGetLastError());
     }
+    if (R.flags & PT_SORT_MATERIAL) {
+        // intersections (logical order) -> histogram + scan -> scatter into the other pool, dense and
+        // sorted; the shade/compact kernel then reads that pool and writes back into the first one
+        StageTimer tm(PT_STAGE_SORT);
+        SortArgs sa{};
+        sa.in = a.in; sa.out = R.pool[R.cur ^ 1];
+        sa.isect = R.isect; sa.isect_out = Isect{R.isect2_mem, R.cap};
+        sa.dir_in = a.dir_in; sa.ctl = R.ctl; sa.table = R.sort_table;
+        sa.depth = depth; sa.nbins = R.scene.nmats + 1; sa.pool_n = a.pool_n; sa.compact = compact ? 1 : 0;
+        const size_t lds = ((size_t)LDS_CTL_WORDS + (size_t)WAVES * SORT_MAX_BINS) * 4;
+        hipLaunchKernelGGL(k_sort_hist, dim3(R.grid), dim3(BLOCK), lds, R.stream, sa);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_sort_scatter, dim3(R.grid), dim3(BLOCK), lds, R.stream, sa);
+        HIPCHK(hipGetLastError());
+        a.in = sa.out; a.out = R.pool[R.cur];
+        a.isect = sa.isect_out;
+        a.dir_in = tile_dir(-1);                         // the sorted pool is dense
+    }
     StageTimer tm(PT_STAGE_BOUNCE);
     if (unfused) {
         if (compact) launch_bounce<MODE_ISECT, true>(a); else launch_bounce<MODE_ISECT, false>(a);
@@ -943,7 +1121,12 @@ int enqueue_bounce(int depth) {
         if (compact) launch_bounce<MODE_FUSED, true>(a); else launch_bounce<MODE_FUSED, false>(a);
     }
     HIPCHK(hipGetLastError());
-    if (compact) { R.cur ^= 1; R.cur_dir = depth; }
+    if (R.flags & PT_SORT_MATERIAL) {
+        // pool[cur] was rewritten in place of the pre-sort state; without compaction the survivors
+        // stay where the sorted pass put them, i.e. in pool[cur] as well
+        if (compact) R.cur_dir = depth;
+        R.sorted_isects = true;
+    } else if (compact) { R.cur ^= 1; R.cur_dir = depth; }
     R.step_depth = depth + 1;
     return PT_OK;
 }
@@ -1028,6 +1211,8 @@ void pt_free(void) {
     if (R.stream) (void)hipStreamSynchronize(R.stream);
     for (int k = 0; k < 2; ++k) if (R.pool_mem[k]) (void)hipFree(R.pool_mem[k]);
     if (R.isect_mem) (void)hipFree(R.isect_mem);
+    if (R.isect2_mem) (void)hipFree(R.isect2_mem);
+    if (R.sort_table) (void)hipFree(R.sort_table);
     if (R.final_mem) (void)hipFree(R.final_mem);
     if (R.image && R.own_image) (void)hipFree(R.image);
     if (R.d_geoms) (void)hipFree(R.d_geoms);
@@ -1187,6 +1372,12 @@ static int init_impl(const pt_scene_desc *d) {
     if (per_cu > 8) per_cu = 8;
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
     if (R.grid < 1) R.grid = 1;
+    if (R.flags & PT_SORT_MATERIAL) {
+        if (d->num_materials + 1 > SORT_MAX_BINS)
+            return fail(PT_ERR_INVALID, "pt_init: PT_SORT_MATERIAL supports at most %d materials", SORT_MAX_BINS - 1);
+        HIPCHK(hipMalloc(&R.isect2_mem, capz * 5 * 4));
+        HIPCHK(hipMalloc((void **)&R.sort_table, (size_t)(d->num_materials + 1) * R.grid * WAVES * sizeof(uint32_t)));
+    }
     {   // range directory: one count + one base per wave of the persistent grid, per bounce
         const size_t Wp = ((size_t)R.grid * WAVES + 3) & ~(size_t)3;
         R.dir_stride = 2 * Wp + 8;
@@ -1324,7 +1515,8 @@ int pt_export_intersections(pt_shadeable_intersection *host_isects, uint8_t *hos
     if (rc) return rc;
     uint8_t *d_out = (uint8_t *)R.scratch + (size_t)n * sizeof(pt_shadeable_intersection);
     if (n) {
-        hipLaunchKernelGGL(k_export_isects, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.isect, n,
+        hipLaunchKernelGGL(k_export_isects, dim3((n + 255) / 256), dim3(256), 0, R.stream,
+                           R.sorted_isects ? Isect{R.isect2_mem, R.cap} : R.isect, n,
                            (pt_shadeable_intersection *)R.scratch, host_outside ? d_out : (uint8_t *)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(host_isects, R.scratch, (size_t)n * sizeof(pt_shadeable_intersection), hipMemcpyDeviceToHost, R.stream));

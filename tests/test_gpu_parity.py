@@ -103,17 +103,18 @@ def test_first_bounce_intersections_c2(pt, po, scenes, golden):
     pt.pathtraceFree()
 
 
-@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact"])
+@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort"])
 @pytest.mark.parametrize("scene_name", ["cornell_64", "cornell_glass_64", "cornell_diffuse_64"])
 def test_bounce_by_bounce(pt, po, scenes, scene_name, flags_name):
     """Every bounce: live count, compacted pixelIndex sequence and full path state bit-exact."""
     s = scenes[scene_name]
-    flags = {"fused": pt.PT_COMPACT, "unfused": pt.PT_COMPACT | pt.PT_UNFUSED, "nocompact": 0}[flags_name]
+    flags = {"fused": pt.PT_COMPACT, "unfused": pt.PT_COMPACT | pt.PT_UNFUSED, "nocompact": 0,
+             "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL}[flags_name]
     scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
     n = scene.resolution[0] * scene.resolution[1]
     pt.pathtraceInit(scene, flags=flags)
-    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"],
-                    flags=po.F_COMPACT if flags & pt.PT_COMPACT else 0, trig=po.TRIG_SHARED)
+    oflags = (po.F_COMPACT if flags & pt.PT_COMPACT else 0) | (po.F_SORT if flags & pt.PT_SORT_MATERIAL else 0)
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], flags=oflags, trig=po.TRIG_SHARED)
     for it in (1, 2, 3):
         snaps = []
         st = ref.iterate(it, snapshots=snaps)
@@ -151,12 +152,13 @@ def _after(snaps, d, ref):
     return snaps[d]["paths"]
 
 
-@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact"])
+@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort", "sort_nocompact"])
 def test_c2_full_iteration(pt, po, scenes, golden, flags_name):
     """Config C2 (800x800, depth 8): image, live counts and compaction order vs golden + oracle."""
     z = golden["completion"]
     s = scenes["cornell"]
-    flags = {"fused": pt.PT_COMPACT, "unfused": pt.PT_COMPACT | pt.PT_UNFUSED, "nocompact": 0}[flags_name]
+    flags = {"fused": pt.PT_COMPACT, "unfused": pt.PT_COMPACT | pt.PT_UNFUSED, "nocompact": 0,
+             "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL, "sort_nocompact": pt.PT_SORT_MATERIAL}[flags_name]
     scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
     pt.pathtraceInit(scene, flags=flags)
     for it in (1, 2):
