@@ -12,3 +12,4 @@ from .binding import (  # noqa: F401
 )
 from .build import build  # noqa: F401
 from . import sharding  # noqa: F401,E402
+from . import meshes  # noqa: F401,E402

@@ -297,3 +297,41 @@ def test_tile_order_matches_host_sharding(pt, scenes):
         assert live == len(want)
         assert (paths["pixelIndex"] == want).all()
         pt.pathtraceFree()
+
+
+def _mesh_scene(pt, scenes, n_lat, n_lon, res_scene="cornell_64"):
+    s = scenes[res_scene]
+    tris = pt.meshes.uv_sphere(n_lat=n_lat, n_lon=n_lon)
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
+    return s, geoms, tris, meshes
+
+
+@pytest.mark.parametrize("size", [(8, 16), (30, 60)])       # 224 and 3480 triangles (1 and 4 LDS tiles)
+def test_triangle_mesh(pt, po, scenes, size):
+    """Config C4's path: naive triangle loop through LDS tiles, glm::intersectRayTriangle arithmetic."""
+    s, geoms, tris, meshes = _mesh_scene(pt, scenes, *size)
+    assert len(tris) == pt.meshes.triangle_count(*size)
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
+    n = 64 * 64
+    # standalone intersect kernel vs oracle on the camera rays
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED)
+    rays = po.generate_rays(s["camera"], s["depth"])
+    got, got_out = pt.intersect_once(rays.view(pt.PATH_DT))
+    want, want_out = po.compute_intersections(rays, geoms.view(po.GEOM_DT), tris.view(po.TRI_DT),
+                                              meshes.view(po.MESH_DT))
+    assert got.tobytes() == want.tobytes()
+    mesh_hits = (want["t"] > 0) & (want["materialId"] == 1) & (np.abs(want["normal"]).max(axis=1) < 0.999)
+    assert mesh_hits.sum() > 50
+    pt.pathtraceFree()
+    for flags in (pt.PT_COMPACT, pt.PT_COMPACT | pt.PT_UNFUSED, 0):
+        pt.pathtraceInit(scene, flags=flags)
+        ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], s["depth"],
+                        flags=po.F_COMPACT if flags & pt.PT_COMPACT else 0, trig=po.TRIG_SHARED,
+                        tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
+        for it in (1, 2):
+            img = pt.pathtrace(None, 0, it)
+            st = ref.iterate(it)
+            gs = pt.get_stats()
+            assert list(gs.live[:s["depth"]]) == list(st.live[:s["depth"]])
+            assert img.tobytes() == ref.image.tobytes()
+        pt.pathtraceFree()
