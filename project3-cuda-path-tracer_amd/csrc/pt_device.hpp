@@ -200,7 +200,9 @@ template <typename P> PTD bool box_candidate(P g, f3 ro, f3 rd, Candidate &c) {
     if (tmax >= tmin && tmax > 0) {
         c.outside = 1;
         if (tmin <= 0) { tmin = tmax; tmin_n = tmax_n; c.outside = 0; }
-        c.qo = qo; c.qd = qd; c.t_obj = tmin; c.face_n = tmin_n;
+        c.qo = qo; c.qd = qd; c.t_obj = tmin;
+        c.face_n = mk(__int_as_float((tmin_n.x != 0.0f ? 0 : tmin_n.y != 0.0f ? 2 : tmin_n.z != 0.0f ? 4 : 6) +
+                                      ((tmin_n.x + tmin_n.y + tmin_n.z) > 0.0f ? 1 : (tmin_n.x == 0.0f && tmin_n.y == 0.0f && tmin_n.z == 0.0f ? 1 : 0))), 0.0f, 0.0f);
         return true;
     }
     return false;
@@ -238,31 +240,40 @@ template <typename P> PTD float candidate_distance(P g, f3 ro, const Candidate &
     return length(sub(ro, p));
 }
 
-// boxIntersectionTest (intersections.h:48-90) without the normal (deferred).
+// boxIntersectionTest (intersections.h:48-90) without the normal (deferred).  The candidate face
+// normals tmin_n / tmax_n are carried as a 3-bit code (axis*2 + (sign>0), 7 = the zero vector
+// glm's default constructor leaves when no slab updates them) instead of three floats: one
+// select per update instead of three.  face_from_code() rebuilds the exact vector.
+PTD f3 face_from_code(int code) {
+    const float s = (code & 1) ? 1.0f : -1.0f;
+    const int axis = code >> 1;
+    return mk(axis == 0 ? s : 0.0f, axis == 1 ? s : 0.0f, axis == 2 ? s : 0.0f);   // code 7 -> (0,0,0)
+}
+
 template <typename P> PTD float box_test(P g, f3 ro, f3 rd, f3 &face_n, int &outside) {
     f3 qo = mv_point(g + G_INV, ro);
     f3 qd = normalize(mv_dir(g + G_INV, rd));
     float tmin = -1e38f, tmax = 1e38f;
-    f3 tmin_n = mk(0, 0, 0), tmax_n = mk(0, 0, 0);
-#define PTD_SLAB(QO, QD, NX, NY, NZ)                                      \
+    int tmin_c = 7, tmax_c = 7;
+#define PTD_SLAB(QO, QD, AXIS)                                            \
     {                                                                     \
         float t1 = (-0.5f - (QO)) / (QD);                                 \
         float t2 = (+0.5f - (QO)) / (QD);                                 \
         float ta = t1 < t2 ? t1 : t2;                                     \
         float tb = t1 > t2 ? t1 : t2;                                     \
-        float sgn = t2 < t1 ? 1.0f : -1.0f;                               \
-        if (ta > 0 && ta > tmin) { tmin = ta; tmin_n = mk(NX, NY, NZ); }  \
-        if (tb < tmax) { tmax = tb; tmax_n = mk(NX, NY, NZ); }            \
+        int code = (AXIS) * 2 + (t2 < t1 ? 1 : 0);                        \
+        if (ta > 0 && ta > tmin) { tmin = ta; tmin_c = code; }            \
+        if (tb < tmax) { tmax = tb; tmax_c = code; }                      \
     }
-    PTD_SLAB(qo.x, qd.x, sgn, 0.0f, 0.0f)
-    PTD_SLAB(qo.y, qd.y, 0.0f, sgn, 0.0f)
-    PTD_SLAB(qo.z, qd.z, 0.0f, 0.0f, sgn)
+    PTD_SLAB(qo.x, qd.x, 0)
+    PTD_SLAB(qo.y, qd.y, 1)
+    PTD_SLAB(qo.z, qd.z, 2)
 #undef PTD_SLAB
     if (tmax >= tmin && tmax > 0) {
         outside = 1;
-        if (tmin <= 0) { tmin = tmax; tmin_n = tmax_n; outside = 0; }
+        if (tmin <= 0) { tmin = tmax; tmin_c = tmax_c; outside = 0; }
         f3 p = mv_point(g + G_FWD, point_on_ray(qo, qd, tmin));
-        face_n = tmin_n;
+        face_n = mk(__int_as_float(tmin_c), 0.0f, 0.0f);                  // decoded by cube_normal
         return length(sub(ro, p));
     }
     return -1.0f;
@@ -297,7 +308,9 @@ template <typename P> PTD float sphere_test(P g, f3 ro, f3 rd, f3 &obj_p, int &o
 
 // surface normal of the winning primitive (the part of the two tests above
 // that the reference evaluates for every candidate)
-template <typename P> PTD f3 cube_normal(P g, f3 face_n) { return normalize(mv_dir(g + G_FWD, face_n)); }
+template <typename P> PTD f3 cube_normal(P g, f3 face_n) {
+    return normalize(mv_dir(g + G_FWD, face_from_code(__float_as_int(face_n.x))));
+}
 template <typename P> PTD f3 sphere_normal(P g, f3 obj_p, int outside) {
     f3 n = normalize(mv_dir(g + G_INVT, obj_p));
     return outside ? n : neg(n);

@@ -73,6 +73,14 @@ constexpr uint32_t DEAD_PID = 0xffffffffu;
 // device-side parameter blocks (few pointers: every extra pointer pair costs
 // 2 SGPRs per wave for the whole kernel)
 // ---------------------------------------------------------------------------
+// element `i` of a wave-uniform plane pointer through a 32-bit byte offset: the address is
+// SGPR base + zero-extended VGPR offset (one global_load/store, no 64-bit VALU address math).
+// pt_init guarantees cap * 4 < 2^32.
+template <typename T>
+__device__ __forceinline__ T &at(T *plane, uint32_t i) {
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(plane) + (i << 2));
+}
+
 struct Pool {            // SoA planes of `cap` elements: ox oy oz dx dy dz cr cg cb pid
     float *base;
     uint32_t cap;
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             if (a.gen_rays) {
                 pid = i;
             } else {
-                pid = a.in.pid()[src];
+                pid = at(a.in.pid(), src);
                 if (pid == DEAD_PID) active = false;
             }
         }
@@ -712,8 +720,8 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
                 ro = ptd::mk(a.cam.position.x, a.cam.position.y, a.cam.position.z);
                 rd = camera_dir(a.cam, pixel, a.map.W);
             } else {
-                ro = ptd::mk(a.in.plane(0)[src], a.in.plane(1)[src], a.in.plane(2)[src]);
-                rd = ptd::mk(a.in.plane(3)[src], a.in.plane(4)[src], a.in.plane(5)[src]);
+                ro = ptd::mk(at(a.in.plane(0), src), at(a.in.plane(1), src), at(a.in.plane(2), src));
+                rd = ptd::mk(at(a.in.plane(3), src), at(a.in.plane(4), src), at(a.in.plane(5), src));
             }
         }
         float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
@@ -727,20 +735,21 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             intersect_scene<HAS_MESH>(gsrc, a.scene.ngeoms, a.scene.tris, tri_lds, active, ro, rd, h);
             if (active) { resolve_hit(gsrc, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
         } else if (active) {
-            t = a.isect.plane(0)[i];
-            nrm = ptd::mk(a.isect.plane(1)[i], a.isect.plane(2)[i], a.isect.plane(3)[i]);
-            const int m = a.isect.mat()[i];
+            t = at(a.isect.plane(0), i);
+            nrm = ptd::mk(at(a.isect.plane(1), i), at(a.isect.plane(2), i), at(a.isect.plane(3), i));
+            const int m = at(a.isect.mat(), i);
             mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
         }
         bool alive = false;
         ptd::PathState ps;
         ps.o = ro; ps.d = rd; ps.c = ptd::mk(1.0f, 1.0f, 1.0f);
         if (active) {
-            if (!a.gen_rays) ps.c = ptd::mk(a.in.plane(6)[src], a.in.plane(7)[src], a.in.plane(8)[src]);
+            if (!a.gen_rays) ps.c = ptd::mk(at(a.in.plane(6), src), at(a.in.plane(7), src), at(a.in.plane(8), src));
             alive = ptd::shade_scatter(ps, t, nrm, mat, outside, mats, a.iter0 + (int)smp, pixel, a.depth,
                                        last_bounce);
             if (!alive) {
-                a.fin[pid] = ps.c.x; a.fin[(size_t)a.in.cap + pid] = ps.c.y; a.fin[2 * (size_t)a.in.cap + pid] = ps.c.z;
+                at(a.fin, pid) = ps.c.x; at(a.fin + (size_t)a.in.cap, pid) = ps.c.y;
+                at(a.fin + 2 * (size_t)a.in.cap, pid) = ps.c.z;
             }
         }
         // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
@@ -753,12 +762,12 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             packed += (uint32_t)__popcll((unsigned long long)bal);
         }
         if (alive) {
-            a.out.plane(0)[dst] = ps.o.x; a.out.plane(1)[dst] = ps.o.y; a.out.plane(2)[dst] = ps.o.z;
-            a.out.plane(3)[dst] = ps.d.x; a.out.plane(4)[dst] = ps.d.y; a.out.plane(5)[dst] = ps.d.z;
-            a.out.plane(6)[dst] = ps.c.x; a.out.plane(7)[dst] = ps.c.y; a.out.plane(8)[dst] = ps.c.z;
-            a.out.pid()[dst] = pid;
+            at(a.out.plane(0), dst) = ps.o.x; at(a.out.plane(1), dst) = ps.o.y; at(a.out.plane(2), dst) = ps.o.z;
+            at(a.out.plane(3), dst) = ps.d.x; at(a.out.plane(4), dst) = ps.d.y; at(a.out.plane(5), dst) = ps.d.z;
+            at(a.out.plane(6), dst) = ps.c.x; at(a.out.plane(7), dst) = ps.c.y; at(a.out.plane(8), dst) = ps.c.z;
+            at(a.out.pid(), dst) = pid;
         } else if (!COMPACT && have && i < n) {
-            a.out.pid()[dst] = DEAD_PID;
+            at(a.out.pid(), dst) = DEAD_PID;
         }
     }
     if (lane == 0 && traced) atomicAdd(&a.ctl->alive[a.depth], traced);
@@ -1277,8 +1286,8 @@ static int init_impl(const pt_scene_desc *d) {
     R.map.tile_pixels = tile_rows(d->tile_index, tile_count, R.map.strip_rows, H) * W;
     if (R.map.tile_pixels <= 0) return fail(PT_ERR_INVALID, "pt_init: tile owns no rows");
     R.max_batch = d->max_batch < 1 ? 1 : d->max_batch;
-    if ((int64_t)R.max_batch * R.map.tile_pixels >= (int64_t)0xfffffff0u)
-        return fail(PT_ERR_INVALID, "pt_init: max_batch * tile pixels overflows the 32-bit path id");
+    if ((int64_t)R.max_batch * R.map.tile_pixels >= (int64_t)0x3ffffff0)
+        return fail(PT_ERR_INVALID, "pt_init: max_batch * tile pixels must stay below 2^30 (32-bit byte offsets into the planes)");
     R.cap = (uint32_t)R.max_batch * (uint32_t)R.map.tile_pixels;
     if (d->stream) { R.stream = (hipStream_t)d->stream; R.own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking)); R.own_stream = true; }
