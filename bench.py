@@ -50,7 +50,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="iterations (spp) per step per full frame")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
+                    help="c2: BASELINE configs[1] (the metric's workload); c3: glass ball 1280x720 depth 16; "
+                         "c4: Cornell + 100k-triangle mesh (parity-test cases, selectable for measurement)")
     ap.add_argument("--flags", default="compact", help="comma list: compact,sort,unfused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -77,8 +79,14 @@ def main():
 
     pt = ge.load_package()
     pt.library()
-    scene_name = {"c2": "cornell", "c3": "cornell_glass"}[args.config]
+    scene_name = {"c2": "cornell", "c3": "cornell_glass", "c4": "cornell"}[args.config]
     scene = load_scene(pt, scene_name)
+    if args.config == "c4":       # BASELINE configs[3]: naive loop over a 100 032-triangle UV sphere, material 1
+        tris = pt.meshes.uv_sphere(n_lat=97, n_lon=521)
+        assert len(tris) == 100032
+        geoms, tris, meshes = pt.meshes.add_mesh(scene.geoms, tris, material_id=1)
+        scene = pt.Scene(geoms, scene.materials, scene.camera, scene.traceDepth, triangles=tris, meshes=meshes,
+                         name="cornell+mesh")
     W, H = scene.resolution
     npix = W * H
     flags = 0
@@ -138,9 +146,10 @@ def main():
         ms, launches = prof["bounce"]
         algo_bytes = rank_rays * BYTES_PER_RAY + survivors * BYTES_PER_SURVIVOR
         achieved = algo_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": "k_bounce<fused,compact>", "achieved": round(achieved, 1),
+        roofline = {"bound": "hbm", "kernel": "k_bounce<fused,compact>" if args.flags == "compact" else
+                    "k_bounce (" + args.flags + "; byte model of the fused kernel)", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None, "launches": int(launches),
+                    "traffic": measured_traffic(args, world), "launches": int(launches),
                     "avg_launch_us": round(ms * 1e3 / max(1, launches), 2),
                     "algorithmic_bytes_per_launch": int(algo_bytes / max(1, launches)),
                     "stage_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]},
@@ -154,7 +163,8 @@ def main():
     pt.pathtraceFree()
     if rank == 0:
         out = {
-            "metric": "Mrays/sec (live paths x bounces) at 800x800 Cornell depth 8",
+            "metric": "Mrays/sec (live paths x bounces) at 800x800 Cornell depth 8" if args.config == "c2" else
+                      "Mrays/sec (live paths x bounces), config %s" % args.config,
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -174,6 +184,22 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(args, world):
+    """HBM bytes per k_bounce launch from the rocprofv3 PMC passes of THIS command line (FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950;
+    profiles/traffic.json is written by profiles/summarize.py).  None when no matching profile exists."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    if t.get("config") != args.config or t.get("batch") != args.batch or t.get("flags") != args.flags:
+        return None
+    return t.get("bytes_per_launch")
 
 
 def _total_rays(pt):

@@ -17,5 +17,5 @@ timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_L
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
 cd "$ROOT"
-python3 profiles/summarize.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 profiles/summarize.py "$OUT" "$OUT/traffic.json" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

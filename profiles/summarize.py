@@ -13,7 +13,12 @@ def short(name):
         if k in name:
             tail = ""
             if "k_bounce" in name:
-                tail = "<%s,%s>" % ("isect" if "Li1E" in name else "fused", "compact" if "Lb1E" in name else "inplace")
+                import re
+                m = re.search(r"k_bounce<(\d), (true|false)(?:, (true|false))?>", name)
+                if m:
+                    tail = "<%s,%s%s>" % ("isect" if m.group(1) == "1" else "fused",
+                                          "compact" if m.group(2) == "true" else "inplace",
+                                          ",mesh" if m.group(3) == "true" else "")
             return k + tail
     return name[:60]
 
@@ -46,5 +51,29 @@ def main(d):
                     print("%-34s %-24s dispatches=%-6d sum=%-16.0f per_dispatch=%.1f" % (k, c, n, v, v / n))
 
 
+def traffic_json(d, out_path, meta):
+    """bytes per k_bounce launch = 2 * FETCH_SIZE (gfx950 reports half of a coalesced read) + WRITE_SIZE,
+    both in KiB, from their separate PMC passes."""
+    import json
+    tot = {}
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        vals = []
+        for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == name and "k_bounce" in r["Kernel_Name"]:
+                    vals.append(float(r["Counter_Value"]))
+        if vals:
+            tot[name] = sum(vals) / len(vals)
+    if len(tot) == 2:
+        meta = dict(meta)
+        meta.update({"fetch_kib_per_launch_raw": tot["FETCH_SIZE"], "write_kib_per_launch": tot["WRITE_SIZE"],
+                     "bytes_per_launch": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024),
+                     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 "
+                             "(gfx950 counts 64 B per 128-B request; calibrated on k_gather's known bytes)"})
+        json.dump(meta, open(out_path, "w"), indent=1)
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    if len(sys.argv) > 2:
+        traffic_json(sys.argv[1], sys.argv[2], {"config": "c2", "batch": 16, "flags": "compact"})

@@ -6,9 +6,9 @@ import numpy as np
 from .binding import GEOM_DT, MESH_DT, TRI_DT
 
 
-def uv_sphere(center=(1.5, 3.0, 1.0), radius=1.5, n_lat=158, n_lon=317):
-    """Outward-facing (counter-clockwise from outside) triangles of a UV sphere.
-    n_lat x n_lon = 158 x 317 gives 2*317*(158-1) = 99 538 ... use triangle_count() to pick sizes."""
+def uv_sphere(center=(1.5, 3.0, 1.0), radius=1.5, n_lat=97, n_lon=521):
+    """Outward-facing (counter-clockwise from outside) triangles of a UV sphere; the default
+    97 x 521 grid has 2*521*96 = 100 032 triangles (BASELINE config C4)."""
     c = np.asarray(center, dtype=np.float64)
     th = np.linspace(0.0, np.pi, n_lat + 1)                  # polar
     ph = np.linspace(0.0, 2.0 * np.pi, n_lon + 1)            # azimuth
