@@ -57,6 +57,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--strip-rows", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --same-device exercises the N>1 code path on a single GPU (debug)")
+    ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--digest", action="store_true", help="add the md5 of the (reduced) accumulation image")
     args = ap.parse_args()
 
     import torch
@@ -71,11 +75,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":      # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pt = ge.load_package()
     pt.library()
@@ -94,21 +103,34 @@ def main():
         flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED, "": 0}[f]
     per_step_iters = pt.sharding.step_iterations(0, args.batch, world)[1]     # = batch * world
 
-    stream = torch.cuda.current_stream()
+    # an explicit (non-null) torch stream: the library launches on it, torch copies / RCCL order against it
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     image = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")     # accumulation buffer (torch-owned)
     frame = torch.zeros_like(image) if world > 1 else None                # reduce target / staging
+    torch.cuda.synchronize()
     pt.pathtraceInit(scene, flags=flags, device=local_rank, stream=stream.cuda_stream,
                      tile=(rank, world, args.strip_rows), max_batch=per_step_iters,
                      device_image=image.data_ptr())
+    pending = [None]
 
     def step(i):
         iter0, count = pt.sharding.step_iterations(i, args.batch, world)
-        pt.trace_batch_async(iter0, count)
+        pt.trace_batch_async(iter0, count)                   # enqueue only
         if world > 1:
-            pt.sharding.reduce_frame(dist, image, frame, dst=0)  # RCCL reduce(SUM) over xGMI, once per step
+            # the reduce of step i runs on RCCL's stream while step i+1 traces; only the staging
+            # buffer hand-over is ordered
+            if pending[0] is not None:
+                pending[0].wait()
+            frame.copy_(image)
+            pending[0] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)   # once per step, over xGMI
 
     def barrier():
         if world > 1:
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -160,6 +182,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(scene)
 
+    digest = None
+    if args.digest:
+        import hashlib
+        barrier()
+        final = image
+        if world > 1:
+            final = pt.sharding.reduce_frame(dist, image, frame, dst=0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            digest = hashlib.md5(final.cpu().numpy().tobytes()).hexdigest()
     pt.pathtraceFree()
     if rank == 0:
         out = {
@@ -177,6 +209,8 @@ def main():
                        % (args.strip_rows, world),
                        "rays_per_step": int(rays / args.steps)},
         }
+        if digest:
+            out["image_md5"] = digest
         if roofline:
             out["roofline"] = roofline
         if cpu:

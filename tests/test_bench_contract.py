@@ -1,0 +1,46 @@
+"""bench.py's contract (one JSON line, required keys) and the N > 1 launch path.  The 2-rank run
+uses gloo with both ranks on cuda:0 (RCCL refuses two ranks on one device): same code path as the
+driver's torch.distributed.run launch except for the collective backend; the reduced frame must be
+bit-identical to the 1-rank frame over the same iterations."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, timeout=600):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_single_gpu_line():
+    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
+             "--digest"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["value"] > 100
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches"] == 3 * 8
+    test_single_gpu_line.md5 = d["image_md5"]
+
+
+def test_two_ranks_same_frame():
+    one = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
+               "--no-roofline", "--digest"])
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "3",
+               "--warmup", "1", "--batch", "2", "--no-roofline", "--backend", "gloo", "--same-device", "--digest"])
+    assert two["n_gpus"] == 2
+    assert two["config"]["rays_per_step"] == one["config"]["rays_per_step"]      # same 4 iterations per step
+    assert two["image_md5"] == one["image_md5"]                                   # tiles + reduce(SUM) == whole frame
