@@ -53,6 +53,7 @@ using std::cos; using std::sin;
 #endif
 #if defined(REF_TU_A)
 #include "scene.h"
+#include "image.h"
 #endif
 
 static_assert(sizeof(Geom) == 236 && sizeof(Material) == 44 && sizeof(Camera) == 84 &&
@@ -201,6 +202,20 @@ void ref_camera_orbit(Camera *camp) {
     cam.position = cameraPosition;
     cameraPosition += cam.lookAt;
     cam.position = cameraPosition;
+}
+
+// saveImage (main.cpp:78-99) through the reference's image class + stb_image_write (image.cpp,
+// stb.cpp compiled as they are): writes <base>.png
+void ref_save_image(const float *image_sum, int width, int height, float samples, const char *base) {
+    image img(width, height);
+    for (int x = 0; x < width; x++) {
+        for (int y = 0; y < height; y++) {
+            int index = x + (y * width);
+            glm::vec3 pix(image_sum[3 * index], image_sum[3 * index + 1], image_sum[3 * index + 2]);
+            img.setPixel(width - 1 - x, y, glm::vec3(pix) / samples);
+        }
+    }
+    img.savePNG(std::string(base));
 }
 #endif  // REF_TU_A
 

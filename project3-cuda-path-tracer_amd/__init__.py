@@ -13,3 +13,5 @@ from .binding import (  # noqa: F401
 from .build import build  # noqa: F401
 from . import sharding  # noqa: F401,E402
 from . import meshes  # noqa: F401,E402
+from . import host_binding  # noqa: F401,E402
+from .host_binding import build_host, build_ptbench, image_to_rgb8, load_scene, save_pfm, save_png  # noqa: F401,E402

@@ -1,0 +1,87 @@
+// ptbench.cpp -- headless host: the reference's main.cpp / runCuda() loop without GLFW
+// (src/main.cpp:33-76,101-147): load the scene, recompute the camera, pathtraceFree();
+// pathtraceInit(); pathtrace() x ITERATIONS; saveImage(); pathtraceFree().
+//
+//   ptbench SCENEFILE.txt [--iters N] [--batch B] [--out BASENAME] [--sort] [--no-compact]
+//           [--cache-first] [--pfm] [--device D]
+//
+// Links libptmi355.so (the HIP library) and host/pthost.cpp.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pthost.h"
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        printf("Usage: %s SCENEFILE.txt [--iters N] [--batch B] [--out BASE] [--sort] [--no-compact] [--pfm] [--device D]\n", argv[0]);
+        return 1;
+    }
+    int iters = -1, batch = 1, device = 0;
+    unsigned flags = PT_COMPACT;
+    bool pfm = false;
+    std::string out;
+    for (int i = 2; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
+        else if (a == "--batch" && i + 1 < argc) batch = atoi(argv[++i]);
+        else if (a == "--out" && i + 1 < argc) out = argv[++i];
+        else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
+        else if (a == "--sort") flags |= PT_SORT_MATERIAL;
+        else if (a == "--no-compact") flags &= ~PT_COMPACT;
+        else if (a == "--pfm") pfm = true;
+        else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
+    }
+    pth_scene *sc = pth_load_scene(argv[1]);
+    if (!sc) { fprintf(stderr, "%s\n", pth_last_error()); return 1; }
+    if (iters < 0) iters = sc->iterations;
+    if (batch < 1) batch = 1;
+    const int W = sc->camera.resolution[0], H = sc->camera.resolution[1];
+    printf("scene %s: %d geoms, %d materials, %d triangles, %dx%d, depth %d, %d iterations\n", argv[1],
+           sc->num_geoms, sc->num_materials, sc->num_triangles, W, H, sc->trace_depth, iters);
+
+    pt_scene_desc d;
+    memset(&d, 0, sizeof d);
+    d.geoms = sc->geoms; d.num_geoms = sc->num_geoms;
+    d.materials = sc->materials; d.num_materials = sc->num_materials;
+    d.triangles = sc->triangles; d.num_triangles = sc->num_triangles;
+    d.meshes = sc->meshes; d.num_meshes = sc->num_meshes;
+    d.camera = sc->camera; d.trace_depth = sc->trace_depth; d.flags = flags; d.device = device;
+    d.tile_count = 1; d.strip_rows = 8; d.max_batch = batch;
+    pt_free();                                            // main.cpp:126
+    if (pt_init(&d) != PT_OK) { fprintf(stderr, "pathtraceInit: %s\n", pt_last_error()); return 1; }
+
+    std::vector<float> image((size_t)W * H * 3, 0.0f);    // scene->state.image
+    const auto t0 = std::chrono::steady_clock::now();
+    int iteration = 0;
+    while (iteration < iters) {                            // runCuda: iteration++ ; pathtrace(pbo, 0, iteration)
+        const int n = (iters - iteration < batch) ? iters - iteration : batch;
+        const int last = (iteration + n == iters);
+        int rc = (n == 1) ? pt_trace(NULL, 0, iteration + 1, last ? image.data() : NULL)
+                          : pt_trace_batch(iteration + 1, n, last ? image.data() : NULL);
+        if (rc != PT_OK) { fprintf(stderr, "pathtrace: %s\n", pt_last_error()); return 1; }
+        iteration += n;
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const long long rays = pt_total_rays();
+    printf("%d iterations, %lld rays, %.3f s, %.1f Mrays/s\n", iteration, rays, sec, rays / sec / 1e6);
+
+    if (out.empty()) out = std::string(sc->image_name[0] ? sc->image_name : "render");
+    char name[512];
+    snprintf(name, sizeof name, "%s.%dsamp.png", out.c_str(), iteration);   // saveImage(): <FILE>.<time>.<N>samp
+    std::vector<uint8_t> rgb((size_t)W * H * 3);
+    pth_image_to_rgb8(image.data(), W, H, (float)iteration, rgb.data());
+    if (pth_write_png(name, rgb.data(), W, H) != 0) { fprintf(stderr, "%s\n", pth_last_error()); return 1; }
+    printf("Saved %s.\n", name);
+    if (pfm) {
+        snprintf(name, sizeof name, "%s.%dsamp.pfm", out.c_str(), iteration);
+        pth_write_pfm(name, image.data(), W, H, (float)iteration);
+        printf("Saved %s.\n", name);
+    }
+    pt_free();
+    pth_free_scene(sc);
+    return 0;
+}

@@ -291,6 +291,16 @@ def main():
     print("C2 live counts iter1:", r["live"][0], "rays", r["rays"])
     np.savez_compressed(os.path.join(OUT, "completion.npz"), **comp)
 
+    # ---- image output through the reference's saveImage / image::savePNG (+ stb_image_write) -------
+    from PIL import Image as _Image
+    img_in = f64.copy()                                  # 3-iteration fake-shader sum, 64x64
+    img_in[5] = [-1.0, 7.5, np.nan]                      # clamp edges
+    img_in[6] = [3.0, 2.999999, 0.0]
+    base = os.path.join(tempfile.mkdtemp(), "out")
+    A.ref_save_image(P(np.ascontiguousarray(img_in)), 64, 64, C.c_float(3.0), base.encode())
+    rgb = np.asarray(_Image.open(base + ".png").convert("RGB"), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "imageout.npz"), image_sum=img_in, samples=np.float32(3.0), rgb=rgb)
+
     # ---- golden PNG statistic (the PNG itself stays in /root/reference) -----------
     try:
         from PIL import Image

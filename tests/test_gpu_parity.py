@@ -335,3 +335,27 @@ def test_triangle_mesh(pt, po, scenes, size):
             assert list(gs.live[:s["depth"]]) == list(st.live[:s["depth"]])
             assert img.tobytes() == ref.image.tobytes()
         pt.pathtraceFree()
+
+
+def test_ptbench_headless_host(pt, po, scenes, tmp_path):
+    """The C++ headless host (host/ptbench.cpp = main.cpp/runCuda without GLFW): scene file in, PNG out;
+    the PNG equals the oracle's image pushed through the same saveImage pipeline."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         64 64")
+    scene_file = tmp_path / "cornell64.txt"
+    scene_file.write_text(txt)
+    exe = pt.build_ptbench()
+    p = subprocess.run([exe, str(scene_file), "--iters", "5", "--batch", "2", "--out", str(tmp_path / "r")],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "Mrays/s" in p.stdout
+    from PIL import Image
+    got = np.asarray(Image.open(str(tmp_path / "r.5samp.png")).convert("RGB"), dtype=np.uint8)
+    s = scenes["cornell_64"]
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
+    for it in range(1, 6):
+        ref.iterate(it)
+    want = pt.image_to_rgb8(ref.image, 64, 64, 5.0)
+    assert got.tobytes() == want.tobytes()
