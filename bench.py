@@ -100,7 +100,8 @@ def main():
     npix = W * H
     flags = 0
     for f in args.flags.split(","):
-        flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED, "": 0}[f]
+        flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED,
+                  "cache": pt.PT_CACHE_FIRST, "": 0}[f]
     per_step_iters = pt.sharding.step_iterations(0, args.batch, world)[1]     # = batch * world
 
     # an explicit (non-null) torch stream: the library launches on it, torch copies / RCCL order against it

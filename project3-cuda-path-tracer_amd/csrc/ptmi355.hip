@@ -667,7 +667,8 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
 // ---------------------------------------------------------------------------
 // MODE_FUSED   : intersect inline (ShadeableIntersection never touches HBM)
 // MODE_ISECT   : read the materialised planes written by k_intersect (PT_UNFUSED / sort)
-enum { MODE_FUSED = 0, MODE_ISECT = 1 };
+// MODE_CACHE0  : bounce 0 with PT_CACHE_FIRST: the per-pixel intersection cache (INSTRUCTION.md:87-89)
+enum { MODE_FUSED = 0, MODE_ISECT = 1, MODE_CACHE0 = 2 };
 
 template <int MODE, bool COMPACT, bool HAS_MESH>
 __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
@@ -735,9 +736,11 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             intersect_scene<HAS_MESH>(gsrc, a.scene.ngeoms, a.scene.tris, tri_lds, active, ro, rd, h);
             if (active) { resolve_hit(gsrc, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
         } else if (active) {
-            t = at(a.isect.plane(0), i);
-            nrm = ptd::mk(at(a.isect.plane(1), i), at(a.isect.plane(2), i), at(a.isect.plane(3), i));
-            const int m = at(a.isect.mat(), i);
+            // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
+            const uint32_t q = (MODE == MODE_CACHE0) ? pid - smp * (uint32_t)a.map.tile_pixels : i;
+            t = at(a.isect.plane(0), q);
+            nrm = ptd::mk(at(a.isect.plane(1), q), at(a.isect.plane(2), q), at(a.isect.plane(3), q));
+            const int m = at(a.isect.mat(), q);
             mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
         }
         bool alive = false;
@@ -793,6 +796,39 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             scan_range_counts(a.dir_out, &a.ctl->nlive[a.depth + 1], sctl + 2);
             if (threadIdx.x == 0) a.ctl->scan_ticks[a.depth] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
+        }
+    }
+}
+
+// First-bounce cache (INSTRUCTION.md:87-89): camera rays do not depend on the iteration (no
+// jitter, pathtrace.cu:134), so computeIntersections of bounce 0 is evaluated once per pixel and
+// camera and reused by every sample.
+template <bool HAS_MESH>
+__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache, SceneDev sc, pt_camera cam,
+                                                                      TileMap map) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    float *mats_lds = lds_raw + LDS_CTL_WORDS;
+    float *tri_lds = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_GEOM_LDS * sc.ngeoms * ptd::GEOM_WORDS;
+#if PT_GEOM_LDS
+    stage_scene(mats_lds, sc);
+    const float *gsrc = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
+#else
+    const float *gsrc = sc.geoms;
+#endif
+    const uint32_t n = (uint32_t)map.tile_pixels;
+    const uint32_t tiles = (n + BLOCK - 1) / BLOCK;
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t j = tile * BLOCK + threadIdx.x;
+        const bool active = j < n;
+        f3 ro = ptd::mk(cam.position.x, cam.position.y, cam.position.z), rd = ptd::mk(0, 0, 1);
+        if (active) rd = camera_dir(cam, local_to_pixel(map, (int)j), map.W);
+        ptd::Hit h;
+        intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h);
+        if (active) {
+            float t; f3 nrm; int mat;
+            resolve_hit(gsrc, sc.tris, h, t, nrm, mat);
+            cache.plane(0)[j] = t; cache.plane(1)[j] = nrm.x; cache.plane(2)[j] = nrm.y; cache.plane(3)[j] = nrm.z;
+            cache.mat()[j] = mat | (h.outside ? 0 : (int)0x80000000u);
         }
     }
 }
@@ -958,6 +994,8 @@ struct Renderer {
     float *isect_mem = nullptr;
     float *isect2_mem = nullptr;  // sorted intersections (PT_SORT_MATERIAL)
     uint32_t *sort_table = nullptr;
+    float *cache_mem = nullptr;   // first-bounce cache: 5 planes of tile_pixels (PT_CACHE_FIRST)
+    bool cache_valid = false;
     Isect isect{};
     float *final_mem = nullptr;   // 3 planes of cap floats
     float *image = nullptr;
@@ -1123,8 +1161,21 @@ int enqueue_bounce(int depth) {
         a.isect = sa.isect_out;
         a.dir_in = tile_dir(-1);                         // the sorted pool is dense
     }
+    const bool cached0 = depth == 0 && !unfused && (R.flags & PT_CACHE_FIRST);
+    if (cached0 && !R.cache_valid) {
+        StageTimer tm(PT_STAGE_INTERSECT);
+        const Isect cache{R.cache_mem, (uint32_t)R.map.tile_pixels};
+        const int blocks = std::min(R.grid, (R.map.tile_pixels + BLOCK - 1) / BLOCK);
+        if (R.has_mesh) hipLaunchKernelGGL((k_cache_first<true>), dim3(blocks), dim3(BLOCK), R.lds_bytes, R.stream, cache, R.scene, R.cam, R.map);
+        else hipLaunchKernelGGL((k_cache_first<false>), dim3(blocks), dim3(BLOCK), R.lds_bytes, R.stream, cache, R.scene, R.cam, R.map);
+        HIPCHK(hipGetLastError());
+        R.cache_valid = true;
+    }
     StageTimer tm(PT_STAGE_BOUNCE);
-    if (unfused) {
+    if (cached0) {
+        a.isect = Isect{R.cache_mem, (uint32_t)R.map.tile_pixels};
+        if (compact) launch_bounce<MODE_CACHE0, true>(a); else launch_bounce<MODE_CACHE0, false>(a);
+    } else if (unfused) {
         if (compact) launch_bounce<MODE_ISECT, true>(a); else launch_bounce<MODE_ISECT, false>(a);
     } else {
         if (compact) launch_bounce<MODE_FUSED, true>(a); else launch_bounce<MODE_FUSED, false>(a);
@@ -1222,6 +1273,7 @@ void pt_free(void) {
     if (R.isect_mem) (void)hipFree(R.isect_mem);
     if (R.isect2_mem) (void)hipFree(R.isect2_mem);
     if (R.sort_table) (void)hipFree(R.sort_table);
+    if (R.cache_mem) (void)hipFree(R.cache_mem);
     if (R.final_mem) (void)hipFree(R.final_mem);
     if (R.image && R.own_image) (void)hipFree(R.image);
     if (R.d_geoms) (void)hipFree(R.d_geoms);
@@ -1381,6 +1433,7 @@ static int init_impl(const pt_scene_desc *d) {
     if (per_cu > 8) per_cu = 8;
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
     if (R.grid < 1) R.grid = 1;
+    if (R.flags & PT_CACHE_FIRST) HIPCHK(hipMalloc(&R.cache_mem, (size_t)R.map.tile_pixels * 5 * 4));
     if (R.flags & PT_SORT_MATERIAL) {
         if (d->num_materials + 1 > SORT_MAX_BINS)
             return fail(PT_ERR_INVALID, "pt_init: PT_SORT_MATERIAL supports at most %d materials", SORT_MAX_BINS - 1);
@@ -1405,6 +1458,7 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
                     R.map.W, R.map.H, camera->resolution[0], camera->resolution[1]);
     if (trace_depth < 1 || trace_depth > R.desc.trace_depth)
         return fail(PT_ERR_INVALID, "pt_set_camera: trace_depth %d outside [1, %d]", trace_depth, R.desc.trace_depth);
+    if (memcmp(&R.cam, camera, sizeof R.cam) != 0) R.cache_valid = false;     // new camera: refill the bounce-0 cache
     R.cam = *camera;
     R.trace_depth = trace_depth;
     return PT_OK;

@@ -103,13 +103,13 @@ def test_first_bounce_intersections_c2(pt, po, scenes, golden):
     pt.pathtraceFree()
 
 
-@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort"])
+@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort", "cache"])
 @pytest.mark.parametrize("scene_name", ["cornell_64", "cornell_glass_64", "cornell_diffuse_64"])
 def test_bounce_by_bounce(pt, po, scenes, scene_name, flags_name):
     """Every bounce: live count, compacted pixelIndex sequence and full path state bit-exact."""
     s = scenes[scene_name]
     flags = {"fused": pt.PT_COMPACT, "unfused": pt.PT_COMPACT | pt.PT_UNFUSED, "nocompact": 0,
-             "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL}[flags_name]
+             "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL, "cache": pt.PT_COMPACT | pt.PT_CACHE_FIRST}[flags_name]
     scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
     n = scene.resolution[0] * scene.resolution[1]
     pt.pathtraceInit(scene, flags=flags)
@@ -152,13 +152,14 @@ def _after(snaps, d, ref):
     return snaps[d]["paths"]
 
 
-@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort", "sort_nocompact"])
+@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort", "sort_nocompact", "cache"])
 def test_c2_full_iteration(pt, po, scenes, golden, flags_name):
     """Config C2 (800x800, depth 8): image, live counts and compaction order vs golden + oracle."""
     z = golden["completion"]
     s = scenes["cornell"]
     flags = {"fused": pt.PT_COMPACT, "unfused": pt.PT_COMPACT | pt.PT_UNFUSED, "nocompact": 0,
-             "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL, "sort_nocompact": pt.PT_SORT_MATERIAL}[flags_name]
+             "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL, "sort_nocompact": pt.PT_SORT_MATERIAL,
+             "cache": pt.PT_COMPACT | pt.PT_CACHE_FIRST}[flags_name]
     scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
     pt.pathtraceInit(scene, flags=flags)
     for it in (1, 2):
@@ -359,3 +360,27 @@ def test_ptbench_headless_host(pt, po, scenes, tmp_path):
         ref.iterate(it)
     want = pt.image_to_rgb8(ref.image, 64, 64, 5.0)
     assert got.tobytes() == want.tobytes()
+
+
+def test_first_bounce_cache_follows_camera(pt, po, scenes):
+    """PT_CACHE_FIRST (INSTRUCTION.md:87-89): batches reuse the cached bounce-0 intersections; a camera
+    change through pathtrace()'s per-call re-read invalidates them."""
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_CACHE_FIRST, max_batch=3)
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
+    img = np.zeros((64 * 64, 3), dtype=np.float32)
+    pt.trace_batch(1, 3, img)
+    pt.trace_batch(4, 2, img)
+    for it in range(1, 6):
+        ref.iterate(it)
+    assert img.tobytes() == ref.image.tobytes()
+    cam2 = s["camera"].copy()
+    cam2["position"][0][0] += 0.75                       # move the eye: same resolution, new rays
+    scene.camera = cam2
+    got = pt.pathtrace(None, 0, 6).copy()
+    ref2 = po.Tracer(s["geoms"], s["materials"], cam2, s["depth"])
+    ref2.image[:] = ref.image
+    ref2.iterate(6)
+    assert got.tobytes() == ref2.image.tobytes()
+    pt.pathtraceFree()
