@@ -170,13 +170,9 @@ void pto_trace_iteration_mt(const pto_scene *sc, int iter, pto_vec3 *image,
 
 uint64_t pto_fnv1a_i32(const int32_t *v, int stride_bytes, int n);
 
-/* ---- host-side scene math ("next" row f1: scene.cpp / utilities.cpp / main.cpp) ---- */
-pto_mat4 pto_build_transformation_matrix(pto_vec3 translation, pto_vec3 rotation,
-                                         pto_vec3 scale);      /* utilities.cpp:65-72 */
-pto_mat4 pto_mat4_inverse(const pto_mat4 *m);                  /* glm func_matrix.inl inverse */
-pto_mat4 pto_mat4_inverse_transpose(const pto_mat4 *m);        /* glm gtc/matrix_inverse.inl */
-void pto_camera_from_scene(pto_camera *cam, float fovy_deg);   /* scene.cpp:133-142 */
-void pto_camera_orbit_recompute(pto_camera *cam);              /* main.cpp:53-67,102-120 */
+/* The host-side rows (scene loader, camera set-up, image writer) have no oracle
+ * restatement: the product's C++ host (host/pthost.cpp) is checked directly against fixtures produced
+ * by the reference's own scene.cpp / utilities.cpp / image.cpp (tests/test_host_loader.py). */
 
 #ifdef __cplusplus
 }
