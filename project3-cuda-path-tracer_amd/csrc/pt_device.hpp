@@ -250,9 +250,11 @@ PTD f3 face_from_code(int code) {
     return mk(axis == 0 ? s : 0.0f, axis == 1 ? s : 0.0f, axis == 2 ? s : 0.0f);   // code 7 -> (0,0,0)
 }
 
-template <typename P> PTD float box_test(P g, f3 ro, f3 rd, f3 &face_n, int &outside) {
-    f3 qo = mv_point(g + G_INV, ro);
-    f3 qd = normalize(mv_dir(g + G_INV, rd));
+// object-space part of boxIntersectionTest (intersections.h:48-84): true when the slab test passes;
+// qo/qd = object-space ray, t_obj = the parameter the test settles on, code = face normal code.
+template <typename P> PTD bool box_slab(P g, f3 ro, f3 rd, f3 &qo, f3 &qd, float &t_obj, int &code_out, int &outside) {
+    qo = mv_point(g + G_INV, ro);
+    qd = normalize(mv_dir(g + G_INV, rd));
     float tmin = -1e38f, tmax = 1e38f;
     int tmin_c = 7, tmax_c = 7;
 #define PTD_SLAB(QO, QD, AXIS)                                            \
@@ -272,38 +274,53 @@ template <typename P> PTD float box_test(P g, f3 ro, f3 rd, f3 &face_n, int &out
     if (tmax >= tmin && tmax > 0) {
         outside = 1;
         if (tmin <= 0) { tmin = tmax; tmin_c = tmax_c; outside = 0; }
-        f3 p = mv_point(g + G_FWD, point_on_ray(qo, qd, tmin));
-        face_n = mk(__int_as_float(tmin_c), 0.0f, 0.0f);                  // decoded by cube_normal
-        return length(sub(ro, p));
+        t_obj = tmin; code_out = tmin_c;
+        return true;
     }
-    return -1.0f;
+    return false;
 }
 
-// sphereIntersectionTest (intersections.h:102-144) without the normal (deferred).
-template <typename P> PTD float sphere_test(P g, f3 ro, f3 rd, f3 &obj_p, int &outside) {
-    f3 o = mv_point(g + G_INV, ro);
-    f3 d = normalize(mv_dir(g + G_INV, rd));
+// shared tail of both tests (intersections.h:85-87,136-143): objP = getPointOnRay(q, t_obj);
+// worldP = transform * objP; t = length(r.origin - worldP).  `fwd` = 12 floats of the transform.
+template <typename P> PTD float world_distance(P fwd, f3 ro, f3 qo, f3 qd, float t_obj, f3 &obj_p) {
+    obj_p = point_on_ray(qo, qd, t_obj);
+    return length(sub(ro, mv_point(fwd, obj_p)));
+}
+
+template <typename P> PTD float box_test(P g, f3 ro, f3 rd, f3 &face_n, int &outside) {
+    f3 qo, qd, obj_p; float t_obj; int code;
+    if (!box_slab(g, ro, rd, qo, qd, t_obj, code, outside)) return -1.0f;
+    face_n = mk(__int_as_float(code), 0.0f, 0.0f);                        // decoded by cube_normal
+    return world_distance(g + G_FWD, ro, qo, qd, t_obj, obj_p);
+}
+
+// object-space part of sphereIntersectionTest (intersections.h:102-134)
+template <typename P> PTD bool sphere_quad(P g, f3 ro, f3 rd, f3 &o, f3 &d, float &t_obj, int &outside) {
+    o = mv_point(g + G_INV, ro);
+    d = normalize(mv_dir(g + G_INV, rd));
     float vDotDirection = dot(o, d);
     float radicand = vDotDirection * vDotDirection - (dot(o, o) - (0.5f * 0.5f));
-    if (radicand < 0) return -1.0f;
+    if (radicand < 0) return false;
     float squareRoot = __builtin_sqrtf(radicand);
     float firstTerm = -vDotDirection;
     float t1 = firstTerm + squareRoot;
     float t2 = firstTerm - squareRoot;
-    float t;
     if (t1 < 0 && t2 < 0) {
-        return -1.0f;
+        return false;
     } else if (t1 > 0 && t2 > 0) {
-        t = (t2 < t1) ? t2 : t1;      // std::min(t1, t2)
+        t_obj = (t2 < t1) ? t2 : t1;      // std::min(t1, t2)
         outside = 1;
     } else {
-        t = (t1 < t2) ? t2 : t1;      // std::max(t1, t2)
+        t_obj = (t1 < t2) ? t2 : t1;      // std::max(t1, t2)
         outside = 0;
     }
-    f3 op = point_on_ray(o, d, t);
-    f3 p = mv_point(g + G_FWD, op);
-    obj_p = op;
-    return length(sub(ro, p));
+    return true;
+}
+
+template <typename P> PTD float sphere_test(P g, f3 ro, f3 rd, f3 &obj_p, int &outside) {
+    f3 o, d; float t_obj;
+    if (!sphere_quad(g, ro, rd, o, d, t_obj, outside)) return -1.0f;
+    return world_distance(g + G_FWD, ro, o, d, t_obj, obj_p);
 }
 
 // surface normal of the winning primitive (the part of the two tests above

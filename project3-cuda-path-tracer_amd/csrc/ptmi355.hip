@@ -59,6 +59,9 @@ namespace {
 #ifndef PT_GEOM_LDS
 #define PT_GEOM_LDS 0                      // 1: broadcast geom records from LDS, 0: scalar loads (SGPRs)
 #endif
+#ifndef PT_QUEUE
+#define PT_QUEUE 1                         // evaluate the world-distance tails lane-dense from a per-wave LDS queue
+#endif
 #ifndef PT_DEFER
 #define PT_DEFER 0                         // share the world-distance tail of the box/sphere tests across geoms
 #endif
@@ -206,11 +209,28 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, TileMap
 // fetched with wave-uniform (scalar, SGPR) loads straight from the 1-KB record array, which
 // costs no VGPRs and no LDS bandwidth; materials are per-lane gathers and live in LDS.
 constexpr int LDS_CTL_WORDS = 16;    // [0] last-block flag, [2..5] scan scratch
+constexpr int GF_WORDS = 16;         // staged per geom for gathers: transform[12], type, materialid, 2 pad
+// per-wave candidate queue (PT_QUEUE): ring of 128 slots, SoA: qo.xyz qd.xyz t_obj (7 planes), meta, and
+// the 64 per-lane best keys (u64)
+constexpr int Q_SLOTS = 128;
+constexpr int Q_WORDS = 7 * Q_SLOTS + Q_SLOTS + 2 * 64;
+__host__ __device__ constexpr int scene_lds_words(int nmats, int ngeoms) {
+    return ((nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * ngeoms * GF_WORDS + PT_GEOM_LDS * ngeoms * ptd::GEOM_WORDS;
+}
 __device__ __forceinline__ void stage_scene(float *lds_mats, const SceneDev &sc) {
     const int mw = sc.nmats * ptd::MAT_WORDS;
     for (int k = threadIdx.x; k < mw; k += BLOCK) lds_mats[k] = sc.mats[k];
+#if PT_QUEUE
+    {   // per-lane gathers of the tail: forward transform (12) + type + material per geom
+        float *gf = lds_mats + ((mw + 3) & ~3);
+        for (int k = threadIdx.x; k < sc.ngeoms * GF_WORDS; k += BLOCK) {
+            const int g = k / GF_WORDS, w = k - g * GF_WORDS;
+            gf[k] = w < 12 ? sc.geoms[g * ptd::GEOM_WORDS + ptd::G_FWD + w] : sc.geoms[g * ptd::GEOM_WORDS + (w - 12)];
+        }
+    }
+#endif
 #if PT_GEOM_LDS
-    float *lds_geoms = lds_mats + ((mw + 3) & ~3);
+    float *lds_geoms = lds_mats + ((mw + 3) & ~3) + PT_QUEUE * sc.ngeoms * GF_WORDS;
     for (int k = threadIdx.x; k < sc.ngeoms * ptd::GEOM_WORDS; k += BLOCK) lds_geoms[k] = sc.geoms[k];
 #endif
     __syncthreads();
@@ -226,13 +246,71 @@ __device__ __forceinline__ cfloat *as_const(const float *p) {
     return (cfloat *)(unsigned long long)p;
 }
 
+#if PT_QUEUE
+// One lane-dense pass over up to 64 queued candidates [head, head+count): lane k evaluates the
+// shared tail of candidate head+k for whichever lane queued it and folds the distance into that
+// lane's best key with an LDS 64-bit min.  key = (bits(t) << 32) | absolute slot: positive floats
+// order like their bit patterns and slots are issued in geom order, so the minimum key is the
+// smallest t with the lowest geom index on ties -- pathtrace.cu:192's strict `t_min > t` scan.
+__device__ __forceinline__ void queue_pass(float *wq, const float *gf, uint32_t head, uint32_t count, f3 ro) {
+    const int lane = threadIdx.x & 63;
+    float *qf = wq;
+    uint32_t *qi = reinterpret_cast<uint32_t *>(wq + 7 * Q_SLOTS);
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(wq + 8 * Q_SLOTS);
+    const bool on = (uint32_t)lane < count;
+    const uint32_t abs_slot = head + (uint32_t)lane;
+    const uint32_t s = abs_slot & (Q_SLOTS - 1);
+    const uint32_t meta = on ? qi[s] : 0u;
+    const int origin = (int)(meta & 63u);
+    // the queued lane's world-space ray origin
+    const f3 oro = ptd::mk(__shfl(ro.x, origin), __shfl(ro.y, origin), __shfl(ro.z, origin));
+    if (on) {
+        const f3 qo = ptd::mk(qf[0 * Q_SLOTS + s], qf[1 * Q_SLOTS + s], qf[2 * Q_SLOTS + s]);
+        const f3 qd = ptd::mk(qf[3 * Q_SLOTS + s], qf[4 * Q_SLOTS + s], qf[5 * Q_SLOTS + s]);
+        const float t_obj = qf[6 * Q_SLOTS + s];
+        const float *fwd = gf + (meta >> 10) * GF_WORDS;                  // per-lane gather of the transform
+        f3 obj_p;
+        const float t = ptd::world_distance(fwd, oro, qo, qd, t_obj, obj_p);
+        qf[0 * Q_SLOTS + s] = obj_p.x; qf[1 * Q_SLOTS + s] = obj_p.y; qf[2 * Q_SLOTS + s] = obj_p.z;
+        if (t > 0.0f)
+            __hip_atomic_fetch_min(&best[origin], ((unsigned long long)__float_as_uint(t) << 32) | abs_slot,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+#endif
+
 template <bool HAS_MESH>
 __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms, int ngeoms,
                                                 const float *__restrict__ tris, float *tri_lds, bool active,
-                                                f3 ro, f3 rd, ptd::Hit &h) {
+                                                f3 ro, f3 rd, ptd::Hit &h, float *wq = nullptr,
+                                                const float *gf = nullptr) {
     h.t = FLT_MAX; h.geom = -1; h.outside = 1; h.aux = ptd::mk(0, 0, 0);
     int outside = 1;                                    // shared across tests, pathtrace.cu:169
     (void)outside;
+#if PT_QUEUE
+    const int lane_q = threadIdx.x & 63;
+    float *qf = wq;
+    uint32_t *qi = reinterpret_cast<uint32_t *>(wq + 7 * Q_SLOTS);
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(wq + 8 * Q_SLOTS);
+    best[lane_q] = ~0ull;
+    unsigned long long seen = ~0ull;
+    uint32_t q_head = 0, q_total = 0;                   // wave-uniform
+    int w_geom = -1, w_meta = 0;
+    f3 w_objp = ptd::mk(0, 0, 0);
+    // after a pass: lanes whose best key changed latch the winner's record while it is still intact
+    auto latch = [&]() {
+        const unsigned long long key = best[lane_q];
+        if (key != seen) {
+            seen = key;
+            const uint32_t s = (uint32_t)key & (Q_SLOTS - 1);
+            w_meta = (int)qi[s];
+            w_geom = w_meta >> 10;
+            w_objp = ptd::mk(qf[0 * Q_SLOTS + s], qf[1 * Q_SLOTS + s], qf[2 * Q_SLOTS + s]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+#endif
 #if PT_DEFER
     ptd::Candidate pend;
     pend.geom = -1; pend.outside = 1; pend.t_obj = 0.0f;
@@ -294,6 +372,37 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
             }
             continue;
         }
+#if PT_QUEUE
+        {   // object-space test per lane; hits are queued and their tails run lane-dense (queue_pass)
+            f3 qo = ptd::mk(0, 0, 0), qd = ptd::mk(0, 0, 1);
+            float t_obj = 0.0f;
+            int code = 7, cand_outside = 1;
+            bool hit = false;
+            if (active) {
+                if (type == PT_CUBE) hit = ptd::box_slab(rec, ro, rd, qo, qd, t_obj, code, cand_outside);
+                else if (type == PT_SPHERE) hit = ptd::sphere_quad(rec, ro, rd, qo, qd, t_obj, cand_outside);
+            }
+            const uint64_t m = __ballot(hit);
+            if (m) {
+                if (hit) {
+                    const uint32_t s = (q_total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane_q) - 1)))) &
+                                       (Q_SLOTS - 1);
+                    qf[0 * Q_SLOTS + s] = qo.x; qf[1 * Q_SLOTS + s] = qo.y; qf[2 * Q_SLOTS + s] = qo.z;
+                    qf[3 * Q_SLOTS + s] = qd.x; qf[4 * Q_SLOTS + s] = qd.y; qf[5 * Q_SLOTS + s] = qd.z;
+                    qf[6 * Q_SLOTS + s] = t_obj;
+                    qi[s] = (uint32_t)lane_q | ((uint32_t)cand_outside << 6) | ((uint32_t)code << 7) | ((uint32_t)g << 10);
+                }
+                q_total += (uint32_t)__popcll((unsigned long long)m);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (q_total - q_head >= 64) {            // a full wave of tails is waiting
+                    queue_pass(wq, gf, q_head, 64, ro);
+                    q_head += 64;
+                    latch();
+                }
+            }
+            continue;
+        }
+#endif
 #if !PT_DEFER
         {   // monolithic reference-shaped tests (object-space test + world-distance tail in one body)
             float t = -1.0f;
@@ -327,6 +436,21 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
     }
 #if PT_DEFER
     if (__ballot(pend.geom >= 0)) flush();
+#endif
+#if PT_QUEUE
+    if (q_total > q_head) {
+        queue_pass(wq, gf, q_head, q_total - q_head, ro);
+        latch();
+    }
+    if (w_geom >= 0) {
+        const unsigned long long key = seen;
+        const float t = __uint_as_float((uint32_t)(key >> 32));
+        if (h.t > t || (h.t == t && w_geom < h.geom)) {      // meshes fold straight into h: keep geom order on ties
+            h.t = t; h.geom = w_geom; h.outside = (w_meta >> 6) & 1;
+            const int type = __float_as_int(gf[w_geom * GF_WORDS + 12]);
+            h.aux = (type == PT_CUBE) ? ptd::mk(__int_as_float((w_meta >> 7) & 7), 0.0f, 0.0f) : w_objp;
+        }
+    }
 #endif
 }
 
@@ -411,10 +535,14 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
                                                                     Control *ctl) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     float *mats_lds = lds_raw + LDS_CTL_WORDS;
-    float *tri_lds = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_GEOM_LDS * sc.ngeoms * ptd::GEOM_WORDS;
-#if PT_GEOM_LDS
+    const float *gf = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
+    float *wq = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
+    float *tri_lds = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + PT_QUEUE * WAVES * Q_WORDS;
+#if PT_GEOM_LDS || PT_QUEUE
     stage_scene(mats_lds, sc);
-    const float *gsrc = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
+#endif
+#if PT_GEOM_LDS
+    const float *gsrc = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * sc.ngeoms * GF_WORDS;
 #else
     const float *gsrc = sc.geoms;
 #endif
@@ -443,7 +571,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
             rd = ptd::mk(in.plane(3)[src], in.plane(4)[src], in.plane(5)[src]);
         }
         ptd::Hit h;
-        intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h);
+        intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h, wq, gf);
         if (have && i < n) {
             float t; f3 nrm; int mat;
             resolve_hit(gsrc, sc.tris, h, t, nrm, mat);
@@ -675,7 +803,9 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
     float *mats = lds_raw + LDS_CTL_WORDS;
-    float *tri_lds = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_GEOM_LDS * a.scene.ngeoms * ptd::GEOM_WORDS;
+    const float *gf = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
+    float *wq = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
+    float *tri_lds = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + PT_QUEUE * WAVES * Q_WORDS;
     stage_scene(mats, a.scene);
     const int lane = threadIdx.x & 63;
     const uint32_t W = gridDim.x * WAVES;
@@ -729,11 +859,11 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         if (MODE == MODE_FUSED) {
             ptd::Hit h;
 #if PT_GEOM_LDS
-            const float *gsrc = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
+            const float *gsrc = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * a.scene.ngeoms * GF_WORDS;
 #else
             const float *gsrc = a.scene.geoms;
 #endif
-            intersect_scene<HAS_MESH>(gsrc, a.scene.ngeoms, a.scene.tris, tri_lds, active, ro, rd, h);
+            intersect_scene<HAS_MESH>(gsrc, a.scene.ngeoms, a.scene.tris, tri_lds, active, ro, rd, h, wq, gf);
             if (active) { resolve_hit(gsrc, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
         } else if (active) {
             // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
@@ -808,10 +938,14 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache
                                                                       TileMap map) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     float *mats_lds = lds_raw + LDS_CTL_WORDS;
-    float *tri_lds = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_GEOM_LDS * sc.ngeoms * ptd::GEOM_WORDS;
-#if PT_GEOM_LDS
+    const float *gf = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
+    float *wq = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
+    float *tri_lds = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + PT_QUEUE * WAVES * Q_WORDS;
+#if PT_GEOM_LDS || PT_QUEUE
     stage_scene(mats_lds, sc);
-    const float *gsrc = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
+#endif
+#if PT_GEOM_LDS
+    const float *gsrc = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * sc.ngeoms * GF_WORDS;
 #else
     const float *gsrc = sc.geoms;
 #endif
@@ -823,7 +957,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache
         f3 ro = ptd::mk(cam.position.x, cam.position.y, cam.position.z), rd = ptd::mk(0, 0, 1);
         if (active) rd = camera_dir(cam, local_to_pixel(map, (int)j), map.W);
         ptd::Hit h;
-        intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h);
+        intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h, wq, gf);
         if (active) {
             float t; f3 nrm; int mat;
             resolve_hit(gsrc, sc.tris, h, t, nrm, mat);
@@ -1388,8 +1522,8 @@ static int init_impl(const pt_scene_desc *d) {
     R.scene.tris = R.d_tris; R.scene.ntris = d->num_triangles;
     R.has_mesh = false;
     for (int i = 0; i < d->num_geoms; ++i) R.has_mesh |= d->geoms[i].type == PT_TRIANGLE_MESH;
-    R.lds_bytes = ((size_t)LDS_CTL_WORDS + (((size_t)d->num_materials * ptd::MAT_WORDS + 3) & ~(size_t)3) +
-                   (size_t)PT_GEOM_LDS * d->num_geoms * ptd::GEOM_WORDS) * 4;
+    R.lds_bytes = ((size_t)LDS_CTL_WORDS + (size_t)scene_lds_words(d->num_materials, d->num_geoms) +
+                   (size_t)PT_QUEUE * WAVES * Q_WORDS) * 4;
     R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
     if (const char *pad = getenv("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
     if (R.has_mesh) R.lds_bytes += (size_t)TRI_TILE * 9 * 4;
