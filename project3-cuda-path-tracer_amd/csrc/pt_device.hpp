@@ -164,82 +164,6 @@ struct Hit {
                     // mesh: (bits of) the winning triangle index in aux.x
 };
 
-// A primitive whose object-space test succeeded but whose world-space distance has not been
-// evaluated yet.  Both reference tests end the same way -- objP = getPointOnRay(q, t_obj);
-// worldP = transform * objP; t = length(r.origin - worldP) (intersections.h:85-87,136-143) --
-// so that tail is shared and, because incoherent waves have different lanes hitting different
-// primitives, run once per *pending slot* instead of once per primitive (intersect_scene).
-struct Candidate {
-    f3 qo, qd;      // object-space ray (qd normalised)
-    float t_obj;    // object-space parameter chosen by the test
-    f3 face_n;      // cube only: tmin_n
-    int geom;       // -1 = empty
-    int outside;
-};
-
-// boxIntersectionTest, object-space part (intersections.h:48-84)
-template <typename P> PTD bool box_candidate(P g, f3 ro, f3 rd, Candidate &c) {
-    f3 qo = mv_point(g + G_INV, ro);
-    f3 qd = normalize(mv_dir(g + G_INV, rd));
-    float tmin = -1e38f, tmax = 1e38f;
-    f3 tmin_n = mk(0, 0, 0), tmax_n = mk(0, 0, 0);
-#define PTD_SLAB(QO, QD, NX, NY, NZ)                                      \
-    {                                                                     \
-        float t1 = (-0.5f - (QO)) / (QD);                                 \
-        float t2 = (+0.5f - (QO)) / (QD);                                 \
-        float ta = t1 < t2 ? t1 : t2;                                     \
-        float tb = t1 > t2 ? t1 : t2;                                     \
-        float sgn = t2 < t1 ? 1.0f : -1.0f;                               \
-        if (ta > 0 && ta > tmin) { tmin = ta; tmin_n = mk(NX, NY, NZ); }  \
-        if (tb < tmax) { tmax = tb; tmax_n = mk(NX, NY, NZ); }            \
-    }
-    PTD_SLAB(qo.x, qd.x, sgn, 0.0f, 0.0f)
-    PTD_SLAB(qo.y, qd.y, 0.0f, sgn, 0.0f)
-    PTD_SLAB(qo.z, qd.z, 0.0f, 0.0f, sgn)
-#undef PTD_SLAB
-    if (tmax >= tmin && tmax > 0) {
-        c.outside = 1;
-        if (tmin <= 0) { tmin = tmax; tmin_n = tmax_n; c.outside = 0; }
-        c.qo = qo; c.qd = qd; c.t_obj = tmin;
-        c.face_n = mk(__int_as_float((tmin_n.x != 0.0f ? 0 : tmin_n.y != 0.0f ? 2 : tmin_n.z != 0.0f ? 4 : 6) +
-                                      ((tmin_n.x + tmin_n.y + tmin_n.z) > 0.0f ? 1 : (tmin_n.x == 0.0f && tmin_n.y == 0.0f && tmin_n.z == 0.0f ? 1 : 0))), 0.0f, 0.0f);
-        return true;
-    }
-    return false;
-}
-
-// sphereIntersectionTest, object-space part (intersections.h:102-134)
-template <typename P> PTD bool sphere_candidate(P g, f3 ro, f3 rd, Candidate &c) {
-    f3 o = mv_point(g + G_INV, ro);
-    f3 d = normalize(mv_dir(g + G_INV, rd));
-    float vDotDirection = dot(o, d);
-    float radicand = vDotDirection * vDotDirection - (dot(o, o) - (0.5f * 0.5f));
-    if (radicand < 0) return false;
-    float squareRoot = __builtin_sqrtf(radicand);
-    float firstTerm = -vDotDirection;
-    float t1 = firstTerm + squareRoot;
-    float t2 = firstTerm - squareRoot;
-    float t;
-    if (t1 < 0 && t2 < 0) {
-        return false;
-    } else if (t1 > 0 && t2 > 0) {
-        t = (t2 < t1) ? t2 : t1;      // std::min(t1, t2)
-        c.outside = 1;
-    } else {
-        t = (t1 < t2) ? t2 : t1;      // std::max(t1, t2)
-        c.outside = 0;
-    }
-    c.qo = o; c.qd = d; c.t_obj = t; c.face_n = mk(0, 0, 0);
-    return true;
-}
-
-// shared tail of both tests: world distance of a candidate; objP is returned for the sphere normal
-template <typename P> PTD float candidate_distance(P g, f3 ro, const Candidate &c, f3 &obj_p) {
-    obj_p = point_on_ray(c.qo, c.qd, c.t_obj);
-    f3 p = mv_point(g + G_FWD, obj_p);
-    return length(sub(ro, p));
-}
-
 // boxIntersectionTest (intersections.h:48-90) without the normal (deferred).  The candidate face
 // normals tmin_n / tmax_n are carried as a 3-bit code (axis*2 + (sign>0), 7 = the zero vector
 // glm's default constructor leaves when no slab updates them) instead of three floats: one

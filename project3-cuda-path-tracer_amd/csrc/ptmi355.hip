@@ -62,9 +62,6 @@ namespace {
 #ifndef PT_QUEUE
 #define PT_QUEUE 1                         // evaluate the world-distance tails lane-dense from a per-wave LDS queue
 #endif
-#ifndef PT_DEFER
-#define PT_DEFER 0                         // share the world-distance tail of the box/sphere tests across geoms
-#endif
 constexpr int BLOCK = 256;                 // 4 waves of 64
 constexpr int WAVES = BLOCK / 64;
 constexpr int TILE = 64;                   // paths per tile = one wave64
@@ -311,23 +308,6 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
 #endif
-#if PT_DEFER
-    ptd::Candidate pend;
-    pend.geom = -1; pend.outside = 1; pend.t_obj = 0.0f;
-    pend.qo = ptd::mk(0, 0, 0); pend.qd = ptd::mk(0, 0, 1); pend.face_n = ptd::mk(0, 0, 0);
-    auto flush = [&]() {
-        if (pend.geom >= 0) {
-            const float *rec = geoms + pend.geom * ptd::GEOM_WORDS;    // per-lane record (cached gather)
-            f3 obj_p;
-            const float t = ptd::candidate_distance(rec, ro, pend, obj_p);
-            if (t > 0.0f && h.t > t) {
-                h.t = t; h.geom = pend.geom; h.outside = pend.outside;
-                h.aux = (__float_as_int(rec[0]) == PT_CUBE) ? pend.face_n : obj_p;
-            }
-            pend.geom = -1;
-        }
-    };
-#endif
     for (int g = 0; g < ngeoms; ++g) {
 #if PT_GEOM_LDS
         const float *rec = geoms + g * ptd::GEOM_WORDS;                // LDS broadcast
@@ -337,9 +317,6 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
         const int type = __float_as_int(rec[0]);
 #endif
         if (HAS_MESH && type == PT_TRIANGLE_MESH) {
-#if PT_DEFER
-            if (__ballot(pend.geom >= 0)) flush();          // keep geom order
-#endif
             // completion spec 8.0: nearest triangle by strictly smaller bary.z, first wins ties
             const int first = __float_as_int(rec[2]);
             const int count = __float_as_int(rec[3]);
@@ -403,7 +380,6 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
             continue;
         }
 #endif
-#if !PT_DEFER
         {   // monolithic reference-shaped tests (object-space test + world-distance tail in one body)
             float t = -1.0f;
             f3 aux = ptd::mk(0, 0, 0);
@@ -414,29 +390,7 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
             }
             continue;
         }
-#endif
-        if (!active) continue;
-        ptd::Candidate c;
-        bool hit = false;
-        if (type == PT_CUBE) hit = ptd::box_candidate(rec, ro, rd, c);
-        else if (type == PT_SPHERE) hit = ptd::sphere_candidate(rec, ro, rd, c);
-#if PT_DEFER
-        if (__ballot(hit && pend.geom >= 0)) flush();
-        if (hit) { pend = c; pend.geom = g; }
-#else
-        if (hit) {
-            f3 obj_p;
-            const float t = ptd::candidate_distance(rec, ro, c, obj_p);
-            if (t > 0.0f && h.t > t) {                  // pathtrace.cu:192 (first geom wins ties)
-                h.t = t; h.geom = g; h.outside = c.outside;
-                h.aux = (type == PT_CUBE) ? c.face_n : obj_p;
-            }
-        }
-#endif
     }
-#if PT_DEFER
-    if (__ballot(pend.geom >= 0)) flush();
-#endif
 #if PT_QUEUE
     if (q_total > q_head) {
         queue_pass(wq, gf, q_head, q_total - q_head, ro);
