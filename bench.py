@@ -61,6 +61,10 @@ def main():
                     help="gloo + --same-device exercises the N>1 code path on a single GPU (debug)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--digest", action="store_true", help="add the md5 of the (reduced) accumulation image")
+    ap.add_argument("--pcie", action="store_true",
+                    help="also time the reference's own calling pattern: one pathtrace() per iteration with the "
+                         "running sum copied to host memory every call (pathtrace.cu:389-390); reported as "
+                         "config.pcie_inclusive_mrays_per_s, never as value")
     args = ap.parse_args()
 
     import torch
@@ -183,6 +187,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(scene)
 
+    pcie = None
+    if args.pcie and world == 1:
+        host = np.zeros((npix, 3), dtype=np.float32)
+        r0 = pt.total_rays()
+        t1 = time.perf_counter()
+        n_it = 64
+        for k in range(n_it):
+            pt.library().pt_trace(None, 0, 1 + k, host.ctypes.data)          # synchronous, D2H of W*H*12 B per call
+        el = time.perf_counter() - t1
+        pcie = round((pt.total_rays() - r0) / el / 1e6, 2)
     digest = None
     if args.digest:
         import hashlib
@@ -212,6 +226,8 @@ def main():
         }
         if digest:
             out["image_md5"] = digest
+        if pcie:
+            out["config"]["pcie_inclusive_mrays_per_s"] = pcie
         if roofline:
             out["roofline"] = roofline
         if cpu:

@@ -384,3 +384,25 @@ def test_first_bounce_cache_follows_camera(pt, po, scenes):
     ref2.iterate(6)
     assert got.tobytes() == ref2.image.tobytes()
     pt.pathtraceFree()
+
+
+def test_c5_tile_of_4k_frame(pt, po, scenes):
+    """Config C5's sharding at full size: rank 3 of 8 at 3840x2160 (interleaved 8-row strips); its pixels
+    must equal the same pixels of the oracle's whole-frame iteration (global pixelIndex keys the RNG)."""
+    import os
+    s = scenes["cornell_4k"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    W, H = scene.resolution
+    assert (W, H) == (3840, 2160)
+    pt.pathtraceInit(scene, tile=(3, 8, 8))
+    img = pt.pathtrace(None, 0, 1).copy()
+    gs = pt.get_stats()
+    pt.pathtraceFree()
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
+    ref.iterate(1, threads=min(64, os.cpu_count() or 8))
+    own = pt.sharding.tile_pixel_indices(3, 8, 8, W, H)
+    assert len(own) == gs.live[0] == W * H // 8
+    assert img[own].tobytes() == ref.image[own].tobytes()
+    other = np.ones(W * H, dtype=bool)
+    other[own] = False
+    assert not img[other].any()                           # zero-padded elsewhere: reduce(SUM) is exact
