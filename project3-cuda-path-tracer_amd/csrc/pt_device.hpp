@@ -259,13 +259,23 @@ template <typename P> PTD f3 sphere_normal(P g, f3 obj_p, int outside) {
 
 // glm::intersectRayTriangle (gtx/intersect.inl:37-74) on (v0, e1 = v1-v0, e2 = v2-v0);
 // returns true and bary.z in tz on a hit.
+//
+// The reference divides first (f = 1/a) and then rejects on bary.x = f*dot(s,p) outside [0,1].
+// Almost every (ray, triangle) pair is rejected there, so the divide is skipped whenever the
+// outcome of that test is certain from dot(s,p) and a alone:
+//   * sp < -(a*1e-30)      =>  f*sp is negative and cannot round to -0   =>  bary.x < 0
+//   * sp >  a*(1 + 2^-20)  =>  f*sp > 1 after both roundings (2^-24 each) =>  bary.x > 1
+// (only for a < 1e30, where f is a normal number).  Anything else -- including every NaN -- takes
+// the exact path below, so the result is identical to the straight transcription in every case.
 PTD bool ray_triangle(f3 orig, f3 dir, f3 v0, f3 e1, f3 e2, float &tz) {
     f3 p = cross(dir, e2);
     float a = dot(e1, p);
     if (a < 1.1920928955078125e-07f) return false;
-    float f = 1.0f / a;
     f3 s = sub(orig, v0);
-    float bx = f * dot(s, p);
+    float sp = dot(s, p);
+    if (a < 1e30f && (sp < -(a * 1e-30f) || sp > a * 1.00000095367431640625f)) return false;
+    float f = 1.0f / a;
+    float bx = f * sp;
     if (bx < 0.0f) return false;
     if (bx > 1.0f) return false;
     f3 q = cross(s, e1);

@@ -65,7 +65,8 @@ namespace {
 constexpr int BLOCK = 256;                 // 4 waves of 64
 constexpr int WAVES = BLOCK / 64;
 constexpr int TILE = 64;                   // paths per tile = one wave64
-constexpr int TRI_TILE = 1024;             // triangles staged in LDS per pass (36 KiB)
+constexpr int TRI_TILE = 512;              // triangles staged in LDS per pass (24 KiB)
+constexpr int TRI_WORDS = 12;              // v0 e1 e2 + 3 pad: three 16-B words per triangle
 constexpr int MAX_DEPTH = 64;
 constexpr uint32_t DEAD_PID = 0xffffffffu;
 
@@ -140,7 +141,7 @@ struct Persist {         // survives the per-batch memset
 struct SceneDev {
     const float *geoms;  int ngeoms;       // GEOM_WORDS dwords each
     const float *mats;   int nmats;        // MAT_WORDS dwords each
-    const float *tris;   int ntris;        // v0, e1, e2 (9 dwords each)
+    const float *tris;   int ntris;        // v0, e1, e2 + pad (12 dwords each)
 };
 
 struct BounceArgs {
@@ -324,17 +325,31 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
             int best_i = -1;
             for (int base = 0; base < count; base += TRI_TILE) {
                 const int nt = min(TRI_TILE, count - base);
+                const int nt4 = (nt + 3) & ~3;                   // the tile is zero-padded to a multiple of 4
                 __syncthreads();
-                const float *src = tris + (size_t)(first + base) * 9;
-                for (int k = threadIdx.x; k < nt * 9; k += BLOCK) tri_lds[k] = src[k];
+                {   // global -> LDS, 16 B per thread per step; zero triangles (a = 0 < eps: never hit) as padding
+                    const float4 *src = reinterpret_cast<const float4 *>(tris + (size_t)(first + base) * TRI_WORDS);
+                    float4 *dst = reinterpret_cast<float4 *>(tri_lds);
+                    for (int k = threadIdx.x; k < nt4 * 3; k += BLOCK)
+                        dst[k] = k < nt * 3 ? src[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
                 __syncthreads();
                 if (active) {
-                    for (int k = 0; k < nt; ++k) {
-                        const float *tv = tri_lds + k * 9;
-                        float tz;
-                        if (ptd::ray_triangle(ro, rd, ptd::mk(tv[0], tv[1], tv[2]), ptd::mk(tv[3], tv[4], tv[5]),
-                                              ptd::mk(tv[6], tv[7], tv[8]), tz)) {
-                            if (tz > 0.0f && best > tz) { best = tz; best_i = first + base + k; }
+                    // four triangles per step: their twelve ds_read_b128 (wave-uniform addresses, LDS
+                    // broadcasts) are issued together so the LDS latency is paid once per four tests
+                    const float4 *tl = reinterpret_cast<const float4 *>(tri_lds);
+                    for (int k = 0; k < nt4; k += 4) {
+                        float4 w[12];
+#pragma unroll
+                        for (int j = 0; j < 12; ++j) w[j] = tl[k * 3 + j];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float4 A = w[3 * j], B = w[3 * j + 1], C = w[3 * j + 2];
+                            float tz;
+                            if (ptd::ray_triangle(ro, rd, ptd::mk(A.x, A.y, A.z), ptd::mk(A.w, B.x, B.y),
+                                                  ptd::mk(B.z, B.w, C.x), tz)) {
+                                if (tz > 0.0f && best > tz) { best = tz; best_i = first + base + k + j; }
+                            }
                         }
                     }
                 }
@@ -420,7 +435,7 @@ __device__ __forceinline__ void resolve_hit(const float *__restrict__ geoms, con
     if (type == PT_CUBE) n = ptd::cube_normal(rec, h.aux);
     else if (type == PT_SPHERE) n = ptd::sphere_normal(rec, h.aux, h.outside);
     else {
-        const float *tv = tris + (size_t)__float_as_int(h.aux.x) * 9;
+        const float *tv = tris + (size_t)__float_as_int(h.aux.x) * TRI_WORDS;
         n = ptd::normalize(ptd::cross(ptd::mk(tv[3], tv[4], tv[5]), ptd::mk(tv[6], tv[7], tv[8])));
     }
 }
@@ -1456,10 +1471,10 @@ static int init_impl(const pt_scene_desc *d) {
         r[3] = m.specular.color.x; r[4] = m.specular.color.y; r[5] = m.specular.color.z;
         r[6] = m.hasReflective; r[7] = m.hasRefractive; r[8] = m.indexOfRefraction; r[9] = m.emittance;
     }
-    std::vector<float> trec((size_t)std::max(1, d->num_triangles) * 9, 0.0f);
+    std::vector<float> trec((size_t)std::max(1, d->num_triangles) * TRI_WORDS, 0.0f);
     for (int i = 0; i < d->num_triangles; ++i) {
         const pt_triangle &t = d->triangles[i];
-        float *r = trec.data() + (size_t)i * 9;
+        float *r = trec.data() + (size_t)i * TRI_WORDS;
         r[0] = t.v0.x; r[1] = t.v0.y; r[2] = t.v0.z;
         // e1 = v1 - v0, e2 = v2 - v0: the first two statements of glm::intersectRayTriangle, hoisted
         r[3] = t.v1.x - t.v0.x; r[4] = t.v1.y - t.v0.y; r[5] = t.v1.z - t.v0.z;
@@ -1480,7 +1495,7 @@ static int init_impl(const pt_scene_desc *d) {
                    (size_t)PT_QUEUE * WAVES * Q_WORDS) * 4;
     R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
     if (const char *pad = getenv("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
-    if (R.has_mesh) R.lds_bytes += (size_t)TRI_TILE * 9 * 4;
+    if (R.has_mesh) R.lds_bytes += (size_t)TRI_TILE * TRI_WORDS * 4;
     if (R.lds_bytes > 60 * 1024) return fail(PT_ERR_INVALID, "pt_init: material records need %zu B of LDS (> 60 KiB)", R.lds_bytes);
 
     // pools, intersections, final colours, image, control
