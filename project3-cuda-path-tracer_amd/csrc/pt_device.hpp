@@ -174,26 +174,79 @@ PTD f3 face_from_code(int code) {
     return mk(axis == 0 ? s : 0.0f, axis == 1 ? s : 0.0f, axis == 2 ? s : 0.0f);   // code 7 -> (0,0,0)
 }
 
+// ---- correctly rounded divides that share one reciprocal ---------------------------------
+// hipcc expands `n / d` into v_div_scale x2, v_rcp, a Newton step on the reciprocal, a quotient
+// with two residual corrections (v_div_fmas last) and v_div_fixup: 11 instructions.  When neither
+// operand needs v_div_scale's rescaling and the quotient is a normal number, the two scales are
+// identities, v_div_fmas is a plain fma and v_div_fixup returns its input, so the same value comes
+// out of the 8 instructions below -- and the 3 that refine the reciprocal are shared by every
+// divide with the same denominator (the slab test divides twice by each direction component).
+// No-rescale conditions (ISA, v_div_scale_f32): d normal, 1/d normal, |exp(n) - exp(d)| < 96,
+// n/d normal, biased exp(n) > 23; they hold for 2^-40 <= |d| <= 2^40 and (n == +0 or
+// 2^-25 <= |n| < 2^55).  slab_fast_ok() establishes that per wave; otherwise the plain `/` runs.
+PTD float rcp_refined(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+PTD float div_by_rcp(float n, float d, float r) {
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+#ifndef PT_FASTDIV
+#define PT_FASTDIV 1
+#endif
+// every lane of the wave: direction components in [2^-40, 2^40] and |origin components| < 2^54.
+// The numerators are (+-0.5 - qo): exactly +0, or at least half an ulp of 0.5 (2^-25) -- never tiny,
+// never -0 -- and below 2^55.  NaNs fail the ordered compares.
+PTD bool slab_fast_ok(f3 qo, f3 qd) {
+#if PT_FASTDIV
+    const float dmin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(qd.x), __builtin_fabsf(qd.y)), __builtin_fabsf(qd.z));
+    const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(qd.x), __builtin_fabsf(qd.y)), __builtin_fabsf(qd.z));
+    const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(qo.x), __builtin_fabsf(qo.y)), __builtin_fabsf(qo.z));
+    // fmin/fmax drop NaNs, so test the NaNs explicitly through self-comparison of the sums
+    const bool finite = (qd.x + qd.y + qd.z) == (qd.x + qd.y + qd.z) && (qo.x + qo.y + qo.z) == (qo.x + qo.y + qo.z);
+    const bool ok = finite && dmin >= 9.094947017729282e-13f && dmax <= 1.099511627776e12f && omax < 1.8014398509481984e16f;
+    return __all(ok);
+#else
+    (void)qo; (void)qd;
+    return false;
+#endif
+}
+
 // object-space part of boxIntersectionTest (intersections.h:48-84): true when the slab test passes;
 // qo/qd = object-space ray, t_obj = the parameter the test settles on, code = face normal code.
 template <typename P> PTD bool box_slab(P g, f3 ro, f3 rd, f3 &qo, f3 &qd, float &t_obj, int &code_out, int &outside) {
     qo = mv_point(g + G_INV, ro);
     qd = normalize(mv_dir(g + G_INV, rd));
+    float t1x, t2x, t1y, t2y, t1z, t2z;
+    if (slab_fast_ok(qo, qd)) {                                           // wave-uniform
+        const float rx = rcp_refined(qd.x), ry = rcp_refined(qd.y), rz = rcp_refined(qd.z);
+        t1x = div_by_rcp(-0.5f - qo.x, qd.x, rx); t2x = div_by_rcp(+0.5f - qo.x, qd.x, rx);
+        t1y = div_by_rcp(-0.5f - qo.y, qd.y, ry); t2y = div_by_rcp(+0.5f - qo.y, qd.y, ry);
+        t1z = div_by_rcp(-0.5f - qo.z, qd.z, rz); t2z = div_by_rcp(+0.5f - qo.z, qd.z, rz);
+    } else {
+        t1x = (-0.5f - qo.x) / qd.x; t2x = (+0.5f - qo.x) / qd.x;
+        t1y = (-0.5f - qo.y) / qd.y; t2y = (+0.5f - qo.y) / qd.y;
+        t1z = (-0.5f - qo.z) / qd.z; t2z = (+0.5f - qo.z) / qd.z;
+    }
     float tmin = -1e38f, tmax = 1e38f;
     int tmin_c = 7, tmax_c = 7;
-#define PTD_SLAB(QO, QD, AXIS)                                            \
+#define PTD_SLAB(T1, T2, AXIS)                                            \
     {                                                                     \
-        float t1 = (-0.5f - (QO)) / (QD);                                 \
-        float t2 = (+0.5f - (QO)) / (QD);                                 \
+        float t1 = (T1), t2 = (T2);                                       \
         float ta = t1 < t2 ? t1 : t2;                                     \
         float tb = t1 > t2 ? t1 : t2;                                     \
         int code = (AXIS) * 2 + (t2 < t1 ? 1 : 0);                        \
         if (ta > 0 && ta > tmin) { tmin = ta; tmin_c = code; }            \
         if (tb < tmax) { tmax = tb; tmax_c = code; }                      \
     }
-    PTD_SLAB(qo.x, qd.x, 0)
-    PTD_SLAB(qo.y, qd.y, 1)
-    PTD_SLAB(qo.z, qd.z, 2)
+    PTD_SLAB(t1x, t2x, 0)
+    PTD_SLAB(t1y, t2y, 1)
+    PTD_SLAB(t1z, t2z, 2)
 #undef PTD_SLAB
     if (tmax >= tmin && tmax > 0) {
         outside = 1;
