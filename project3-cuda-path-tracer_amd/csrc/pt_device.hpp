@@ -174,6 +174,9 @@ PTD f3 face_from_code(int code) {
     return mk(axis == 0 ? s : 0.0f, axis == 1 ? s : 0.0f, axis == 2 ? s : 0.0f);   // code 7 -> (0,0,0)
 }
 
+#ifndef PT_FASTDIV
+#define PT_FASTDIV 1
+#endif
 // ---- correctly rounded divides that share one reciprocal ---------------------------------
 // hipcc expands `n / d` into v_div_scale x2, v_rcp, a Newton step on the reciprocal, a quotient
 // with two residual corrections (v_div_fmas last) and v_div_fixup: 11 instructions.  When neither
@@ -196,23 +199,50 @@ PTD float div_by_rcp(float n, float d, float r) {
     e = __builtin_fmaf(-d, q, n);
     return __builtin_fmaf(e, r, q);
 }
-#ifndef PT_FASTDIV
-#define PT_FASTDIV 1
-#endif
-// every lane of the wave: direction components in [2^-40, 2^40] and |origin components| < 2^54.
-// The numerators are (+-0.5 - qo): exactly +0, or at least half an ulp of 0.5 (2^-25) -- never tiny,
-// never -0 -- and below 2^55.  NaNs fail the ordered compares.
-PTD bool slab_fast_ok(f3 qo, f3 qd) {
+// Correctly rounded sqrt without hipcc's prescale / class fix-up (16 -> 9 instructions): v_sqrt_f32
+// (1 ulp) followed by the same two residual tests the compiler emits, picking s-1ulp, s or s+1ulp.
+// Valid for 2^-96 <= x < inf (below that the compiler's sequence rescales; 0 and inf take its
+// class path).
+PTD float sqrt_normal_range(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u);
+    const float sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float e1 = __builtin_fmaf(-sm, s, x);
+    const float e2 = __builtin_fmaf(-sp, s, x);
+    float r = (0.0f >= e1) ? sm : s;
+    r = (0.0f < e2) ? sp : r;
+    return r;
+}
+// wave-uniform gates for the two helpers below (NaN fails; inactive lanes do not vote)
+PTD bool all_in_range(float x, float lo, float hi) {
 #if PT_FASTDIV
-    const float dmin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(qd.x), __builtin_fabsf(qd.y)), __builtin_fabsf(qd.z));
-    const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(qd.x), __builtin_fabsf(qd.y)), __builtin_fabsf(qd.z));
+    return __all(x >= lo && x <= hi);
+#else
+    (void)x; (void)lo; (void)hi;
+    return false;
+#endif
+}
+// glm normalize, v * (1 / sqrt(dot)), for 2^-80 <= dot <= 2^80 (sqrt and divide both rescale-free)
+PTD f3 normalize_normal_range(f3 a, float dt) {
+    const float s = sqrt_normal_range(dt);
+    return scale(a, div_by_rcp(1.0f, s, rcp_refined(s)));
+}
+// Wave-uniform gate for the rescale-free paths of one cube test, evaluated BEFORE the direction is
+// normalised (the squares are the ones the dot product needs anyway): with v = M^-1 d, x = |v|^2,
+//   2^-80 <= x <= 2^80                    -> sqrt and 1/sqrt need no rescaling,
+//   min(v_k^2) >= 2^-78 x                  -> every normalised component is at least 2^-40 (and <= 1+),
+//   max|qo_k| < 2^54                       -> numerators (+-0.5 - qo) are +0 or in [2^-25, 2^55).
+// NaNs fail the ordered compares.  Inactive lanes do not vote.
+PTD bool cube_fast_ok(f3 qo, f3 v, float x) {
+#if PT_FASTDIV
+    const float sq_min = __builtin_fminf(__builtin_fminf(v.x * v.x, v.y * v.y), v.z * v.z);
     const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(qo.x), __builtin_fabsf(qo.y)), __builtin_fabsf(qo.z));
-    // fmin/fmax drop NaNs, so test the NaNs explicitly through self-comparison of the sums
-    const bool finite = (qd.x + qd.y + qd.z) == (qd.x + qd.y + qd.z) && (qo.x + qo.y + qo.z) == (qo.x + qo.y + qo.z);
-    const bool ok = finite && dmin >= 9.094947017729282e-13f && dmax <= 1.099511627776e12f && omax < 1.8014398509481984e16f;
+    const bool finite = (qo.x + qo.y + qo.z) == (qo.x + qo.y + qo.z);          // fmax drops NaNs
+    const bool ok = finite && x >= 8.271806125530277e-25f && x <= 1.2089258196146292e24f &&
+                    sq_min >= x * 3.308722450212111e-24f && omax < 1.8014398509481984e16f;
     return __all(ok);
 #else
-    (void)qo; (void)qd;
+    (void)qo; (void)v; (void)x;
     return false;
 #endif
 }
@@ -221,14 +251,17 @@ PTD bool slab_fast_ok(f3 qo, f3 qd) {
 // qo/qd = object-space ray, t_obj = the parameter the test settles on, code = face normal code.
 template <typename P> PTD bool box_slab(P g, f3 ro, f3 rd, f3 &qo, f3 &qd, float &t_obj, int &code_out, int &outside) {
     qo = mv_point(g + G_INV, ro);
-    qd = normalize(mv_dir(g + G_INV, rd));
+    const f3 v = mv_dir(g + G_INV, rd);
+    const float x = dot(v, v);
     float t1x, t2x, t1y, t2y, t1z, t2z;
-    if (slab_fast_ok(qo, qd)) {                                           // wave-uniform
+    if (cube_fast_ok(qo, v, x)) {                                         // wave-uniform
+        qd = normalize_normal_range(v, x);
         const float rx = rcp_refined(qd.x), ry = rcp_refined(qd.y), rz = rcp_refined(qd.z);
         t1x = div_by_rcp(-0.5f - qo.x, qd.x, rx); t2x = div_by_rcp(+0.5f - qo.x, qd.x, rx);
         t1y = div_by_rcp(-0.5f - qo.y, qd.y, ry); t2y = div_by_rcp(+0.5f - qo.y, qd.y, ry);
         t1z = div_by_rcp(-0.5f - qo.z, qd.z, rz); t2z = div_by_rcp(+0.5f - qo.z, qd.z, rz);
     } else {
+        qd = scale(v, 1.0f / __builtin_sqrtf(x));                         // glm normalize
         t1x = (-0.5f - qo.x) / qd.x; t2x = (+0.5f - qo.x) / qd.x;
         t1y = (-0.5f - qo.y) / qd.y; t2y = (+0.5f - qo.y) / qd.y;
         t1z = (-0.5f - qo.z) / qd.z; t2z = (+0.5f - qo.z) / qd.z;
@@ -257,11 +290,23 @@ template <typename P> PTD bool box_slab(P g, f3 ro, f3 rd, f3 &qo, f3 &qd, float
     return false;
 }
 
+// glm normalize / length with the wave-uniform rescale-free gate
+PTD f3 normalize_gated(f3 a) {
+    const float x = dot(a, a);
+    if (all_in_range(x, 8.271806125530277e-25f, 1.2089258196146292e24f)) return normalize_normal_range(a, x);
+    return scale(a, 1.0f / __builtin_sqrtf(x));
+}
+PTD float length_gated(f3 a) {
+    const float x = dot(a, a);
+    if (all_in_range(x, 1.2621774483536189e-29f, 3.0e38f)) return sqrt_normal_range(x);
+    return __builtin_sqrtf(x);
+}
+
 // shared tail of both tests (intersections.h:85-87,136-143): objP = getPointOnRay(q, t_obj);
 // worldP = transform * objP; t = length(r.origin - worldP).  `fwd` = 12 floats of the transform.
 template <typename P> PTD float world_distance(P fwd, f3 ro, f3 qo, f3 qd, float t_obj, f3 &obj_p) {
-    obj_p = point_on_ray(qo, qd, t_obj);
-    return length(sub(ro, mv_point(fwd, obj_p)));
+    obj_p = add(qo, scale(normalize_gated(qd), (t_obj - .0001f)));        // getPointOnRay
+    return length_gated(sub(ro, mv_point(fwd, obj_p)));
 }
 
 template <typename P> PTD float box_test(P g, f3 ro, f3 rd, f3 &face_n, int &outside) {
@@ -274,7 +319,7 @@ template <typename P> PTD float box_test(P g, f3 ro, f3 rd, f3 &face_n, int &out
 // object-space part of sphereIntersectionTest (intersections.h:102-134)
 template <typename P> PTD bool sphere_quad(P g, f3 ro, f3 rd, f3 &o, f3 &d, float &t_obj, int &outside) {
     o = mv_point(g + G_INV, ro);
-    d = normalize(mv_dir(g + G_INV, rd));
+    d = normalize_gated(mv_dir(g + G_INV, rd));
     float vDotDirection = dot(o, d);
     float radicand = vDotDirection * vDotDirection - (dot(o, o) - (0.5f * 0.5f));
     if (radicand < 0) return false;
