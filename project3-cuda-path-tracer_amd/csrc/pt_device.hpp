@@ -29,10 +29,14 @@ PTD f3 scale(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
 PTD f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
 // glm dot(vec3): (x*x' + y*y') + z*z'   (func_geometric.inl:64-72)
 PTD float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-// correctly rounded sqrt / divide: hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt)
-PTD float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
+// correctly rounded sqrt / divide (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt), through
+// the wave-gated rescale-free sequences defined further down when every lane is in their range
+PTD float length_gated(f3 a);
+PTD f3 normalize_gated(f3 a);
+PTD float sqrt_gated(float x);
+PTD float length(f3 a) { return length_gated(a); }
 // glm normalize: x * (1 / sqrt(dot(x,x)))   (func_geometric.inl:153-159)
-PTD f3 normalize(f3 a) { return scale(a, 1.0f / __builtin_sqrtf(dot(a, a))); }
+PTD f3 normalize(f3 a) { return normalize_gated(a); }
 PTD f3 cross(f3 x, f3 y) {
     return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
 }
@@ -112,8 +116,8 @@ PTD void sincos_shared(float x, float &s, float &c) {
 PTD f3 hemisphere(f3 normal, uint32_t &rng) {
     const float TWO_PI = 6.2831853071795864769252867665590057683943f;
     const float SQRT_OF_ONE_THIRD = 0.5773502691896257645091487805019574556476f;
-    float up = __builtin_sqrtf(u01(rng));
-    float over = __builtin_sqrtf(1 - up * up);
+    float up = sqrt_gated(u01(rng));
+    float over = sqrt_gated(1 - up * up);
     float around = u01(rng) * TWO_PI;
     f3 notN;
     if (__builtin_fabsf(normal.x) < SQRT_OF_ONE_THIRD) notN = mk(1, 0, 0);
@@ -296,11 +300,11 @@ PTD f3 normalize_gated(f3 a) {
     if (all_in_range(x, 8.271806125530277e-25f, 1.2089258196146292e24f)) return normalize_normal_range(a, x);
     return scale(a, 1.0f / __builtin_sqrtf(x));
 }
-PTD float length_gated(f3 a) {
-    const float x = dot(a, a);
+PTD float sqrt_gated(float x) {
     if (all_in_range(x, 1.2621774483536189e-29f, 3.0e38f)) return sqrt_normal_range(x);
     return __builtin_sqrtf(x);
 }
+PTD float length_gated(f3 a) { return sqrt_gated(dot(a, a)); }
 
 // shared tail of both tests (intersections.h:85-87,136-143): objP = getPointOnRay(q, t_obj);
 // worldP = transform * objP; t = length(r.origin - worldP).  `fwd` = 12 floats of the transform.
@@ -323,7 +327,7 @@ template <typename P> PTD bool sphere_quad(P g, f3 ro, f3 rd, f3 &o, f3 &d, floa
     float vDotDirection = dot(o, d);
     float radicand = vDotDirection * vDotDirection - (dot(o, o) - (0.5f * 0.5f));
     if (radicand < 0) return false;
-    float squareRoot = __builtin_sqrtf(radicand);
+    float squareRoot = sqrt_gated(radicand);
     float firstTerm = -vDotDirection;
     float t1 = firstTerm + squareRoot;
     float t2 = firstTerm - squareRoot;
@@ -429,7 +433,7 @@ PTD bool shade_scatter(PathState &ps, float t, f3 n, int matId, int outside, con
                 float u = u01(rng);
                 refl = u < R;
                 if (!refl) {
-                    ps.d = sub(scale(I, eta), scale(nn, (eta * dv + __builtin_sqrtf(k))));
+                    ps.d = sub(scale(I, eta), scale(nn, (eta * dv + sqrt_gated(k))));
                     ps.o = add(P, scale(I, 0.0002f));
                 }
             }

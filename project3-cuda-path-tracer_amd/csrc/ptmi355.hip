@@ -100,7 +100,17 @@ struct TileMap {         // local pixel index -> global pixelIndex (x + y*W)
     int W, H;
     int tile_index, tile_count, strip_rows;
     int tile_pixels;     // pixels owned by this tile
+    uint32_t div_magic;  // pid / tile_pixels without an integer divide (see sample_of)
+    uint32_t div_shift;
 };
+
+// pid / tile_pixels for every 32-bit pid: round-up magic number, branch-free form
+// (q = mulhi(magic, n); ((n - q) >> 1) + q) >> shift), magic/shift chosen by make_div_magic().
+__device__ __forceinline__ uint32_t sample_of(const TileMap &m, uint32_t pid) {
+    if (m.tile_pixels == 1) return pid;                  // the branch-free form needs a divisor >= 2
+    const uint32_t q = __umulhi(m.div_magic, pid);
+    return (((pid - q) >> 1) + q) >> m.div_shift;
+}
 
 struct Control {         // zeroed by one hipMemsetAsync per batch (1 KiB)
     uint32_t nlive[MAX_DEPTH + 1];  // nlive[d] = paths entering bounce d (compaction on)
@@ -814,7 +824,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         uint32_t smp = 0;
         int pixel = 0;
         if (active) {
-            smp = pid / (uint32_t)a.map.tile_pixels;
+            smp = sample_of(a.map, pid);
             pixel = local_to_pixel(a.map, (int)(pid - smp * (uint32_t)a.map.tile_pixels));
             if (a.gen_rays) {
                 ro = ptd::mk(a.cam.position.x, a.cam.position.y, a.cam.position.z);
@@ -942,7 +952,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const fl
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint32_t pid = p.pid()[i];
-    const uint32_t s = pid / (uint32_t)map.tile_pixels;
+    const uint32_t s = sample_of(map, pid);
     const int idx = local_to_pixel(map, (int)(pid - s * (uint32_t)map.tile_pixels));
     f3 c = ptd::mk(p.plane(6)[i], p.plane(7)[i], p.plane(8)[i]);
     const float t = is.plane(0)[i];
@@ -1028,7 +1038,7 @@ __global__ void k_export_paths(Pool p, TileMap map, uint32_t n_total, uint32_t n
     const uint32_t pid = p.pid()[src];
     if (pid == DEAD_PID) { s.pixelIndex = -1; s.remainingBounces = 0; }
     else {
-        const uint32_t sm = pid / (uint32_t)map.tile_pixels;
+        const uint32_t sm = sample_of(map, pid);
         s.pixelIndex = local_to_pixel(map, (int)(pid - sm * (uint32_t)map.tile_pixels));
         s.remainingBounces = i < n_live ? remaining : 0;
     }
@@ -1160,6 +1170,21 @@ struct StageTimer {                  // brackets one launch when profiling is on
 };
 
 Pool carve_pool(float *mem, uint32_t cap) { return Pool{mem, cap}; }
+
+// magic / shift for n / d, d >= 1, exact for all 32-bit n (checked on probes in pt_init)
+void make_div_magic(uint32_t d, uint32_t *magic, uint32_t *shift) {
+    if (d == 1) { *magic = 0; *shift = 0; return; }                     // handled separately in sample_of
+    uint32_t L = 31;
+    while (!((d >> L) & 1u)) --L;                                       // floor(log2 d)
+    if ((d & (d - 1)) == 0) { *magic = 0; *shift = L - 1; return; }     // power of two: (n >> 1) >> (L - 1)
+    const uint64_t num = 1ull << (32 + L);
+    uint64_t m = num / d, rem = num % d;
+    m += m;
+    const uint64_t twice = rem + rem;
+    if (twice >= d) m += 1;
+    *magic = (uint32_t)(m + 1);
+    *shift = L;
+}
 
 int tile_rows(int tile_index, int tile_count, int strip_rows, int H) {
     if (tile_count <= 1) return H;
@@ -1440,6 +1465,24 @@ static int init_impl(const pt_scene_desc *d) {
     R.map.strip_rows = tile_count > 1 ? d->strip_rows : H;
     R.map.tile_pixels = tile_rows(d->tile_index, tile_count, R.map.strip_rows, H) * W;
     if (R.map.tile_pixels <= 0) return fail(PT_ERR_INVALID, "pt_init: tile owns no rows");
+    make_div_magic((uint32_t)R.map.tile_pixels, &R.map.div_magic, &R.map.div_shift);
+    {   // the magic must reproduce n / tile_pixels exactly; probe the edges of every sample and the extremes
+        const uint32_t d = (uint32_t)R.map.tile_pixels;
+        auto fast = [&](uint32_t n) {
+            if (d == 1) return n;
+            const uint32_t q = (uint32_t)(((uint64_t)R.map.div_magic * n) >> 32);
+            return (((n - q) >> 1) + q) >> R.map.div_shift;
+        };
+        for (uint64_t k = 0; k <= 0xffffffffull / d && k < 4096; ++k)
+            for (int e = -1; e <= 1; ++e) {
+                const uint64_t n = k * d + (uint64_t)(int64_t)e;
+                if (n <= 0xffffffffull && fast((uint32_t)n) != (uint32_t)n / d)
+                    return fail(PT_ERR_INTERNAL, "pt_init: division magic failed for %u / %u", (uint32_t)n, d);
+            }
+        const uint32_t probes[] = {0u, 1u, d - 1, d, d + 1, 0x7fffffffu, 0x80000000u, 0xfffffffeu, 0xffffffffu};
+        for (uint32_t n : probes)
+            if (fast(n) != n / d) return fail(PT_ERR_INTERNAL, "pt_init: division magic failed for %u / %u", n, d);
+    }
     R.max_batch = d->max_batch < 1 ? 1 : d->max_batch;
     if ((int64_t)R.max_batch * R.map.tile_pixels >= (int64_t)0x3ffffff0)
         return fail(PT_ERR_INVALID, "pt_init: max_batch * tile pixels must stay below 2^30 (32-bit byte offsets into the planes)");
