@@ -82,12 +82,21 @@ __device__ __forceinline__ T &at(T *plane, uint32_t i) {
     return *reinterpret_cast<T *>(reinterpret_cast<char *>(plane) + (i << 2));
 }
 
-struct Pool {            // SoA planes of `cap` elements: ox oy oz dx dy dz cr cg cb pid
+// Path pool: SoA *per 64-path tile* -- tile T holds its ten planes (ox oy oz dx dy dz cr cg cb pid)
+// as ten consecutive 256-B rows, 2560 B per tile.  A wave reads/writes whole rows (coalesced),
+// and all ten fields of slot s sit at one per-lane address plus the immediates 0, 256, ... 2304:
+// one address computation per path instead of ten, and no plane base pointers in SGPRs.
+struct Pool {
     float *base;
-    uint32_t cap;
-    __device__ __forceinline__ float *plane(int k) const { return base + (size_t)k * cap; }
-    __device__ __forceinline__ uint32_t *pid() const { return reinterpret_cast<uint32_t *>(base + (size_t)9 * cap); }
+    uint32_t cap;        // slots, a multiple of 64
+    __device__ __forceinline__ char *slot(uint32_t s) const {
+        return reinterpret_cast<char *>(base) + (size_t)(s >> 6) * 2560u + ((s & 63u) << 2);
+    }
+    __device__ __forceinline__ float &f(uint32_t s, int k) const { return *reinterpret_cast<float *>(slot(s) + k * 256); }
+    __device__ __forceinline__ uint32_t &pid(uint32_t s) const { return *reinterpret_cast<uint32_t *>(slot(s) + 9 * 256); }
 };
+__device__ __forceinline__ float &pf(char *slot, int k) { return *reinterpret_cast<float *>(slot + k * 256); }
+__device__ __forceinline__ uint32_t &ppid(char *slot) { return *reinterpret_cast<uint32_t *>(slot + 9 * 256); }
 
 struct Isect {           // ShadeableIntersection planes t nx ny nz mat (unfused / sort / fake-shader modes)
     float *base;         // mat: bit 31 carries the winning test's !outside
@@ -202,10 +211,11 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, TileMap
     if (i >= total) return;
     uint32_t j = i % (uint32_t)map.tile_pixels;
     f3 d = camera_dir(cam, local_to_pixel(map, (int)j), map.W);
-    p.plane(0)[i] = cam.position.x; p.plane(1)[i] = cam.position.y; p.plane(2)[i] = cam.position.z;
-    p.plane(3)[i] = d.x; p.plane(4)[i] = d.y; p.plane(5)[i] = d.z;
-    p.plane(6)[i] = 1.0f; p.plane(7)[i] = 1.0f; p.plane(8)[i] = 1.0f;
-    p.pid()[i] = i;
+    char *q = p.slot(i);
+    pf(q, 0) = cam.position.x; pf(q, 1) = cam.position.y; pf(q, 2) = cam.position.z;
+    pf(q, 3) = d.x; pf(q, 4) = d.y; pf(q, 5) = d.z;
+    pf(q, 6) = 1.0f; pf(q, 7) = 1.0f; pf(q, 8) = 1.0f;
+    ppid(q) = i;
 }
 
 // ---------------------------------------------------------------------------
@@ -545,9 +555,10 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
         if (packed && have) src = resolve_src(dir_in, span, cur, i, active, ctl);
         f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
         if (active) {
-            if (in.pid()[src] == DEAD_PID) active = false;
-            ro = ptd::mk(in.plane(0)[src], in.plane(1)[src], in.plane(2)[src]);
-            rd = ptd::mk(in.plane(3)[src], in.plane(4)[src], in.plane(5)[src]);
+            char *q = in.slot(src);
+            if (ppid(q) == DEAD_PID) active = false;
+            ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
+            rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
         }
         ptd::Hit h;
         intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h, wq, gf);
@@ -759,9 +770,10 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
             rem &= ~m;
         }
         if (valid) {
+            char *qs = a.in.slot(src), *qd = a.out.slot(dst);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) a.out.plane(k)[dst] = a.in.plane(k)[src];
-            a.out.pid()[dst] = a.in.pid()[src];
+            for (int k = 0; k < 9; ++k) pf(qd, k) = pf(qs, k);
+            ppid(qd) = ppid(qs);
 #pragma unroll
             for (int k = 0; k < 4; ++k) a.isect_out.plane(k)[dst] = a.isect.plane(k)[i];
             a.isect_out.mat()[dst] = a.isect.mat()[i];
@@ -817,7 +829,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             if (a.gen_rays) {
                 pid = i;
             } else {
-                pid = at(a.in.pid(), src);
+                pid = a.in.pid(src);
                 if (pid == DEAD_PID) active = false;
             }
         }
@@ -830,8 +842,9 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
                 ro = ptd::mk(a.cam.position.x, a.cam.position.y, a.cam.position.z);
                 rd = camera_dir(a.cam, pixel, a.map.W);
             } else {
-                ro = ptd::mk(at(a.in.plane(0), src), at(a.in.plane(1), src), at(a.in.plane(2), src));
-                rd = ptd::mk(at(a.in.plane(3), src), at(a.in.plane(4), src), at(a.in.plane(5), src));
+                char *q = a.in.slot(src);
+                ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
+                rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
             }
         }
         float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
@@ -856,7 +869,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         ptd::PathState ps;
         ps.o = ro; ps.d = rd; ps.c = ptd::mk(1.0f, 1.0f, 1.0f);
         if (active) {
-            if (!a.gen_rays) ps.c = ptd::mk(at(a.in.plane(6), src), at(a.in.plane(7), src), at(a.in.plane(8), src));
+            if (!a.gen_rays) { char *q = a.in.slot(src); ps.c = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8)); }
             alive = ptd::shade_scatter(ps, t, nrm, mat, outside, mats, a.iter0 + (int)smp, pixel, a.depth,
                                        last_bounce);
             if (!alive) {
@@ -874,12 +887,13 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             packed += (uint32_t)__popcll((unsigned long long)bal);
         }
         if (alive) {
-            at(a.out.plane(0), dst) = ps.o.x; at(a.out.plane(1), dst) = ps.o.y; at(a.out.plane(2), dst) = ps.o.z;
-            at(a.out.plane(3), dst) = ps.d.x; at(a.out.plane(4), dst) = ps.d.y; at(a.out.plane(5), dst) = ps.d.z;
-            at(a.out.plane(6), dst) = ps.c.x; at(a.out.plane(7), dst) = ps.c.y; at(a.out.plane(8), dst) = ps.c.z;
-            at(a.out.pid(), dst) = pid;
+            char *q = a.out.slot(dst);
+            pf(q, 0) = ps.o.x; pf(q, 1) = ps.o.y; pf(q, 2) = ps.o.z;
+            pf(q, 3) = ps.d.x; pf(q, 4) = ps.d.y; pf(q, 5) = ps.d.z;
+            pf(q, 6) = ps.c.x; pf(q, 7) = ps.c.y; pf(q, 8) = ps.c.z;
+            ppid(q) = pid;
         } else if (!COMPACT && have && i < n) {
-            at(a.out.pid(), dst) = DEAD_PID;
+            a.out.pid(dst) = DEAD_PID;
         }
     }
     if (lane == 0 && traced) atomicAdd(&a.ctl->alive[a.depth], traced);
@@ -951,10 +965,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const fl
                                                       int iter0, uint32_t n, float *fin) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const uint32_t pid = p.pid()[i];
+    const uint32_t pid = p.pid(i);
     const uint32_t s = sample_of(map, pid);
     const int idx = local_to_pixel(map, (int)(pid - s * (uint32_t)map.tile_pixels));
-    f3 c = ptd::mk(p.plane(6)[i], p.plane(7)[i], p.plane(8)[i]);
+    f3 c = ptd::mk(p.f(i, 6), p.f(i, 7), p.f(i, 8));
     const float t = is.plane(0)[i];
     if (t > 0.0f) {
         uint32_t rng = ptd::seeded_engine(iter0 + (int)s, idx, 0);
@@ -973,7 +987,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const fl
     } else {
         c = ptd::mk(0.0f, 0.0f, 0.0f);
     }
-    p.plane(6)[i] = c.x; p.plane(7)[i] = c.y; p.plane(8)[i] = c.z;
+    p.f(i, 6) = c.x; p.f(i, 7) = c.y; p.f(i, 8) = c.z;
     fin[pid] = c.x; fin[(size_t)p.cap + pid] = c.y; fin[2 * (size_t)p.cap + pid] = c.z;
 }
 
@@ -1032,10 +1046,10 @@ __global__ void k_export_paths(Pool p, TileMap map, uint32_t n_total, uint32_t n
         src = lo * span + (i - base[lo]);
     }
     pt_path_segment s;
-    s.ray.origin = {p.plane(0)[src], p.plane(1)[src], p.plane(2)[src]};
-    s.ray.direction = {p.plane(3)[src], p.plane(4)[src], p.plane(5)[src]};
-    s.color = {p.plane(6)[src], p.plane(7)[src], p.plane(8)[src]};
-    const uint32_t pid = p.pid()[src];
+    s.ray.origin = {p.f(src, 0), p.f(src, 1), p.f(src, 2)};
+    s.ray.direction = {p.f(src, 3), p.f(src, 4), p.f(src, 5)};
+    s.color = {p.f(src, 6), p.f(src, 7), p.f(src, 8)};
+    const uint32_t pid = p.pid(src);
     if (pid == DEAD_PID) { s.pixelIndex = -1; s.remainingBounces = 0; }
     else {
         const uint32_t sm = sample_of(map, pid);
@@ -1049,10 +1063,10 @@ __global__ void k_import_paths(Pool p, const pt_path_segment *in, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const pt_path_segment s = in[i];
-    p.plane(0)[i] = s.ray.origin.x; p.plane(1)[i] = s.ray.origin.y; p.plane(2)[i] = s.ray.origin.z;
-    p.plane(3)[i] = s.ray.direction.x; p.plane(4)[i] = s.ray.direction.y; p.plane(5)[i] = s.ray.direction.z;
-    p.plane(6)[i] = s.color.x; p.plane(7)[i] = s.color.y; p.plane(8)[i] = s.color.z;
-    p.pid()[i] = i;
+    p.f(i, 0) = s.ray.origin.x; p.f(i, 1) = s.ray.origin.y; p.f(i, 2) = s.ray.origin.z;
+    p.f(i, 3) = s.ray.direction.x; p.f(i, 4) = s.ray.direction.y; p.f(i, 5) = s.ray.direction.z;
+    p.f(i, 6) = s.color.x; p.f(i, 7) = s.color.y; p.f(i, 8) = s.color.z;
+    p.pid(i) = i;
 }
 
 __global__ void k_export_isects(Isect is, uint32_t n, pt_shadeable_intersection *out, uint8_t *outside) {
@@ -1544,7 +1558,7 @@ static int init_impl(const pt_scene_desc *d) {
     // pools, intersections, final colours, image, control
     const size_t capz = R.cap;
     for (int k = 0; k < 2; ++k) {
-        HIPCHK(hipMalloc(&R.pool_mem[k], capz * 10 * 4));
+        HIPCHK(hipMalloc(&R.pool_mem[k], (((capz + 63) / 64) * 64) * 10 * 4));     // whole 64-path tiles
         R.pool[k] = carve_pool(R.pool_mem[k], R.cap);
     }
     HIPCHK(hipMalloc(&R.isect_mem, capz * 5 * 4));
