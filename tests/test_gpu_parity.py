@@ -406,3 +406,53 @@ def test_c5_tile_of_4k_frame(pt, po, scenes):
     other = np.ones(W * H, dtype=bool)
     other[own] = False
     assert not img[other].any()                           # zero-padded elsewhere: reduce(SUM) is exact
+
+
+def test_division_fast_path_gates(pt, po, scenes, golden):
+    """The rescale-free divide / sqrt sequences (csrc/pt_device.hpp: div_by_rcp, sqrt_normal_range) are
+    gated per wave; rays on both sides of every gate (direction components around 2^-40, origins around
+    2^54, exact zeros, denormals, huge magnitudes, NaN/inf) must still equal the oracle's IEEE results."""
+    rng = np.random.default_rng(2026)
+    s = scenes["cornell"]
+    geoms = np.concatenate([s["geoms"], golden["geomtests"]["extra_geoms"]])
+    geoms = geoms.copy()
+    geoms["materialid"] = np.minimum(geoms["materialid"], len(s["materials"]) - 1)
+    n = 1 << 16
+    o = rng.uniform(-6, 11, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    k = np.arange(n) % 16
+    # tiny direction components straddling the 2^-40 gate, and far smaller
+    m = (k == 1) | (k == 2)
+    d[m, rng.integers(0, 3, m.sum())] = rng.choice([-1, 1], m.sum()) * 2.0 ** rng.uniform(-44, -36, m.sum())
+    m = k == 3
+    d[m, rng.integers(0, 3, m.sum())] = rng.choice([-1, 1], m.sum()) * 2.0 ** rng.uniform(-140, -60, m.sum())
+    m = k == 4                                                   # exact zeros (axis-parallel)
+    d[m, rng.integers(0, 3, m.sum())] = 0.0
+    m = k == 5                                                   # un-normalised, enormous / minute directions
+    d[m] *= (10.0 ** rng.uniform(-30, 30, m.sum()))[:, None]
+    m = k == 6                                                   # origins around the 2^54 gate (object space is 1/scale larger)
+    o[m] = rng.normal(size=(m.sum(), 3)) * 2.0 ** rng.uniform(40, 60, m.sum())[:, None]
+    m = k == 7                                                   # origins exactly on cube faces (numerator == 0)
+    o[m, 1] = 0.005
+    m = k == 8
+    d[m, 0] = np.nan
+    m = k == 9
+    o[m, 2] = np.inf
+    paths = np.zeros(n, dtype=pt.PATH_DT)
+    paths["origin"], paths["direction"] = o.astype(np.float32), d.astype(np.float32)
+    paths["color"] = 1.0
+    paths["pixelIndex"] = np.arange(n)
+    paths["remainingBounces"] = 8
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene, max_batch=1)
+    # the pool holds 640000 slots: plenty for 65536 imported rays
+    got, got_out = pt.intersect_once(paths)
+    want, want_out = po.compute_intersections(paths.view(po.PATH_DT), geoms.view(po.GEOM_DT))
+    assert (bits(got["t"]) == bits(want["t"])).all()
+    hit = want["t"] > 0
+    assert hit.sum() > 10000
+    assert (bits(got["normal"][hit]) == bits(want["normal"][hit])).all()
+    assert (got["materialId"][hit] == want["materialId"][hit]).all()
+    assert (got_out[hit] == want_out[hit]).all()
+    pt.pathtraceFree()
