@@ -329,6 +329,9 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
 #endif
+#ifdef PT_GEOM_UNROLL
+#pragma unroll PT_GEOM_UNROLL
+#endif
     for (int g = 0; g < ngeoms; ++g) {
 #if PT_GEOM_LDS
         const float *rec = geoms + g * ptd::GEOM_WORDS;                // LDS broadcast
@@ -586,13 +589,20 @@ __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t 
     const uint32_t W = dir.W;
     const uint4 *count4 = reinterpret_cast<const uint4 *>(dir.count());
     uint4 *base4 = reinterpret_cast<uint4 *>(dir.base());
-    const uint32_t steps = (W + 4 * BLOCK - 1) / (4 * BLOCK);
+    const uint32_t steps = (W + 4 * BLOCK - 1) / (4 * BLOCK);       // <= 8 for W <= 8192
+    uint4 pre[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                                    // every load in flight before the first use
+        const uint32_t e = ((uint32_t)k * BLOCK + threadIdx.x) * 4;
+        pre[k] = (e < W) ? count4[e >> 2] : make_uint4(0, 0, 0, 0);
+    }
     uint32_t carry = 0;
-    for (uint32_t step = 0; step < steps; ++step) {
+#pragma unroll
+    for (uint32_t step = 0; step < 8; ++step) {
+        if (step >= steps) break;
         const uint32_t e = (step * BLOCK + threadIdx.x) * 4;          // first entry of this thread
-        uint4 v = make_uint4(0, 0, 0, 0);
+        uint4 v = pre[step];
         if (e < W) {
-            v = count4[e >> 2];
             if (e + 1 >= W) v.y = 0;
             if (e + 2 >= W) v.z = 0;
             if (e + 3 >= W) v.w = 0;
@@ -824,12 +834,17 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         uint32_t src = i;
         if (packed_in && have) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
         uint32_t pid = DEAD_PID;
-        f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
+        f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1), col = ptd::mk(1.0f, 1.0f, 1.0f);
         if (active) {
             if (a.gen_rays) {
                 pid = i;
             } else {
-                pid = a.in.pid(src);
+                // all ten fields of the slot in one burst of loads (one memory latency per tile)
+                char *q = a.in.slot(src);
+                pid = ppid(q);
+                ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
+                rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
+                col = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8));
                 if (pid == DEAD_PID) active = false;
             }
         }
@@ -841,10 +856,6 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             if (a.gen_rays) {
                 ro = ptd::mk(a.cam.position.x, a.cam.position.y, a.cam.position.z);
                 rd = camera_dir(a.cam, pixel, a.map.W);
-            } else {
-                char *q = a.in.slot(src);
-                ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
-                rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
             }
         }
         float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
@@ -867,9 +878,8 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         }
         bool alive = false;
         ptd::PathState ps;
-        ps.o = ro; ps.d = rd; ps.c = ptd::mk(1.0f, 1.0f, 1.0f);
+        ps.o = ro; ps.d = rd; ps.c = col;
         if (active) {
-            if (!a.gen_rays) { char *q = a.in.slot(src); ps.c = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8)); }
             alive = ptd::shade_scatter(ps, t, nrm, mat, outside, mats, a.iter0 + (int)smp, pixel, a.depth,
                                        last_bounce);
             if (!alive) {
