@@ -121,15 +121,37 @@ __device__ __forceinline__ uint32_t sample_of(const TileMap &m, uint32_t pid) {
     return (((pid - q) >> 1) + q) >> m.div_shift;
 }
 
-struct Control {         // zeroed by one hipMemsetAsync per batch (1 KiB)
+struct Control {         // zeroed by one hipMemsetAsync per batch (2 KiB)
+    unsigned long long stamp[16];   // -DPT_STAMPS: s_memrealtime at the phases of wave 0 / the last workgroup
     uint32_t nlive[MAX_DEPTH + 1];  // nlive[d] = paths entering bounce d (compaction on)
     uint32_t alive[MAX_DEPTH + 1];  // paths actually traced at bounce d
-    uint32_t done[MAX_DEPTH];       // workgroups that finished bounce d (last-one-out election)
+    uint32_t done[MAX_DEPTH];       // election buckets that finished bounce d (last-one-out election, top level)
     uint32_t done_sort[MAX_DEPTH];  // same for the material-sort histogram of bounce d
     uint32_t error;
-    uint32_t scan_ticks[MAX_DEPTH];  // 100 MHz ticks the last workgroup spent scanning (diagnostic)
-    uint32_t pad[61 - MAX_DEPTH + 64 - MAX_DEPTH + 64];
+    uint32_t scan_ticks[MAX_DEPTH]; // 100 MHz ticks the last workgroup spent scanning (diagnostic)
+    uint32_t pad[512 - 32 - 2 * (MAX_DEPTH + 1) - 3 * MAX_DEPTH - 1];
+    // first-level election counters: 32 buckets per bounce, one 64-B line apart
+    uint32_t bucket[MAX_DEPTH][2][32 * 16];       // [bounce][bounce kernel | sort histogram][bucket * 16]
 };
+constexpr int ELECT_BUCKETS = 32;
+static_assert(sizeof(Control) == 2048 + 2 * MAX_DEPTH * 32 * 16 * 4, "Control is one memset block");
+static_assert(sizeof(Control) % 16 == 0, "memset block is a multiple of 16 B");
+
+// Last-workgroup-out election without hammering one address: a same-address atomic costs ~12 ns at
+// the memory side, so 1-2 thousand workgroups finishing together would serialise for tens of
+// microseconds.  Workgroup b adds to bucket b % 32 (own cache line); the last arriver of a bucket
+// adds to the top counter; the last of those is the last workgroup of the launch.  Call from ONE
+// thread, after the workgroup's stores have drained and its barrier.
+__device__ __forceinline__ bool elect_last(uint32_t *buckets /* [32*16] */, uint32_t *top) {
+    const uint32_t G = gridDim.x;
+    const uint32_t k = blockIdx.x % ELECT_BUCKETS;
+    const uint32_t members = (G - k + ELECT_BUCKETS - 1) / ELECT_BUCKETS;       // workgroups with b % 32 == k
+    const uint32_t used = G < ELECT_BUCKETS ? G : ELECT_BUCKETS;                 // buckets that have members
+    const uint32_t old = __hip_atomic_fetch_add(&buckets[k * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old != members - 1) return false;
+    const uint32_t t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t == used - 1;
+}
 
 // Range directory of one bounce's OUTPUT pool.  Wave w of the persistent grid owns the
 // contiguous run of `R` logical tiles [wR, (w+1)R) (R = ceil(tiles / W)) and packs every
@@ -144,6 +166,14 @@ struct RangeDir {
     __device__ __forceinline__ uint32_t *count() const { return mem; }
     __device__ __forceinline__ uint32_t *base() const { return mem + ((W + 3u) & ~3u); }
 };
+
+// Which run of tiles a wave owns: wave j of workgroup b takes run j*G + b, so the first G runs go
+// to G different workgroups.  When a bounce has fewer runs than waves (small pools, late
+// bounces) the busy waves are then spread over every CU instead of filling the first workgroups
+// the dispatcher happens to co-locate (measured at 800x800, 1 spp, bounce 7: 42 -> 2x shorter).
+__device__ __forceinline__ uint32_t run_id() {
+    return __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+}
 
 // tiles per range for a pool of n paths split over W waves
 __host__ __device__ __forceinline__ uint32_t range_tiles(uint32_t n, uint32_t W) {
@@ -540,7 +570,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
 #endif
     const int lane = threadIdx.x & 63;
     const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    const uint32_t wid = run_id();
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);
@@ -706,7 +736,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_hist(SortArgs a) {
     uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * SORT_MAX_BINS;   // per-wave bins
     const int lane = threadIdx.x & 63;
     const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    const uint32_t wid = run_id();
     const uint32_t n = a.compact ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);
@@ -732,9 +762,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_hist(SortArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t old = __hip_atomic_fetch_add(&a.ctl->done_sort[a.depth], 1u, __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = (old == gridDim.x - 1);
+        const bool last = elect_last(a.ctl->bucket[a.depth][1], &a.ctl->done_sort[a.depth]);
         if (last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -751,7 +779,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
     uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * SORT_MAX_BINS;   // per-wave running offsets
     const int lane = threadIdx.x & 63;
     const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    const uint32_t wid = run_id();
     const uint32_t n = a.compact ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);
@@ -807,10 +835,17 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     const float *gf = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
     float *wq = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
     float *tri_lds = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + PT_QUEUE * WAVES * Q_WORDS;
+#ifdef PT_STAMPS
+#define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.depth == PT_STAMPS) a.ctl->stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+    STAMP(0);
     stage_scene(mats, a.scene);
+    STAMP(1);
     const int lane = threadIdx.x & 63;
     const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    const uint32_t wid = run_id();
     const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);                        // logical tiles per wave (one contiguous run)
@@ -822,6 +857,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     uint32_t cur = 0;                                            // source range of the run's current position
     if (a.gen_rays && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = a.pool_n;   // k_raygen's job otherwise
     if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), W, wid * R * TILE);
+    STAMP(2);
 
     // every wave walks its own run of R consecutive 64-path tiles; no workgroup barrier inside
     // the loop unless a mesh needs block-wide triangle staging (then all waves run R iterations)
@@ -858,6 +894,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
                 rd = camera_dir(a.cam, pixel, a.map.W);
             }
         }
+        if (r == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(3); }
         float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
         if (MODE == MODE_FUSED) {
             ptd::Hit h;
@@ -876,6 +913,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             const int m = at(a.isect.mat(), q);
             mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
         }
+        if (r == 0) STAMP(4);
         bool alive = false;
         ptd::PathState ps;
         ps.o = ro; ps.d = rd; ps.c = col;
@@ -887,6 +925,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
                 at(a.fin + 2 * (size_t)a.in.cap, pid) = ps.c.z;
             }
         }
+        if (r == 0) STAMP(5);
         // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
         const uint64_t bal = __ballot(alive);
         const uint64_t act = __ballot(active);
@@ -906,7 +945,19 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             a.out.pid(dst) = DEAD_PID;
         }
     }
-    if (lane == 0 && traced) atomicAdd(&a.ctl->alive[a.depth], traced);
+    STAMP(6);
+    // paths traced this bounce: with compaction it is simply the live count; otherwise count the alive
+    // slots, one atomic per workgroup (summed through LDS) rather than one per wave on a single address
+    if (COMPACT) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->alive[a.depth] = n;
+    } else {
+        if (lane == 0) sctl[8 + (threadIdx.x >> 6)] = traced;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tb = sctl[8] + sctl[9] + sctl[10] + sctl[11];
+            if (tb) atomicAdd(&a.ctl->alive[a.depth], tb);
+        }
+    }
 
     if (COMPACT) {
         // every wave publishes its range count; the last workgroup out scans them
@@ -915,9 +966,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's count store has left
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t old = __hip_atomic_fetch_add(&a.ctl->done[a.depth], 1u, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-            const bool last = (old == gridDim.x - 1);
+            const bool last = elect_last(a.ctl->bucket[a.depth][0], &a.ctl->done[a.depth]);
             if (last) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -925,10 +974,14 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             sctl[0] = last ? 1u : 0u;
         }
         __syncthreads();
+        STAMP(7);
         if (sctl[0]) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             scan_range_counts(a.dir_out, &a.ctl->nlive[a.depth + 1], sctl + 2);
             if (threadIdx.x == 0) a.ctl->scan_ticks[a.depth] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
+#ifdef PT_STAMPS
+            if (threadIdx.x == 0 && a.depth == PT_STAMPS) { a.ctl->stamp[8] = t0; a.ctl->stamp[9] = __builtin_amdgcn_s_memrealtime(); }
+#endif
         }
     }
 }
@@ -1398,6 +1451,12 @@ int collect_stats(void) {
             if (c.alive[d]) R.stats.bounces = d + 1;
         }
     }
+#ifdef PT_STAMPS
+    fprintf(stderr, "[ptmi355] stamps (us since block 0 start, bounce %d): stage %.1f range %.1f loaded %.1f isect %.1f shade %.1f loop-end %.1f elect %.1f | last block: scan-start %.1f scan-end %.1f\n",
+            (int)PT_STAMPS, (c.stamp[1] - c.stamp[0]) / 100.0, (c.stamp[2] - c.stamp[0]) / 100.0, (c.stamp[3] - c.stamp[0]) / 100.0,
+            (c.stamp[4] - c.stamp[0]) / 100.0, (c.stamp[5] - c.stamp[0]) / 100.0, (c.stamp[6] - c.stamp[0]) / 100.0,
+            (c.stamp[7] - c.stamp[0]) / 100.0, ((double)c.stamp[8] - (double)c.stamp[0]) / 100.0, ((double)c.stamp[9] - (double)c.stamp[0]) / 100.0);
+#endif
     if (getenv("PTMI355_DEBUG_SCAN")) {
         fprintf(stderr, "[ptmi355] scan us per bounce:");
         for (int d = 0; d < R.trace_depth; ++d) fprintf(stderr, " %.1f", c.scan_ticks[d] / 100.0);
@@ -1581,9 +1640,9 @@ static int init_impl(const pt_scene_desc *d) {
         HIPCHK(hipMemsetAsync(R.image, 0, (size_t)R.npix * 3 * 4, R.stream));      // pathtrace.cu:85
     }
     R.max_tiles = (R.cap + TILE - 1) / TILE;
-    R.ctl_bytes = sizeof(Control);
-    static_assert(sizeof(Control) % 16 == 0, "memset block is a multiple of 16 B");
-    HIPCHK(hipMalloc((void **)&R.ctl, R.ctl_bytes));
+    // only the election buckets of the bounces this scene can run are cleared per batch
+    R.ctl_bytes = offsetof(Control, bucket) + (size_t)R.trace_depth * sizeof(((Control *)nullptr)->bucket[0]);
+    HIPCHK(hipMalloc((void **)&R.ctl, sizeof(Control)));
 
     HIPCHK(hipMalloc((void **)&R.persist, sizeof(Persist)));
     HIPCHK(hipMemsetAsync(R.persist, 0, sizeof(Persist), R.stream));
