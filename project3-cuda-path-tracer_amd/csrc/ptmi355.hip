@@ -615,54 +615,55 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
 // on dispatch order.
 __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t *n_out,
                                                   uint32_t *lds_scan /* >= 8 words */) {
+    // One step: thread t owns the `per` consecutive entries [t*per, (t+1)*per) (per = ceil(W/256) rounded
+    // to a multiple of 4, at most 32 for W <= 8192), loads them with 16-B loads all issued up front,
+    // and the 256 partial sums cross through one wave scan + one LDS exchange.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t W = dir.W;
     const uint4 *count4 = reinterpret_cast<const uint4 *>(dir.count());
     uint4 *base4 = reinterpret_cast<uint4 *>(dir.base());
-    const uint32_t steps = (W + 4 * BLOCK - 1) / (4 * BLOCK);       // <= 8 for W <= 8192
-    uint4 pre[8];
+    const uint32_t per4 = ((W + BLOCK - 1) / BLOCK + 3) / 4;          // uint4s per thread, <= 8
+    const uint32_t first = threadIdx.x * per4 * 4;                    // first entry of this thread
+    uint4 v[8];
+    uint32_t sum = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {                                    // every load in flight before the first use
-        const uint32_t e = ((uint32_t)k * BLOCK + threadIdx.x) * 4;
-        pre[k] = (e < W) ? count4[e >> 2] : make_uint4(0, 0, 0, 0);
+    for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t e = first + 4 * k;
+        v[k] = make_uint4(0, 0, 0, 0);
+        if (k < per4 && e < W) {
+            v[k] = count4[e >> 2];                                      // count[] is padded to a multiple of 4
+            if (e + 1 >= W) v[k].y = 0;
+            if (e + 2 >= W) v[k].z = 0;
+            if (e + 3 >= W) v[k].w = 0;
+        }
+        sum += v[k].x + v[k].y + v[k].z + v[k].w;
     }
-    uint32_t carry = 0;
-#pragma unroll
-    for (uint32_t step = 0; step < 8; ++step) {
-        if (step >= steps) break;
-        const uint32_t e = (step * BLOCK + threadIdx.x) * 4;          // first entry of this thread
-        uint4 v = pre[step];
-        if (e < W) {
-            if (e + 1 >= W) v.y = 0;
-            if (e + 2 >= W) v.z = 0;
-            if (e + 3 >= W) v.w = 0;
-        }
-        const uint32_t sum = v.x + v.y + v.z + v.w;
-        uint32_t incl = sum;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t u = __shfl_up(incl, off);
-            if (lane >= off) incl += u;
-        }
-        uint32_t *slot = lds_scan + (step & 1) * WAVES;
-        if (lane == 63) slot[wave] = incl;
-        __syncthreads();
-        uint32_t wave_off = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const uint32_t c = slot[w];
-            if (w < wave) wave_off += c;
-            total += c;
-        }
-        if (e < W) {
-            uint4 b;
-            b.x = carry + wave_off + incl - sum;
-            b.y = b.x + v.x; b.z = b.y + v.y; b.w = b.z + v.z;
-            base4[e >> 2] = b;                                           // base[] has 4 spare entries
-        }
-        carry += total;
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off);
+        if (lane >= off) incl += u;
     }
+    if (lane == 63) lds_scan[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) { dir.base()[W] = carry; *n_out = carry; }
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = lds_scan[w];
+        if (w < wave) wave_off += c;
+        total += c;
+    }
+    uint32_t run = wave_off + incl - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t e = first + 4 * k;
+        if (k < per4 && e < W) {
+            uint4 b;
+            b.x = run; b.y = b.x + v[k].x; b.z = b.y + v[k].y; b.w = b.z + v[k].z;
+            base4[e >> 2] = b;                                           // base[] has 4 spare entries
+            run = b.w + v[k].w;
+        }
+    }
+    if (threadIdx.x == 0) { dir.base()[W] = total; *n_out = total; }
 }
 
 // ---------------------------------------------------------------------------
@@ -1437,7 +1438,7 @@ int enqueue_batch(int iter0, int count) {
 // reads the control block back (after a sync) and folds it into the stats
 int collect_stats(void) {
     Control c;
-    HIPCHK(hipMemcpyAsync(&c, R.ctl, sizeof(Control), hipMemcpyDeviceToHost, R.stream));
+    HIPCHK(hipMemcpyAsync(&c, R.ctl, offsetof(Control, bucket), hipMemcpyDeviceToHost, R.stream));
     HIPCHK(hipStreamSynchronize(R.stream));
     if (c.error) return fail(PT_ERR_INTERNAL, "kernel watchdog tripped: inconsistent tile directory (control.error=%u)", c.error);
     R.stats.bounces = 0; R.stats.rays = 0;
