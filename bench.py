@@ -171,10 +171,14 @@ def main():
         pt.set_profiling(False)
         survivors = rank_rays - first                 # paths that survived a compaction = rays of bounces >= 1
         ms, launches = prof["bounce"]
-        algo_bytes = rank_rays * BYTES_PER_RAY + survivors * BYTES_PER_SURVIVOR
+        # the fused launch does intersect + shade/scatter + compaction; with `unfused`/`sort` the timed
+        # k_bounce launch only shades and compacts (the intersections come from k_intersect): 104 + 4 B/ray
+        fused = not (flags & (pt.PT_UNFUSED | pt.PT_SORT_MATERIAL))
+        per_ray = BYTES_PER_RAY if fused else (104 + 4)
+        algo_bytes = rank_rays * per_ray + survivors * BYTES_PER_SURVIVOR
         achieved = algo_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": "k_bounce<fused,compact>" if args.flags == "compact" else
-                    "k_bounce (" + args.flags + "; byte model of the fused kernel)", "achieved": round(achieved, 1),
+                    "k_bounce (" + args.flags + ")", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": measured_traffic(args, world), "launches": int(launches),
                     "avg_launch_us": round(ms * 1e3 / max(1, launches), 2),
