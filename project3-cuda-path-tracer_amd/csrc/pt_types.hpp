@@ -1,0 +1,186 @@
+// pt_types.hpp -- device-side data structures of libptmi355.so (included by ptmi355.hip only):
+// build switches, the path pool / intersection planes / range directory / control block layouts
+// and the kernel parameter blocks.  See DESIGN.md sections 2 and 6.
+#pragma once
+
+namespace {
+
+
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 4                     // waves per SIMD the bounce kernels are register-budgeted for
+#endif
+#ifndef PT_GEOM_LDS
+#define PT_GEOM_LDS 0                      // 1: broadcast geom records from LDS, 0: scalar loads (SGPRs)
+#endif
+#ifndef PT_QUEUE
+#define PT_QUEUE 1                         // evaluate the world-distance tails lane-dense from a per-wave LDS queue
+#endif
+constexpr int BLOCK = 256;                 // 4 waves of 64
+constexpr int WAVES = BLOCK / 64;
+constexpr int TILE = 64;                   // paths per tile = one wave64
+constexpr int TRI_TILE = 512;              // triangles staged in LDS per pass (24 KiB)
+constexpr int TRI_WORDS = 12;              // v0 e1 e2 + 3 pad: three 16-B words per triangle
+constexpr int MAX_DEPTH = 64;
+constexpr uint32_t DEAD_PID = 0xffffffffu;
+
+// ---------------------------------------------------------------------------
+// device-side parameter blocks (few pointers: every extra pointer pair costs
+// 2 SGPRs per wave for the whole kernel)
+// ---------------------------------------------------------------------------
+// element `i` of a wave-uniform plane pointer through a 32-bit byte offset: the address is
+// SGPR base + zero-extended VGPR offset (one global_load/store, no 64-bit VALU address math).
+// pt_init guarantees cap * 4 < 2^32.
+template <typename T>
+__device__ __forceinline__ T &at(T *plane, uint32_t i) {
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(plane) + (i << 2));
+}
+
+// Path pool: SoA *per 64-path tile* -- tile T holds its ten planes (ox oy oz dx dy dz cr cg cb pid)
+// as ten consecutive 256-B rows, 2560 B per tile.  A wave reads/writes whole rows (coalesced),
+// and all ten fields of slot s sit at one per-lane address plus the immediates 0, 256, ... 2304:
+// one address computation per path instead of ten, and no plane base pointers in SGPRs.
+struct Pool {
+    float *base;
+    uint32_t cap;        // slots, a multiple of 64
+    __device__ __forceinline__ char *slot(uint32_t s) const {
+        return reinterpret_cast<char *>(base) + (size_t)(s >> 6) * 2560u + ((s & 63u) << 2);
+    }
+    __device__ __forceinline__ float &f(uint32_t s, int k) const { return *reinterpret_cast<float *>(slot(s) + k * 256); }
+    __device__ __forceinline__ uint32_t &pid(uint32_t s) const { return *reinterpret_cast<uint32_t *>(slot(s) + 9 * 256); }
+};
+__device__ __forceinline__ float &pf(char *slot, int k) { return *reinterpret_cast<float *>(slot + k * 256); }
+__device__ __forceinline__ uint32_t &ppid(char *slot) { return *reinterpret_cast<uint32_t *>(slot + 9 * 256); }
+
+struct Isect {           // ShadeableIntersection planes t nx ny nz mat (unfused / sort / fake-shader modes)
+    float *base;         // mat: bit 31 carries the winning test's !outside
+    uint32_t cap;
+    __device__ __forceinline__ float *plane(int k) const { return base + (size_t)k * cap; }
+    __device__ __forceinline__ int *mat() const { return reinterpret_cast<int *>(base + (size_t)4 * cap); }
+};
+
+struct TileMap {         // local pixel index -> global pixelIndex (x + y*W)
+    int W, H;
+    int tile_index, tile_count, strip_rows;
+    int tile_pixels;     // pixels owned by this tile
+    uint32_t div_magic;  // pid / tile_pixels without an integer divide (see sample_of)
+    uint32_t div_shift;
+};
+
+// pid / tile_pixels for every 32-bit pid: round-up magic number, branch-free form
+// (q = mulhi(magic, n); ((n - q) >> 1) + q) >> shift), magic/shift chosen by make_div_magic().
+__device__ __forceinline__ uint32_t sample_of(const TileMap &m, uint32_t pid) {
+    if (m.tile_pixels == 1) return pid;                  // the branch-free form needs a divisor >= 2
+    const uint32_t q = __umulhi(m.div_magic, pid);
+    return (((pid - q) >> 1) + q) >> m.div_shift;
+}
+
+struct Control {         // zeroed by one hipMemsetAsync per batch (2 KiB)
+    unsigned long long stamp[16];   // -DPT_STAMPS: s_memrealtime at the phases of wave 0 / the last workgroup
+    uint32_t nlive[MAX_DEPTH + 1];  // nlive[d] = paths entering bounce d (compaction on)
+    uint32_t alive[MAX_DEPTH + 1];  // paths actually traced at bounce d
+    uint32_t done[MAX_DEPTH];       // election buckets that finished bounce d (last-one-out election, top level)
+    uint32_t done_sort[MAX_DEPTH];  // same for the material-sort histogram of bounce d
+    uint32_t error;
+    uint32_t scan_ticks[MAX_DEPTH]; // 100 MHz ticks the last workgroup spent scanning (diagnostic)
+    uint32_t pad[512 - 32 - 2 * (MAX_DEPTH + 1) - 3 * MAX_DEPTH - 1];
+    // first-level election counters: 32 buckets per bounce, one 64-B line apart
+    uint32_t bucket[MAX_DEPTH][2][32 * 16];       // [bounce][bounce kernel | sort histogram][bucket * 16]
+};
+constexpr int ELECT_BUCKETS = 32;
+static_assert(sizeof(Control) == 2048 + 2 * MAX_DEPTH * 32 * 16 * 4, "Control is one memset block");
+static_assert(sizeof(Control) % 16 == 0, "memset block is a multiple of 16 B");
+
+// Last-workgroup-out election without hammering one address: a same-address atomic costs ~12 ns at
+// the memory side, so 1-2 thousand workgroups finishing together would serialise for tens of
+// microseconds.  Workgroup b adds to bucket b % 32 (own cache line); the last arriver of a bucket
+// adds to the top counter; the last of those is the last workgroup of the launch.  Call from ONE
+// thread, after the workgroup's stores have drained and its barrier.
+__device__ __forceinline__ bool elect_last(uint32_t *buckets /* [32*16] */, uint32_t *top) {
+    const uint32_t G = gridDim.x;
+    const uint32_t k = blockIdx.x % ELECT_BUCKETS;
+    const uint32_t members = (G - k + ELECT_BUCKETS - 1) / ELECT_BUCKETS;       // workgroups with b % 32 == k
+    const uint32_t used = G < ELECT_BUCKETS ? G : ELECT_BUCKETS;                 // buckets that have members
+    const uint32_t old = __hip_atomic_fetch_add(&buckets[k * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old != members - 1) return false;
+    const uint32_t t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t == used - 1;
+}
+
+// Range directory of one bounce's OUTPUT pool.  Wave w of the persistent grid owns the
+// contiguous run of `R` logical tiles [wR, (w+1)R) (R = ceil(tiles / W)) and packs every
+// survivor of that run, in order, to the front of the run's own span of R*64 slots; count[w]
+// is how many it packed, base[] the exclusive scan of count[] (W+1 entries).  Logical path i
+// of the output therefore lives in slot r*R*64 + (i - base[r]) for the range r with
+// base[r] <= i < base[r+1] -- the stable partition's order, with no cross-wave communication
+// inside the launch and only W (<= 8192) words to scan at its end.
+struct RangeDir {
+    uint32_t *mem;       // count[Wp] | base[Wp+4]  (Wp = W rounded up to 4); nullptr = dense pool
+    uint32_t W;          // waves in the persistent grid = ranges
+    __device__ __forceinline__ uint32_t *count() const { return mem; }
+    __device__ __forceinline__ uint32_t *base() const { return mem + ((W + 3u) & ~3u); }
+};
+
+// Which run of tiles a wave owns: wave j of workgroup b takes run j*G + b, so the first G runs go
+// to G different workgroups.  When a bounce has fewer runs than waves (small pools, late
+// bounces) the busy waves are then spread over every CU instead of filling the first workgroups
+// the dispatcher happens to co-locate (measured at 800x800, 1 spp, bounce 7: 42 -> 2x shorter).
+__device__ __forceinline__ uint32_t run_id() {
+    return __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+}
+
+// tiles per range for a pool of n paths split over W waves
+__host__ __device__ __forceinline__ uint32_t range_tiles(uint32_t n, uint32_t W) {
+    const uint32_t tiles = (n + 63u) / 64u;
+    return (tiles + W - 1) / W;
+}
+
+struct Persist {         // survives the per-batch memset
+    unsigned long long rays;        // sum over bounces of paths traced since pt_init
+    unsigned long long iterations;
+    unsigned long long first_rays;  // paths traced at bounce 0 (rays - first_rays = compaction survivors)
+};
+
+struct SceneDev {
+    const float *geoms;  int ngeoms;       // GEOM_WORDS dwords each
+    const float *mats;   int nmats;        // MAT_WORDS dwords each
+    const float *tris;   int ntris;        // v0, e1, e2 + pad (12 dwords each)
+};
+
+struct BounceArgs {
+    Pool in, out;
+    Isect isect;
+    SceneDev scene;
+    TileMap map;
+    Control *ctl;
+    RangeDir dir_in;       // directory of the pool being read (mem == nullptr: dense)
+    RangeDir dir_out;      // directory this launch produces
+    float *fin;            // final colour planes r g b (stride in.cap), index = pid
+    pt_camera cam;         // used when gen_rays != 0
+    int depth, trace_depth, iter0;
+    uint32_t pool_n;       // paths in the pool when compaction is off / at bounce 0
+    int gen_rays;          // bounce 0 generates the camera ray instead of loading it
+};
+
+__device__ __forceinline__ int local_to_pixel(const TileMap &m, int j) {
+    if (m.tile_count == 1) return j;
+    int ly = j / m.W;
+    int x = j - ly * m.W;
+    int ls = ly / m.strip_rows;
+    int y = (ls * m.tile_count + m.tile_index) * m.strip_rows + (ly - ls * m.strip_rows);
+    return x + y * m.W;
+}
+
+// generateRayFromCamera (pathtrace.cu:122-143) for one pixel
+__device__ __forceinline__ f3 camera_dir(const pt_camera &cam, int pix, int W) {
+    const int y = pix / W;
+    const int x = pix - y * W;
+    f3 view = ptd::mk(cam.view.x, cam.view.y, cam.view.z);
+    f3 right = ptd::mk(cam.right.x, cam.right.y, cam.right.z);
+    f3 up = ptd::mk(cam.up.x, cam.up.y, cam.up.z);
+    f3 a = ptd::scale(ptd::scale(right, cam.pixelLength[0]), ((float)x - (float)cam.resolution[0] * 0.5f));
+    f3 b = ptd::scale(ptd::scale(up, cam.pixelLength[1]), ((float)y - (float)cam.resolution[1] * 0.5f));
+    return ptd::normalize(ptd::sub(ptd::sub(view, a), b));
+}
+
+
+}  // namespace

@@ -51,1099 +51,10 @@ static_assert(sizeof(pt_triangle) == 36, "triangle ABI");
 
 using ptd::f3;
 
+#include "pt_types.hpp"
+#include "pt_kernels.hpp"
+
 namespace {
-
-#ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 4                     // waves per SIMD the bounce kernels are register-budgeted for
-#endif
-#ifndef PT_GEOM_LDS
-#define PT_GEOM_LDS 0                      // 1: broadcast geom records from LDS, 0: scalar loads (SGPRs)
-#endif
-#ifndef PT_QUEUE
-#define PT_QUEUE 1                         // evaluate the world-distance tails lane-dense from a per-wave LDS queue
-#endif
-constexpr int BLOCK = 256;                 // 4 waves of 64
-constexpr int WAVES = BLOCK / 64;
-constexpr int TILE = 64;                   // paths per tile = one wave64
-constexpr int TRI_TILE = 512;              // triangles staged in LDS per pass (24 KiB)
-constexpr int TRI_WORDS = 12;              // v0 e1 e2 + 3 pad: three 16-B words per triangle
-constexpr int MAX_DEPTH = 64;
-constexpr uint32_t DEAD_PID = 0xffffffffu;
-
-// ---------------------------------------------------------------------------
-// device-side parameter blocks (few pointers: every extra pointer pair costs
-// 2 SGPRs per wave for the whole kernel)
-// ---------------------------------------------------------------------------
-// element `i` of a wave-uniform plane pointer through a 32-bit byte offset: the address is
-// SGPR base + zero-extended VGPR offset (one global_load/store, no 64-bit VALU address math).
-// pt_init guarantees cap * 4 < 2^32.
-template <typename T>
-__device__ __forceinline__ T &at(T *plane, uint32_t i) {
-    return *reinterpret_cast<T *>(reinterpret_cast<char *>(plane) + (i << 2));
-}
-
-// Path pool: SoA *per 64-path tile* -- tile T holds its ten planes (ox oy oz dx dy dz cr cg cb pid)
-// as ten consecutive 256-B rows, 2560 B per tile.  A wave reads/writes whole rows (coalesced),
-// and all ten fields of slot s sit at one per-lane address plus the immediates 0, 256, ... 2304:
-// one address computation per path instead of ten, and no plane base pointers in SGPRs.
-struct Pool {
-    float *base;
-    uint32_t cap;        // slots, a multiple of 64
-    __device__ __forceinline__ char *slot(uint32_t s) const {
-        return reinterpret_cast<char *>(base) + (size_t)(s >> 6) * 2560u + ((s & 63u) << 2);
-    }
-    __device__ __forceinline__ float &f(uint32_t s, int k) const { return *reinterpret_cast<float *>(slot(s) + k * 256); }
-    __device__ __forceinline__ uint32_t &pid(uint32_t s) const { return *reinterpret_cast<uint32_t *>(slot(s) + 9 * 256); }
-};
-__device__ __forceinline__ float &pf(char *slot, int k) { return *reinterpret_cast<float *>(slot + k * 256); }
-__device__ __forceinline__ uint32_t &ppid(char *slot) { return *reinterpret_cast<uint32_t *>(slot + 9 * 256); }
-
-struct Isect {           // ShadeableIntersection planes t nx ny nz mat (unfused / sort / fake-shader modes)
-    float *base;         // mat: bit 31 carries the winning test's !outside
-    uint32_t cap;
-    __device__ __forceinline__ float *plane(int k) const { return base + (size_t)k * cap; }
-    __device__ __forceinline__ int *mat() const { return reinterpret_cast<int *>(base + (size_t)4 * cap); }
-};
-
-struct TileMap {         // local pixel index -> global pixelIndex (x + y*W)
-    int W, H;
-    int tile_index, tile_count, strip_rows;
-    int tile_pixels;     // pixels owned by this tile
-    uint32_t div_magic;  // pid / tile_pixels without an integer divide (see sample_of)
-    uint32_t div_shift;
-};
-
-// pid / tile_pixels for every 32-bit pid: round-up magic number, branch-free form
-// (q = mulhi(magic, n); ((n - q) >> 1) + q) >> shift), magic/shift chosen by make_div_magic().
-__device__ __forceinline__ uint32_t sample_of(const TileMap &m, uint32_t pid) {
-    if (m.tile_pixels == 1) return pid;                  // the branch-free form needs a divisor >= 2
-    const uint32_t q = __umulhi(m.div_magic, pid);
-    return (((pid - q) >> 1) + q) >> m.div_shift;
-}
-
-struct Control {         // zeroed by one hipMemsetAsync per batch (2 KiB)
-    unsigned long long stamp[16];   // -DPT_STAMPS: s_memrealtime at the phases of wave 0 / the last workgroup
-    uint32_t nlive[MAX_DEPTH + 1];  // nlive[d] = paths entering bounce d (compaction on)
-    uint32_t alive[MAX_DEPTH + 1];  // paths actually traced at bounce d
-    uint32_t done[MAX_DEPTH];       // election buckets that finished bounce d (last-one-out election, top level)
-    uint32_t done_sort[MAX_DEPTH];  // same for the material-sort histogram of bounce d
-    uint32_t error;
-    uint32_t scan_ticks[MAX_DEPTH]; // 100 MHz ticks the last workgroup spent scanning (diagnostic)
-    uint32_t pad[512 - 32 - 2 * (MAX_DEPTH + 1) - 3 * MAX_DEPTH - 1];
-    // first-level election counters: 32 buckets per bounce, one 64-B line apart
-    uint32_t bucket[MAX_DEPTH][2][32 * 16];       // [bounce][bounce kernel | sort histogram][bucket * 16]
-};
-constexpr int ELECT_BUCKETS = 32;
-static_assert(sizeof(Control) == 2048 + 2 * MAX_DEPTH * 32 * 16 * 4, "Control is one memset block");
-static_assert(sizeof(Control) % 16 == 0, "memset block is a multiple of 16 B");
-
-// Last-workgroup-out election without hammering one address: a same-address atomic costs ~12 ns at
-// the memory side, so 1-2 thousand workgroups finishing together would serialise for tens of
-// microseconds.  Workgroup b adds to bucket b % 32 (own cache line); the last arriver of a bucket
-// adds to the top counter; the last of those is the last workgroup of the launch.  Call from ONE
-// thread, after the workgroup's stores have drained and its barrier.
-__device__ __forceinline__ bool elect_last(uint32_t *buckets /* [32*16] */, uint32_t *top) {
-    const uint32_t G = gridDim.x;
-    const uint32_t k = blockIdx.x % ELECT_BUCKETS;
-    const uint32_t members = (G - k + ELECT_BUCKETS - 1) / ELECT_BUCKETS;       // workgroups with b % 32 == k
-    const uint32_t used = G < ELECT_BUCKETS ? G : ELECT_BUCKETS;                 // buckets that have members
-    const uint32_t old = __hip_atomic_fetch_add(&buckets[k * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old != members - 1) return false;
-    const uint32_t t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return t == used - 1;
-}
-
-// Range directory of one bounce's OUTPUT pool.  Wave w of the persistent grid owns the
-// contiguous run of `R` logical tiles [wR, (w+1)R) (R = ceil(tiles / W)) and packs every
-// survivor of that run, in order, to the front of the run's own span of R*64 slots; count[w]
-// is how many it packed, base[] the exclusive scan of count[] (W+1 entries).  Logical path i
-// of the output therefore lives in slot r*R*64 + (i - base[r]) for the range r with
-// base[r] <= i < base[r+1] -- the stable partition's order, with no cross-wave communication
-// inside the launch and only W (<= 8192) words to scan at its end.
-struct RangeDir {
-    uint32_t *mem;       // count[Wp] | base[Wp+4]  (Wp = W rounded up to 4); nullptr = dense pool
-    uint32_t W;          // waves in the persistent grid = ranges
-    __device__ __forceinline__ uint32_t *count() const { return mem; }
-    __device__ __forceinline__ uint32_t *base() const { return mem + ((W + 3u) & ~3u); }
-};
-
-// Which run of tiles a wave owns: wave j of workgroup b takes run j*G + b, so the first G runs go
-// to G different workgroups.  When a bounce has fewer runs than waves (small pools, late
-// bounces) the busy waves are then spread over every CU instead of filling the first workgroups
-// the dispatcher happens to co-locate (measured at 800x800, 1 spp, bounce 7: 42 -> 2x shorter).
-__device__ __forceinline__ uint32_t run_id() {
-    return __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
-}
-
-// tiles per range for a pool of n paths split over W waves
-__host__ __device__ __forceinline__ uint32_t range_tiles(uint32_t n, uint32_t W) {
-    const uint32_t tiles = (n + 63u) / 64u;
-    return (tiles + W - 1) / W;
-}
-
-struct Persist {         // survives the per-batch memset
-    unsigned long long rays;        // sum over bounces of paths traced since pt_init
-    unsigned long long iterations;
-    unsigned long long first_rays;  // paths traced at bounce 0 (rays - first_rays = compaction survivors)
-};
-
-struct SceneDev {
-    const float *geoms;  int ngeoms;       // GEOM_WORDS dwords each
-    const float *mats;   int nmats;        // MAT_WORDS dwords each
-    const float *tris;   int ntris;        // v0, e1, e2 + pad (12 dwords each)
-};
-
-struct BounceArgs {
-    Pool in, out;
-    Isect isect;
-    SceneDev scene;
-    TileMap map;
-    Control *ctl;
-    RangeDir dir_in;       // directory of the pool being read (mem == nullptr: dense)
-    RangeDir dir_out;      // directory this launch produces
-    float *fin;            // final colour planes r g b (stride in.cap), index = pid
-    pt_camera cam;         // used when gen_rays != 0
-    int depth, trace_depth, iter0;
-    uint32_t pool_n;       // paths in the pool when compaction is off / at bounce 0
-    int gen_rays;          // bounce 0 generates the camera ray instead of loading it
-};
-
-__device__ __forceinline__ int local_to_pixel(const TileMap &m, int j) {
-    if (m.tile_count == 1) return j;
-    int ly = j / m.W;
-    int x = j - ly * m.W;
-    int ls = ly / m.strip_rows;
-    int y = (ls * m.tile_count + m.tile_index) * m.strip_rows + (ly - ls * m.strip_rows);
-    return x + y * m.W;
-}
-
-// generateRayFromCamera (pathtrace.cu:122-143) for one pixel
-__device__ __forceinline__ f3 camera_dir(const pt_camera &cam, int pix, int W) {
-    const int y = pix / W;
-    const int x = pix - y * W;
-    f3 view = ptd::mk(cam.view.x, cam.view.y, cam.view.z);
-    f3 right = ptd::mk(cam.right.x, cam.right.y, cam.right.z);
-    f3 up = ptd::mk(cam.up.x, cam.up.y, cam.up.z);
-    f3 a = ptd::scale(ptd::scale(right, cam.pixelLength[0]), ((float)x - (float)cam.resolution[0] * 0.5f));
-    f3 b = ptd::scale(ptd::scale(up, cam.pixelLength[1]), ((float)y - (float)cam.resolution[1] * 0.5f));
-    return ptd::normalize(ptd::sub(ptd::sub(view, a), b));
-}
-
-// ---------------------------------------------------------------------------
-// generateRayFromCamera -> SoA pool, `count` samples (stepping interface; the
-// batch path generates rays inside bounce 0)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, TileMap map, int count,
-                                                  Control *ctl) {
-    uint32_t total = (uint32_t)map.tile_pixels * (uint32_t)count;
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i == 0) { ctl->nlive[0] = total; }
-    if (i >= total) return;
-    uint32_t j = i % (uint32_t)map.tile_pixels;
-    f3 d = camera_dir(cam, local_to_pixel(map, (int)j), map.W);
-    char *q = p.slot(i);
-    pf(q, 0) = cam.position.x; pf(q, 1) = cam.position.y; pf(q, 2) = cam.position.z;
-    pf(q, 3) = d.x; pf(q, 4) = d.y; pf(q, 5) = d.z;
-    pf(q, 6) = 1.0f; pf(q, 7) = 1.0f; pf(q, 8) = 1.0f;
-    ppid(q) = i;
-}
-
-// ---------------------------------------------------------------------------
-// scene staging + intersection (computeIntersections, pathtrace.cu:149-213)
-// ---------------------------------------------------------------------------
-// Dynamic LDS carve (no static __shared__: the dynamic base stays 16-B aligned, guide G17):
-// [ctl: 16 dwords][mats: nmats*12 dwords][tri tile: TRI_TILE*9 dwords (if any)]
-// Geom records are NOT staged: every lane of every wave reads the same record, so they are
-// fetched with wave-uniform (scalar, SGPR) loads straight from the 1-KB record array, which
-// costs no VGPRs and no LDS bandwidth; materials are per-lane gathers and live in LDS.
-constexpr int LDS_CTL_WORDS = 16;    // [0] last-block flag, [2..5] scan scratch
-constexpr int GF_WORDS = 16;         // staged per geom for gathers: transform[12], type, materialid, 2 pad
-// per-wave candidate queue (PT_QUEUE): ring of 128 slots, SoA: qo.xyz qd.xyz t_obj (7 planes), meta, and
-// the 64 per-lane best keys (u64)
-constexpr int Q_SLOTS = 128;
-constexpr int Q_WORDS = 7 * Q_SLOTS + Q_SLOTS + 2 * 64;
-__host__ __device__ constexpr int scene_lds_words(int nmats, int ngeoms) {
-    return ((nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * ngeoms * GF_WORDS + PT_GEOM_LDS * ngeoms * ptd::GEOM_WORDS;
-}
-__device__ __forceinline__ void stage_scene(float *lds_mats, const SceneDev &sc) {
-    const int mw = sc.nmats * ptd::MAT_WORDS;
-    for (int k = threadIdx.x; k < mw; k += BLOCK) lds_mats[k] = sc.mats[k];
-#if PT_QUEUE
-    {   // per-lane gathers of the tail: forward transform (12) + type + material per geom
-        float *gf = lds_mats + ((mw + 3) & ~3);
-        for (int k = threadIdx.x; k < sc.ngeoms * GF_WORDS; k += BLOCK) {
-            const int g = k / GF_WORDS, w = k - g * GF_WORDS;
-            gf[k] = w < 12 ? sc.geoms[g * ptd::GEOM_WORDS + ptd::G_FWD + w] : sc.geoms[g * ptd::GEOM_WORDS + (w - 12)];
-        }
-    }
-#endif
-#if PT_GEOM_LDS
-    float *lds_geoms = lds_mats + ((mw + 3) & ~3) + PT_QUEUE * sc.ngeoms * GF_WORDS;
-    for (int k = threadIdx.x; k < sc.ngeoms * ptd::GEOM_WORDS; k += BLOCK) lds_geoms[k] = sc.geoms[k];
-#endif
-    __syncthreads();
-}
-
-// `uniform_trips` != 0: every wave of the block executes the same geom sequence (needed when
-// meshes stage triangle tiles through LDS with block barriers); `active` masks idle lanes.
-// Geom records are read through the CONSTANT address space: the array is immutable for the
-// lifetime of the launch and the address is wave-uniform, so the loads become s_load_dwordxN
-// (scalar cache -> SGPRs) instead of per-lane vector loads.
-typedef const __attribute__((address_space(4))) float cfloat;
-__device__ __forceinline__ cfloat *as_const(const float *p) {
-    return (cfloat *)(unsigned long long)p;
-}
-
-#if PT_QUEUE
-// One lane-dense pass over up to 64 queued candidates [head, head+count): lane k evaluates the
-// shared tail of candidate head+k for whichever lane queued it and folds the distance into that
-// lane's best key with an LDS 64-bit min.  key = (bits(t) << 32) | absolute slot: positive floats
-// order like their bit patterns and slots are issued in geom order, so the minimum key is the
-// smallest t with the lowest geom index on ties -- pathtrace.cu:192's strict `t_min > t` scan.
-__device__ __forceinline__ void queue_pass(float *wq, const float *gf, uint32_t head, uint32_t count, f3 ro) {
-    const int lane = threadIdx.x & 63;
-    float *qf = wq;
-    uint32_t *qi = reinterpret_cast<uint32_t *>(wq + 7 * Q_SLOTS);
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(wq + 8 * Q_SLOTS);
-    const bool on = (uint32_t)lane < count;
-    const uint32_t abs_slot = head + (uint32_t)lane;
-    const uint32_t s = abs_slot & (Q_SLOTS - 1);
-    const uint32_t meta = on ? qi[s] : 0u;
-    const int origin = (int)(meta & 63u);
-    // the queued lane's world-space ray origin
-    const f3 oro = ptd::mk(__shfl(ro.x, origin), __shfl(ro.y, origin), __shfl(ro.z, origin));
-    if (on) {
-        const f3 qo = ptd::mk(qf[0 * Q_SLOTS + s], qf[1 * Q_SLOTS + s], qf[2 * Q_SLOTS + s]);
-        const f3 qd = ptd::mk(qf[3 * Q_SLOTS + s], qf[4 * Q_SLOTS + s], qf[5 * Q_SLOTS + s]);
-        const float t_obj = qf[6 * Q_SLOTS + s];
-        const float *fwd = gf + (meta >> 10) * GF_WORDS;                  // per-lane gather of the transform
-        f3 obj_p;
-        const float t = ptd::world_distance(fwd, oro, qo, qd, t_obj, obj_p);
-        qf[0 * Q_SLOTS + s] = obj_p.x; qf[1 * Q_SLOTS + s] = obj_p.y; qf[2 * Q_SLOTS + s] = obj_p.z;
-        if (t > 0.0f)
-            __hip_atomic_fetch_min(&best[origin], ((unsigned long long)__float_as_uint(t) << 32) | abs_slot,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-}
-#endif
-
-template <bool HAS_MESH>
-__device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms, int ngeoms,
-                                                const float *__restrict__ tris, float *tri_lds, bool active,
-                                                f3 ro, f3 rd, ptd::Hit &h, float *wq = nullptr,
-                                                const float *gf = nullptr) {
-    h.t = FLT_MAX; h.geom = -1; h.outside = 1; h.aux = ptd::mk(0, 0, 0);
-    int outside = 1;                                    // shared across tests, pathtrace.cu:169
-    (void)outside;
-#if PT_QUEUE
-    const int lane_q = threadIdx.x & 63;
-    float *qf = wq;
-    uint32_t *qi = reinterpret_cast<uint32_t *>(wq + 7 * Q_SLOTS);
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(wq + 8 * Q_SLOTS);
-    best[lane_q] = ~0ull;
-    unsigned long long seen = ~0ull;
-    uint32_t q_head = 0, q_total = 0;                   // wave-uniform
-    int w_geom = -1, w_meta = 0;
-    f3 w_objp = ptd::mk(0, 0, 0);
-    // after a pass: lanes whose best key changed latch the winner's record while it is still intact
-    auto latch = [&]() {
-        const unsigned long long key = best[lane_q];
-        if (key != seen) {
-            seen = key;
-            const uint32_t s = (uint32_t)key & (Q_SLOTS - 1);
-            w_meta = (int)qi[s];
-            w_geom = w_meta >> 10;
-            w_objp = ptd::mk(qf[0 * Q_SLOTS + s], qf[1 * Q_SLOTS + s], qf[2 * Q_SLOTS + s]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-#endif
-#ifdef PT_GEOM_UNROLL
-#pragma unroll PT_GEOM_UNROLL
-#endif
-    for (int g = 0; g < ngeoms; ++g) {
-#if PT_GEOM_LDS
-        const float *rec = geoms + g * ptd::GEOM_WORDS;                // LDS broadcast
-        const int type = __builtin_amdgcn_readfirstlane(__float_as_int(rec[0]));
-#else
-        cfloat *rec = as_const(geoms) + g * ptd::GEOM_WORDS;           // wave-uniform address -> s_load
-        const int type = __float_as_int(rec[0]);
-#endif
-        if (HAS_MESH && type == PT_TRIANGLE_MESH) {
-            // completion spec 8.0: nearest triangle by strictly smaller bary.z, first wins ties
-            const int first = __float_as_int(rec[2]);
-            const int count = __float_as_int(rec[3]);
-            float best = FLT_MAX;
-            int best_i = -1;
-            for (int base = 0; base < count; base += TRI_TILE) {
-                const int nt = min(TRI_TILE, count - base);
-                const int nt4 = (nt + 3) & ~3;                   // the tile is zero-padded to a multiple of 4
-                __syncthreads();
-                {   // global -> LDS, 16 B per thread per step; zero triangles (a = 0 < eps: never hit) as padding
-                    const float4 *src = reinterpret_cast<const float4 *>(tris + (size_t)(first + base) * TRI_WORDS);
-                    float4 *dst = reinterpret_cast<float4 *>(tri_lds);
-                    for (int k = threadIdx.x; k < nt4 * 3; k += BLOCK)
-                        dst[k] = k < nt * 3 ? src[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-                __syncthreads();
-                if (active) {
-                    // four triangles per step: their twelve ds_read_b128 (wave-uniform addresses, LDS
-                    // broadcasts) are issued together so the LDS latency is paid once per four tests
-                    const float4 *tl = reinterpret_cast<const float4 *>(tri_lds);
-                    for (int k = 0; k < nt4; k += 4) {
-                        float4 w[12];
-#pragma unroll
-                        for (int j = 0; j < 12; ++j) w[j] = tl[k * 3 + j];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float4 A = w[3 * j], B = w[3 * j + 1], C = w[3 * j + 2];
-                            float tz;
-                            if (ptd::ray_triangle(ro, rd, ptd::mk(A.x, A.y, A.z), ptd::mk(A.w, B.x, B.y),
-                                                  ptd::mk(B.z, B.w, C.x), tz)) {
-                                if (tz > 0.0f && best > tz) { best = tz; best_i = first + base + k + j; }
-                            }
-                        }
-                    }
-                }
-            }
-            if (active && best_i >= 0) {
-                f3 p = ptd::add(ro, ptd::scale(rd, best));
-                const float t = ptd::length(ptd::sub(ro, p));
-                if (t > 0.0f && h.t > t) {
-                    h.t = t; h.geom = g; h.outside = 1;
-                    h.aux = ptd::mk(__int_as_float(best_i), 0.0f, 0.0f);
-                }
-            }
-            continue;
-        }
-#if PT_QUEUE
-        {   // object-space test per lane; hits are queued and their tails run lane-dense (queue_pass)
-            f3 qo = ptd::mk(0, 0, 0), qd = ptd::mk(0, 0, 1);
-            float t_obj = 0.0f;
-            int code = 7, cand_outside = 1;
-            bool hit = false;
-            if (active) {
-                if (type == PT_CUBE) hit = ptd::box_slab(rec, ro, rd, qo, qd, t_obj, code, cand_outside);
-                else if (type == PT_SPHERE) hit = ptd::sphere_quad(rec, ro, rd, qo, qd, t_obj, cand_outside);
-            }
-            const uint64_t m = __ballot(hit);
-            if (m) {
-                if (hit) {
-                    const uint32_t s = (q_total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane_q) - 1)))) &
-                                       (Q_SLOTS - 1);
-                    qf[0 * Q_SLOTS + s] = qo.x; qf[1 * Q_SLOTS + s] = qo.y; qf[2 * Q_SLOTS + s] = qo.z;
-                    qf[3 * Q_SLOTS + s] = qd.x; qf[4 * Q_SLOTS + s] = qd.y; qf[5 * Q_SLOTS + s] = qd.z;
-                    qf[6 * Q_SLOTS + s] = t_obj;
-                    qi[s] = (uint32_t)lane_q | ((uint32_t)cand_outside << 6) | ((uint32_t)code << 7) | ((uint32_t)g << 10);
-                }
-                q_total += (uint32_t)__popcll((unsigned long long)m);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (q_total - q_head >= 64) {            // a full wave of tails is waiting
-                    queue_pass(wq, gf, q_head, 64, ro);
-                    q_head += 64;
-                    latch();
-                }
-            }
-            continue;
-        }
-#endif
-        {   // monolithic reference-shaped tests (object-space test + world-distance tail in one body)
-            float t = -1.0f;
-            f3 aux = ptd::mk(0, 0, 0);
-            if (type == PT_CUBE) { if (active) t = ptd::box_test(rec, ro, rd, aux, outside); }
-            else if (type == PT_SPHERE) { if (active) t = ptd::sphere_test(rec, ro, rd, aux, outside); }
-            if (t > 0.0f && h.t > t) {                  // pathtrace.cu:192 (first geom wins ties)
-                h.t = t; h.geom = g; h.outside = outside; h.aux = aux;
-            }
-            continue;
-        }
-    }
-#if PT_QUEUE
-    if (q_total > q_head) {
-        queue_pass(wq, gf, q_head, q_total - q_head, ro);
-        latch();
-    }
-    if (w_geom >= 0) {
-        const unsigned long long key = seen;
-        const float t = __uint_as_float((uint32_t)(key >> 32));
-        if (h.t > t || (h.t == t && w_geom < h.geom)) {      // meshes fold straight into h: keep geom order on ties
-            h.t = t; h.geom = w_geom; h.outside = (w_meta >> 6) & 1;
-            const int type = __float_as_int(gf[w_geom * GF_WORDS + 12]);
-            h.aux = (type == PT_CUBE) ? ptd::mk(__int_as_float((w_meta >> 7) & 7), 0.0f, 0.0f) : w_objp;
-        }
-    }
-#endif
-}
-
-// normal + materialId of the winning primitive (per-lane record: cached gather from the
-// 1-KB record array)
-__device__ __forceinline__ void resolve_hit(const float *__restrict__ geoms, const float *__restrict__ tris,
-                                            const ptd::Hit &h, float &t, f3 &n, int &mat) {
-    if (h.geom < 0) { t = -1.0f; n = ptd::mk(0, 0, 0); mat = 0; return; }
-    const float *rec = geoms + h.geom * ptd::GEOM_WORDS;
-    const int type = __float_as_int(rec[0]);
-    t = h.t;
-    mat = __float_as_int(rec[1]);
-    if (type == PT_CUBE) n = ptd::cube_normal(rec, h.aux);
-    else if (type == PT_SPHERE) n = ptd::sphere_normal(rec, h.aux, h.outside);
-    else {
-        const float *tv = tris + (size_t)__float_as_int(h.aux.x) * TRI_WORDS;
-        n = ptd::normalize(ptd::cross(ptd::mk(tv[3], tv[4], tv[5]), ptd::mk(tv[6], tv[7], tv[8])));
-    }
-}
-
-// ---- reading a range-packed pool -------------------------------------------------------
-// Wave-cooperative 64-ary search: largest r in [0, W) with base[r] <= P (P < base[W]).
-__device__ __forceinline__ uint32_t find_range(const uint32_t *base, uint32_t W, uint32_t P) {
-    const int lane = threadIdx.x & 63;
-    uint32_t lo = 0, hi = W;                        // answer in [lo, hi)
-    for (int guard = 0; guard < 8 && hi - lo > 1; ++guard) {
-        const uint32_t step = (hi - lo + 63u) / 64u;
-        const uint32_t idx = lo + (uint32_t)lane * step;
-        const uint32_t v = idx < hi ? base[idx] : 0xffffffffu;
-        const uint64_t ok = __ballot(v <= P);       // base[] is non-decreasing: a prefix of the lanes
-        const uint32_t k = (uint32_t)__popcll((unsigned long long)ok);
-        const uint32_t nlo = lo + (k ? k - 1 : 0) * step;
-        hi = min(hi, nlo + step);
-        lo = nlo;
-    }
-    return lo;
-}
-
-// Source slots of the 64 logical paths p = p0 + lane, starting the search at range `cur`
-// (wave-uniform, base[cur] <= p0).  Lane l first holds base[cur + l]; a 6-step binary search
-// reads other lanes' values with ds_bpermute.  Returns the slot; `cur` advances to the range of
-// the tile's last path so the next tile of the run starts where this one ended.
-__device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t span, uint32_t &cur, uint32_t p,
-                                                bool active, Control *ctl) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t *base = dir.base();
-    bool resolved = !active;
-    uint32_t src = 0, rng = cur;
-    uint32_t s = cur;
-    // bounded: a sane directory resolves within W/63 + 1 windows; every wave reaches the exit
-    for (uint32_t guard = 0;; ++guard) {
-        if (guard > dir.W / 63 + 1) {
-            if (lane == 0) atomicOr(&ctl->error, 2u);
-            break;
-        }
-        const uint32_t t = s + (uint32_t)lane;
-        const uint32_t w = t <= dir.W ? base[t] : 0xffffffffu;
-        int lo = 0, hi = 63;                        // w(lane 0) <= p always holds for unresolved lanes
-#pragma unroll
-        for (int step = 0; step < 6; ++step) {
-            const int mid = (lo + hi + 1) >> 1;
-            const uint32_t wm = (uint32_t)__shfl((int)w, mid);
-            if (wm <= p) lo = mid; else hi = mid - 1;
-        }
-        const uint32_t wl = (uint32_t)__shfl((int)w, lo);
-        if (!resolved && lo < 63) { resolved = true; rng = s + (uint32_t)lo; src = rng * span + (p - wl); }
-        if (!__any(!resolved)) break;
-        s += 63;
-    }
-    // the highest active lane holds the tile's last path
-    const uint64_t act = __ballot(active);
-    if (act) cur = (uint32_t)__builtin_amdgcn_readlane((int)rng, 63 - __builtin_clzll((unsigned long long)act));
-    return src;
-}
-
-// standalone computeIntersections: materialises the ShadeableIntersection planes
-// (indexed by LOGICAL path index)
-template <bool HAS_MESH>
-__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc,
-                                                                    const uint32_t *n_ptr, uint32_t n_fixed,
-                                                                    RangeDir dir_in, const uint32_t *nprev_ptr,
-                                                                    Control *ctl) {
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    float *mats_lds = lds_raw + LDS_CTL_WORDS;
-    const float *gf = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
-    float *wq = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
-    float *tri_lds = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + PT_QUEUE * WAVES * Q_WORDS;
-#if PT_GEOM_LDS || PT_QUEUE
-    stage_scene(mats_lds, sc);
-#endif
-#if PT_GEOM_LDS
-    const float *gsrc = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * sc.ngeoms * GF_WORDS;
-#else
-    const float *gsrc = sc.geoms;
-#endif
-    const int lane = threadIdx.x & 63;
-    const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = run_id();
-    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    const uint32_t tiles = (n + TILE - 1) / TILE;
-    const uint32_t R = range_tiles(n, W);
-    const bool packed = dir_in.mem && nprev_ptr;
-    const uint32_t span = packed ? range_tiles(*nprev_ptr, W) * TILE : 0;
-    uint32_t cur = 0;
-    if (packed && wid * R < tiles) cur = find_range(dir_in.base(), W, wid * R * TILE);
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t tile = wid * R + r;
-        if (!HAS_MESH && tile >= tiles) break;
-        const bool have = tile < tiles;
-        const uint32_t i = tile * TILE + lane;
-        bool active = have && i < n;
-        uint32_t src = i;
-        if (packed && have) src = resolve_src(dir_in, span, cur, i, active, ctl);
-        f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
-        if (active) {
-            char *q = in.slot(src);
-            if (ppid(q) == DEAD_PID) active = false;
-            ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
-            rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
-        }
-        ptd::Hit h;
-        intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h, wq, gf);
-        if (have && i < n) {
-            float t; f3 nrm; int mat;
-            resolve_hit(gsrc, sc.tris, h, t, nrm, mat);
-            // a miss writes only t; the other fields read as the zeros of pathtrace.cu:343's memset
-            out.plane(0)[i] = t; out.plane(1)[i] = nrm.x; out.plane(2)[i] = nrm.y; out.plane(3)[i] = nrm.z;
-            out.mat()[i] = mat | (h.outside ? 0 : (int)0x80000000u);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// stable compaction: range counts -> range bases, by the last workgroup out
-// ---------------------------------------------------------------------------
-// Hand-off (guide G16): each wave stores its range count with an agent-scope atomic
-// (write-through) store and drains it (s_waitcnt vmcnt(0)); after the workgroup's barrier one
-// lane adds 1 to done[depth]; the workgroup whose add returns grid-1 is last, acquires once
-// (agent scope) and scans the W counts (<= 8 steps of 1024).  Nothing spins; nothing depends
-// on dispatch order.
-__device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t *n_out,
-                                                  uint32_t *lds_scan /* >= 8 words */) {
-    // One step: thread t owns the `per` consecutive entries [t*per, (t+1)*per) (per = ceil(W/256) rounded
-    // to a multiple of 4, at most 32 for W <= 8192), loads them with 16-B loads all issued up front,
-    // and the 256 partial sums cross through one wave scan + one LDS exchange.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t W = dir.W;
-    const uint4 *count4 = reinterpret_cast<const uint4 *>(dir.count());
-    uint4 *base4 = reinterpret_cast<uint4 *>(dir.base());
-    const uint32_t per4 = ((W + BLOCK - 1) / BLOCK + 3) / 4;          // uint4s per thread, <= 8
-    const uint32_t first = threadIdx.x * per4 * 4;                    // first entry of this thread
-    uint4 v[8];
-    uint32_t sum = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) {
-        const uint32_t e = first + 4 * k;
-        v[k] = make_uint4(0, 0, 0, 0);
-        if (k < per4 && e < W) {
-            v[k] = count4[e >> 2];                                      // count[] is padded to a multiple of 4
-            if (e + 1 >= W) v[k].y = 0;
-            if (e + 2 >= W) v[k].z = 0;
-            if (e + 3 >= W) v[k].w = 0;
-        }
-        sum += v[k].x + v[k].y + v[k].z + v[k].w;
-    }
-    uint32_t incl = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t u = __shfl_up(incl, off);
-        if (lane >= off) incl += u;
-    }
-    if (lane == 63) lds_scan[wave] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        const uint32_t c = lds_scan[w];
-        if (w < wave) wave_off += c;
-        total += c;
-    }
-    uint32_t run = wave_off + incl - sum;
-#pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) {
-        const uint32_t e = first + 4 * k;
-        if (k < per4 && e < W) {
-            uint4 b;
-            b.x = run; b.y = b.x + v[k].x; b.z = b.y + v[k].y; b.w = b.z + v[k].z;
-            base4[e >> 2] = b;                                           // base[] has 4 spare entries
-            run = b.w + v[k].w;
-        }
-    }
-    if (threadIdx.x == 0) { dir.base()[W] = total; *n_out = total; }
-}
-
-// ---------------------------------------------------------------------------
-// material sort (INSTRUCTION.md:78-86; spec 8.0): stable counting sort of the live paths and
-// their intersections by key = materialId (misses last), before shading
-// ---------------------------------------------------------------------------
-// Pass 1 (k_sort_hist): every wave histograms the keys of its run of R tiles (wave64
-// match-ballot, per-wave bins in LDS) into table[bin][wave]; the last workgroup out scans the
-// bin-major table (nbins * W words) in place into start offsets.  Pass 2 (k_sort_scatter):
-// every wave walks its run again and moves path state + intersection to
-// offset[key][wave] + (same-key paths already seen in the run) + (same-key lanes below it),
-// which is the stable order.  The sorted pool is dense.
-constexpr int SORT_MAX_BINS = 256;
-
-struct SortArgs {
-    Pool in, out;            // out: dense, sorted
-    Isect isect, isect_out;  // logical order in, sorted order out
-    RangeDir dir_in;
-    Control *ctl;
-    uint32_t *table;         // nbins * W words
-    int depth, nbins;        // nbins = nmats + 1 (misses)
-    uint32_t pool_n;
-    int compact;
-};
-
-__device__ __forceinline__ uint32_t sort_key(const Isect &is, uint32_t i, int nbins) {
-    const float t = is.plane(0)[i];
-    const int m = is.mat()[i] & 0x7fffffff;
-    return t > 0.0f ? (uint32_t)m : (uint32_t)(nbins - 1);
-}
-
-// in-place exclusive scan of `total` words by one workgroup (1024 words per step)
-__device__ __forceinline__ void scan_words_inplace(uint32_t *w, uint32_t total, uint32_t *lds_scan) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t steps = (total + 4 * BLOCK - 1) / (4 * BLOCK);
-    uint32_t carry = 0;
-    for (uint32_t step = 0; step < steps; ++step) {
-        const uint32_t e = (step * BLOCK + threadIdx.x) * 4;
-        uint32_t v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (e + k < total) ? w[e + k] : 0u;
-        const uint32_t sum = v[0] + v[1] + v[2] + v[3];
-        uint32_t incl = sum;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t u = __shfl_up(incl, off);
-            if (lane >= off) incl += u;
-        }
-        uint32_t *slot = lds_scan + (step & 1) * WAVES;
-        if (lane == 63) slot[wave] = incl;
-        __syncthreads();
-        uint32_t wave_off = 0, tot = 0;
-#pragma unroll
-        for (int k = 0; k < WAVES; ++k) {
-            const uint32_t c = slot[k];
-            if (k < wave) wave_off += c;
-            tot += c;
-        }
-        uint32_t run = carry + wave_off + incl - sum;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (e + k < total) w[e + k] = run;
-            run += v[k];
-        }
-        carry += tot;
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_sort_hist(SortArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
-    uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * SORT_MAX_BINS;   // per-wave bins
-    const int lane = threadIdx.x & 63;
-    const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = run_id();
-    const uint32_t n = a.compact ? a.ctl->nlive[a.depth] : a.pool_n;
-    const uint32_t tiles = (n + TILE - 1) / TILE;
-    const uint32_t R = range_tiles(n, W);
-    for (int b = lane; b < a.nbins; b += 64) bins[b] = 0;
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t tile = wid * R + r;
-        if (tile >= tiles) break;
-        const uint32_t i = tile * TILE + lane;
-        const bool valid = i < n;
-        const uint32_t key = valid ? sort_key(a.isect, i, a.nbins) : 0u;
-        uint64_t rem = __ballot(valid);
-        while (rem) {                                           // one round per distinct key in the tile
-            const int l = __ffsll((unsigned long long)rem) - 1;
-            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
-            const uint64_t m = __ballot(valid && key == k);
-            if (lane == 0) bins[k] += (uint32_t)__popcll((unsigned long long)m);
-            rem &= ~m;
-        }
-    }
-    // publish table[bin][wave] (write-through), then elect the last workgroup to scan it
-    for (int b = lane; b < a.nbins; b += 64)
-        __hip_atomic_store(&a.table[(size_t)b * W + wid], bins[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const bool last = elect_last(a.ctl->bucket[a.depth][1], &a.ctl->done_sort[a.depth]);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        sctl[0] = last ? 1u : 0u;
-    }
-    __syncthreads();
-    if (sctl[0]) scan_words_inplace(a.table, (uint32_t)a.nbins * W, sctl + 2);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
-    uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * SORT_MAX_BINS;   // per-wave running offsets
-    const int lane = threadIdx.x & 63;
-    const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = run_id();
-    const uint32_t n = a.compact ? a.ctl->nlive[a.depth] : a.pool_n;
-    const uint32_t tiles = (n + TILE - 1) / TILE;
-    const uint32_t R = range_tiles(n, W);
-    const bool packed = a.compact && a.dir_in.mem != nullptr;
-    const uint32_t span = packed ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
-    uint32_t cur = 0;
-    if (packed && wid * R < tiles) cur = find_range(a.dir_in.base(), W, wid * R * TILE);
-    for (int b = lane; b < a.nbins; b += 64) bins[b] = a.table[(size_t)b * W + wid];
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t tile = wid * R + r;
-        if (tile >= tiles) break;
-        const uint32_t i = tile * TILE + lane;
-        const bool valid = i < n;
-        uint32_t src = i;
-        if (packed) src = resolve_src(a.dir_in, span, cur, i, valid, a.ctl);
-        const uint32_t key = valid ? sort_key(a.isect, i, a.nbins) : 0u;
-        uint32_t dst = 0;
-        uint64_t rem = __ballot(valid);
-        while (rem) {
-            const int l = __ffsll((unsigned long long)rem) - 1;
-            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
-            const uint64_t m = __ballot(valid && key == k);
-            const uint32_t base = bins[k];                          // same address for the whole wave
-            if (valid && key == k) dst = base + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)));
-            if (lane == 0) bins[k] = base + (uint32_t)__popcll((unsigned long long)m);
-            rem &= ~m;
-        }
-        if (valid) {
-            char *qs = a.in.slot(src), *qd = a.out.slot(dst);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) pf(qd, k) = pf(qs, k);
-            ppid(qd) = ppid(qs);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a.isect_out.plane(k)[dst] = a.isect.plane(k)[i];
-            a.isect_out.mat()[dst] = a.isect.mat()[i];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// the fused bounce kernel
-// ---------------------------------------------------------------------------
-// MODE_FUSED   : intersect inline (ShadeableIntersection never touches HBM)
-// MODE_ISECT   : read the materialised planes written by k_intersect (PT_UNFUSED / sort)
-// MODE_CACHE0  : bounce 0 with PT_CACHE_FIRST: the per-pixel intersection cache (INSTRUCTION.md:87-89)
-enum { MODE_FUSED = 0, MODE_ISECT = 1, MODE_CACHE0 = 2 };
-
-template <int MODE, bool COMPACT, bool HAS_MESH>
-__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
-    float *mats = lds_raw + LDS_CTL_WORDS;
-    const float *gf = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
-    float *wq = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
-    float *tri_lds = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + PT_QUEUE * WAVES * Q_WORDS;
-#ifdef PT_STAMPS
-#define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.depth == PT_STAMPS) a.ctl->stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
-    STAMP(0);
-    stage_scene(mats, a.scene);
-    STAMP(1);
-    const int lane = threadIdx.x & 63;
-    const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = run_id();
-    const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
-    const uint32_t tiles = (n + TILE - 1) / TILE;
-    const uint32_t R = range_tiles(n, W);                        // logical tiles per wave (one contiguous run)
-    const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
-    const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
-    const bool last_bounce = (a.depth == a.trace_depth - 1);
-    uint32_t traced = 0;
-    uint32_t packed = 0;                                         // survivors this wave has written (wave-uniform)
-    uint32_t cur = 0;                                            // source range of the run's current position
-    if (a.gen_rays && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = a.pool_n;   // k_raygen's job otherwise
-    if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), W, wid * R * TILE);
-    STAMP(2);
-
-    // every wave walks its own run of R consecutive 64-path tiles; no workgroup barrier inside
-    // the loop unless a mesh needs block-wide triangle staging (then all waves run R iterations)
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t tile = wid * R + r;
-        if (!HAS_MESH && tile >= tiles) break;
-        const bool have = tile < tiles;
-        const uint32_t i = tile * TILE + lane;                    // logical path index
-        bool active = have && i < n;
-        uint32_t src = i;
-        if (packed_in && have) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
-        uint32_t pid = DEAD_PID;
-        f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1), col = ptd::mk(1.0f, 1.0f, 1.0f);
-        if (active) {
-            if (a.gen_rays) {
-                pid = i;
-            } else {
-                // all ten fields of the slot in one burst of loads (one memory latency per tile)
-                char *q = a.in.slot(src);
-                pid = ppid(q);
-                ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
-                rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
-                col = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8));
-                if (pid == DEAD_PID) active = false;
-            }
-        }
-        uint32_t smp = 0;
-        int pixel = 0;
-        if (active) {
-            smp = sample_of(a.map, pid);
-            pixel = local_to_pixel(a.map, (int)(pid - smp * (uint32_t)a.map.tile_pixels));
-            if (a.gen_rays) {
-                ro = ptd::mk(a.cam.position.x, a.cam.position.y, a.cam.position.z);
-                rd = camera_dir(a.cam, pixel, a.map.W);
-            }
-        }
-        if (r == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(3); }
-        float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
-        if (MODE == MODE_FUSED) {
-            ptd::Hit h;
-#if PT_GEOM_LDS
-            const float *gsrc = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * a.scene.ngeoms * GF_WORDS;
-#else
-            const float *gsrc = a.scene.geoms;
-#endif
-            intersect_scene<HAS_MESH>(gsrc, a.scene.ngeoms, a.scene.tris, tri_lds, active, ro, rd, h, wq, gf);
-            if (active) { resolve_hit(gsrc, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
-        } else if (active) {
-            // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
-            const uint32_t q = (MODE == MODE_CACHE0) ? pid - smp * (uint32_t)a.map.tile_pixels : i;
-            t = at(a.isect.plane(0), q);
-            nrm = ptd::mk(at(a.isect.plane(1), q), at(a.isect.plane(2), q), at(a.isect.plane(3), q));
-            const int m = at(a.isect.mat(), q);
-            mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
-        }
-        if (r == 0) STAMP(4);
-        bool alive = false;
-        ptd::PathState ps;
-        ps.o = ro; ps.d = rd; ps.c = col;
-        if (active) {
-            alive = ptd::shade_scatter(ps, t, nrm, mat, outside, mats, a.iter0 + (int)smp, pixel, a.depth,
-                                       last_bounce);
-            if (!alive) {
-                at(a.fin, pid) = ps.c.x; at(a.fin + (size_t)a.in.cap, pid) = ps.c.y;
-                at(a.fin + 2 * (size_t)a.in.cap, pid) = ps.c.z;
-            }
-        }
-        if (r == 0) STAMP(5);
-        // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
-        const uint64_t bal = __ballot(alive);
-        const uint64_t act = __ballot(active);
-        traced += (uint32_t)__popcll((unsigned long long)act);
-        uint32_t dst = i;
-        if (COMPACT) {
-            dst = wid * R * TILE + packed + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
-            packed += (uint32_t)__popcll((unsigned long long)bal);
-        }
-        if (alive) {
-            char *q = a.out.slot(dst);
-            pf(q, 0) = ps.o.x; pf(q, 1) = ps.o.y; pf(q, 2) = ps.o.z;
-            pf(q, 3) = ps.d.x; pf(q, 4) = ps.d.y; pf(q, 5) = ps.d.z;
-            pf(q, 6) = ps.c.x; pf(q, 7) = ps.c.y; pf(q, 8) = ps.c.z;
-            ppid(q) = pid;
-        } else if (!COMPACT && have && i < n) {
-            a.out.pid(dst) = DEAD_PID;
-        }
-    }
-    STAMP(6);
-    // paths traced this bounce: with compaction it is simply the live count; otherwise count the alive
-    // slots, one atomic per workgroup (summed through LDS) rather than one per wave on a single address
-    if (COMPACT) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->alive[a.depth] = n;
-    } else {
-        if (lane == 0) sctl[8 + (threadIdx.x >> 6)] = traced;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t tb = sctl[8] + sctl[9] + sctl[10] + sctl[11];
-            if (tb) atomicAdd(&a.ctl->alive[a.depth], tb);
-        }
-    }
-
-    if (COMPACT) {
-        // every wave publishes its range count; the last workgroup out scans them
-        if (lane == 0)
-            __hip_atomic_store(&a.dir_out.count()[wid], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's count store has left
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const bool last = elect_last(a.ctl->bucket[a.depth][0], &a.ctl->done[a.depth]);
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            sctl[0] = last ? 1u : 0u;
-        }
-        __syncthreads();
-        STAMP(7);
-        if (sctl[0]) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            scan_range_counts(a.dir_out, &a.ctl->nlive[a.depth + 1], sctl + 2);
-            if (threadIdx.x == 0) a.ctl->scan_ticks[a.depth] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
-#ifdef PT_STAMPS
-            if (threadIdx.x == 0 && a.depth == PT_STAMPS) { a.ctl->stamp[8] = t0; a.ctl->stamp[9] = __builtin_amdgcn_s_memrealtime(); }
-#endif
-        }
-    }
-}
-
-// First-bounce cache (INSTRUCTION.md:87-89): camera rays do not depend on the iteration (no
-// jitter, pathtrace.cu:134), so computeIntersections of bounce 0 is evaluated once per pixel and
-// camera and reused by every sample.
-template <bool HAS_MESH>
-__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache, SceneDev sc, pt_camera cam,
-                                                                      TileMap map) {
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    float *mats_lds = lds_raw + LDS_CTL_WORDS;
-    const float *gf = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
-    float *wq = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
-    float *tri_lds = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + PT_QUEUE * WAVES * Q_WORDS;
-#if PT_GEOM_LDS || PT_QUEUE
-    stage_scene(mats_lds, sc);
-#endif
-#if PT_GEOM_LDS
-    const float *gsrc = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * sc.ngeoms * GF_WORDS;
-#else
-    const float *gsrc = sc.geoms;
-#endif
-    const uint32_t n = (uint32_t)map.tile_pixels;
-    const uint32_t tiles = (n + BLOCK - 1) / BLOCK;
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint32_t j = tile * BLOCK + threadIdx.x;
-        const bool active = j < n;
-        f3 ro = ptd::mk(cam.position.x, cam.position.y, cam.position.z), rd = ptd::mk(0, 0, 1);
-        if (active) rd = camera_dir(cam, local_to_pixel(map, (int)j), map.W);
-        ptd::Hit h;
-        intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h, wq, gf);
-        if (active) {
-            float t; f3 nrm; int mat;
-            resolve_hit(gsrc, sc.tris, h, t, nrm, mat);
-            cache.plane(0)[j] = t; cache.plane(1)[j] = nrm.x; cache.plane(2)[j] = nrm.y; cache.plane(3)[j] = nrm.z;
-            cache.mat()[j] = mat | (h.outside ? 0 : (int)0x80000000u);
-        }
-    }
-}
-
-// shadeFakeMaterial (pathtrace.cu:224-266): one bounce, never spawns a ray
-__global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const float *mats_g, TileMap map,
-                                                      int iter0, uint32_t n, float *fin) {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t pid = p.pid(i);
-    const uint32_t s = sample_of(map, pid);
-    const int idx = local_to_pixel(map, (int)(pid - s * (uint32_t)map.tile_pixels));
-    f3 c = ptd::mk(p.f(i, 6), p.f(i, 7), p.f(i, 8));
-    const float t = is.plane(0)[i];
-    if (t > 0.0f) {
-        uint32_t rng = ptd::seeded_engine(iter0 + (int)s, idx, 0);
-        const float *m = mats_g + (is.mat()[i] & 0x7fffffff) * ptd::MAT_WORDS;
-        f3 mc = ptd::mk(m[0], m[1], m[2]);
-        if (m[9] > 0.0f) {
-            c = ptd::mul(c, ptd::scale(mc, m[9]));
-        } else {
-            f3 nrm = ptd::mk(is.plane(1)[i], is.plane(2)[i], is.plane(3)[i]);
-            float lightTerm = ptd::dot(nrm, ptd::mk(0.0f, 1.0f, 0.0f));
-            f3 x = ptd::scale(ptd::scale(mc, lightTerm), 0.3f);
-            f3 y = ptd::scale(ptd::scale(mc, (1.0f - t * 0.02f)), 0.7f);
-            c = ptd::mul(c, ptd::add(x, y));
-            c = ptd::scale(c, ptd::u01(rng));
-        }
-    } else {
-        c = ptd::mk(0.0f, 0.0f, 0.0f);
-    }
-    p.f(i, 6) = c.x; p.f(i, 7) = c.y; p.f(i, 8) = c.z;
-    fin[pid] = c.x; fin[(size_t)p.cap + pid] = c.y; fin[2 * (size_t)p.cap + pid] = c.z;
-}
-
-// finalGather (pathtrace.cu:269-278): image[pixelIndex] += colour, one add per
-// pixel per iteration, samples added in iteration order
-__global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin, uint32_t cap, TileMap map,
-                                                  int count, const Control *ctl, Persist *per, int depths,
-                                                  uint32_t fake_rays) {
-    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j == 0) {                    // fold this batch's ray count into the persistent counter
-        unsigned long long r = fake_rays;
-        for (int d = 0; d < depths; ++d) r += ctl->alive[d];
-        per->rays += r;
-        per->iterations += (unsigned long long)count;
-        per->first_rays += depths > 0 ? ctl->alive[0] : fake_rays;
-    }
-    if (j >= (uint32_t)map.tile_pixels) return;
-    const int pix = local_to_pixel(map, (int)j);
-    float r = image[3 * pix + 0], g = image[3 * pix + 1], b = image[3 * pix + 2];
-    for (int s = 0; s < count; ++s) {
-        const size_t k = (size_t)s * map.tile_pixels + j;
-        r += fin[k]; g += fin[(size_t)cap + k]; b += fin[2 * (size_t)cap + k];
-    }
-    image[3 * pix + 0] = r; image[3 * pix + 1] = g; image[3 * pix + 2] = b;
-}
-
-// sendImageToPBO (pathtrace.cu:48-68)
-__global__ __launch_bounds__(BLOCK) void k_tonemap(uint8_t *pbo, const float *image, int npix, int iter) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= npix) return;
-    int c[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double v = (double)(image[3 * i + k] / (float)iter) * 255.0;
-        int q = (int)v;                      // v_cvt_i32_f64: saturating, NaN -> 0
-        c[k] = q < 0 ? 0 : (q > 255 ? 255 : q);
-    }
-    uchar4 o;
-    o.x = (unsigned char)c[0]; o.y = (unsigned char)c[1]; o.z = (unsigned char)c[2]; o.w = 0;
-    reinterpret_cast<uchar4 *>(pbo)[i] = o;
-}
-
-// pool <-> reference AoS (debug / parity export and pt_intersect_once)
-__global__ void k_export_paths(Pool p, TileMap map, uint32_t n_total, uint32_t n_live, int remaining,
-                               pt_path_segment *out, RangeDir dir, uint32_t span) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    uint32_t src = i;
-    if (dir.mem) {                        // logical -> physical: largest r with base[r] <= i
-        const uint32_t *base = dir.base();
-        uint32_t lo = 0, hi = dir.W - 1;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if (base[mid] <= i) lo = mid; else hi = mid - 1;
-        }
-        src = lo * span + (i - base[lo]);
-    }
-    pt_path_segment s;
-    s.ray.origin = {p.f(src, 0), p.f(src, 1), p.f(src, 2)};
-    s.ray.direction = {p.f(src, 3), p.f(src, 4), p.f(src, 5)};
-    s.color = {p.f(src, 6), p.f(src, 7), p.f(src, 8)};
-    const uint32_t pid = p.pid(src);
-    if (pid == DEAD_PID) { s.pixelIndex = -1; s.remainingBounces = 0; }
-    else {
-        const uint32_t sm = sample_of(map, pid);
-        s.pixelIndex = local_to_pixel(map, (int)(pid - sm * (uint32_t)map.tile_pixels));
-        s.remainingBounces = i < n_live ? remaining : 0;
-    }
-    out[i] = s;
-}
-
-__global__ void k_import_paths(Pool p, const pt_path_segment *in, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const pt_path_segment s = in[i];
-    p.f(i, 0) = s.ray.origin.x; p.f(i, 1) = s.ray.origin.y; p.f(i, 2) = s.ray.origin.z;
-    p.f(i, 3) = s.ray.direction.x; p.f(i, 4) = s.ray.direction.y; p.f(i, 5) = s.ray.direction.z;
-    p.f(i, 6) = s.color.x; p.f(i, 7) = s.color.y; p.f(i, 8) = s.color.z;
-    p.pid(i) = i;
-}
-
-__global__ void k_export_isects(Isect is, uint32_t n, pt_shadeable_intersection *out, uint8_t *outside) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    pt_shadeable_intersection s;
-    const int m = is.mat()[i];
-    s.t = is.plane(0)[i];
-    if (s.t > 0.0f) { s.surfaceNormal = {is.plane(1)[i], is.plane(2)[i], is.plane(3)[i]}; s.materialId = m & 0x7fffffff; }
-    else { s.surfaceNormal = {0, 0, 0}; s.materialId = 0; }      // memset(0) + t = -1 only
-    out[i] = s;
-    if (outside) outside[i] = (m < 0) ? 0 : 1;
-}
 
 // ---------------------------------------------------------------------------
 // host side
