@@ -351,11 +351,12 @@ template <typename P> PTD float sphere_test(P g, f3 ro, f3 rd, f3 &obj_p, int &o
 
 // surface normal of the winning primitive (the part of the two tests above
 // that the reference evaluates for every candidate)
-template <typename P> PTD f3 cube_normal(P g, f3 face_n) {
-    return normalize(mv_dir(g + G_FWD, face_from_code(__float_as_int(face_n.x))));
+// `fwd` / `invt`: the 12 floats (4 columns x 3 rows) of the transform / inverse-transpose
+template <typename P> PTD f3 cube_normal(P fwd, f3 face_n) {
+    return normalize(mv_dir(fwd, face_from_code(__float_as_int(face_n.x))));
 }
-template <typename P> PTD f3 sphere_normal(P g, f3 obj_p, int outside) {
-    f3 n = normalize(mv_dir(g + G_INVT, obj_p));
+template <typename P> PTD f3 sphere_normal(P invt, f3 obj_p, int outside) {
+    f3 n = normalize(mv_dir(invt, obj_p));
     return outside ? n : neg(n);
 }
 

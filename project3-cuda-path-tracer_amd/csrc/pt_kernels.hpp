@@ -35,7 +35,8 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, TileMap
 // fetched with wave-uniform (scalar, SGPR) loads straight from the 1-KB record array, which
 // costs no VGPRs and no LDS bandwidth; materials are per-lane gathers and live in LDS.
 constexpr int LDS_CTL_WORDS = 16;    // [0] last-block flag, [2..5] scan scratch
-constexpr int GF_WORDS = 16;         // staged per geom for gathers: transform[12], type, materialid, 2 pad
+constexpr int GF_WORDS = 32;         // staged per geom for per-lane gathers: transform[12], type, materialid, 2 pad,
+                                     // invTranspose[12], 4 pad
 // per-wave candidate queue (PT_QUEUE): ring of 128 slots, SoA: qo.xyz qd.xyz t_obj (7 planes), meta, and
 // the 64 per-lane best keys (u64)
 constexpr int Q_SLOTS = 128;
@@ -51,7 +52,11 @@ __device__ __forceinline__ void stage_scene(float *lds_mats, const SceneDev &sc)
         float *gf = lds_mats + ((mw + 3) & ~3);
         for (int k = threadIdx.x; k < sc.ngeoms * GF_WORDS; k += BLOCK) {
             const int g = k / GF_WORDS, w = k - g * GF_WORDS;
-            gf[k] = w < 12 ? sc.geoms[g * ptd::GEOM_WORDS + ptd::G_FWD + w] : sc.geoms[g * ptd::GEOM_WORDS + (w - 12)];
+            float v = 0.0f;
+            if (w < 12) v = sc.geoms[g * ptd::GEOM_WORDS + ptd::G_FWD + w];
+            else if (w < 16) v = sc.geoms[g * ptd::GEOM_WORDS + (w - 12)];          // type, materialid, mesh range
+            else if (w < 28) v = sc.geoms[g * ptd::GEOM_WORDS + ptd::G_INVT + (w - 16)];
+            gf[k] = v;
         }
     }
 #endif
@@ -254,17 +259,28 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
 #endif
 }
 
-// normal + materialId of the winning primitive (per-lane record: cached gather from the
-// 1-KB record array)
-__device__ __forceinline__ void resolve_hit(const float *__restrict__ geoms, const float *__restrict__ tris,
-                                            const ptd::Hit &h, float &t, f3 &n, int &mat) {
+// normal + materialId of the winning primitive: a per-lane gather from the records staged in LDS
+// (gf, PT_QUEUE) -- ~100 cycles instead of an L2 round trip -- or from the global record array
+__device__ __forceinline__ void resolve_hit(const float *__restrict__ geoms, const float *gf,
+                                            const float *__restrict__ tris, const ptd::Hit &h, float &t, f3 &n,
+                                            int &mat) {
     if (h.geom < 0) { t = -1.0f; n = ptd::mk(0, 0, 0); mat = 0; return; }
+#if PT_QUEUE
+    (void)geoms;
+    const float *rec = gf + h.geom * GF_WORDS;
+    const int type = __float_as_int(rec[12]);
+    mat = __float_as_int(rec[13]);
+    const float *fwd = rec, *invt = rec + 16;
+#else
+    (void)gf;
     const float *rec = geoms + h.geom * ptd::GEOM_WORDS;
     const int type = __float_as_int(rec[0]);
-    t = h.t;
     mat = __float_as_int(rec[1]);
-    if (type == PT_CUBE) n = ptd::cube_normal(rec, h.aux);
-    else if (type == PT_SPHERE) n = ptd::sphere_normal(rec, h.aux, h.outside);
+    const float *fwd = rec + ptd::G_FWD, *invt = rec + ptd::G_INVT;
+#endif
+    t = h.t;
+    if (type == PT_CUBE) n = ptd::cube_normal(fwd, h.aux);
+    else if (type == PT_SPHERE) n = ptd::sphere_normal(invt, h.aux, h.outside);
     else {
         const float *tv = tris + (size_t)__float_as_int(h.aux.x) * TRI_WORDS;
         n = ptd::normalize(ptd::cross(ptd::mk(tv[3], tv[4], tv[5]), ptd::mk(tv[6], tv[7], tv[8])));
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
         intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h, wq, gf);
         if (have && i < n) {
             float t; f3 nrm; int mat;
-            resolve_hit(gsrc, sc.tris, h, t, nrm, mat);
+            resolve_hit(gsrc, gf, sc.tris, h, t, nrm, mat);
             // a miss writes only t; the other fields read as the zeros of pathtrace.cu:343's memset
             out.plane(0)[i] = t; out.plane(1)[i] = nrm.x; out.plane(2)[i] = nrm.y; out.plane(3)[i] = nrm.z;
             out.mat()[i] = mat | (h.outside ? 0 : (int)0x80000000u);
@@ -683,7 +699,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
             const float *gsrc = a.scene.geoms;
 #endif
             intersect_scene<HAS_MESH>(gsrc, a.scene.ngeoms, a.scene.tris, tri_lds, active, ro, rd, h, wq, gf);
-            if (active) { resolve_hit(gsrc, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
+            if (active) { resolve_hit(gsrc, gf, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
         } else if (active) {
             // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
             const uint32_t q = (MODE == MODE_CACHE0) ? pid - smp * (uint32_t)a.map.tile_pixels : i;
@@ -795,7 +811,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache
         intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h, wq, gf);
         if (active) {
             float t; f3 nrm; int mat;
-            resolve_hit(gsrc, sc.tris, h, t, nrm, mat);
+            resolve_hit(gsrc, gf, sc.tris, h, t, nrm, mat);
             cache.plane(0)[j] = t; cache.plane(1)[j] = nrm.x; cache.plane(2)[j] = nrm.y; cache.plane(3)[j] = nrm.z;
             cache.mat()[j] = mat | (h.outside ? 0 : (int)0x80000000u);
         }
