@@ -258,32 +258,40 @@ template <typename P> PTD bool box_slab(P g, f3 ro, f3 rd, f3 &qo, f3 &qd, float
     const f3 v = mv_dir(g + G_INV, rd);
     const float x = dot(v, v);
     float t1x, t2x, t1y, t2y, t1z, t2z;
+    float tax, tbx, tay, tby, taz, tbz;
     if (cube_fast_ok(qo, v, x)) {                                         // wave-uniform
         qd = normalize_normal_range(v, x);
         const float rx = rcp_refined(qd.x), ry = rcp_refined(qd.y), rz = rcp_refined(qd.z);
         t1x = div_by_rcp(-0.5f - qo.x, qd.x, rx); t2x = div_by_rcp(+0.5f - qo.x, qd.x, rx);
         t1y = div_by_rcp(-0.5f - qo.y, qd.y, ry); t2y = div_by_rcp(+0.5f - qo.y, qd.y, ry);
         t1z = div_by_rcp(-0.5f - qo.z, qd.z, rz); t2z = div_by_rcp(+0.5f - qo.z, qd.z, rz);
+        // all six quotients are finite and non-NaN here (|d| >= 2^-40, |n| < 2^55): glm's min/max
+        // selects reduce to v_min/v_max (they can differ only in the sign of a zero, which no
+        // comparison below distinguishes)
+        tax = __builtin_fminf(t1x, t2x); tbx = __builtin_fmaxf(t1x, t2x);
+        tay = __builtin_fminf(t1y, t2y); tby = __builtin_fmaxf(t1y, t2y);
+        taz = __builtin_fminf(t1z, t2z); tbz = __builtin_fmaxf(t1z, t2z);
     } else {
         qd = scale(v, 1.0f / __builtin_sqrtf(x));                         // glm normalize
         t1x = (-0.5f - qo.x) / qd.x; t2x = (+0.5f - qo.x) / qd.x;
         t1y = (-0.5f - qo.y) / qd.y; t2y = (+0.5f - qo.y) / qd.y;
         t1z = (-0.5f - qo.z) / qd.z; t2z = (+0.5f - qo.z) / qd.z;
+        tax = t1x < t2x ? t1x : t2x; tbx = t1x > t2x ? t1x : t2x;         // glm::min / glm::max
+        tay = t1y < t2y ? t1y : t2y; tby = t1y > t2y ? t1y : t2y;
+        taz = t1z < t2z ? t1z : t2z; tbz = t1z > t2z ? t1z : t2z;
     }
     float tmin = -1e38f, tmax = 1e38f;
     int tmin_c = 7, tmax_c = 7;
-#define PTD_SLAB(T1, T2, AXIS)                                            \
+#define PTD_SLAB(T1, T2, TA, TB, AXIS)                                    \
     {                                                                     \
-        float t1 = (T1), t2 = (T2);                                       \
-        float ta = t1 < t2 ? t1 : t2;                                     \
-        float tb = t1 > t2 ? t1 : t2;                                     \
-        int code = (AXIS) * 2 + (t2 < t1 ? 1 : 0);                        \
+        float ta = (TA), tb = (TB);                                       \
+        int code = (AXIS) * 2 + ((T2) < (T1) ? 1 : 0);                    \
         if (ta > 0 && ta > tmin) { tmin = ta; tmin_c = code; }            \
         if (tb < tmax) { tmax = tb; tmax_c = code; }                      \
     }
-    PTD_SLAB(t1x, t2x, 0)
-    PTD_SLAB(t1y, t2y, 1)
-    PTD_SLAB(t1z, t2z, 2)
+    PTD_SLAB(t1x, t2x, tax, tbx, 0)
+    PTD_SLAB(t1y, t2y, tay, tby, 1)
+    PTD_SLAB(t1z, t2z, taz, tbz, 2)
 #undef PTD_SLAB
     if (tmax >= tmin && tmax > 0) {
         outside = 1;
