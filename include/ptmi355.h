@@ -93,8 +93,11 @@ enum pt_flags {
     PT_FAKE_SHADER   = 1u << 2,  /* the reference as shipped: one bounce + shadeFakeMaterial
                                     (pathtrace.cu:224-266,339-377) */
     PT_CACHE_FIRST   = 1u << 3,  /* cache the bounce-0 intersections (INSTRUCTION.md:87-89) */
-    PT_UNFUSED       = 1u << 4   /* debug: separate intersect / shade kernels with the
+    PT_UNFUSED       = 1u << 4,  /* debug: separate intersect / shade kernels with the
                                     ShadeableIntersection planes materialised in HBM */
+    PT_MESH_BVH      = 1u << 5   /* cull triangle tests with a bounding-volume hierarchy built at
+                                    pt_init (INSTRUCTION.md:129-139,218-240); same winner as the
+                                    loop over every triangle */
 };
 
 typedef struct pt_scene_desc {
@@ -190,6 +193,18 @@ typedef struct pt_profile {
 } pt_profile;
 int pt_set_profiling(int enable);      /* also clears the accumulated profile */
 int pt_get_profile(pt_profile *out);   /* synchronises the stream, drains pending events */
+/* PT_MESH_BVH: what pt_init built (all meshes together) */
+typedef struct pt_bvh_info {
+    int32_t nodes, triangles, depth;
+    float   pad;                       /* box padding, world units */
+    float   prune;                     /* additive slack of the distance prune */
+} pt_bvh_info;
+int pt_get_bvh_info(pt_bvh_info *out);
+/* host-only (no GPU): build the hierarchy of `count` triangles; returns the node count, or the
+ * required count when `node_capacity` is too small (nothing written then).  nodes: 16 dwords
+ * each (layout in csrc/pt_bvh.hpp); order: leaf slot -> triangle index. */
+int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node_capacity,
+                 int32_t *order);
 const char *pt_last_error(void);
 const char *pt_version(void);
 

@@ -308,8 +308,7 @@ int pto_ray_triangle(pto_vec3 orig, pto_vec3 dir, pto_vec3 v0, pto_vec3 v1, pto_
  * P = o + d*tz, the geometric normal normalize(cross(e1,e2)) and
  * t = length(o - P).  Back-face culled (a < eps -> miss), so `outside` is
  * always true. */
-float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r, pto_vec3 *point,
-                    pto_vec3 *normal, int *outside) {
+int pto_mesh_winner(const pto_tri *tris, int first, int count, pto_ray r, float *tz) {
     float best = FLT_MAX;
     int hit = -1;
     for (int i = first; i < first + count; ++i) {
@@ -321,6 +320,19 @@ float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r, pto_ve
             }
         }
     }
+    *tz = best;
+    return hit;
+}
+
+void pto_mesh_winners(const pto_tri *tris, int first, int count, const pto_path *paths, int n,
+                      int32_t *index, float *tz) {
+    for (int k = 0; k < n; ++k) index[k] = pto_mesh_winner(tris, first, count, paths[k].ray, &tz[k]);
+}
+
+float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r, pto_vec3 *point,
+                    pto_vec3 *normal, int *outside) {
+    float best;
+    int hit = pto_mesh_winner(tris, first, count, r, &best);
     if (hit < 0) return -1;
     *outside = 1;
     *point = add3(r.origin, muls(r.direction, best));

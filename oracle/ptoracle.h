@@ -108,6 +108,10 @@ float pto_sphere_test(const pto_geom *sphere, pto_ray r, pto_vec3 *point,
                       pto_vec3 *normal, int *outside);                   /* intersections.h:102-144 */
 int   pto_ray_triangle(pto_vec3 orig, pto_vec3 dir, pto_vec3 v0, pto_vec3 v1,
                        pto_vec3 v2, pto_vec3 *bary);                     /* glm/gtx/intersect.inl:37-74 */
+int   pto_mesh_winner(const pto_tri *tris, int first, int count, pto_ray r, float *tz); /* spec 8.0: smallest
+                       bary.z > 0 over the triangles in index order, first wins ties; -1: none */
+void  pto_mesh_winners(const pto_tri *tris, int first, int count, const pto_path *paths, int n,
+                       int32_t *index, float *tz);
 float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r,
                     pto_vec3 *point, pto_vec3 *normal, int *outside);    /* spec 8.0 */
 pto_vec3 pto_hemisphere(pto_vec3 normal, uint32_t *rng, int trig);       /* interactions.h:10-42 */

@@ -106,6 +106,7 @@ def lib():
             f.argtypes = [C.c_void_p, Ray, C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(C.c_int)]
         L.pto_ray_triangle.restype = C.c_int
         L.pto_ray_triangle.argtypes = [Vec3, Vec3, Vec3, Vec3, Vec3, C.POINTER(Vec3)]
+        L.pto_mesh_winners.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pto_hemisphere.restype = Vec3
         L.pto_hemisphere.argtypes = [Vec3, C.POINTER(C.c_uint32), C.c_int]
         L.pto_reflect.restype = Vec3
@@ -206,6 +207,15 @@ def compute_intersections(paths, geoms, tris=None, meshes=None, n=None):
     lib().pto_compute_intersections(n, _p(paths), _p(geoms), len(geoms), _p(tris), _p(meshes),
                                     0 if meshes is None else len(meshes), _p(isects), _p(outside))
     return isects, outside
+
+
+def mesh_winners(tris, paths, first=0, count=None):
+    """Winning triangle index (-1: none) and its bary.z for every ray: the loop over all triangles."""
+    count = len(tris) - first if count is None else count
+    idx = np.zeros(len(paths), dtype=np.int32)
+    tz = np.zeros(len(paths), dtype=np.float32)
+    lib().pto_mesh_winners(_p(tris), first, count, _p(paths), len(paths), _p(idx), _p(tz))
+    return idx, tz
 
 
 def make_scene(geoms, materials, cam_np, trace_depth, flags=F_COMPACT, trig=TRIG_SHARED,

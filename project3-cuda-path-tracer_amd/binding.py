@@ -32,7 +32,8 @@ ISECT_DT = np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("materialId", "<i4")])
 TRI_DT = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3)])
 MESH_DT = np.dtype([("geom_index", "<i4"), ("first_triangle", "<i4"), ("triangle_count", "<i4")])
 
-PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED = 1, 2, 4, 8, 16
+PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH = 1, 2, 4, 8, 16, 32
+BVH_NODE_WORDS = 16
 
 
 class PtError(RuntimeError):
@@ -57,6 +58,11 @@ class _SceneDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("bounces", C.c_int32), ("rays", C.c_int64), ("live", C.c_int32 * 64),
                 ("total_rays", C.c_int64), ("total_iterations", C.c_int64)]
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [("nodes", C.c_int32), ("triangles", C.c_int32), ("depth", C.c_int32),
+                ("pad", C.c_float), ("prune", C.c_float)]
 
 
 class Profile(C.Structure):
@@ -128,6 +134,8 @@ def library():
         L.pt_get_counters.argtypes = [C.POINTER(C.c_int64)] * 3
         L.pt_set_profiling.argtypes = [C.c_int]
         L.pt_get_profile.argtypes = [C.POINTER(Profile)]
+        L.pt_get_bvh_info.argtypes = [C.POINTER(BvhInfo)]
+        L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.pt_free.restype = None
         _lib = L
     return _lib
@@ -273,6 +281,26 @@ def get_profile():
     p = Profile()
     _chk(library().pt_get_profile(C.byref(p)))
     return {name: (p.ms[i], p.launches[i]) for i, name in enumerate(STAGES)}
+
+
+def bvh_info():
+    info = BvhInfo()
+    _chk(library().pt_get_bvh_info(C.byref(info)))
+    return info
+
+
+def bvh_build(triangles):
+    """Host-only: the hierarchy pt_init builds under PT_MESH_BVH.  Returns (nodes[n, 16] float32 -- words
+    6..15 are int32 --, order[count] int32)."""
+    tris = np.ascontiguousarray(triangles, dtype=TRI_DT)
+    L = library()
+    need = L.pt_bvh_build(_p(tris), len(tris), None, 0, None)
+    if need < 0:
+        raise PtError(L.pt_last_error().decode())
+    nodes = np.zeros((need, BVH_NODE_WORDS), dtype=np.float32)
+    order = np.zeros(max(1, len(tris)), dtype=np.int32)
+    _chk(min(0, L.pt_bvh_build(_p(tris), len(tris), _p(nodes), need, _p(order))))
+    return nodes, order[:len(tris)]
 
 
 def total_rays():

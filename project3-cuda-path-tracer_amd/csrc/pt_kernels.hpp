@@ -111,12 +111,60 @@ __device__ __forceinline__ void queue_pass(float *wq, const float *gf, uint32_t 
 }
 #endif
 
-template <bool HAS_MESH>
-__device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms, int ngeoms,
-                                                const float *__restrict__ tris, float *tri_lds, bool active,
+// Stackless walk of one mesh's hierarchy (layout and link construction: pt_bvh.hpp).  Per lane:
+// fetch the 64-B node (box + link + info as two 16-B loads, the octant's miss link as a third),
+// slab-test the padded box against [0, best + prune], then either descend to the near child, test
+// the leaf's <= 4 triangles, or follow the miss link.  The box test only has to be conservative
+// (it decides which exact triangle tests run, never their outcome), so it uses v_rcp and fused
+// multiply-adds; NaNs from 0 * inf drop out of v_min/v_max, which errs towards visiting.
+// Every link points forward in the octant's depth-first order, so the walk ends after at most
+// `guard` nodes; the guard also bounds it for NaN rays.
+__device__ __forceinline__ void bvh_walk(const float *__restrict__ nodes, const float *__restrict__ btris,
+                                         float prune, int guard, f3 ro, f3 rd, float &best, int &best_i) {
+    const float ix = __builtin_amdgcn_rcpf(rd.x), iy = __builtin_amdgcn_rcpf(rd.y), iz = __builtin_amdgcn_rcpf(rd.z);
+    const float nx = -(ro.x * ix), ny = -(ro.y * iy), nz = -(ro.z * iz);
+    const int oct = (rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0);
+    int node = 0;
+    for (int it = 0; it < guard && node >= 0; ++it) {
+        const float4 *n4 = reinterpret_cast<const float4 *>(nodes + (size_t)node * BVH_NODE_WORDS);
+        const float4 A = n4[0], B = n4[1];
+        int next = reinterpret_cast<const int *>(n4)[8 + oct];
+        const float t1x = __builtin_fmaf(A.x, ix, nx), t2x = __builtin_fmaf(A.w, ix, nx);
+        const float t1y = __builtin_fmaf(A.y, iy, ny), t2y = __builtin_fmaf(B.x, iy, ny);
+        const float t1z = __builtin_fmaf(A.z, iz, nz), t2z = __builtin_fmaf(B.y, iz, nz);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
+                                         __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+                                         __builtin_fmaxf(t1z, t2z));
+        if (tn <= tf && tn <= best + prune) {
+            const int link = __float_as_int(B.z), info = __float_as_int(B.w);
+            const int cnt = info >> 2;
+            if (cnt == 0) {
+                next = link + ((oct >> (info & 3)) & 1);             // near child first
+            } else {
+                const float4 *t4 = reinterpret_cast<const float4 *>(btris + (size_t)link * TRI_WORDS);
+                for (int k = 0; k < cnt; ++k) {
+                    const float4 P = t4[3 * k], Q = t4[3 * k + 1], S = t4[3 * k + 2];
+                    float tz;
+                    if (ptd::ray_triangle(ro, rd, ptd::mk(P.x, P.y, P.z), ptd::mk(P.w, Q.x, Q.y), ptd::mk(Q.z, Q.w, S.x), tz)) {
+                        const int orig = __float_as_int(S.y);                // index in the caller's triangle array
+                        if (tz > 0.0f && (best > tz || (best == tz && orig < best_i))) { best = tz; best_i = orig; }
+                    }
+                }
+            }
+        }
+        node = next;
+    }
+}
+
+template <int MESH>
+__device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms, const SceneDev &sc,
+                                                float *tri_lds, bool active,
                                                 f3 ro, f3 rd, ptd::Hit &h, float *wq = nullptr,
                                                 const float *gf = nullptr) {
     h.t = FLT_MAX; h.geom = -1; h.outside = 1; h.aux = ptd::mk(0, 0, 0);
+    const int ngeoms = sc.ngeoms;
+    const float *__restrict__ tris = sc.tris;
     int outside = 1;                                    // shared across tests, pathtrace.cu:169
     (void)outside;
 #if PT_QUEUE
@@ -153,7 +201,27 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
         cfloat *rec = as_const(geoms) + g * ptd::GEOM_WORDS;           // wave-uniform address -> s_load
         const int type = __float_as_int(rec[0]);
 #endif
-        if (HAS_MESH && type == PT_TRIANGLE_MESH) {
+        if (MESH == MESH_BVH && type == PT_TRIANGLE_MESH) {
+            // same winner as the loop below (smallest bary.z, lowest triangle index on ties), found by
+            // walking the mesh's bounding-volume hierarchy instead of testing every triangle
+            const int root = __float_as_int(rec[2]);
+            const int count = __float_as_int(rec[3]);
+            float best = FLT_MAX;
+            int best_i = -1;
+            if (active && count > 0)
+                bvh_walk(sc.bvh_nodes + (size_t)root * BVH_NODE_WORDS, sc.bvh_tris, sc.bvh_prune, sc.bvh_guard, ro, rd,
+                         best, best_i);
+            if (active && best_i >= 0) {
+                f3 p = ptd::add(ro, ptd::scale(rd, best));
+                const float t = ptd::length(ptd::sub(ro, p));
+                if (t > 0.0f && h.t > t) {
+                    h.t = t; h.geom = g; h.outside = 1;
+                    h.aux = ptd::mk(__int_as_float(best_i), 0.0f, 0.0f);
+                }
+            }
+            continue;
+        }
+        if (MESH == MESH_TILES && type == PT_TRIANGLE_MESH) {
             // completion spec 8.0: nearest triangle by strictly smaller bary.z, first wins ties
             const int first = __float_as_int(rec[2]);
             const int count = __float_as_int(rec[3]);
@@ -344,7 +412,7 @@ __device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t sp
 
 // standalone computeIntersections: materialises the ShadeableIntersection planes
 // (indexed by LOGICAL path index)
-template <bool HAS_MESH>
+template <int MESH>
 __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc,
                                                                     const uint32_t *n_ptr, uint32_t n_fixed,
                                                                     RangeDir dir_in, const uint32_t *nprev_ptr,
@@ -374,7 +442,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
     if (packed && wid * R < tiles) cur = find_range(dir_in.base(), W, wid * R * TILE);
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t tile = wid * R + r;
-        if (!HAS_MESH && tile >= tiles) break;
+        if (MESH != MESH_TILES && tile >= tiles) break;
         const bool have = tile < tiles;
         const uint32_t i = tile * TILE + lane;
         bool active = have && i < n;
@@ -388,7 +456,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
             rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
         }
         ptd::Hit h;
-        intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h, wq, gf);
+        intersect_scene<MESH>(gsrc, sc, tri_lds, active, ro, rd, h, wq, gf);
         if (have && i < n) {
             float t; f3 nrm; int mat;
             resolve_hit(gsrc, gf, sc.tris, h, t, nrm, mat);
@@ -622,7 +690,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
 // MODE_CACHE0  : bounce 0 with PT_CACHE_FIRST: the per-pixel intersection cache (INSTRUCTION.md:87-89)
 enum { MODE_FUSED = 0, MODE_ISECT = 1, MODE_CACHE0 = 2 };
 
-template <int MODE, bool COMPACT, bool HAS_MESH>
+template <int MODE, bool COMPACT, int MESH>
 __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
@@ -658,7 +726,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     // the loop unless a mesh needs block-wide triangle staging (then all waves run R iterations)
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t tile = wid * R + r;
-        if (!HAS_MESH && tile >= tiles) break;
+        if (MESH != MESH_TILES && tile >= tiles) break;
         const bool have = tile < tiles;
         const uint32_t i = tile * TILE + lane;                    // logical path index
         bool active = have && i < n;
@@ -698,7 +766,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 #else
             const float *gsrc = a.scene.geoms;
 #endif
-            intersect_scene<HAS_MESH>(gsrc, a.scene.ngeoms, a.scene.tris, tri_lds, active, ro, rd, h, wq, gf);
+            intersect_scene<MESH>(gsrc, a.scene, tri_lds, active, ro, rd, h, wq, gf);
             if (active) { resolve_hit(gsrc, gf, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
         } else if (active) {
             // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
@@ -784,7 +852,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 // First-bounce cache (INSTRUCTION.md:87-89): camera rays do not depend on the iteration (no
 // jitter, pathtrace.cu:134), so computeIntersections of bounce 0 is evaluated once per pixel and
 // camera and reused by every sample.
-template <bool HAS_MESH>
+template <int MESH>
 __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache, SceneDev sc, pt_camera cam,
                                                                       TileMap map) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
@@ -808,7 +876,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache
         f3 ro = ptd::mk(cam.position.x, cam.position.y, cam.position.z), rd = ptd::mk(0, 0, 1);
         if (active) rd = camera_dir(cam, local_to_pixel(map, (int)j), map.W);
         ptd::Hit h;
-        intersect_scene<HAS_MESH>(gsrc, sc.ngeoms, sc.tris, tri_lds, active, ro, rd, h, wq, gf);
+        intersect_scene<MESH>(gsrc, sc, tri_lds, active, ro, rd, h, wq, gf);
         if (active) {
             float t; f3 nrm; int mat;
             resolve_hit(gsrc, gf, sc.tris, h, t, nrm, mat);

@@ -20,6 +20,8 @@ constexpr int WAVES = BLOCK / 64;
 constexpr int TILE = 64;                   // paths per tile = one wave64
 constexpr int TRI_TILE = 512;              // triangles staged in LDS per pass (24 KiB)
 constexpr int TRI_WORDS = 12;              // v0 e1 e2 + 3 pad: three 16-B words per triangle
+constexpr int BVH_NODE_WORDS = 16;         // pt_bvh.hpp
+enum { MESH_NONE = 0, MESH_TILES = 1, MESH_BVH = 2 };   // how triangle meshes are intersected (template switch)
 constexpr int MAX_DEPTH = 64;
 constexpr uint32_t DEAD_PID = 0xffffffffu;
 
@@ -144,6 +146,9 @@ struct SceneDev {
     const float *geoms;  int ngeoms;       // GEOM_WORDS dwords each
     const float *mats;   int nmats;        // MAT_WORDS dwords each
     const float *tris;   int ntris;        // v0, e1, e2 + pad (12 dwords each)
+    const float *bvh_nodes;                // PT_MESH_BVH: all meshes' trees, BVH_NODE_WORDS per node
+    const float *bvh_tris;                 //   leaf-ordered triangle records, word 9 = original index
+    float bvh_prune;  int bvh_guard;       //   prune margin; upper bound on nodes visited per walk
 };
 
 struct BounceArgs {

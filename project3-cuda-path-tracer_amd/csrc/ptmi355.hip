@@ -53,6 +53,7 @@ using ptd::f3;
 
 #include "pt_types.hpp"
 #include "pt_kernels.hpp"
+#include "pt_bvh.hpp"
 
 namespace {
 
@@ -115,7 +116,9 @@ struct Renderer {
     int grid = 0;                 // persistent grid size
     bool sorted_isects = false;   // the last bounce's intersections live in isect2 (sorted order)
     bool gen_fused = false;       // bounce 0 of the current batch generates its own rays
-    bool has_mesh = false;
+    int mesh_mode = MESH_NONE;    // MESH_TILES: every triangle per ray; MESH_BVH: PT_MESH_BVH culling
+    float *d_bvh_nodes = nullptr, *d_bvh_tris = nullptr;
+    pt_bvh_info bvh_info{};
     void *scratch = nullptr;      // export / import staging
     size_t scratch_bytes = 0;
     // stepping state
@@ -235,17 +238,24 @@ int enqueue_begin(int iter0, int count, bool stepping) {
     return PT_OK;
 }
 
-template <bool HAS_MESH>
+// the mesh mode is a template switch of every kernel that intersects: pick the instantiation
+#define PT_MESH_DISPATCH(CALL)                                          \
+    do {                                                                \
+        if (R.mesh_mode == MESH_BVH) { constexpr int MESH = MESH_BVH; CALL; }            \
+        else if (R.mesh_mode == MESH_TILES) { constexpr int MESH = MESH_TILES; CALL; }   \
+        else { constexpr int MESH = MESH_NONE; CALL; }                  \
+    } while (0)
+
 void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, const RangeDir &dir,
                       const uint32_t *nprev) {
-    hipLaunchKernelGGL((k_intersect<HAS_MESH>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, in, R.isect,
-                       R.scene, n_ptr, n_fixed, dir, nprev, R.ctl);
+    PT_MESH_DISPATCH(hipLaunchKernelGGL((k_intersect<MESH>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, in,
+                                        R.isect, R.scene, n_ptr, n_fixed, dir, nprev, R.ctl));
 }
 
 template <int MODE, bool COMPACT>
 void launch_bounce(const BounceArgs &a) {
-    if (R.has_mesh) hipLaunchKernelGGL((k_bounce<MODE, COMPACT, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
-    else hipLaunchKernelGGL((k_bounce<MODE, COMPACT, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+    PT_MESH_DISPATCH(hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH>), dim3(R.grid), dim3(BLOCK), R.lds_bytes,
+                                        R.stream, a));
 }
 
 int enqueue_bounce(int depth) {
@@ -256,8 +266,7 @@ int enqueue_bounce(int depth) {
         StageTimer tm(PT_STAGE_INTERSECT);
         const uint32_t *n_ptr = compact ? &R.ctl->nlive[depth] : (const uint32_t *)nullptr;
         const uint32_t *nprev = (compact && depth > 0) ? &R.ctl->nlive[depth - 1] : (const uint32_t *)nullptr;
-        if (R.has_mesh) launch_intersect<true>(a.in, n_ptr, a.pool_n, a.dir_in, nprev);
-        else launch_intersect<false>(a.in, n_ptr, a.pool_n, a.dir_in, nprev);
+        launch_intersect(a.in, n_ptr, a.pool_n, a.dir_in, nprev);
         HIPCHK(hipGetLastError());
     }
     if (R.flags & PT_SORT_MATERIAL) {
@@ -283,8 +292,8 @@ int enqueue_bounce(int depth) {
         StageTimer tm(PT_STAGE_INTERSECT);
         const Isect cache{R.cache_mem, (uint32_t)R.map.tile_pixels};
         const int blocks = std::min(R.grid, (R.map.tile_pixels + BLOCK - 1) / BLOCK);
-        if (R.has_mesh) hipLaunchKernelGGL((k_cache_first<true>), dim3(blocks), dim3(BLOCK), R.lds_bytes, R.stream, cache, R.scene, R.cam, R.map);
-        else hipLaunchKernelGGL((k_cache_first<false>), dim3(blocks), dim3(BLOCK), R.lds_bytes, R.stream, cache, R.scene, R.cam, R.map);
+        PT_MESH_DISPATCH(hipLaunchKernelGGL((k_cache_first<MESH>), dim3(blocks), dim3(BLOCK), R.lds_bytes, R.stream,
+                                            cache, R.scene, R.cam, R.map));
         HIPCHK(hipGetLastError());
         R.cache_valid = true;
     }
@@ -311,8 +320,7 @@ int enqueue_bounce(int depth) {
 int enqueue_fake(void) {
     // the reference as shipped (pathtrace.cu:339-377): one bounce, fake shader
     const uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
-    if (R.has_mesh) launch_intersect<true>(R.pool[R.cur], nullptr, total, tile_dir(-1), nullptr);
-    else launch_intersect<false>(R.pool[R.cur], nullptr, total, tile_dir(-1), nullptr);
+    launch_intersect(R.pool[R.cur], nullptr, total, tile_dir(-1), nullptr);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_shade_fake, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.pool[R.cur],
                        R.isect, R.scene.mats, R.map, R.step_iter0, total, R.final_mem);
@@ -402,6 +410,8 @@ void pt_free(void) {
     if (R.d_geoms) (void)hipFree(R.d_geoms);
     if (R.d_mats) (void)hipFree(R.d_mats);
     if (R.d_tris) (void)hipFree(R.d_tris);
+    if (R.d_bvh_nodes) (void)hipFree(R.d_bvh_nodes);
+    if (R.d_bvh_tris) (void)hipFree(R.d_bvh_tris);
     if (R.ctl) (void)hipFree(R.ctl);
     if (R.dir_mem) (void)hipFree(R.dir_mem);
     if (R.persist) (void)hipFree(R.persist);
@@ -412,6 +422,57 @@ void pt_free(void) {
 }
 
 static int init_impl(const pt_scene_desc *d);
+
+// PT_MESH_BVH: one tree per mesh (pt_bvh.hpp), all trees in one node buffer; the leaf-ordered copies
+// of the triangle records carry the original index in word 9.  Geom record words 2/3 of a mesh
+// become (root node, triangle count).
+static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
+    std::vector<float> nodes, btris;
+    float prune = 0.0f;
+    int guard = 1;
+    R.bvh_info = pt_bvh_info{};
+    for (int k = 0; k < d->num_meshes; ++k) {
+        const pt_mesh &m = d->meshes[k];
+        ptbvh::Tree tree;
+        ptbvh::build(reinterpret_cast<const float *>(d->triangles + m.first_triangle), m.triangle_count, tree);
+        const int root = (int)(nodes.size() / BVH_NODE_WORDS);
+        const int slot0 = (int)(btris.size() / TRI_WORDS);
+        for (int n = 0; n < tree.num_nodes(); ++n) {           // leaves: slot in the tree -> slot in the shared buffer
+            float *w = &tree.nodes[(size_t)n * BVH_NODE_WORDS];
+            int32_t info, first;
+            memcpy(&info, &w[7], 4);
+            if (info >> 2) { memcpy(&first, &w[6], 4); first += slot0; memcpy(&w[6], &first, 4); }
+        }
+        nodes.insert(nodes.end(), tree.nodes.begin(), tree.nodes.end());
+        for (int s = 0; s < m.triangle_count; ++s) {
+            const int32_t orig = m.first_triangle + tree.order[(size_t)s];
+            const pt_triangle &t = d->triangles[orig];
+            float r[TRI_WORDS] = {t.v0.x, t.v0.y, t.v0.z,
+                                  t.v1.x - t.v0.x, t.v1.y - t.v0.y, t.v1.z - t.v0.z,
+                                  t.v2.x - t.v0.x, t.v2.y - t.v0.y, t.v2.z - t.v0.z, 0.0f, 0.0f, 0.0f};
+            memcpy(&r[9], &orig, 4);
+            btris.insert(btris.end(), r, r + TRI_WORDS);
+        }
+        float *g = grec.data() + (size_t)m.geom_index * ptd::GEOM_WORDS;
+        memcpy(&g[2], &root, 4); memcpy(&g[3], &m.triangle_count, 4);
+        prune = std::max(prune, tree.prune);
+        guard = std::max(guard, tree.num_nodes() + 1);
+        R.bvh_info.nodes += tree.num_nodes();
+        R.bvh_info.triangles += m.triangle_count;
+        R.bvh_info.depth = std::max(R.bvh_info.depth, tree.depth);
+        R.bvh_info.pad = std::max(R.bvh_info.pad, tree.pad);
+    }
+    R.bvh_info.prune = prune;
+    if (nodes.empty()) nodes.assign(BVH_NODE_WORDS, 0.0f);
+    if (btris.empty()) btris.assign(TRI_WORDS, 0.0f);
+    HIPCHK(hipMalloc(&R.d_bvh_nodes, nodes.size() * 4));
+    HIPCHK(hipMalloc(&R.d_bvh_tris, btris.size() * 4));
+    HIPCHK(hipMemcpy(R.d_bvh_nodes, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(R.d_bvh_tris, btris.data(), btris.size() * 4, hipMemcpyHostToDevice));
+    R.scene.bvh_nodes = R.d_bvh_nodes; R.scene.bvh_tris = R.d_bvh_tris;
+    R.scene.bvh_prune = prune; R.scene.bvh_guard = guard;
+    return PT_OK;
+}
 
 int pt_init(const pt_scene_desc *d) {
     if (!d) return fail(PT_ERR_INVALID, "pt_init: null descriptor");
@@ -527,13 +588,19 @@ static int init_impl(const pt_scene_desc *d) {
     R.scene.geoms = R.d_geoms; R.scene.ngeoms = d->num_geoms;
     R.scene.mats = R.d_mats; R.scene.nmats = d->num_materials;
     R.scene.tris = R.d_tris; R.scene.ntris = d->num_triangles;
-    R.has_mesh = false;
-    for (int i = 0; i < d->num_geoms; ++i) R.has_mesh |= d->geoms[i].type == PT_TRIANGLE_MESH;
+    R.mesh_mode = MESH_NONE;
+    for (int i = 0; i < d->num_geoms; ++i)
+        if (d->geoms[i].type == PT_TRIANGLE_MESH) R.mesh_mode = (d->flags & PT_MESH_BVH) ? MESH_BVH : MESH_TILES;
+    if (R.mesh_mode == MESH_BVH) {
+        const int rc = upload_bvh(d, grec);
+        if (rc != PT_OK) return rc;
+        HIPCHK(hipMemcpy(R.d_geoms, grec.data(), grec.size() * 4, hipMemcpyHostToDevice));   // records now name tree roots
+    }
     R.lds_bytes = ((size_t)LDS_CTL_WORDS + (size_t)scene_lds_words(d->num_materials, d->num_geoms) +
                    (size_t)PT_QUEUE * WAVES * Q_WORDS) * 4;
     R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
     if (const char *pad = getenv("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
-    if (R.has_mesh) R.lds_bytes += (size_t)TRI_TILE * TRI_WORDS * 4;
+    if (R.mesh_mode == MESH_TILES) R.lds_bytes += (size_t)TRI_TILE * TRI_WORDS * 4;
     if (R.lds_bytes > 60 * 1024) return fail(PT_ERR_INVALID, "pt_init: material records need %zu B of LDS (> 60 KiB)", R.lds_bytes);
 
     // pools, intersections, final colours, image, control
@@ -564,12 +631,8 @@ static int init_impl(const pt_scene_desc *d) {
     // persistent grid: as many workgroups as are co-resident for the fused kernel (tiles are
     // dealt round-robin, so more workgroups than that only re-stage the scene)
     int per_cu = 0;
-    if (R.has_mesh)
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bounce<MODE_FUSED, true, true>,
-                                                            BLOCK, R.lds_bytes));
-    else
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bounce<MODE_FUSED, true, false>,
-                                                            BLOCK, R.lds_bytes));
+    PT_MESH_DISPATCH(HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH>, BLOCK, R.lds_bytes)));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
@@ -743,8 +806,7 @@ int pt_intersect_once(const pt_path_segment *host_paths, int n, pt_shadeable_int
     hipLaunchKernelGGL(k_import_paths, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.pool[0],
                        (const pt_path_segment *)R.scratch, (uint32_t)n);
     HIPCHK(hipGetLastError());
-    if (R.has_mesh) launch_intersect<true>(R.pool[0], nullptr, (uint32_t)n, tile_dir(-1), nullptr);
-    else launch_intersect<false>(R.pool[0], nullptr, (uint32_t)n, tile_dir(-1), nullptr);
+    launch_intersect(R.pool[0], nullptr, (uint32_t)n, tile_dir(-1), nullptr);
     HIPCHK(hipGetLastError());
     uint8_t *d_out = (uint8_t *)R.scratch + (size_t)n * sizeof(pt_shadeable_intersection);
     hipLaunchKernelGGL(k_export_isects, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.isect, (uint32_t)n,
@@ -793,6 +855,23 @@ long long pt_total_rays(void) {
         hipStreamSynchronize(R.stream) != hipSuccess)
         return fail(PT_ERR_DEVICE, "pt_total_rays: device read failed");
     return (long long)p.rays;
+}
+
+int pt_get_bvh_info(pt_bvh_info *out) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_get_bvh_info: not initialised");
+    if (R.mesh_mode != MESH_BVH) return fail(PT_ERR_INVALID, "pt_get_bvh_info: PT_MESH_BVH is off or the scene has no mesh");
+    if (out) *out = R.bvh_info;
+    return PT_OK;
+}
+
+int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node_capacity, int32_t *order) {
+    if (count < 0 || (count > 0 && !triangles)) return fail(PT_ERR_INVALID, "pt_bvh_build: bad triangle list");
+    ptbvh::Tree tree;
+    ptbvh::build(reinterpret_cast<const float *>(triangles), count, tree);
+    if (tree.num_nodes() > node_capacity || !nodes) return tree.num_nodes();
+    memcpy(nodes, tree.nodes.data(), tree.nodes.size() * 4);
+    if (order && count > 0) memcpy(order, tree.order.data(), (size_t)count * 4);
+    return tree.num_nodes();
 }
 
 int pt_get_counters(int64_t *rays, int64_t *first_bounce_rays, int64_t *iterations) {

@@ -338,6 +338,89 @@ def test_triangle_mesh(pt, po, scenes, size):
         pt.pathtraceFree()
 
 
+@pytest.mark.parametrize("size", [(8, 16), (30, 60)])
+def test_mesh_bvh_vs_oracle(pt, po, scenes, size):
+    """PT_MESH_BVH: culling the triangle tests with the hierarchy leaves every result unchanged."""
+    s, geoms, tris, meshes = _mesh_scene(pt, scenes, *size)
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | pt.PT_MESH_BVH)
+    info = pt.binding.bvh_info()
+    assert info.triangles == len(tris) and info.nodes >= len(tris) // 4 and 0 < info.pad < 1e-2
+    rays = po.generate_rays(s["camera"], s["depth"])
+    got, got_out = pt.intersect_once(rays.view(pt.PATH_DT))
+    want, want_out = po.compute_intersections(rays, geoms.view(po.GEOM_DT), tris.view(po.TRI_DT),
+                                              meshes.view(po.MESH_DT))
+    assert got.tobytes() == want.tobytes()
+    pt.pathtraceFree()
+    for flags in (pt.PT_COMPACT, pt.PT_COMPACT | pt.PT_SORT_MATERIAL, pt.PT_COMPACT | pt.PT_CACHE_FIRST, 0):
+        pt.pathtraceInit(scene, flags=flags | pt.PT_MESH_BVH)
+        ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], s["depth"],
+                        flags=po.F_COMPACT if flags & pt.PT_COMPACT else 0, trig=po.TRIG_SHARED,
+                        tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
+        for it in (1, 2):
+            img = pt.pathtrace(None, 0, it)
+            st = ref.iterate(it)
+            assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
+            assert img.tobytes() == ref.image.tobytes()
+        pt.pathtraceFree()
+
+
+def test_mesh_bvh_adversarial_rays(pt, po, scenes):
+    """Rays aimed exactly at vertices and edges (where several triangles tie or just miss), from outside and
+    from inside the mesh, plus two meshes in one scene: winner index and distance come out as the oracle's loop
+    over every triangle has them."""
+    s = scenes["cornell"]                                    # 800x800: room for 20 000 rays
+    a = pt.meshes.uv_sphere(n_lat=40, n_lon=80)
+    b = pt.meshes.uv_sphere(center=(-2.0, 6.0, -1.0), radius=1.0, n_lat=12, n_lon=20)
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], a, material_id=1)
+    geoms, tris, meshes = pt.meshes.add_mesh(geoms, b, material_id=2, existing_triangles=tris, existing_meshes=meshes)
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
+    rng = np.random.default_rng(11)
+    verts = np.stack([tris["v0"], tris["v1"], tris["v2"]], axis=1).astype(np.float64)
+    n = 20000
+    rays = np.zeros(n, dtype=pt.PATH_DT)
+    T = verts[rng.integers(len(tris), size=n)]
+    w = rng.dirichlet((1, 1, 1), size=n)
+    kind = np.arange(n) % 4
+    w[kind == 0] = np.eye(3)[rng.integers(3, size=(kind == 0).sum())]           # a vertex
+    e = rng.uniform(0, 1, size=(kind == 1).sum())
+    w[kind == 1] = np.stack([e, 1 - e, np.zeros_like(e)], axis=1)                # a point on an edge
+    target = np.einsum("nk,nkc->nc", w, T)
+    target[kind == 3] += rng.normal(size=((kind == 3).sum(), 3))                 # near misses / other triangles
+    o = rng.uniform(-4.5, 9.5, size=(n, 3))
+    inside = np.arange(n) % 10 == 9
+    o[inside] = np.array([1.5, 3.0, 1.0]) + rng.normal(size=(inside.sum(), 3)) * 0.3
+    dvec = target - o
+    dvec /= np.linalg.norm(dvec, axis=1, keepdims=True)
+    rays["origin"], rays["direction"] = o, dvec
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | pt.PT_MESH_BVH)
+    got, _ = pt.intersect_once(rays)
+    pt.pathtraceFree()
+    want, _ = po.compute_intersections(rays.view(po.PATH_DT), geoms.view(po.GEOM_DT), tris.view(po.TRI_DT),
+                                       meshes.view(po.MESH_DT))
+    assert got.tobytes() == want.tobytes()
+    assert ((want["t"] > 0) & (want["materialId"] == 1)).sum() > 3000
+    assert ((want["t"] > 0) & (want["materialId"] == 2)).sum() > 100
+
+
+def test_mesh_bvh_c4_equals_every_triangle(pt, scenes):
+    """BASELINE config C4 at full size (800x800, 100 032 triangles, depth 8): the culled walk and the loop over
+    every triangle give the same image and the same live counts at every bounce."""
+    s = scenes["cornell"]
+    tris = pt.meshes.uv_sphere()
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
+    out = {}
+    for name, flags in (("loop", pt.PT_COMPACT), ("bvh", pt.PT_COMPACT | pt.PT_MESH_BVH)):
+        pt.pathtraceInit(scene, flags=flags)
+        img = pt.pathtrace(None, 0, 1)
+        out[name] = (img.copy(), list(pt.get_stats().live[:s["depth"]]))
+        pt.pathtraceFree()
+    assert out["loop"][1] == out["bvh"][1]
+    assert out["loop"][0].tobytes() == out["bvh"][0].tobytes()
+    assert out["loop"][1][1] > 100000
+
+
 def test_ptbench_headless_host(pt, po, scenes, tmp_path):
     """The C++ headless host (host/ptbench.cpp = main.cpp/runCuda without GLFW): scene file in, PNG out;
     the PNG equals the oracle's image pushed through the same saveImage pipeline."""
