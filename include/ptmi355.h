@@ -201,7 +201,7 @@ typedef struct pt_bvh_info {
 } pt_bvh_info;
 int pt_get_bvh_info(pt_bvh_info *out);
 /* host-only (no GPU): build the hierarchy of `count` triangles; returns the node count, or the
- * required count when `node_capacity` is too small (nothing written then).  nodes: 16 dwords
+ * required count when `node_capacity` is too small (nothing written then).  nodes: 32 dwords
  * each (layout in csrc/pt_bvh.hpp); order: leaf slot -> triangle index. */
 int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node_capacity,
                  int32_t *order);

@@ -33,7 +33,7 @@ TRI_DT = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3)])
 MESH_DT = np.dtype([("geom_index", "<i4"), ("first_triangle", "<i4"), ("triangle_count", "<i4")])
 
 PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH = 1, 2, 4, 8, 16, 32
-BVH_NODE_WORDS = 16
+BVH_NODE_WORDS = 32
 
 
 class PtError(RuntimeError):
@@ -290,8 +290,8 @@ def bvh_info():
 
 
 def bvh_build(triangles):
-    """Host-only: the hierarchy pt_init builds under PT_MESH_BVH.  Returns (nodes[n, 16] float32 -- words
-    6..15 are int32 --, order[count] int32)."""
+    """Host-only: the hierarchy pt_init builds under PT_MESH_BVH.  Returns (nodes[n, 32] float32 -- words
+    12..23 are int32 --, order[count] int32)."""
     tris = np.ascontiguousarray(triangles, dtype=TRI_DT)
     L = library()
     need = L.pt_bvh_build(_p(tris), len(tris), None, 0, None)

@@ -2,18 +2,26 @@
 // (the assignment's "hierarchical spatial data structure", INSTRUCTION.md:129-139,
 // 218-240 -- the reference has none).  Included by ptmi355.hip only; no device code here.
 //
-// Layout: binary tree, children stored as adjacent pairs, 16 dwords per node
-//   [0..2] box min   [3..5] box max            (padded, see `pad` below)
-//   [6]    internal: index of the left child (right = left + 1); leaf: first record in the leaf-ordered
-//          triangle array
-//   [7]    (count << 2) | split axis; count == 0 marks an internal node, leaves hold 1..LEAF_MAX triangles
-//   [8..15] miss link per ray-direction octant (bit k set when dir[k] < 0): the node to visit when
-//          this node's box is missed or its subtree is finished; -1 ends the walk.
-// The kernel walks the tree WITHOUT a stack: on a box hit an internal node continues with its near
-// child (left + sign bit of dir[axis]), everything else follows miss[octant].  For a fixed octant
-// the links spell out one depth-first, near-child-first order, so a ray visits nodes front to back.
+// Layout: a binary tree (binned surface-area splits, leaves of 1..4
+// triangles) stored as one 128-byte record per INTERNAL node that carries the boxes of BOTH
+// children, so one cache line fetched per step decides two boxes:
+//   [0..5]   left child box  (min xyz, max xyz)      [6..11] right child box      (padded, see `pad`)
+//   [12]     left link   [13] left info    [14] right link   [15] right info
+//              info = count | leaf << 3 | split axis of THIS node << 4   (axis only in the left info)
+//              leaf child: link = first record in the leaf-ordered triangle array, count = 0..4
+//              internal child: link = record index of that child
+//   [16..23] miss link per ray-direction octant (bit k set when dir[k] < 0): the record to continue
+//            with when this subtree is finished; -1 ends the walk
+//   [24..31] unused (the record is one 128-B cache line)
+// The kernel walks the tree WITHOUT a stack.  At a record it tests both child boxes, intersects
+// the triangles of hit leaf children at once, and continues with a hit internal child -- the
+// nearer one (by the sign of dir[axis]) when both are hit; otherwise it follows miss[octant].
+// The miss link of a near internal child is its internal sibling, that of a far or only internal
+// child is the parent's: for a fixed octant the links spell out one depth-first, near-first order.
+// A sibling reached through a miss link is entered without knowing whether its own box was hit;
+// child boxes lie inside the parent's, so a missed sibling simply fails both child tests.
 //
-// Culling must never change which triangle wins (the naive loop over all triangles is the
+// Culling must never change which triangle wins (the loop over all triangles is the
 // specification).  Boxes are therefore padded by `pad` = 2^-13 * max(1, largest |coordinate|),
 // orders of magnitude above the rounding error of glm::intersectRayTriangle for rays that are
 // not within ~1e-3 rad of a triangle's plane, and the kernel prunes against the best distance
@@ -27,9 +35,10 @@
 
 namespace ptbvh {
 
-constexpr int NODE_WORDS = 16;
+constexpr int NODE_WORDS = 32;
 constexpr int LEAF_MAX = 4;
 constexpr int SAH_BINS = 16;
+constexpr int INFO_LEAF = 8;         // bit 3 of an info word
 
 struct Box {
     float lo[3], hi[3];
@@ -43,7 +52,7 @@ struct Box {
 };
 
 struct Tree {
-    std::vector<float> nodes;        // NODE_WORDS per node, node 0 is the root
+    std::vector<float> nodes;        // NODE_WORDS per record, record 0 is the root
     std::vector<int32_t> order;      // leaf-ordered triangle slots -> index into the caller's triangle range
     float pad = 0.0f, prune = 0.0f;
     int depth = 0;
@@ -52,25 +61,28 @@ struct Tree {
 
 namespace detail {
 
+struct Split {                       // the binary tree before it is laid out
+    Box box;
+    int left = -1;                   // children left, left + 1; -1: leaf
+    int lo = 0, count = 0;           // leaf: slots [lo, lo + count)
+    int axis = 0;
+};
+
 struct Work {
     std::vector<Box> tbox;
     std::vector<float> cen;          // 3 per triangle
     std::vector<int32_t> idx;        // permutation being partitioned
-    Tree *out;
+    std::vector<Split> split;
 };
 
 inline void set_i(float *w, int32_t v) { memcpy(w, &v, 4); }
-inline int32_t get_i(const float *w) { int32_t v; memcpy(&v, w, 4); return v; }
 
-// builds the subtree of idx[lo, hi) into node `self`; returns its depth
+// builds the subtree of idx[lo, hi) into split[self]; returns its depth
 inline int build(Work &w, int self, int lo, int hi, int level) {
     Box b; b.reset();
     Box cb; cb.reset();
     for (int k = lo; k < hi; ++k) { b.grow(w.tbox[w.idx[k]]); cb.grow(&w.cen[3 * (size_t)w.idx[k]]); }
-    {
-        float *n = &w.out->nodes[(size_t)self * NODE_WORDS];
-        for (int k = 0; k < 3; ++k) { n[k] = b.lo[k] - w.out->pad; n[3 + k] = b.hi[k] + w.out->pad; }
-    }
+    w.split[self].box = b;
     const int count = hi - lo;
     int axis = 0;
     {
@@ -130,38 +142,46 @@ inline int build(Work &w, int self, int lo, int hi, int level) {
         }
     }
     if (mid < 0) {                    // leaf
-        float *n = &w.out->nodes[(size_t)self * NODE_WORDS];
-        set_i(&n[6], lo);
-        set_i(&n[7], (count << 2) | axis);
+        w.split[self].lo = lo; w.split[self].count = count; w.split[self].axis = axis;
         return 1;
     }
-    const int left = w.out->num_nodes();
-    w.out->nodes.resize(w.out->nodes.size() + 2 * NODE_WORDS, 0.0f);
-    {
-        float *n = &w.out->nodes[(size_t)self * NODE_WORDS];
-        set_i(&n[6], left);
-        set_i(&n[7], axis);
-    }
+    const int left = (int)w.split.size();
+    w.split.resize(w.split.size() + 2);
+    w.split[self].left = left; w.split[self].axis = axis;
     const int dl = build(w, left, lo, mid, level + 1);
     const int dr = build(w, left + 1, mid, hi, level + 1);
     return 1 + std::max(dl, dr);
 }
 
-// miss links: for octant `o` the children of a node with split axis a are visited near-first
-inline void link(Tree &t, int self, const int32_t miss[8]) {
-    float *n = &t.nodes[(size_t)self * NODE_WORDS];
-    for (int o = 0; o < 8; ++o) set_i(&n[8 + o], miss[o]);
-    const int32_t info = get_i(&n[7]);
-    if (info >> 2) return;                                   // leaf
-    const int left = get_i(&n[6]), axis = info & 3;
-    int32_t ml[8], mr[8];
-    for (int o = 0; o < 8; ++o) {
-        const bool right_first = (o >> axis) & 1;            // dir[axis] < 0: the upper child is nearer
-        ml[o] = right_first ? miss[o] : left + 1;
-        mr[o] = right_first ? left : miss[o];
+// records in depth-first order: rec[s] = record index of internal split node s
+inline void number(const Work &w, int s, std::vector<int32_t> &rec, int &next) {
+    if (w.split[s].left < 0) return;
+    rec[(size_t)s] = next++;
+    number(w, w.split[s].left, rec, next);
+    number(w, w.split[s].left + 1, rec, next);
+}
+
+inline void emit(const Work &w, const std::vector<int32_t> &rec, int s, const int32_t miss[8], float pad, Tree &out) {
+    const Split &n = w.split[s];
+    float *r = &out.nodes[(size_t)rec[(size_t)s] * NODE_WORDS];
+    const int kid[2] = {n.left, n.left + 1};
+    bool inner[2];
+    for (int c = 0; c < 2; ++c) {
+        const Split &k = w.split[kid[c]];
+        for (int a = 0; a < 3; ++a) { r[6 * c + a] = k.box.lo[a] - pad; r[6 * c + 3 + a] = k.box.hi[a] + pad; }
+        inner[c] = k.left >= 0;
+        set_i(&r[12 + 2 * c], inner[c] ? rec[(size_t)kid[c]] : k.lo);
+        set_i(&r[13 + 2 * c], (inner[c] ? 0 : (k.count | INFO_LEAF)) | (c == 0 ? n.axis << 4 : 0));
     }
-    link(t, left, ml);
-    link(t, left + 1, mr);
+    for (int o = 0; o < 8; ++o) set_i(&r[16 + o], miss[o]);
+    int32_t m[2][8];
+    for (int o = 0; o < 8; ++o) {
+        const int near = (o >> n.axis) & 1;                  // dir[axis] < 0: the upper (right) child is nearer
+        m[near][o] = inner[near ^ 1] ? rec[(size_t)kid[near ^ 1]] : miss[o];
+        m[near ^ 1][o] = miss[o];
+    }
+    for (int c = 0; c < 2; ++c)
+        if (inner[c]) emit(w, rec, kid[c], m[c], pad, out);
 }
 
 }  // namespace detail
@@ -170,7 +190,6 @@ inline void link(Tree &t, int self, const int32_t miss[8]) {
 inline void build(const float *v, int count, Tree &out) {
     out.nodes.clear(); out.order.clear(); out.depth = 0;
     detail::Work w;
-    w.out = &out;
     w.tbox.resize((size_t)count); w.cen.resize(3 * (size_t)count); w.idx.resize((size_t)count);
     float amax = 0.0f;
     for (int i = 0; i < count; ++i) {
@@ -185,15 +204,29 @@ inline void build(const float *v, int count, Tree &out) {
     }
     out.pad = std::ldexp(std::max(1.0f, amax), -13);
     out.prune = 16.0f * out.pad;
-    out.nodes.assign(NODE_WORDS, 0.0f);
+    w.split.resize(1);
     if (count > 0) out.depth = detail::build(w, 0, 0, count, 0);
-    else {                                                    // empty mesh: one leaf whose inverted box nothing hits
-        float *n = out.nodes.data();
-        for (int k = 0; k < 3; ++k) { n[k] = 1.0f; n[3 + k] = -1.0f; }
-        detail::set_i(&n[6], 0); detail::set_i(&n[7], 1 << 2);
-    }
     const int32_t end[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    detail::link(out, 0, end);
+    if (count > 0 && w.split[0].left >= 0) {
+        std::vector<int32_t> rec(w.split.size(), -1);
+        int next = 0;
+        detail::number(w, 0, rec, next);
+        out.nodes.assign((size_t)next * NODE_WORDS, 0.0f);
+        detail::emit(w, rec, 0, end, out.pad, out);
+    } else {
+        // at most LEAF_MAX triangles: one record whose left child is that leaf (its box when there is
+        // one, else inverted) and whose right child is an empty leaf with an inverted box nothing hits
+        out.nodes.assign(NODE_WORDS, 0.0f);
+        float *r = out.nodes.data();
+        for (int a = 0; a < 3; ++a) {
+            r[a] = count > 0 ? w.split[0].box.lo[a] - out.pad : 1.0f;
+            r[3 + a] = count > 0 ? w.split[0].box.hi[a] + out.pad : -1.0f;
+            r[6 + a] = 1.0f; r[9 + a] = -1.0f;
+        }
+        detail::set_i(&r[12], 0); detail::set_i(&r[13], count | INFO_LEAF);
+        detail::set_i(&r[14], 0); detail::set_i(&r[15], INFO_LEAF);
+        for (int o = 0; o < 8; ++o) detail::set_i(&r[16 + o], -1);
+    }
     out.order = w.idx;
 }
 

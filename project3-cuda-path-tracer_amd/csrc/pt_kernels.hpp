@@ -111,48 +111,59 @@ __device__ __forceinline__ void queue_pass(float *wq, const float *gf, uint32_t 
 }
 #endif
 
-// Stackless walk of one mesh's hierarchy (layout and link construction: pt_bvh.hpp).  Per lane:
-// fetch the 64-B node (box + link + info as two 16-B loads, the octant's miss link as a third),
-// slab-test the padded box against [0, best + prune], then either descend to the near child, test
-// the leaf's <= 4 triangles, or follow the miss link.  The box test only has to be conservative
-// (it decides which exact triangle tests run, never their outcome), so it uses v_rcp and fused
-// multiply-adds; NaNs from 0 * inf drop out of v_min/v_max, which errs towards visiting.
-// Every link points forward in the octant's depth-first order, so the walk ends after at most
-// `guard` nodes; the guard also bounds it for NaN rays.
+// Stackless walk of one mesh's hierarchy (record layout and link construction: pt_bvh.hpp).
+// Per lane and step: fetch one 128-B record (both child boxes + links as four 16-B loads, the
+// octant's miss link as a fifth), slab-test both boxes against [0, best + prune], intersect the
+// triangles of hit leaf children, then continue with a hit internal child (the nearer one when
+// both are hit) or follow the miss link.  The box test only has to be conservative (it decides
+// which exact triangle tests run, never their outcome), so it uses v_rcp and fused multiply-adds;
+// NaNs from 0 * inf drop out of v_min/v_max, which errs towards visiting.  Every link points
+// forward in the octant's depth-first order, so the walk ends after at most `guard` records; the
+// guard also bounds it for NaN rays.
 __device__ __forceinline__ void bvh_walk(const float *__restrict__ nodes, const float *__restrict__ btris,
                                          float prune, int guard, f3 ro, f3 rd, float &best, int &best_i) {
     const float ix = __builtin_amdgcn_rcpf(rd.x), iy = __builtin_amdgcn_rcpf(rd.y), iz = __builtin_amdgcn_rcpf(rd.z);
     const float nx = -(ro.x * ix), ny = -(ro.y * iy), nz = -(ro.z * iz);
     const int oct = (rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0);
+    auto slab = [&](float lx, float ly, float lz, float hx, float hy, float hz, float &tn, float &tf) {
+        const float t1x = __builtin_fmaf(lx, ix, nx), t2x = __builtin_fmaf(hx, ix, nx);
+        const float t1y = __builtin_fmaf(ly, iy, ny), t2y = __builtin_fmaf(hy, iy, ny);
+        const float t1z = __builtin_fmaf(lz, iz, nz), t2z = __builtin_fmaf(hz, iz, nz);
+        tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
+                             __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
+        tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+                             __builtin_fmaxf(t1z, t2z));
+    };
+    auto leaf = [&](int first, int cnt) {
+        const float4 *t4 = reinterpret_cast<const float4 *>(btris + (size_t)first * TRI_WORDS);
+        for (int k = 0; k < cnt; ++k) {
+            const float4 P = t4[3 * k], Q = t4[3 * k + 1], S = t4[3 * k + 2];
+            float tz;
+            if (ptd::ray_triangle(ro, rd, ptd::mk(P.x, P.y, P.z), ptd::mk(P.w, Q.x, Q.y), ptd::mk(Q.z, Q.w, S.x), tz)) {
+                const int orig = __float_as_int(S.y);                    // index in the caller's triangle array
+                if (tz > 0.0f && (best > tz || (best == tz && orig < best_i))) { best = tz; best_i = orig; }
+            }
+        }
+    };
     int node = 0;
     for (int it = 0; it < guard && node >= 0; ++it) {
         const float4 *n4 = reinterpret_cast<const float4 *>(nodes + (size_t)node * BVH_NODE_WORDS);
-        const float4 A = n4[0], B = n4[1];
-        int next = reinterpret_cast<const int *>(n4)[8 + oct];
-        const float t1x = __builtin_fmaf(A.x, ix, nx), t2x = __builtin_fmaf(A.w, ix, nx);
-        const float t1y = __builtin_fmaf(A.y, iy, ny), t2y = __builtin_fmaf(B.x, iy, ny);
-        const float t1z = __builtin_fmaf(A.z, iz, nz), t2z = __builtin_fmaf(B.y, iz, nz);
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
-                                         __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
-                                         __builtin_fmaxf(t1z, t2z));
-        if (tn <= tf && tn <= best + prune) {
-            const int link = __float_as_int(B.z), info = __float_as_int(B.w);
-            const int cnt = info >> 2;
-            if (cnt == 0) {
-                next = link + ((oct >> (info & 3)) & 1);             // near child first
-            } else {
-                const float4 *t4 = reinterpret_cast<const float4 *>(btris + (size_t)link * TRI_WORDS);
-                for (int k = 0; k < cnt; ++k) {
-                    const float4 P = t4[3 * k], Q = t4[3 * k + 1], S = t4[3 * k + 2];
-                    float tz;
-                    if (ptd::ray_triangle(ro, rd, ptd::mk(P.x, P.y, P.z), ptd::mk(P.w, Q.x, Q.y), ptd::mk(Q.z, Q.w, S.x), tz)) {
-                        const int orig = __float_as_int(S.y);                // index in the caller's triangle array
-                        if (tz > 0.0f && (best > tz || (best == tz && orig < best_i))) { best = tz; best_i = orig; }
-                    }
-                }
-            }
-        }
+        const float4 A = n4[0], B = n4[1], C = n4[2], D = n4[3];
+        int next = reinterpret_cast<const int *>(n4)[16 + oct];
+        const int link_l = __float_as_int(D.x), info_l = __float_as_int(D.y);
+        const int link_r = __float_as_int(D.z), info_r = __float_as_int(D.w);
+        float tn_l, tf_l, tn_r, tf_r;
+        slab(A.x, A.y, A.z, A.w, B.x, B.y, tn_l, tf_l);
+        slab(B.z, B.w, C.x, C.y, C.z, C.w, tn_r, tf_r);
+        const bool hit_l = tn_l <= tf_l && tn_l <= best + prune;
+        if (hit_l && (info_l & 8)) leaf(link_l, info_l & 7);
+        const bool hit_r = tn_r <= tf_r && tn_r <= best + prune;
+        if (hit_r && (info_r & 8)) leaf(link_r, info_r & 7);
+        const bool go_l = hit_l && !(info_l & 8), go_r = hit_r && !(info_r & 8);
+        const bool right_near = (oct >> ((info_l >> 4) & 3)) & 1;
+        if (go_l && go_r) next = right_near ? link_r : link_l;         // the far one follows through the near one's miss link
+        else if (go_l) next = link_l;
+        else if (go_r) next = link_r;
         node = next;
     }
 }

@@ -20,7 +20,7 @@ constexpr int WAVES = BLOCK / 64;
 constexpr int TILE = 64;                   // paths per tile = one wave64
 constexpr int TRI_TILE = 512;              // triangles staged in LDS per pass (24 KiB)
 constexpr int TRI_WORDS = 12;              // v0 e1 e2 + 3 pad: three 16-B words per triangle
-constexpr int BVH_NODE_WORDS = 16;         // pt_bvh.hpp
+constexpr int BVH_NODE_WORDS = 32;         // one 128-B record per internal node, pt_bvh.hpp
 enum { MESH_NONE = 0, MESH_TILES = 1, MESH_BVH = 2 };   // how triangle meshes are intersected (template switch)
 constexpr int MAX_DEPTH = 64;
 constexpr uint32_t DEAD_PID = 0xffffffffu;

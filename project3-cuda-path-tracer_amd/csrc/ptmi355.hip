@@ -437,11 +437,13 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
         ptbvh::build(reinterpret_cast<const float *>(d->triangles + m.first_triangle), m.triangle_count, tree);
         const int root = (int)(nodes.size() / BVH_NODE_WORDS);
         const int slot0 = (int)(btris.size() / TRI_WORDS);
-        for (int n = 0; n < tree.num_nodes(); ++n) {           // leaves: slot in the tree -> slot in the shared buffer
+        for (int n = 0; n < tree.num_nodes(); ++n) {           // leaf children: slot in the tree -> slot in the shared buffer
             float *w = &tree.nodes[(size_t)n * BVH_NODE_WORDS];
-            int32_t info, first;
-            memcpy(&info, &w[7], 4);
-            if (info >> 2) { memcpy(&first, &w[6], 4); first += slot0; memcpy(&w[6], &first, 4); }
+            for (int c = 0; c < 2; ++c) {
+                int32_t info, first;
+                memcpy(&info, &w[13 + 2 * c], 4);
+                if (info & ptbvh::INFO_LEAF) { memcpy(&first, &w[12 + 2 * c], 4); first += slot0; memcpy(&w[12 + 2 * c], &first, 4); }
+            }
         }
         nodes.insert(nodes.end(), tree.nodes.begin(), tree.nodes.end());
         for (int s = 0; s < m.triangle_count; ++s) {

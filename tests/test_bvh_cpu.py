@@ -19,35 +19,43 @@ def _tree(pt, tris):
     return nodes, ints, order
 
 
+LEAF = 8
+
+
+def _children(ints, k):
+    """[(link, count, is_leaf)] of record k; split axis"""
+    kids = [(int(ints[k, 12 + 2 * c]), int(ints[k, 13 + 2 * c]) & 7, bool(ints[k, 13 + 2 * c] & LEAF)) for c in (0, 1)]
+    return kids, (int(ints[k, 13]) >> 4) & 3
+
+
 @pytest.mark.parametrize("size", [(8, 16), (30, 60), (97, 521)])
 def test_tree_structure(pt, size):
     tris = pt.meshes.uv_sphere(n_lat=size[0], n_lon=size[1])
     nodes, ints, order = _tree(pt, tris)
     n = len(nodes)
-    count = ints[:, 7] >> 2
-    axis = ints[:, 7] & 3
-    leaf = count > 0
     assert sorted(order.tolist()) == list(range(len(tris)))          # every triangle in exactly one leaf slot
-    assert count[leaf].max() <= 4 and count[leaf].sum() == len(tris)
-    assert (axis <= 2).all()
-    # leaves tile the slot range
-    firsts = ints[leaf, 6]
-    o = np.argsort(firsts)
-    assert firsts[o][0] == 0 and (firsts[o][1:] == (firsts[o] + count[leaf][o])[:-1]).all()
-    # boxes: a leaf's box holds its triangles, a parent's box holds its children's
     verts = np.stack([tris["v0"], tris["v1"], tris["v2"]], axis=1)      # (T, 3, 3)
-    for k in np.nonzero(leaf)[0]:
-        v = verts[order[ints[k, 6]:ints[k, 6] + count[k]]].reshape(-1, 3)
-        assert (v.min(axis=0) > nodes[k, 0:3]).all() and (v.max(axis=0) < nodes[k, 3:6]).all()
-    inner = np.nonzero(~leaf)[0]
-    for c in (0, 1):
-        ch = ints[inner, 6] + c
-        assert (ch > inner).all() and (ch < n).all()
-        assert (nodes[ch, 0:3] >= nodes[inner, 0:3]).all() and (nodes[ch, 3:6] <= nodes[inner, 3:6]).all()
-    # children are claimed by exactly one parent
-    kids = np.concatenate([ints[inner, 6], ints[inner, 6] + 1])
-    assert sorted(kids.tolist()) == list(range(1, n))
-    # per octant: "hit everything" visits every node exactly once and ends; "miss the root" ends at once
+    leaves, parents = [], np.zeros(n, dtype=np.int32)
+    for k in range(n):
+        kids, axis = _children(ints, k)
+        assert axis <= 2
+        for c, (link, count, is_leaf) in enumerate(kids):
+            lo, hi = nodes[k, 6 * c:6 * c + 3], nodes[k, 6 * c + 3:6 * c + 6]
+            if is_leaf:
+                assert 1 <= count <= 4
+                leaves.append((link, count))
+                v = verts[order[link:link + count]].reshape(-1, 3)
+                assert (v.min(axis=0) > lo).all() and (v.max(axis=0) < hi).all()
+            else:
+                assert k < link < n and count == 0                    # records are laid out parent first
+                parents[link] += 1
+                for cc in (0, 1):                                     # a child's boxes lie inside its own box
+                    assert (nodes[link, 6 * cc:6 * cc + 3] >= lo).all() and (nodes[link, 6 * cc + 3:6 * cc + 6] <= hi).all()
+    assert parents[0] == 0 and (parents[1:] == 1).all()
+    leaves.sort()
+    assert leaves[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(leaves, leaves[1:]))
+    assert leaves[-1][0] + leaves[-1][1] == len(tris)
+    # per octant: "hit everything" visits every record exactly once and ends; the root's links end the walk
     for octant in range(8):
         seen = np.zeros(n, dtype=bool)
         node, steps = 0, 0
@@ -55,12 +63,16 @@ def test_tree_structure(pt, size):
             assert not seen[node]
             seen[node] = True
             steps += 1
-            if leaf[node]:
-                node = ints[node, 8 + octant]
+            kids, axis = _children(ints, node)
+            inner = [link for link, _, is_leaf in kids if not is_leaf]
+            if len(inner) == 2:
+                node = kids[(octant >> axis) & 1][0]
+            elif inner:
+                node = inner[0]
             else:
-                node = ints[node, 6] + ((octant >> axis[node]) & 1)
+                node = int(ints[node, 16 + octant])
         assert seen.all() and steps == n
-        assert ints[0, 8 + octant] == -1
+        assert ints[0, 16 + octant] == -1
 
 
 def _walk(nodes, ints, order, tris, po, o, d, prune):
@@ -70,34 +82,44 @@ def _walk(nodes, ints, order, tris, po, o, d, prune):
         inv = (np.float32(1) / d32).astype(np.float32)
         off = (-(o32 * inv)).astype(np.float32)
     octant = int(d32[0] < 0) | (int(d32[1] < 0) << 1) | (int(d32[2] < 0) << 2)
-    best, best_i, node, visited = np.float32(np.finfo(np.float32).max), -1, 0, 0
+    state = {"best": np.float32(np.finfo(np.float32).max), "i": -1}
     bary = po.Vec3()
-    while node >= 0:
-        visited += 1
-        nd = nodes[node]
+
+    def hit(lo, hi):
         with np.errstate(invalid="ignore", over="ignore"):
-            t1 = nd[0:3] * inv + off
-            t2 = nd[3:6] * inv + off
+            t1, t2 = lo * inv + off, hi * inv + off
+            reach = state["best"] + np.float32(prune)
         tn = max(np.fmax.reduce(np.fmin(t1, t2)), 0.0)
         tf = np.fmin.reduce(np.fmax(t1, t2))
-        nxt = int(ints[node, 8 + octant])
-        with np.errstate(over="ignore"):
-            reach = best + np.float32(prune)
-        if tn <= tf and tn <= reach:
-            cnt = ints[node, 7] >> 2
-            if cnt == 0:
-                nxt = int(ints[node, 6]) + ((octant >> (ints[node, 7] & 3)) & 1)
-            else:
-                for s in range(ints[node, 6], ints[node, 6] + cnt):
-                    k = int(order[s])
-                    T = tris[k]
-                    if po.lib().pto_ray_triangle(po.vec3(o32), po.vec3(d32), po.vec3(T["v0"]), po.vec3(T["v1"]),
-                                                 po.vec3(T["v2"]), bary):
-                        tz = np.float32(bary.z)
-                        if tz > 0 and (best > tz or (best == tz and k < best_i)):
-                            best, best_i = tz, k
-        node = nxt
-    return best_i, best, visited
+        return tn <= tf and tn <= reach
+
+    def leaf(first, cnt):
+        for s in range(first, first + cnt):
+            k = int(order[s])
+            T = tris[k]
+            if po.lib().pto_ray_triangle(po.vec3(o32), po.vec3(d32), po.vec3(T["v0"]), po.vec3(T["v1"]),
+                                         po.vec3(T["v2"]), bary):
+                tz = np.float32(bary.z)
+                if tz > 0 and (state["best"] > tz or (state["best"] == tz and k < state["i"])):
+                    state["best"], state["i"] = tz, k
+
+    node, visited = 0, 0
+    while node >= 0:
+        visited += 1
+        kids, axis = _children(ints, node)
+        go = []
+        for c, (link, count, is_leaf) in enumerate(kids):
+            h = hit(nodes[node, 6 * c:6 * c + 3], nodes[node, 6 * c + 3:6 * c + 6])
+            if h and is_leaf:
+                leaf(link, count)
+            go.append(h and not is_leaf)
+        if go[0] and go[1]:
+            node = kids[(octant >> axis) & 1][0]
+        elif go[0] or go[1]:
+            node = kids[1 if go[1] else 0][0]
+        else:
+            node = int(ints[node, 16 + octant])
+    return state["i"], state["best"], visited
 
 
 def test_walk_finds_the_naive_winner(pt, po):
@@ -137,18 +159,24 @@ def test_walk_finds_the_naive_winner(pt, po):
         if gi >= 0:
             assert np.float32(gt).tobytes() == np.float32(want_t[k]).tobytes()
     assert total / len(rays) < 0.05 * len(nodes)                      # it actually culls
+    print("records visited per ray: %.1f of %d" % (total / len(rays), len(nodes)))
 
 
 def test_degenerate_inputs(pt):
     # empty mesh, one triangle, coincident triangles (no split separates them)
     nodes, order = pt.binding.bvh_build(np.zeros(0, dtype=pt.TRI_DT))
-    assert len(nodes) == 1 and (nodes[0, 0:3] > nodes[0, 3:6]).all()
+    ints = nodes.view(np.int32)
+    assert len(nodes) == 1 and (nodes[0, 0:3] > nodes[0, 3:6]).all() and (nodes[0, 6:9] > nodes[0, 9:12]).all()
+    assert ints[0, 13] == LEAF and ints[0, 15] == LEAF and (ints[0, 16:24] == -1).all()
     one = np.zeros(1, dtype=pt.TRI_DT)
     one["v1"][0], one["v2"][0] = (1, 0, 0), (0, 1, 0)
     nodes, order = pt.binding.bvh_build(one)
-    assert len(nodes) == 1 and order.tolist() == [0]
+    ints = nodes.view(np.int32)
+    assert len(nodes) == 1 and order.tolist() == [0] and ints[0, 13] == (LEAF | 1) and ints[0, 15] == LEAF
+    assert (nodes[0, 0:3] < 0).all() and (nodes[0, 3:6] > 0).all() and (nodes[0, 6:9] > nodes[0, 9:12]).all()
     same = np.repeat(one, 37)
     nodes, order = pt.binding.bvh_build(same)
     ints = nodes.view(np.int32)
     assert sorted(order.tolist()) == list(range(37))
-    assert ((ints[:, 7] >> 2)[(ints[:, 7] >> 2) > 0]).sum() == 37
+    counts = [(ints[k, 13 + 2 * c] & 7) for k in range(len(nodes)) for c in (0, 1) if ints[k, 13 + 2 * c] & LEAF]
+    assert sum(counts) == 37 and max(counts) <= 4
