@@ -95,9 +95,12 @@ enum pt_flags {
     PT_CACHE_FIRST   = 1u << 3,  /* cache the bounce-0 intersections (INSTRUCTION.md:87-89) */
     PT_UNFUSED       = 1u << 4,  /* debug: separate intersect / shade kernels with the
                                     ShadeableIntersection planes materialised in HBM */
-    PT_MESH_BVH      = 1u << 5   /* cull triangle tests with a bounding-volume hierarchy built at
+    PT_MESH_BVH      = 1u << 5,  /* cull triangle tests with a bounding-volume hierarchy built at
                                     pt_init (INSTRUCTION.md:129-139,218-240); same winner as the
                                     loop over every triangle */
+    PT_AA_JITTER     = 1u << 6   /* stochastic antialiasing: jitter each camera ray inside its
+                                    pixel (the TODO at pathtrace.cu:134; INSTRUCTION.md:110).
+                                    Excludes PT_CACHE_FIRST (INSTRUCTION.md:113). */
 };
 
 typedef struct pt_scene_desc {
@@ -117,6 +120,10 @@ typedef struct pt_scene_desc {
     float *device_image;           /* optional caller-owned device buffer, W*H*3 floats,
                                       used as the accumulation buffer (e.g. a torch tensor
                                       handed to RCCL); NULL = library-owned */
+    /* thin-lens depth of field (INSTRUCTION.md:111): rays start on a disc of this radius
+     * around camera.position and meet the pinhole ray on the plane focal_distance along
+     * camera.view.  0 (a zeroed descriptor) = the reference's pinhole camera. */
+    float lens_radius, focal_distance;
 } pt_scene_desc;
 
 typedef struct pt_stats {
@@ -139,6 +146,7 @@ void pt_free(void);
  * pathtrace() (pathtrace.cu:285-286); the shim forwards them here each call.
  * Resolution must not change between pt_init and pt_free. */
 int pt_set_camera(const pt_camera *camera, int trace_depth);
+int pt_set_lens(float lens_radius, float focal_distance);   /* see pt_scene_desc */
 
 /* pathtrace (pathtrace.cu:284-393): one iteration `iter` (1-based; RNG key and
  * tonemap divisor).  pbo_rgba: optional DEVICE pointer to W*H RGBA8 (the mapped

@@ -86,7 +86,8 @@ enum { PTO_TRIG_LIBM = 0, PTO_TRIG_SHARED = 1 };
 enum {
     PTO_F_COMPACT   = 1,   /* stable partition of live paths after each bounce */
     PTO_F_SORT      = 2,   /* stable sort of live paths by materialId before shading */
-    PTO_F_FAKESHADE = 4    /* run the reference's as-is one-bounce fake shader */
+    PTO_F_FAKESHADE = 4,   /* run the reference's as-is one-bounce fake shader */
+    PTO_F_AA        = 8    /* jitter the camera rays inside their pixel (pathtrace.cu:134 TODO) */
 };
 
 /* ---- integer / RNG (intersections.h:12-20, pathtrace.cu:41-45, thrust) ---- */
@@ -147,6 +148,7 @@ typedef struct {
     int traceDepth;
     int flags;
     int trig;
+    float lensRadius, focalDistance;   /* thin lens (INSTRUCTION.md:111); lensRadius <= 0: pinhole */
 } pto_scene;
 
 typedef struct {
@@ -156,6 +158,10 @@ typedef struct {
     uint64_t seq_hash[64];         /* FNV-1a of pixelIndex[0..n_live) AFTER bounce d */
     double   sec_intersect, sec_shade, sec_other;
 } pto_stats;
+
+/* generateRayFromCamera with the scene's jitter / lens settings (see ptoracle.c); equals
+ * pto_generate_rays when neither is enabled */
+void pto_generate_rays_ex(const pto_scene *sc, int iter, pto_path *paths);
 
 /* One full iteration (pathtrace.cu:284-393 with the 8.0 loop). `paths`/`isects`
  * are caller scratch of N entries; image (N vec3) accumulates the running sum.

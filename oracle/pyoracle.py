@@ -31,7 +31,7 @@ assert GEOM_DT.itemsize == 236 and MATERIAL_DT.itemsize == 44 and CAMERA_DT.item
 assert PATH_DT.itemsize == 44 and ISECT_DT.itemsize == 20 and TRI_DT.itemsize == 36
 
 TRIG_LIBM, TRIG_SHARED = 0, 1
-F_COMPACT, F_SORT, F_FAKESHADE = 1, 2, 4
+F_COMPACT, F_SORT, F_FAKESHADE, F_AA = 1, 2, 4, 8
 SPHERE, CUBE, TRIMESH = 0, 1, 2
 
 
@@ -57,7 +57,8 @@ class Scene(C.Structure):
                 ("materials", C.c_void_p), ("nmaterials", C.c_int),
                 ("tris", C.c_void_p), ("ntris", C.c_int),
                 ("meshes", C.c_void_p), ("nmeshes", C.c_int),
-                ("camera", Camera), ("traceDepth", C.c_int), ("flags", C.c_int), ("trig", C.c_int)]
+                ("camera", Camera), ("traceDepth", C.c_int), ("flags", C.c_int), ("trig", C.c_int),
+                ("lensRadius", C.c_float), ("focalDistance", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -112,6 +113,7 @@ def lib():
         L.pto_reflect.restype = Vec3
         L.pto_reflect.argtypes = [Vec3, Vec3]
         L.pto_generate_rays.argtypes = [C.POINTER(Camera), C.c_int, C.c_void_p]
+        L.pto_generate_rays_ex.argtypes = [C.POINTER(Scene), C.c_int, C.c_void_p]
         L.pto_compute_intersections.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pto_shade_fake.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -200,6 +202,18 @@ def generate_rays(cam_np, trace_depth):
     return paths
 
 
+def generate_rays_ex(cam_np, trace_depth, it, aa=False, lens=(0.0, 0.0), trig=TRIG_SHARED):
+    """Camera rays of iteration `it` with pixel jitter and / or a thin lens (completion spec)."""
+    sc = Scene()
+    sc.camera = camera_struct(cam_np)
+    sc.traceDepth, sc.flags, sc.trig = trace_depth, F_AA if aa else 0, trig
+    sc.lensRadius, sc.focalDistance = lens
+    n = int(sc.camera.resolution[0]) * int(sc.camera.resolution[1])
+    paths = np.zeros(n, dtype=PATH_DT)
+    lib().pto_generate_rays_ex(C.byref(sc), it, _p(paths))
+    return paths
+
+
 def compute_intersections(paths, geoms, tris=None, meshes=None, n=None):
     n = len(paths) if n is None else n
     isects = np.zeros(len(paths), dtype=ISECT_DT)
@@ -219,7 +233,7 @@ def mesh_winners(tris, paths, first=0, count=None):
 
 
 def make_scene(geoms, materials, cam_np, trace_depth, flags=F_COMPACT, trig=TRIG_SHARED,
-               tris=None, meshes=None):
+               tris=None, meshes=None, lens=(0.0, 0.0)):
     sc = Scene()
     sc.geoms, sc.ngeoms = _p(geoms), len(geoms)
     sc.materials, sc.nmaterials = _p(materials), len(materials)
@@ -227,6 +241,7 @@ def make_scene(geoms, materials, cam_np, trace_depth, flags=F_COMPACT, trig=TRIG
     sc.meshes, sc.nmeshes = _p(meshes), 0 if meshes is None else len(meshes)
     sc.camera = camera_struct(cam_np)
     sc.traceDepth, sc.flags, sc.trig = trace_depth, flags, trig
+    sc.lensRadius, sc.focalDistance = lens
     sc._keep = (geoms, materials, tris, meshes)
     return sc
 
@@ -235,8 +250,8 @@ class Tracer:
     """Stateful wrapper: accumulates `image` (running sum) across iterations."""
 
     def __init__(self, geoms, materials, cam_np, trace_depth, flags=F_COMPACT, trig=TRIG_SHARED,
-                 tris=None, meshes=None):
-        self.scene = make_scene(geoms, materials, cam_np, trace_depth, flags, trig, tris, meshes)
+                 tris=None, meshes=None, lens=(0.0, 0.0)):
+        self.scene = make_scene(geoms, materials, cam_np, trace_depth, flags, trig, tris, meshes, lens)
         self.n = int(self.scene.camera.resolution[0]) * int(self.scene.camera.resolution[1])
         self.image = np.zeros((self.n, 3), dtype=np.float32)
         self.paths = np.zeros(self.n, dtype=PATH_DT)

@@ -32,7 +32,7 @@ ISECT_DT = np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("materialId", "<i4")])
 TRI_DT = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3)])
 MESH_DT = np.dtype([("geom_index", "<i4"), ("first_triangle", "<i4"), ("triangle_count", "<i4")])
 
-PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH = 1, 2, 4, 8, 16, 32
+PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH, PT_AA_JITTER = 1, 2, 4, 8, 16, 32, 64
 BVH_NODE_WORDS = 32
 
 
@@ -52,7 +52,8 @@ class _SceneDesc(C.Structure):
                 ("camera", _Camera), ("trace_depth", C.c_int32), ("flags", C.c_uint32),
                 ("device", C.c_int32), ("stream", C.c_void_p),
                 ("tile_index", C.c_int32), ("tile_count", C.c_int32), ("strip_rows", C.c_int32),
-                ("max_batch", C.c_int32), ("device_image", C.c_void_p)]
+                ("max_batch", C.c_int32), ("device_image", C.c_void_p),
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -119,6 +120,7 @@ def library():
         L.pt_device_image.restype = C.c_void_p
         L.pt_init.argtypes = [C.POINTER(_SceneDesc)]
         L.pt_set_camera.argtypes = [C.c_void_p, C.c_int]
+        L.pt_set_lens.argtypes = [C.c_float, C.c_float]
         L.pt_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.pt_trace_batch.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.pt_trace_batch_async.argtypes = [C.c_int, C.c_int]
@@ -156,7 +158,7 @@ def version():
 
 
 def pathtraceInit(scene, flags=PT_COMPACT, device=0, stream=None, tile=(0, 1, 8), max_batch=1,
-                  device_image=None):
+                  device_image=None, lens=(0.0, 0.0)):
     """pathtraceInit(Scene*) (pathtrace.cu:79-98) + the run-time toggles of include/ptmi355.h."""
     global _scene
     d = _SceneDesc()
@@ -170,6 +172,7 @@ def pathtraceInit(scene, flags=PT_COMPACT, device=0, stream=None, tile=(0, 1, 8)
     d.tile_index, d.tile_count, d.strip_rows = tile
     d.max_batch = max_batch
     d.device_image = device_image
+    d.lens_radius, d.focal_distance = lens
     _chk(library().pt_init(C.byref(d)))
     _scene = scene
 
@@ -191,6 +194,10 @@ def pathtrace(pbo, frame, iteration, copy_image=True):
     _chk(L.pt_set_camera(_p(_scene.camera), _scene.traceDepth))
     _chk(L.pt_trace(pbo, frame, iteration, _p(_scene.image) if copy_image else None))
     return _scene.image
+
+
+def set_lens(lens_radius, focal_distance):
+    _chk(library().pt_set_lens(lens_radius, focal_distance))
 
 
 def set_camera(camera, trace_depth):

@@ -11,16 +11,18 @@ namespace {
 // generateRayFromCamera -> SoA pool, `count` samples (stepping interface; the
 // batch path generates rays inside bounce 0)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, TileMap map, int count,
-                                                  Control *ctl) {
+__global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, Lens lens, TileMap map, int count,
+                                                  int iter0, int trace_depth, Control *ctl) {
     uint32_t total = (uint32_t)map.tile_pixels * (uint32_t)count;
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i == 0) { ctl->nlive[0] = total; }
     if (i >= total) return;
-    uint32_t j = i % (uint32_t)map.tile_pixels;
-    f3 d = camera_dir(cam, local_to_pixel(map, (int)j), map.W);
+    const uint32_t smp = i / (uint32_t)map.tile_pixels;
+    const uint32_t j = i - smp * (uint32_t)map.tile_pixels;
+    f3 o, d;
+    camera_ray(cam, lens, trace_depth, iter0 + (int)smp, local_to_pixel(map, (int)j), map.W, o, d);
     char *q = p.slot(i);
-    pf(q, 0) = cam.position.x; pf(q, 1) = cam.position.y; pf(q, 2) = cam.position.z;
+    pf(q, 0) = o.x; pf(q, 1) = o.y; pf(q, 2) = o.z;
     pf(q, 3) = d.x; pf(q, 4) = d.y; pf(q, 5) = d.z;
     pf(q, 6) = 1.0f; pf(q, 7) = 1.0f; pf(q, 8) = 1.0f;
     ppid(q) = i;
@@ -763,10 +765,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         if (active) {
             smp = sample_of(a.map, pid);
             pixel = local_to_pixel(a.map, (int)(pid - smp * (uint32_t)a.map.tile_pixels));
-            if (a.gen_rays) {
-                ro = ptd::mk(a.cam.position.x, a.cam.position.y, a.cam.position.z);
-                rd = camera_dir(a.cam, pixel, a.map.W);
-            }
+            if (a.gen_rays) camera_ray(a.cam, a.lens, a.trace_depth, a.iter0 + (int)smp, pixel, a.map.W, ro, rd);
         }
         if (r == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(3); }
         float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
@@ -885,7 +884,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache
         const uint32_t j = tile * BLOCK + threadIdx.x;
         const bool active = j < n;
         f3 ro = ptd::mk(cam.position.x, cam.position.y, cam.position.z), rd = ptd::mk(0, 0, 1);
-        if (active) rd = camera_dir(cam, local_to_pixel(map, (int)j), map.W);
+        if (active) camera_ray(cam, Lens{0, 0.0f, 0.0f}, 0, 0, local_to_pixel(map, (int)j), map.W, ro, rd);   // pinhole only (pt_init)
         ptd::Hit h;
         intersect_scene<MESH>(gsrc, sc, tri_lds, active, ro, rd, h, wq, gf);
         if (active) {

@@ -142,6 +142,12 @@ struct Persist {         // survives the per-batch memset
     unsigned long long first_rays;  // paths traced at bounce 0 (rays - first_rays = compaction survivors)
 };
 
+// camera extensions of the completion spec (the TODO at pathtrace.cu:134)
+struct Lens {
+    int aa;                  // jitter the sample position inside its pixel
+    float radius, focal;     // thin lens; radius <= 0: pinhole
+};
+
 struct SceneDev {
     const float *geoms;  int ngeoms;       // GEOM_WORDS dwords each
     const float *mats;   int nmats;        // MAT_WORDS dwords each
@@ -153,6 +159,7 @@ struct SceneDev {
 
 struct BounceArgs {
     Pool in, out;
+    Lens lens;
     Isect isect;
     SceneDev scene;
     TileMap map;
@@ -175,17 +182,38 @@ __device__ __forceinline__ int local_to_pixel(const TileMap &m, int j) {
     return x + y * m.W;
 }
 
-// generateRayFromCamera (pathtrace.cu:122-143) for one pixel
-__device__ __forceinline__ f3 camera_dir(const pt_camera &cam, int pix, int W) {
+// generateRayFromCamera (pathtrace.cu:122-143) for one pixel of iteration `iter`; with no jitter
+// and no lens nothing random is drawn and the ray is the reference's.  `pix` is the global pixel
+// index (it keys the random engine together with the depth slot `trace_depth`, which no bounce uses).
+__device__ __forceinline__ void camera_ray(const pt_camera &cam, const Lens &lens, int trace_depth, int iter,
+                                           int pix, int W, f3 &ro, f3 &rd) {
     const int y = pix / W;
     const int x = pix - y * W;
     f3 view = ptd::mk(cam.view.x, cam.view.y, cam.view.z);
     f3 right = ptd::mk(cam.right.x, cam.right.y, cam.right.z);
     f3 up = ptd::mk(cam.up.x, cam.up.y, cam.up.z);
-    f3 a = ptd::scale(ptd::scale(right, cam.pixelLength[0]), ((float)x - (float)cam.resolution[0] * 0.5f));
-    f3 b = ptd::scale(ptd::scale(up, cam.pixelLength[1]), ((float)y - (float)cam.resolution[1] * 0.5f));
-    return ptd::normalize(ptd::sub(ptd::sub(view, a), b));
+    f3 pos = ptd::mk(cam.position.x, cam.position.y, cam.position.z);
+    float fx = (float)x, fy = (float)y;
+    uint32_t rng = 0;
+    if (lens.aa || lens.radius > 0.0f) rng = ptd::seeded_engine(iter, pix, trace_depth);
+    if (lens.aa) {
+        fx = fx + (ptd::u01(rng) - 0.5f);
+        fy = fy + (ptd::u01(rng) - 0.5f);
+    }
+    f3 a = ptd::scale(ptd::scale(right, cam.pixelLength[0]), (fx - (float)cam.resolution[0] * 0.5f));
+    f3 b = ptd::scale(ptd::scale(up, cam.pixelLength[1]), (fy - (float)cam.resolution[1] * 0.5f));
+    ro = pos;
+    rd = ptd::normalize(ptd::sub(ptd::sub(view, a), b));
+    if (lens.radius > 0.0f) {
+        const float ft = lens.focal / ptd::dot(rd, view);
+        const f3 focus = ptd::add(pos, ptd::scale(rd, ft));
+        const float r = lens.radius * __builtin_sqrtf(ptd::u01(rng));
+        const float theta = ptd::u01(rng) * 6.2831853071795864769252867665590057683943f;
+        float sa, ca;
+        ptd::sincos_shared(theta, sa, ca);
+        ro = ptd::add(ptd::add(pos, ptd::scale(right, r * ca)), ptd::scale(up, r * sa));
+        rd = ptd::normalize(ptd::sub(focus, ro));
+    }
 }
-
 
 }  // namespace

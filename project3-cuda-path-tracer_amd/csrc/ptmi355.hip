@@ -116,6 +116,7 @@ struct Renderer {
     int grid = 0;                 // persistent grid size
     bool sorted_isects = false;   // the last bounce's intersections live in isect2 (sorted order)
     bool gen_fused = false;       // bounce 0 of the current batch generates its own rays
+    Lens lens{0, 0.0f, 0.0f};     // PT_AA_JITTER / thin lens (pt_scene_desc, pt_set_lens)
     int mesh_mode = MESH_NONE;    // MESH_TILES: every triangle per ray; MESH_BVH: PT_MESH_BVH culling
     float *d_bvh_nodes = nullptr, *d_bvh_tris = nullptr;
     pt_bvh_info bvh_info{};
@@ -213,6 +214,7 @@ BounceArgs bounce_args(int depth) {
     a.dir_out = tile_dir(depth);
     a.fin = R.final_mem;
     a.cam = R.cam;
+    a.lens = R.lens;
     a.depth = depth; a.trace_depth = R.trace_depth; a.iter0 = R.step_iter0;
     a.pool_n = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
     a.gen_rays = (depth == 0 && R.gen_fused) ? 1 : 0;
@@ -233,7 +235,7 @@ int enqueue_begin(int iter0, int count, bool stepping) {
     const uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)count;
     StageTimer tm(PT_STAGE_RAYGEN);
     hipLaunchKernelGGL(k_raygen, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.pool[0], R.cam,
-                       R.map, count, R.ctl);
+                       R.lens, R.map, count, iter0, R.trace_depth, R.ctl);
     HIPCHK(hipGetLastError());
     return PT_OK;
 }
@@ -510,6 +512,11 @@ static int init_impl(const pt_scene_desc *d) {
             m.first_triangle < 0 || m.triangle_count < 0 || m.first_triangle + m.triangle_count > d->num_triangles)
             return fail(PT_ERR_INVALID, "pt_init: mesh %d is inconsistent", k);
     }
+    if ((d->flags & PT_CACHE_FIRST) && ((d->flags & PT_AA_JITTER) || d->lens_radius > 0.0f))
+        return fail(PT_ERR_INVALID, "pt_init: PT_CACHE_FIRST needs identical camera rays every iteration; it cannot be "
+                                    "combined with PT_AA_JITTER or a lens (INSTRUCTION.md:113)");
+    if (d->lens_radius > 0.0f && !(d->focal_distance > 0.0f))
+        return fail(PT_ERR_INVALID, "pt_init: a lens needs focal_distance > 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(PT_ERR_DEVICE, "pt_init: no HIP device (this library has no CPU fallback)");
@@ -518,6 +525,7 @@ static int init_impl(const pt_scene_desc *d) {
 
     R = Renderer{};
     R.desc = *d; R.cam = d->camera; R.trace_depth = d->trace_depth; R.flags = d->flags; R.device = d->device;
+    R.lens = Lens{(d->flags & PT_AA_JITTER) ? 1 : 0, d->lens_radius, d->focal_distance};
     R.npix = W * H;
     R.map.W = W; R.map.H = H; R.map.tile_index = d->tile_index; R.map.tile_count = tile_count;
     R.map.strip_rows = tile_count > 1 ? d->strip_rows : H;
@@ -667,6 +675,15 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
     if (memcmp(&R.cam, camera, sizeof R.cam) != 0) R.cache_valid = false;     // new camera: refill the bounce-0 cache
     R.cam = *camera;
     R.trace_depth = trace_depth;
+    return PT_OK;
+}
+
+int pt_set_lens(float lens_radius, float focal_distance) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_set_lens: not initialised");
+    if (lens_radius > 0.0f && !(focal_distance > 0.0f)) return fail(PT_ERR_INVALID, "pt_set_lens: a lens needs focal_distance > 0");
+    if (lens_radius > 0.0f && (R.flags & PT_CACHE_FIRST))
+        return fail(PT_ERR_INVALID, "pt_set_lens: PT_CACHE_FIRST cannot be combined with a lens");
+    R.lens.radius = lens_radius; R.lens.focal = focal_distance;
     return PT_OK;
 }
 

@@ -3,7 +3,7 @@
 // pathtraceInit(); pathtrace() x ITERATIONS; saveImage(); pathtraceFree().
 //
 //   ptbench SCENEFILE.txt [--iters N] [--batch B] [--out BASENAME] [--sort] [--no-compact]
-//           [--cache-first] [--pfm] [--device D]
+//           [--cache-first] [--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D]
 //
 // Links libptmi355.so (the HIP library) and host/pthost.cpp.
 #include <chrono>
@@ -17,12 +17,14 @@
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        printf("Usage: %s SCENEFILE.txt [--iters N] [--batch B] [--out BASE] [--sort] [--no-compact] [--pfm] [--device D]\n", argv[0]);
+        printf("Usage: %s SCENEFILE.txt [--iters N] [--batch B] [--out BASE] [--sort] [--no-compact] [--cache-first] "
+               "[--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D]\n", argv[0]);
         return 1;
     }
     int iters = -1, batch = 1, device = 0;
     unsigned flags = PT_COMPACT;
     bool pfm = false;
+    float lens_radius = 0.0f, focal_distance = 0.0f;
     std::string out;
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
@@ -32,6 +34,10 @@ int main(int argc, char **argv) {
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
         else if (a == "--sort") flags |= PT_SORT_MATERIAL;
         else if (a == "--no-compact") flags &= ~PT_COMPACT;
+        else if (a == "--cache-first") flags |= PT_CACHE_FIRST;
+        else if (a == "--bvh") flags |= PT_MESH_BVH;
+        else if (a == "--aa") flags |= PT_AA_JITTER;
+        else if (a == "--lens" && i + 2 < argc) { lens_radius = (float)atof(argv[++i]); focal_distance = (float)atof(argv[++i]); }
         else if (a == "--pfm") pfm = true;
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
     }
@@ -51,6 +57,7 @@ int main(int argc, char **argv) {
     d.meshes = sc->meshes; d.num_meshes = sc->num_meshes;
     d.camera = sc->camera; d.trace_depth = sc->trace_depth; d.flags = flags; d.device = device;
     d.tile_count = 1; d.strip_rows = 8; d.max_batch = batch;
+    d.lens_radius = lens_radius; d.focal_distance = focal_distance;
     pt_free();                                            // main.cpp:126
     if (pt_init(&d) != PT_OK) { fprintf(stderr, "pathtraceInit: %s\n", pt_last_error()); return 1; }
 

@@ -421,6 +421,73 @@ def test_mesh_bvh_c4_equals_every_triangle(pt, scenes):
     assert out["loop"][1][1] > 100000
 
 
+@pytest.mark.parametrize("mode", ["aa", "lens", "aa+lens"])
+def test_camera_jitter_and_lens(pt, po, scenes, mode):
+    """Stochastic antialiasing and the thin lens (completion spec; pathtrace.cu:134 TODO, INSTRUCTION.md:110-113):
+    the camera rays, every iteration's image and the batched path agree with the oracle bit for bit."""
+    s = scenes["cornell_glass_64"]
+    aa = "aa" in mode
+    lens = (0.35, 9.0) if "lens" in mode else (0.0, 0.0)
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+    gflags = pt.PT_COMPACT | (pt.PT_AA_JITTER if aa else 0)
+    oflags = po.F_COMPACT | (po.F_AA if aa else 0)
+    # the rays themselves (stepping interface -> k_raygen)
+    pt.pathtraceInit(scene, flags=gflags, lens=lens)
+    for it in (1, 5):
+        pt.trace_begin(it, 1)
+        paths, live = pt.export_paths(n)
+        want = po.generate_rays_ex(s["camera"], s["depth"], it, aa=aa, lens=lens)
+        assert live == n and paths.tobytes() == want.tobytes()
+        pt.trace_end()
+    pt.pathtraceFree()
+    # whole iterations, one at a time (rays generated inside bounce 0), then as batches
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], flags=oflags, trig=po.TRIG_SHARED, lens=lens)
+    pt.pathtraceInit(scene, flags=gflags, lens=lens)
+    for it in range(1, 7):
+        img = pt.pathtrace(None, 0, it)
+        st = ref.iterate(it)
+        assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
+        assert img.tobytes() == ref.image.tobytes()
+    pt.pathtraceFree()
+    pt.pathtraceInit(scene, flags=gflags, lens=lens, max_batch=4)
+    img = np.zeros((n, 3), dtype=np.float32)
+    pt.trace_batch(1, 4, img)
+    pt.trace_batch(5, 2, img)
+    assert img.tobytes() == ref.image.tobytes()
+    pt.pathtraceFree()
+    # unfused / sorted pipelines read rays written by k_raygen
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], flags=oflags | po.F_SORT, trig=po.TRIG_SHARED,
+                    lens=lens)
+    pt.pathtraceInit(scene, flags=gflags | pt.PT_SORT_MATERIAL, lens=lens)
+    for it in (1, 2):
+        img = pt.pathtrace(None, 0, it)
+        ref.iterate(it)
+        assert img.tobytes() == ref.image.tobytes()
+    pt.pathtraceFree()
+
+
+def test_camera_extensions_exclude_the_first_bounce_cache(pt, scenes):
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    with pytest.raises(pt.PtError, match="PT_CACHE_FIRST"):
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_CACHE_FIRST | pt.PT_AA_JITTER)
+    with pytest.raises(pt.PtError, match="PT_CACHE_FIRST"):
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_CACHE_FIRST, lens=(0.1, 5.0))
+    with pytest.raises(pt.PtError, match="focal_distance"):
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT, lens=(0.1, 0.0))
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
+    a = pt.pathtrace(None, 0, 1).copy()
+    pt.set_lens(0.3, 9.0)                        # takes effect from the next iteration on
+    pt.clear_image()
+    b = pt.pathtrace(None, 0, 1).copy()
+    pt.set_lens(0.0, 0.0)
+    pt.clear_image()
+    c = pt.pathtrace(None, 0, 1).copy()
+    assert (a != b).any() and a.tobytes() == c.tobytes()
+    pt.pathtraceFree()
+
+
 def test_ptbench_headless_host(pt, po, scenes, tmp_path):
     """The C++ headless host (host/ptbench.cpp = main.cpp/runCuda without GLFW): scene file in, PNG out;
     the PNG equals the oracle's image pushed through the same saveImage pipeline."""
