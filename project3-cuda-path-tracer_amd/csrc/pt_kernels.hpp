@@ -19,6 +19,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, Lens le
     if (i >= total) return;
     const uint32_t smp = i / (uint32_t)map.tile_pixels;
     const uint32_t j = i - smp * (uint32_t)map.tile_pixels;
+    if (iter0 < 0) iter0 = (int)ctl->iter0;                  // graph replay
     f3 o, d;
     camera_ray(cam, lens, trace_depth, iter0 + (int)smp, local_to_pixel(map, (int)j), map.W, o, d);
     char *q = p.slot(i);
@@ -722,6 +723,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t W = gridDim.x * WAVES;
     const uint32_t wid = run_id();
+    const int iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;       // graph replay: arguments are frozen
     const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);                        // logical tiles per wave (one contiguous run)
@@ -765,7 +767,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         if (active) {
             smp = sample_of(a.map, pid);
             pixel = local_to_pixel(a.map, (int)(pid - smp * (uint32_t)a.map.tile_pixels));
-            if (a.gen_rays) camera_ray(a.cam, a.lens, a.trace_depth, a.iter0 + (int)smp, pixel, a.map.W, ro, rd);
+            if (a.gen_rays) camera_ray(a.cam, a.lens, a.trace_depth, iter0 + (int)smp, pixel, a.map.W, ro, rd);
         }
         if (r == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(3); }
         float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         ptd::PathState ps;
         ps.o = ro; ps.d = rd; ps.c = col;
         if (active) {
-            alive = ptd::shade_scatter(ps, t, nrm, mat, outside, mats, a.iter0 + (int)smp, pixel, a.depth,
+            alive = ptd::shade_scatter(ps, t, nrm, mat, outside, mats, iter0 + (int)smp, pixel, a.depth,
                                        last_bounce);
             if (!alive) {
                 at(a.fin, pid) = ps.c.x; at(a.fin + (size_t)a.in.cap, pid) = ps.c.y;

@@ -76,7 +76,9 @@ __device__ __forceinline__ uint32_t sample_of(const TileMap &m, uint32_t pid) {
     return (((pid - q) >> 1) + q) >> m.div_shift;
 }
 
-struct Control {         // zeroed by one hipMemsetAsync per batch (2 KiB)
+struct Control {         // zeroed from `stamp` on by one hipMemsetAsync per batch (2 KiB)
+    uint32_t iter0;                 // first iteration of the batch when the launches come from a replayed graph
+    uint32_t keep[15];              //   (kernel arguments are frozen at capture time); survives the per-batch clear
     unsigned long long stamp[16];   // -DPT_STAMPS: s_memrealtime at the phases of wave 0 / the last workgroup
     uint32_t nlive[MAX_DEPTH + 1];  // nlive[d] = paths entering bounce d (compaction on)
     uint32_t alive[MAX_DEPTH + 1];  // paths actually traced at bounce d
@@ -84,7 +86,7 @@ struct Control {         // zeroed by one hipMemsetAsync per batch (2 KiB)
     uint32_t done_sort[MAX_DEPTH];  // same for the material-sort histogram of bounce d
     uint32_t error;
     uint32_t scan_ticks[MAX_DEPTH]; // 100 MHz ticks the last workgroup spent scanning (diagnostic)
-    uint32_t pad[512 - 32 - 2 * (MAX_DEPTH + 1) - 3 * MAX_DEPTH - 1];
+    uint32_t pad[512 - 16 - 32 - 2 * (MAX_DEPTH + 1) - 3 * MAX_DEPTH - 1];
     // first-level election counters: 32 buckets per bounce, one 64-B line apart
     uint32_t bucket[MAX_DEPTH][2][32 * 16];       // [bounce][bounce kernel | sort histogram][bucket * 16]
 };
@@ -168,7 +170,7 @@ struct BounceArgs {
     RangeDir dir_out;      // directory this launch produces
     float *fin;            // final colour planes r g b (stride in.cap), index = pid
     pt_camera cam;         // used when gen_rays != 0
-    int depth, trace_depth, iter0;
+    int depth, trace_depth, iter0;   // iter0 < 0: read Control::iter0 (graph replay)
     uint32_t pool_n;       // paths in the pool when compaction is off / at bounce 0
     int gen_rays;          // bounce 0 generates the camera ray instead of loading it
 };

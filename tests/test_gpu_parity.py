@@ -488,6 +488,37 @@ def test_camera_extensions_exclude_the_first_bounce_cache(pt, scenes):
     pt.pathtraceFree()
 
 
+def test_graph_replay_equals_direct_launches(pt, scenes, monkeypatch):
+    """PTMI355_GRAPH=1: a batch captured once and replayed with hipGraphLaunch (iteration number through
+    Control::iter0) gives the same image as direct launches, across batch sizes and a camera change."""
+    s = scenes["cornell_glass_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+
+    def run():
+        img = np.zeros((n, 3), dtype=np.float32)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=4)
+        for it in (1, 2, 3):
+            pt.pathtrace(None, 0, it)                 # batch size 1, three replays
+        pt.trace_batch(4, 4, img)                     # batch size 4
+        pt.trace_batch(8, 4, img)
+        pt.trace_batch(12, 3, img)                    # a third size
+        rays = pt.get_stats().total_rays
+        cam = scene.camera.copy()
+        cam["position"][0][0] += 0.5                  # frozen launch arguments change: graphs are re-captured
+        pt.set_camera(cam, s["depth"])
+        pt.trace_batch(15, 4, img)
+        pt.pathtraceFree()
+        return img, rays
+
+    monkeypatch.delenv("PTMI355_GRAPH", raising=False)
+    direct = run()
+    monkeypatch.setenv("PTMI355_GRAPH", "1")
+    replay = run()
+    assert direct[1] == replay[1]
+    assert direct[0].tobytes() == replay[0].tobytes()
+
+
 def test_ptbench_headless_host(pt, po, scenes, tmp_path):
     """The C++ headless host (host/ptbench.cpp = main.cpp/runCuda without GLFW): scene file in, PNG out;
     the PNG equals the oracle's image pushed through the same saveImage pipeline."""
