@@ -194,7 +194,7 @@ int pt_get_counters(int64_t *rays, int64_t *first_bounce_rays, int64_t *iteratio
  * roofline leg).  Off by default; when on, every launch of the per-bounce
  * kernels is bracketed by two events from a preallocated pool. */
 enum pt_stage { PT_STAGE_RAYGEN = 0, PT_STAGE_BOUNCE = 1, PT_STAGE_INTERSECT = 2,
-                PT_STAGE_SORT = 3, PT_STAGE_GATHER = 4, PT_STAGE_COUNT = 5 };
+                PT_STAGE_SORT = 3, PT_STAGE_GATHER = 4, PT_STAGE_MESH = 5, PT_STAGE_COUNT = 6 };
 typedef struct pt_profile {
     double  ms[PT_STAGE_COUNT];        /* summed event-elapsed time per stage */
     int64_t launches[PT_STAGE_COUNT];  /* launches measured */
@@ -209,10 +209,11 @@ typedef struct pt_bvh_info {
 } pt_bvh_info;
 int pt_get_bvh_info(pt_bvh_info *out);
 /* host-only (no GPU): build the hierarchy of `count` triangles; returns the node count, or the
- * required count when `node_capacity` is too small (nothing written then).  nodes: 32 dwords
- * each (layout in csrc/pt_bvh.hpp); order: leaf slot -> triangle index. */
+ * required count when `node_capacity` is too small (nothing written then).  nodes: 16 dwords
+ * each (layout in csrc/pt_bvh.hpp); order: leaf slot -> triangle index; grid (8 floats,
+ * optional): origin xyz, step xyz of the 16-bit box grid, box padding, prune margin. */
 int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node_capacity,
-                 int32_t *order);
+                 int32_t *order, float *grid);
 const char *pt_last_error(void);
 const char *pt_version(void);
 

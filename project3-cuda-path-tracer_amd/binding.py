@@ -33,7 +33,7 @@ TRI_DT = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3)])
 MESH_DT = np.dtype([("geom_index", "<i4"), ("first_triangle", "<i4"), ("triangle_count", "<i4")])
 
 PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH, PT_AA_JITTER = 1, 2, 4, 8, 16, 32, 64
-BVH_NODE_WORDS = 32
+BVH_NODE_WORDS = 16
 
 
 class PtError(RuntimeError):
@@ -67,10 +67,10 @@ class BvhInfo(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("ms", C.c_double * 5), ("launches", C.c_int64 * 5)]
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int64 * 6)]
 
 
-STAGES = ("raygen", "bounce", "intersect", "sort", "gather")
+STAGES = ("raygen", "bounce", "intersect", "sort", "gather", "mesh")
 
 
 class Scene:
@@ -137,7 +137,7 @@ def library():
         L.pt_set_profiling.argtypes = [C.c_int]
         L.pt_get_profile.argtypes = [C.POINTER(Profile)]
         L.pt_get_bvh_info.argtypes = [C.POINTER(BvhInfo)]
-        L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pt_free.restype = None
         _lib = L
     return _lib
@@ -297,17 +297,18 @@ def bvh_info():
 
 
 def bvh_build(triangles):
-    """Host-only: the hierarchy pt_init builds under PT_MESH_BVH.  Returns (nodes[n, 32] float32 -- words
-    12..23 are int32 --, order[count] int32)."""
+    """Host-only: the hierarchy pt_init builds under PT_MESH_BVH.  Returns (nodes[n, 16] uint32 -- layout in
+    csrc/pt_bvh.hpp --, order[count] int32, grid[8] float32 = origin xyz, step xyz, padding, prune margin)."""
     tris = np.ascontiguousarray(triangles, dtype=TRI_DT)
     L = library()
-    need = L.pt_bvh_build(_p(tris), len(tris), None, 0, None)
+    need = L.pt_bvh_build(_p(tris), len(tris), None, 0, None, None)
     if need < 0:
         raise PtError(L.pt_last_error().decode())
-    nodes = np.zeros((need, BVH_NODE_WORDS), dtype=np.float32)
+    nodes = np.zeros((need, BVH_NODE_WORDS), dtype=np.uint32)
     order = np.zeros(max(1, len(tris)), dtype=np.int32)
-    _chk(min(0, L.pt_bvh_build(_p(tris), len(tris), _p(nodes), need, _p(order))))
-    return nodes, order[:len(tris)]
+    grid = np.zeros(8, dtype=np.float32)
+    _chk(min(0, L.pt_bvh_build(_p(tris), len(tris), _p(nodes), need, _p(order), _p(grid))))
+    return nodes, order[:len(tris)], grid
 
 
 def total_rays():

@@ -3,16 +3,20 @@
 // 218-240 -- the reference has none).  Included by ptmi355.hip only; no device code here.
 //
 // Layout: a binary tree (binned surface-area splits, leaves of 1..4
-// triangles) stored as one 128-byte record per INTERNAL node that carries the boxes of BOTH
-// children, so one cache line fetched per step decides two boxes:
-//   [0..5]   left child box  (min xyz, max xyz)      [6..11] right child box      (padded, see `pad`)
-//   [12]     left link   [13] left info    [14] right link   [15] right info
+// triangles) stored as one 64-byte record per INTERNAL node that carries the boxes of BOTH
+// children, so one fetch per step decides two boxes.  A walk is bound by how many address-divergent
+// vector loads the texture path can take, so the record is made small: box planes are 16-bit
+// grid coordinates over the mesh's bounds (rounded outwards; grid step = extent / 65533), two
+// 16-B loads bring both boxes and both links, a third 4-B load the miss link.
+//   [0..2]   left child box   lo.x | lo.y << 16,  lo.z | hi.x << 16,  hi.y | hi.z << 16
+//   [3..5]   right child box, same packing
+//   [6]      left link  | info << 24      [7] right link | info << 24
 //              info = count | leaf << 3 | split axis of THIS node << 4   (axis only in the left info)
 //              leaf child: link = first record in the leaf-ordered triangle array, count = 0..4
-//              internal child: link = record index of that child
-//   [16..23] miss link per ray-direction octant (bit k set when dir[k] < 0): the record to continue
+//              internal child: link = record index of that child                    (links < 2^24)
+//   [8..15]  miss link per ray-direction octant (bit k set when dir[k] < 0): the record to continue
 //            with when this subtree is finished; -1 ends the walk
-//   [24..31] unused (the record is one 128-B cache line)
+// world plane = origin[axis] + grid * step[axis]  (Tree::origin / Tree::step).
 // The kernel walks the tree WITHOUT a stack.  At a record it tests both child boxes, intersects
 // the triangles of hit leaf children at once, and continues with a hit internal child -- the
 // nearer one (by the sign of dir[axis]) when both are hit; otherwise it follows miss[octant].
@@ -25,7 +29,7 @@
 // specification).  Boxes are therefore padded by `pad` = 2^-13 * max(1, largest |coordinate|),
 // orders of magnitude above the rounding error of glm::intersectRayTriangle for rays that are
 // not within ~1e-3 rad of a triangle's plane, and the kernel prunes against the best distance
-// with the additive margin `prune` = 16 * pad.
+// with the additive margin `prune` = 16 * pad.  The grid rounding adds at most two grid steps on top.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -35,7 +39,9 @@
 
 namespace ptbvh {
 
-constexpr int NODE_WORDS = 32;
+constexpr int NODE_WORDS = 16;
+constexpr int GRID_MAX = 65535;
+constexpr int LINK_BITS = 24;
 constexpr int LEAF_MAX = 4;
 constexpr int SAH_BINS = 16;
 constexpr int INFO_LEAF = 8;         // bit 3 of an info word
@@ -55,6 +61,7 @@ struct Tree {
     std::vector<float> nodes;        // NODE_WORDS per record, record 0 is the root
     std::vector<int32_t> order;      // leaf-ordered triangle slots -> index into the caller's triangle range
     float pad = 0.0f, prune = 0.0f;
+    float origin[3] = {0, 0, 0}, step[3] = {1, 1, 1};   // world plane = origin + grid * step
     int depth = 0;
     int num_nodes() const { return (int)(nodes.size() / NODE_WORDS); }
 };
@@ -161,6 +168,28 @@ inline void number(const Work &w, int s, std::vector<int32_t> &rec, int &next) {
     number(w, w.split[s].left + 1, rec, next);
 }
 
+inline void set_u(float *w, uint32_t v) { memcpy(w, &v, 4); }
+
+// grid coordinate of a box plane, rounded outwards with one step to spare (the kernel evaluates
+// origin + grid * step through a fused form that can be an ulp or two off)
+inline uint32_t grid_lo(float x, float o, float s) {
+    const double g = std::floor(((double)x - (double)o) / (double)s) - 1.0;
+    return (uint32_t)std::max(0.0, std::min((double)GRID_MAX, g));
+}
+inline uint32_t grid_hi(float x, float o, float s) {
+    const double g = std::ceil(((double)x - (double)o) / (double)s) + 1.0;
+    return (uint32_t)std::max(0.0, std::min((double)GRID_MAX, g));
+}
+
+inline void pack_box(float *r, const Box &b, float pad, const Tree &t, bool empty) {
+    uint32_t lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = empty ? 2u : grid_lo(b.lo[a] - pad, t.origin[a], t.step[a]);
+        hi[a] = empty ? 1u : grid_hi(b.hi[a] + pad, t.origin[a], t.step[a]);     // inverted: nothing hits it
+    }
+    set_u(&r[0], lo[0] | (lo[1] << 16)); set_u(&r[1], lo[2] | (hi[0] << 16)); set_u(&r[2], hi[1] | (hi[2] << 16));
+}
+
 inline void emit(const Work &w, const std::vector<int32_t> &rec, int s, const int32_t miss[8], float pad, Tree &out) {
     const Split &n = w.split[s];
     float *r = &out.nodes[(size_t)rec[(size_t)s] * NODE_WORDS];
@@ -168,12 +197,13 @@ inline void emit(const Work &w, const std::vector<int32_t> &rec, int s, const in
     bool inner[2];
     for (int c = 0; c < 2; ++c) {
         const Split &k = w.split[kid[c]];
-        for (int a = 0; a < 3; ++a) { r[6 * c + a] = k.box.lo[a] - pad; r[6 * c + 3 + a] = k.box.hi[a] + pad; }
+        pack_box(&r[3 * c], k.box, pad, out, false);
         inner[c] = k.left >= 0;
-        set_i(&r[12 + 2 * c], inner[c] ? rec[(size_t)kid[c]] : k.lo);
-        set_i(&r[13 + 2 * c], (inner[c] ? 0 : (k.count | INFO_LEAF)) | (c == 0 ? n.axis << 4 : 0));
+        const uint32_t link = (uint32_t)(inner[c] ? rec[(size_t)kid[c]] : k.lo);
+        const uint32_t info = (uint32_t)((inner[c] ? 0 : (k.count | INFO_LEAF)) | (c == 0 ? n.axis << 4 : 0));
+        set_u(&r[6 + c], link | (info << LINK_BITS));
     }
-    for (int o = 0; o < 8; ++o) set_i(&r[16 + o], miss[o]);
+    for (int o = 0; o < 8; ++o) set_i(&r[8 + o], miss[o]);
     int32_t m[2][8];
     for (int o = 0; o < 8; ++o) {
         const int near = (o >> n.axis) & 1;                  // dir[axis] < 0: the upper (right) child is nearer
@@ -206,6 +236,16 @@ inline void build(const float *v, int count, Tree &out) {
     out.prune = 16.0f * out.pad;
     w.split.resize(1);
     if (count > 0) out.depth = detail::build(w, 0, 0, count, 0);
+    // the grid spans the padded bounds of the whole mesh with a few steps of margin on either side
+    for (int a = 0; a < 3; ++a) {
+        float lo = 0.0f, hi = 0.0f;
+        if (count > 0 && std::isfinite(w.split[0].box.lo[a]) && std::isfinite(w.split[0].box.hi[a])) {
+            lo = w.split[0].box.lo[a]; hi = w.split[0].box.hi[a];
+        }
+        const float ext = (hi - lo) + 2.0f * out.pad;
+        out.step[a] = std::max(ext / (float)(GRID_MAX - 8), 1e-30f);
+        out.origin[a] = (lo - out.pad) - 4.0f * out.step[a];
+    }
     const int32_t end[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     if (count > 0 && w.split[0].left >= 0) {
         std::vector<int32_t> rec(w.split.size(), -1);
@@ -218,14 +258,11 @@ inline void build(const float *v, int count, Tree &out) {
         // one, else inverted) and whose right child is an empty leaf with an inverted box nothing hits
         out.nodes.assign(NODE_WORDS, 0.0f);
         float *r = out.nodes.data();
-        for (int a = 0; a < 3; ++a) {
-            r[a] = count > 0 ? w.split[0].box.lo[a] - out.pad : 1.0f;
-            r[3 + a] = count > 0 ? w.split[0].box.hi[a] + out.pad : -1.0f;
-            r[6 + a] = 1.0f; r[9 + a] = -1.0f;
-        }
-        detail::set_i(&r[12], 0); detail::set_i(&r[13], count | INFO_LEAF);
-        detail::set_i(&r[14], 0); detail::set_i(&r[15], INFO_LEAF);
-        for (int o = 0; o < 8; ++o) detail::set_i(&r[16 + o], -1);
+        detail::pack_box(&r[0], w.split[0].box, out.pad, out, count == 0);
+        detail::pack_box(&r[3], w.split[0].box, out.pad, out, true);
+        detail::set_u(&r[6], (uint32_t)((count | INFO_LEAF) << LINK_BITS));
+        detail::set_u(&r[7], (uint32_t)(INFO_LEAF << LINK_BITS));
+        for (int o = 0; o < 8; ++o) detail::set_i(&r[8 + o], -1);
     }
     out.order = w.idx;
 }

@@ -123,59 +123,87 @@ __device__ __forceinline__ void queue_pass(float *wq, const float *gf, uint32_t 
 // NaNs from 0 * inf drop out of v_min/v_max, which errs towards visiting.  Every link points
 // forward in the octant's depth-first order, so the walk ends after at most `guard` records; the
 // guard also bounds it for NaN rays.
-__device__ __forceinline__ void bvh_walk(const float *__restrict__ nodes, const float *__restrict__ btris,
-                                         float prune, int guard, f3 ro, f3 rd, float &best, int &best_i) {
-    const float ix = __builtin_amdgcn_rcpf(rd.x), iy = __builtin_amdgcn_rcpf(rd.y), iz = __builtin_amdgcn_rcpf(rd.z);
-    const float nx = -(ro.x * ix), ny = -(ro.y * iy), nz = -(ro.z * iz);
-    const int oct = (rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0);
-    auto slab = [&](float lx, float ly, float lz, float hx, float hy, float hz, float &tn, float &tf) {
-        const float t1x = __builtin_fmaf(lx, ix, nx), t2x = __builtin_fmaf(hx, ix, nx);
-        const float t1y = __builtin_fmaf(ly, iy, ny), t2y = __builtin_fmaf(hy, iy, ny);
-        const float t1z = __builtin_fmaf(lz, iz, nz), t2z = __builtin_fmaf(hz, iz, nz);
-        tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
-                             __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
-        tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
-                             __builtin_fmaxf(t1z, t2z));
-    };
+struct BvhRay {                       // what a walk keeps per (ray, mesh)
+    f3 ro, rd;
+    float kx, ky, kz, bx, by, bz;     // slab form over the mesh's grid: t = grid * k + b
+    int oct;
+};
+// origin / step: the mesh's grid (world plane = origin + grid * step)
+__device__ __forceinline__ BvhRay bvh_ray(f3 ro, f3 rd, f3 origin, f3 step) {
+    BvhRay r;
+    r.ro = ro; r.rd = rd;
+    // A direction component of (nearly) zero would turn that axis' planes into inf - inf = NaN, which the
+    // min/max drop: the box test would then ignore the axis and an axis-parallel ray would visit every record
+    // in front of it.  The box tests use 1e-20 instead (the triangle tests keep the true direction): over any
+    // distance in the scene the ray moves by far less than the box padding, so the test stays conservative.
+    auto off_axis = [](float c) { return __builtin_fabsf(c) < 1e-20f ? __builtin_copysignf(1e-20f, c) : c; };
+    const float ix = __builtin_amdgcn_rcpf(off_axis(rd.x)), iy = __builtin_amdgcn_rcpf(off_axis(rd.y)),
+                iz = __builtin_amdgcn_rcpf(off_axis(rd.z));
+    r.kx = step.x * ix; r.ky = step.y * iy; r.kz = step.z * iz;
+    r.bx = (origin.x - ro.x) * ix; r.by = (origin.y - ro.y) * iy; r.bz = (origin.z - ro.z) * iz;
+    r.oct = (rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0);
+    return r;
+}
+// entry / exit parameters of the box packed in three dwords (pt_bvh.hpp), clipped to t >= 0
+__device__ __forceinline__ void bvh_slab(const BvhRay &r, uint32_t w0, uint32_t w1, uint32_t w2, float &tn, float &tf) {
+    const float lx = (float)(w0 & 0xffffu), ly = (float)(w0 >> 16), lz = (float)(w1 & 0xffffu);
+    const float hx = (float)(w1 >> 16), hy = (float)(w2 & 0xffffu), hz = (float)(w2 >> 16);
+    const float t1x = __builtin_fmaf(lx, r.kx, r.bx), t2x = __builtin_fmaf(hx, r.kx, r.bx);
+    const float t1y = __builtin_fmaf(ly, r.ky, r.by), t2y = __builtin_fmaf(hy, r.ky, r.by);
+    const float t1z = __builtin_fmaf(lz, r.kz, r.bz), t2z = __builtin_fmaf(hz, r.kz, r.bz);
+    tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
+                         __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
+    tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+                         __builtin_fmaxf(t1z, t2z));
+}
+// one step at record `node` (>= 0); returns the record to continue with, < 0 when the walk is over
+__device__ __forceinline__ int bvh_step(const float *__restrict__ nodes, const float *__restrict__ btris,
+                                        float prune, const BvhRay &r, int node, float &best, int &best_i) {
     auto leaf = [&](int first, int cnt) {
         const float4 *t4 = reinterpret_cast<const float4 *>(btris + (size_t)first * TRI_WORDS);
+#pragma unroll 1
         for (int k = 0; k < cnt; ++k) {
             const float4 P = t4[3 * k], Q = t4[3 * k + 1], S = t4[3 * k + 2];
             float tz;
-            if (ptd::ray_triangle(ro, rd, ptd::mk(P.x, P.y, P.z), ptd::mk(P.w, Q.x, Q.y), ptd::mk(Q.z, Q.w, S.x), tz)) {
+            if (ptd::ray_triangle(r.ro, r.rd, ptd::mk(P.x, P.y, P.z), ptd::mk(P.w, Q.x, Q.y), ptd::mk(Q.z, Q.w, S.x), tz)) {
                 const int orig = __float_as_int(S.y);                    // index in the caller's triangle array
                 if (tz > 0.0f && (best > tz || (best == tz && orig < best_i))) { best = tz; best_i = orig; }
             }
         }
     };
+    const uint4 *n4 = reinterpret_cast<const uint4 *>(nodes + (size_t)node * BVH_NODE_WORDS);
+    const uint4 A = n4[0], B = n4[1];
+    int next = reinterpret_cast<const int *>(n4)[8 + r.oct];
+    const int link_l = (int)(B.z & 0xffffffu), info_l = (int)(B.z >> 24);
+    const int link_r = (int)(B.w & 0xffffffu), info_r = (int)(B.w >> 24);
+    float tn_l, tf_l, tn_r, tf_r;
+    bvh_slab(r, A.x, A.y, A.z, tn_l, tf_l);
+    bvh_slab(r, A.w, B.x, B.y, tn_r, tf_r);
+    const bool hit_l = tn_l <= tf_l && tn_l <= best + prune;
+    if (hit_l && (info_l & 8)) leaf(link_l, info_l & 7);
+    const bool hit_r = tn_r <= tf_r && tn_r <= best + prune;
+    if (hit_r && (info_r & 8)) leaf(link_r, info_r & 7);
+    const bool go_l = hit_l && !(info_l & 8), go_r = hit_r && !(info_r & 8);
+    const bool right_near = (r.oct >> ((info_l >> 4) & 3)) & 1;
+    if (go_l && go_r) next = right_near ? link_r : link_l;             // the far one follows through the near one's miss link
+    else if (go_l) next = link_l;
+    else if (go_r) next = link_r;
+    return next;
+}
+// `grid`: origin xyz, step xyz of the mesh (six floats of its geom record)
+template <typename P>
+__device__ __forceinline__ void bvh_walk(const float *__restrict__ nodes, const float *__restrict__ btris, P grid,
+                                         float prune, int guard, f3 ro, f3 rd, float &best, int &best_i) {
+    const BvhRay r = bvh_ray(ro, rd, ptd::mk(grid[0], grid[1], grid[2]), ptd::mk(grid[3], grid[4], grid[5]));
     int node = 0;
-    for (int it = 0; it < guard && node >= 0; ++it) {
-        const float4 *n4 = reinterpret_cast<const float4 *>(nodes + (size_t)node * BVH_NODE_WORDS);
-        const float4 A = n4[0], B = n4[1], C = n4[2], D = n4[3];
-        int next = reinterpret_cast<const int *>(n4)[16 + oct];
-        const int link_l = __float_as_int(D.x), info_l = __float_as_int(D.y);
-        const int link_r = __float_as_int(D.z), info_r = __float_as_int(D.w);
-        float tn_l, tf_l, tn_r, tf_r;
-        slab(A.x, A.y, A.z, A.w, B.x, B.y, tn_l, tf_l);
-        slab(B.z, B.w, C.x, C.y, C.z, C.w, tn_r, tf_r);
-        const bool hit_l = tn_l <= tf_l && tn_l <= best + prune;
-        if (hit_l && (info_l & 8)) leaf(link_l, info_l & 7);
-        const bool hit_r = tn_r <= tf_r && tn_r <= best + prune;
-        if (hit_r && (info_r & 8)) leaf(link_r, info_r & 7);
-        const bool go_l = hit_l && !(info_l & 8), go_r = hit_r && !(info_r & 8);
-        const bool right_near = (oct >> ((info_l >> 4) & 3)) & 1;
-        if (go_l && go_r) next = right_near ? link_r : link_l;         // the far one follows through the near one's miss link
-        else if (go_l) next = link_l;
-        else if (go_r) next = link_r;
-        node = next;
-    }
+    for (int it = 0; it < guard && node >= 0; ++it) node = bvh_step(nodes, btris, prune, r, node, best, best_i);
 }
 
 template <int MESH>
 __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms, const SceneDev &sc,
                                                 float *tri_lds, bool active,
                                                 f3 ro, f3 rd, ptd::Hit &h, float *wq = nullptr,
-                                                const float *gf = nullptr) {
+                                                const float *gf = nullptr, const float4 *pre_hit = nullptr) {
     h.t = FLT_MAX; h.geom = -1; h.outside = 1; h.aux = ptd::mk(0, 0, 0);
     const int ngeoms = sc.ngeoms;
     const float *__restrict__ tris = sc.tris;
@@ -215,6 +243,7 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
         cfloat *rec = as_const(geoms) + g * ptd::GEOM_WORDS;           // wave-uniform address -> s_load
         const int type = __float_as_int(rec[0]);
 #endif
+        if (MESH == MESH_PRE && type == PT_TRIANGLE_MESH) continue;        // k_mesh already walked every mesh
         if (MESH == MESH_BVH && type == PT_TRIANGLE_MESH) {
             // same winner as the loop below (smallest bary.z, lowest triangle index on ties), found by
             // walking the mesh's bounding-volume hierarchy instead of testing every triangle
@@ -223,8 +252,8 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
             float best = FLT_MAX;
             int best_i = -1;
             if (active && count > 0)
-                bvh_walk(sc.bvh_nodes + (size_t)root * BVH_NODE_WORDS, sc.bvh_tris, sc.bvh_prune, sc.bvh_guard, ro, rd,
-                         best, best_i);
+                bvh_walk(sc.bvh_nodes + (size_t)root * BVH_NODE_WORDS, sc.bvh_tris, rec + ptd::G_INV, sc.bvh_prune,
+                         sc.bvh_guard, ro, rd, best, best_i);
             if (active && best_i >= 0) {
                 f3 p = ptd::add(ro, ptd::scale(rd, best));
                 const float t = ptd::length(ptd::sub(ro, p));
@@ -328,6 +357,10 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
     if (q_total > q_head) {
         queue_pass(wq, gf, q_head, q_total - q_head, ro);
         latch();
+    }
+    if (MESH == MESH_PRE && pre_hit) {                           // this lane's nearest mesh hit, found by k_mesh
+        const float4 m = *pre_hit;
+        h.t = m.x; h.geom = __float_as_int(m.y); h.outside = 1; h.aux = ptd::mk(m.z, 0.0f, 0.0f);
     }
     if (w_geom >= 0) {
         const unsigned long long key = seen;
@@ -778,7 +811,16 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 #else
             const float *gsrc = a.scene.geoms;
 #endif
-            intersect_scene<MESH>(gsrc, a.scene, tri_lds, active, ro, rd, h, wq, gf);
+            const float4 *pre_hit = nullptr;
+            if (MESH == MESH_PRE) {
+                // lanes of this tile for which k_mesh found a mesh hit; the mask is consumed (cleared) here
+                const unsigned long long mm = a.mesh_mask[tile];
+                if (mm) {
+                    if (lane == 0) a.mesh_mask[tile] = 0ull;
+                    if (active && ((mm >> lane) & 1ull)) pre_hit = a.mesh_hit + src;
+                }
+            }
+            intersect_scene<MESH>(gsrc, a.scene, tri_lds, active, ro, rd, h, wq, gf, pre_hit);
             if (active) { resolve_hit(gsrc, gf, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
         } else if (active) {
             // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
@@ -859,6 +901,192 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 #endif
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Mesh pre-pass (PT_MESH_BVH, fused path).  Walking a hierarchy inside k_bounce keeps a whole
+// wave waiting on the few lanes whose rays reach a mesh (a mesh covers a few per cent of the
+// directions) while each of their steps is a dependent 128-B fetch.  k_mesh runs first instead:
+// every wave scans its run of tiles, tests each ray against the root record of every mesh (two
+// boxes, wave-uniform scalar loads) and appends the candidates {slot, path, ray} to a per-wave
+// LDS ring; whenever 64 are waiting they are walked lane-dense, one candidate per lane.  Results
+// go to mesh_hit[slot] = {t, geom, triangle} and one bit per path in mesh_mask[tile]; k_bounce
+// <MESH_PRE> folds them with the geom-index tie-break of pathtrace.cu:192.
+// ---------------------------------------------------------------------------
+constexpr int MQ_SLOTS = 128;                 // ring entries per wave (a tile adds <= 64 while < 64 wait)
+constexpr int MQ_WORDS = 8 * MQ_SLOTS;        // src, path, origin xyz, direction xyz
+constexpr int MQ_STEPS = 4;                   // walk steps between two looks at the ring
+constexpr int MQ_LEAVE = 24;                  // lanes still walking when the wave goes back to scanning
+
+// per-lane state of a walk in flight; it survives across the scanning of further tiles
+struct MeshWalker {
+    bool have;
+    uint32_t src, path;
+    BvhRay ray;
+    int mesh, node, steps;            // position in SceneDev::bvh_meshes, record in that mesh's tree
+    float tz; int tri;                // best of the current mesh (bary.z order)
+    float best_t; int best_geom, best_tri;   // best over the meshes finished so far (world distance, geom order)
+};
+
+// the ray in the grid of mesh geom `g` (origin / step sit in the inverse-transform words of its record)
+__device__ __forceinline__ BvhRay mesh_ray(const SceneDev &sc, int g, f3 ro, f3 rd) {
+    const float *q = sc.geoms + (size_t)g * ptd::GEOM_WORDS + ptd::G_INV;
+    return bvh_ray(ro, rd, ptd::mk(q[0], q[1], q[2]), ptd::mk(q[3], q[4], q[5]));
+}
+
+// Lanes without a walk take the next ring entries; every lane with one advances MQ_STEPS records, moving
+// on to the next mesh / publishing its result as it finishes.  Returns when the ring is empty and fewer
+// than `leave` lanes are still walking (0: run dry).
+__device__ __forceinline__ void mesh_drain(MeshWalker &w, const float *mq, uint32_t &q_head, uint32_t q_total,
+                                           const BounceArgs &a, int leave) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t *mi = reinterpret_cast<const uint32_t *>(mq);
+    const int4 *meshes = a.scene.bvh_meshes;
+    for (;;) {
+        const uint64_t idle = __ballot(!w.have);
+        const uint32_t avail = q_total - q_head;
+        if (idle && avail) {
+            const uint32_t rank = (uint32_t)__popcll((unsigned long long)(idle & ((1ull << lane) - 1)));
+            if (!w.have && rank < avail) {
+                const uint32_t s = (q_head + rank) & (MQ_SLOTS - 1);
+                w.src = mi[0 * MQ_SLOTS + s]; w.path = mi[1 * MQ_SLOTS + s];
+                w.ray = mesh_ray(a.scene, meshes[0].x, ptd::mk(mq[2 * MQ_SLOTS + s], mq[3 * MQ_SLOTS + s], mq[4 * MQ_SLOTS + s]),
+                                 ptd::mk(mq[5 * MQ_SLOTS + s], mq[6 * MQ_SLOTS + s], mq[7 * MQ_SLOTS + s]));
+                w.mesh = 0; w.node = 0; w.steps = 0; w.tz = FLT_MAX; w.tri = -1;
+                w.best_t = FLT_MAX; w.best_geom = -1; w.best_tri = -1;
+                w.have = true;
+            }
+            q_head += min((uint32_t)__popcll((unsigned long long)idle), avail);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        const uint64_t busy = __ballot(w.have);
+        if (!busy) return;
+        if (q_total == q_head && (int)__popcll((unsigned long long)busy) < leave) return;
+#pragma unroll 1
+        for (int k = 0; k < MQ_STEPS; ++k) {
+#ifdef PT_MESH_STATS
+            {
+                const uint64_t bb = __ballot(w.have && w.node >= 0);
+                if (lane == 0 && bb) { atomicAdd(&a.ctl->keep[1], (uint32_t)__popcll((unsigned long long)bb)); atomicAdd(&a.ctl->keep[2], 1u); }
+            }
+#endif
+            if (w.have) {
+                const int4 m = meshes[w.mesh];                         // {geom, root record, triangles, -}
+                if (w.node >= 0) {
+                    w.node = bvh_step(a.scene.bvh_nodes + (size_t)m.y * BVH_NODE_WORDS, a.scene.bvh_tris, a.scene.bvh_prune,
+                                      w.ray, w.node, w.tz, w.tri);
+#ifdef PT_MESH_STATS
+                    if (w.steps == 5000) {
+                        atomicAdd(&a.ctl->keep[3], 1u);
+                        a.ctl->keep[4] = __float_as_uint(w.ray.ro.x); a.ctl->keep[5] = __float_as_uint(w.ray.ro.y); a.ctl->keep[6] = __float_as_uint(w.ray.ro.z);
+                        a.ctl->keep[7] = __float_as_uint(w.ray.rd.x); a.ctl->keep[8] = __float_as_uint(w.ray.rd.y); a.ctl->keep[9] = __float_as_uint(w.ray.rd.z);
+                        a.ctl->keep[10] = __float_as_uint(w.tz); a.ctl->keep[11] = (uint32_t)a.depth;
+                    }
+#endif
+                    if (++w.steps > a.scene.bvh_guard) w.node = -1;    // NaN rays: every record is "hit"
+                }
+                if (w.node < 0) {                                      // this mesh is done
+                    if (w.tri >= 0) {                                  // completion spec 8.0: distance to origin + dir * bary.z
+                        const f3 p = ptd::add(w.ray.ro, ptd::scale(w.ray.rd, w.tz));
+                        const float t = ptd::length(ptd::sub(w.ray.ro, p));
+                        if (t > 0.0f && w.best_t > t) { w.best_t = t; w.best_geom = m.x; w.best_tri = w.tri; }
+                    }
+                    if (++w.mesh < a.scene.bvh_nmesh) {
+                        w.ray = mesh_ray(a.scene, meshes[w.mesh].x, w.ray.ro, w.ray.rd);
+                        w.node = 0; w.steps = 0; w.tz = FLT_MAX; w.tri = -1;
+                    } else {
+                        if (w.best_geom >= 0) {
+                            a.mesh_hit[w.src] = make_float4(w.best_t, __int_as_float(w.best_geom), __int_as_float(w.best_tri), 0.0f);
+                            atomicOr(&a.mesh_mask[w.path >> 6], 1ull << (w.path & 63u));
+                        }
+                        w.have = false;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool COMPACT>
+__global__ __launch_bounds__(BLOCK, 5) void k_mesh(BounceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    float *mq = lds_raw + (threadIdx.x >> 6) * MQ_WORDS;
+    uint32_t *mi = reinterpret_cast<uint32_t *>(mq);
+    const int lane = threadIdx.x & 63;
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t wid = run_id();
+    const int iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;
+    // bounce 0 of a batch: nlive[0] is written by that bounce's own kernel, so the count comes from the host
+    const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
+    const uint32_t tiles = (n + TILE - 1) / TILE;
+    const uint32_t R = range_tiles(n, W);
+    const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
+    const uint32_t Wd = a.dir_in.W;                               // waves of the grid that packed the pool
+    const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], Wd) * TILE : 0;
+    uint32_t cur = 0;
+    if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), Wd, wid * R * TILE);
+    uint32_t q_head = 0, q_total = 0;                             // wave-uniform
+    MeshWalker w;
+    w.have = false; w.src = 0; w.path = 0; w.ray = bvh_ray(ptd::mk(0, 0, 0), ptd::mk(0, 0, 1), ptd::mk(0, 0, 0), ptd::mk(1, 1, 1));
+    w.mesh = 0; w.node = -1; w.steps = 0; w.tz = FLT_MAX; w.tri = -1; w.best_t = FLT_MAX; w.best_geom = -1; w.best_tri = -1;
+    for (uint32_t r = 0; r < R; ++r) {
+        // a packed pool is read run by run (the source cursor advances with it); a dense one -- bounce 0, where
+        // neighbouring camera rays reach a mesh together -- is dealt tile by tile so every wave gets its share
+        const uint32_t tile = packed_in ? wid * R + r : r * W + wid;
+        if (tile >= tiles) break;
+        const uint32_t i = tile * TILE + lane;
+        bool active = i < n;
+        uint32_t src = i;
+        if (packed_in) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
+        f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
+        if (active) {
+            if (a.gen_rays) {
+                const uint32_t smp = sample_of(a.map, i);
+                const int pixel = local_to_pixel(a.map, (int)(i - smp * (uint32_t)a.map.tile_pixels));
+                camera_ray(a.cam, a.lens, a.trace_depth, iter0 + (int)smp, pixel, a.map.W, ro, rd);
+            } else {
+                char *q = a.in.slot(src);
+                if (ppid(q) == DEAD_PID) active = false;
+                ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
+                rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
+            }
+        }
+        // candidate: the ray reaches one of the two root boxes of some mesh (wave-uniform scalar loads)
+        bool cand = false;
+#pragma unroll 1
+        for (int k = 0; k < a.scene.bvh_nmesh; ++k) {
+            const __attribute__((address_space(4))) int *mrec =
+                (const __attribute__((address_space(4))) int *)(unsigned long long)(a.scene.bvh_meshes + k);
+            cfloat *grid = as_const(a.scene.geoms) + (size_t)mrec[0] * ptd::GEOM_WORDS + ptd::G_INV;
+            const __attribute__((address_space(4))) uint32_t *b =
+                (const __attribute__((address_space(4))) uint32_t *)(unsigned long long)(a.scene.bvh_nodes + (size_t)mrec[1] * BVH_NODE_WORDS);
+            const BvhRay br = bvh_ray(ro, rd, ptd::mk(grid[0], grid[1], grid[2]), ptd::mk(grid[3], grid[4], grid[5]));
+            float tn, tf;
+            bvh_slab(br, b[0], b[1], b[2], tn, tf);
+            cand |= tn <= tf;
+            bvh_slab(br, b[3], b[4], b[5], tn, tf);
+            cand |= tn <= tf;
+        }
+        cand = cand && active;
+        const uint64_t m = __ballot(cand);
+        if (m) {
+            if (cand) {
+                const uint32_t s = (q_total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))) & (MQ_SLOTS - 1);
+                mi[0 * MQ_SLOTS + s] = src; mi[1 * MQ_SLOTS + s] = i;
+                mq[2 * MQ_SLOTS + s] = ro.x; mq[3 * MQ_SLOTS + s] = ro.y; mq[4 * MQ_SLOTS + s] = ro.z;
+                mq[5 * MQ_SLOTS + s] = rd.x; mq[6 * MQ_SLOTS + s] = rd.y; mq[7 * MQ_SLOTS + s] = rd.z;
+            }
+            q_total += (uint32_t)__popcll((unsigned long long)m);
+#ifdef PT_MESH_STATS
+            if (lane == 0) atomicAdd(&a.ctl->keep[0], (uint32_t)__popcll((unsigned long long)m));
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // keep the ring below 64 waiting entries so the next tile always fits
+            if (q_total - q_head >= 64 - (uint32_t)__popcll((unsigned long long)__ballot(w.have)) || q_total - q_head >= 64)
+                mesh_drain(w, mq, q_head, q_total, a, MQ_LEAVE);
+        }
+    }
+    mesh_drain(w, mq, q_head, q_total, a, 0);
 }
 
 // First-bounce cache (INSTRUCTION.md:87-89): camera rays do not depend on the iteration (no

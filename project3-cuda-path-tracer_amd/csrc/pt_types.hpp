@@ -20,8 +20,10 @@ constexpr int WAVES = BLOCK / 64;
 constexpr int TILE = 64;                   // paths per tile = one wave64
 constexpr int TRI_TILE = 512;              // triangles staged in LDS per pass (24 KiB)
 constexpr int TRI_WORDS = 12;              // v0 e1 e2 + 3 pad: three 16-B words per triangle
-constexpr int BVH_NODE_WORDS = 32;         // one 128-B record per internal node, pt_bvh.hpp
-enum { MESH_NONE = 0, MESH_TILES = 1, MESH_BVH = 2 };   // how triangle meshes are intersected (template switch)
+constexpr int BVH_NODE_WORDS = 16;         // one 64-B record per internal node, pt_bvh.hpp
+enum { MESH_NONE = 0, MESH_TILES = 1, MESH_BVH = 2, MESH_PRE = 3 };   // how triangle meshes are intersected (template
+                                           // switch): every triangle through LDS tiles, hierarchy walked inline, or results
+                                           // of the lane-dense mesh pre-pass (k_mesh) read back
 constexpr int MAX_DEPTH = 64;
 constexpr uint32_t DEAD_PID = 0xffffffffu;
 
@@ -157,6 +159,7 @@ struct SceneDev {
     const float *bvh_nodes;                // PT_MESH_BVH: all meshes' trees, BVH_NODE_WORDS per node
     const float *bvh_tris;                 //   leaf-ordered triangle records, word 9 = original index
     float bvh_prune;  int bvh_guard;       //   prune margin; upper bound on nodes visited per walk
+    const int4 *bvh_meshes; int bvh_nmesh; //   per mesh, in geom order: {geom, root record, triangles, -}
 };
 
 struct BounceArgs {
@@ -173,6 +176,10 @@ struct BounceArgs {
     int depth, trace_depth, iter0;   // iter0 < 0: read Control::iter0 (graph replay)
     uint32_t pool_n;       // paths in the pool when compaction is off / at bounce 0
     int gen_rays;          // bounce 0 generates the camera ray instead of loading it
+    // mesh pre-pass (k_mesh -> k_bounce<MESH_PRE>): nearest mesh hit per source slot {t, geom, triangle, -}
+    // and, per logical 64-path tile, the lanes that have one
+    float4 *mesh_hit;
+    unsigned long long *mesh_mask;
 };
 
 __device__ __forceinline__ int local_to_pixel(const TileMap &m, int j) {

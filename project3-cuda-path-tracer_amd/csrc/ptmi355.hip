@@ -125,6 +125,10 @@ struct Renderer {
     bool capturing = false;
     int mesh_mode = MESH_NONE;    // MESH_TILES: every triangle per ray; MESH_BVH: PT_MESH_BVH culling
     float *d_bvh_nodes = nullptr, *d_bvh_tris = nullptr;
+    int4 *d_bvh_meshes = nullptr;
+    float4 *mesh_hit = nullptr;              // mesh pre-pass results (k_mesh), one per pool slot
+    unsigned long long *mesh_mask = nullptr; // ... and which lanes of each logical tile have one
+    int grid_mesh = 0;
     pt_bvh_info bvh_info{};
     void *scratch = nullptr;      // export / import staging
     size_t scratch_bytes = 0;
@@ -224,6 +228,7 @@ BounceArgs bounce_args(int depth) {
     a.depth = depth; a.trace_depth = R.trace_depth; a.iter0 = R.capturing ? -1 : R.step_iter0;
     a.pool_n = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
     a.gen_rays = (depth == 0 && R.gen_fused) ? 1 : 0;
+    a.mesh_hit = R.mesh_hit; a.mesh_mask = R.mesh_mask;
     return a;
 }
 
@@ -262,6 +267,11 @@ void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, c
 
 template <int MODE, bool COMPACT>
 void launch_bounce(const BounceArgs &a) {
+    if (MODE == MODE_FUSED && R.mesh_mode == MESH_BVH) {
+        // meshes were walked by the pre-pass (enqueue_bounce); this launch reads its results
+        hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH_PRE>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        return;
+    }
     PT_MESH_DISPATCH(hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH>), dim3(R.grid), dim3(BLOCK), R.lds_bytes,
                                         R.stream, a));
 }
@@ -304,6 +314,13 @@ int enqueue_bounce(int depth) {
                                             cache, R.scene, R.cam, R.map));
         HIPCHK(hipGetLastError());
         R.cache_valid = true;
+    }
+    if (!cached0 && !unfused && R.mesh_mode == MESH_BVH) {
+        StageTimer tm(PT_STAGE_MESH);
+        const size_t lds = (size_t)WAVES * MQ_WORDS * 4;
+        if (compact) hipLaunchKernelGGL((k_mesh<true>), dim3(R.grid_mesh), dim3(BLOCK), lds, R.stream, a);
+        else hipLaunchKernelGGL((k_mesh<false>), dim3(R.grid_mesh), dim3(BLOCK), lds, R.stream, a);
+        HIPCHK(hipGetLastError());
     }
     StageTimer tm(PT_STAGE_BOUNCE);
     if (cached0) {
@@ -432,6 +449,15 @@ int collect_stats(void) {
             (c.stamp[4] - c.stamp[0]) / 100.0, (c.stamp[5] - c.stamp[0]) / 100.0, (c.stamp[6] - c.stamp[0]) / 100.0,
             (c.stamp[7] - c.stamp[0]) / 100.0, ((double)c.stamp[8] - (double)c.stamp[0]) / 100.0, ((double)c.stamp[9] - (double)c.stamp[0]) / 100.0);
 #endif
+#ifdef PT_MESH_STATS
+    fprintf(stderr, "[ptmi355] mesh pre-pass since init: %u candidates, %u lane-steps, %u wave-steps (density %.1f lanes)\n",
+            c.keep[0], c.keep[1], c.keep[2], c.keep[2] ? (double)c.keep[1] / c.keep[2] : 0.0);
+    {
+        float f[7]; memcpy(f, &c.keep[4], sizeof f);
+        fprintf(stderr, "[ptmi355] walks past 5000 steps: %u; last: o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) tz=%g depth %u\n", c.keep[3],
+                f[0], f[1], f[2], f[3], f[4], f[5], f[6], c.keep[11]);
+    }
+#endif
     if (getenv("PTMI355_DEBUG_SCAN")) {
         fprintf(stderr, "[ptmi355] scan us per bounce:");
         for (int d = 0; d < R.trace_depth; ++d) fprintf(stderr, " %.1f", c.scan_ticks[d] / 100.0);
@@ -466,7 +492,10 @@ void pt_free(void) {
     if (R.d_mats) (void)hipFree(R.d_mats);
     if (R.d_tris) (void)hipFree(R.d_tris);
     drop_graphs();
+    if (R.mesh_hit) (void)hipFree(R.mesh_hit);
+    if (R.mesh_mask) (void)hipFree(R.mesh_mask);
     if (R.d_bvh_nodes) (void)hipFree(R.d_bvh_nodes);
+    if (R.d_bvh_meshes) (void)hipFree(R.d_bvh_meshes);
     if (R.d_bvh_tris) (void)hipFree(R.d_bvh_tris);
     if (R.ctl) (void)hipFree(R.ctl);
     if (R.dir_mem) (void)hipFree(R.dir_mem);
@@ -484,21 +513,30 @@ static int init_impl(const pt_scene_desc *d);
 // become (root node, triangle count).
 static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
     std::vector<float> nodes, btris;
+    std::vector<int32_t> mesh_list;                          // {geom, root record, triangles, 0} in geom order
     float prune = 0.0f;
     int guard = 1;
     R.bvh_info = pt_bvh_info{};
-    for (int k = 0; k < d->num_meshes; ++k) {
+    std::vector<int> by_geom((size_t)d->num_meshes);
+    for (int k = 0; k < d->num_meshes; ++k) by_geom[(size_t)k] = k;
+    std::sort(by_geom.begin(), by_geom.end(), [&](int x, int y) { return d->meshes[x].geom_index < d->meshes[y].geom_index; });
+    for (int kk = 0; kk < d->num_meshes; ++kk) {
+        const int k = by_geom[(size_t)kk];
         const pt_mesh &m = d->meshes[k];
+        if (kk > 0 && d->meshes[by_geom[(size_t)kk - 1]].geom_index == m.geom_index)
+            return fail(PT_ERR_INVALID, "pt_init: geom %d owns more than one mesh", m.geom_index);
         ptbvh::Tree tree;
         ptbvh::build(reinterpret_cast<const float *>(d->triangles + m.first_triangle), m.triangle_count, tree);
         const int root = (int)(nodes.size() / BVH_NODE_WORDS);
         const int slot0 = (int)(btris.size() / TRI_WORDS);
+        if ((int64_t)slot0 + m.triangle_count >= (1 << ptbvh::LINK_BITS) || tree.num_nodes() >= (1 << ptbvh::LINK_BITS))
+            return fail(PT_ERR_INVALID, "pt_init: PT_MESH_BVH holds at most 2^24 triangles (record links are 24 bits)");
         for (int n = 0; n < tree.num_nodes(); ++n) {           // leaf children: slot in the tree -> slot in the shared buffer
             float *w = &tree.nodes[(size_t)n * BVH_NODE_WORDS];
             for (int c = 0; c < 2; ++c) {
-                int32_t info, first;
-                memcpy(&info, &w[13 + 2 * c], 4);
-                if (info & ptbvh::INFO_LEAF) { memcpy(&first, &w[12 + 2 * c], 4); first += slot0; memcpy(&w[12 + 2 * c], &first, 4); }
+                uint32_t link;
+                memcpy(&link, &w[6 + c], 4);
+                if ((link >> ptbvh::LINK_BITS) & ptbvh::INFO_LEAF) { link += (uint32_t)slot0; memcpy(&w[6 + c], &link, 4); }
             }
         }
         nodes.insert(nodes.end(), tree.nodes.begin(), tree.nodes.end());
@@ -513,6 +551,9 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
         }
         float *g = grec.data() + (size_t)m.geom_index * ptd::GEOM_WORDS;
         memcpy(&g[2], &root, 4); memcpy(&g[3], &m.triangle_count, 4);
+        for (int a = 0; a < 3; ++a) { g[ptd::G_INV + a] = tree.origin[a]; g[ptd::G_INV + 3 + a] = tree.step[a]; }   // the mesh's grid
+        const int32_t entry[4] = {m.geom_index, root, m.triangle_count, 0};
+        mesh_list.insert(mesh_list.end(), entry, entry + 4);
         prune = std::max(prune, tree.prune);
         guard = std::max(guard, tree.num_nodes() + 1);
         R.bvh_info.nodes += tree.num_nodes();
@@ -527,6 +568,10 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
     HIPCHK(hipMalloc(&R.d_bvh_tris, btris.size() * 4));
     HIPCHK(hipMemcpy(R.d_bvh_nodes, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(R.d_bvh_tris, btris.data(), btris.size() * 4, hipMemcpyHostToDevice));
+    if (mesh_list.empty()) mesh_list.assign(4, 0);
+    HIPCHK(hipMalloc((void **)&R.d_bvh_meshes, mesh_list.size() * 4));
+    HIPCHK(hipMemcpy(R.d_bvh_meshes, mesh_list.data(), mesh_list.size() * 4, hipMemcpyHostToDevice));
+    R.scene.bvh_meshes = R.d_bvh_meshes; R.scene.bvh_nmesh = d->num_meshes;
     R.scene.bvh_nodes = R.d_bvh_nodes; R.scene.bvh_tris = R.d_bvh_tris;
     R.scene.bvh_prune = prune; R.scene.bvh_guard = guard;
     return PT_OK;
@@ -697,12 +742,27 @@ static int init_impl(const pt_scene_desc *d) {
     // persistent grid: as many workgroups as are co-resident for the fused kernel (tiles are
     // dealt round-robin, so more workgroups than that only re-stage the scene)
     int per_cu = 0;
-    PT_MESH_DISPATCH(HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH>, BLOCK, R.lds_bytes)));
+    if (R.mesh_mode == MESH_BVH)
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH_PRE>, BLOCK, R.lds_bytes));
+    else
+        PT_MESH_DISPATCH(HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH>, BLOCK, R.lds_bytes)));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
     if (R.grid < 1) R.grid = 1;
+    if (R.mesh_mode == MESH_BVH) {
+        HIPCHK(hipMalloc((void **)&R.mesh_hit, (size_t)(((capz + 63) / 64) * 64) * sizeof(float4)));
+        HIPCHK(hipMalloc((void **)&R.mesh_mask, ((size_t)R.max_tiles + 1) * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(R.mesh_mask, 0, ((size_t)R.max_tiles + 1) * sizeof(unsigned long long), R.stream));
+        int per_cu_mesh = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_mesh, (const void *)k_mesh<true>, BLOCK,
+                                                            (size_t)WAVES * MQ_WORDS * 4));
+        per_cu_mesh = std::max(1, std::min(per_cu_mesh, 8));
+        R.grid_mesh = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu_mesh);
+        if (R.grid_mesh < 1) R.grid_mesh = 1;
+    }
     if (R.flags & PT_CACHE_FIRST) HIPCHK(hipMalloc(&R.cache_mem, (size_t)R.map.tile_pixels * 5 * 4));
     if (R.flags & PT_SORT_MATERIAL) {
         if (d->num_materials + 1 > SORT_MAX_BINS)
@@ -941,13 +1001,14 @@ int pt_get_bvh_info(pt_bvh_info *out) {
     return PT_OK;
 }
 
-int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node_capacity, int32_t *order) {
+int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node_capacity, int32_t *order, float *grid) {
     if (count < 0 || (count > 0 && !triangles)) return fail(PT_ERR_INVALID, "pt_bvh_build: bad triangle list");
     ptbvh::Tree tree;
     ptbvh::build(reinterpret_cast<const float *>(triangles), count, tree);
     if (tree.num_nodes() > node_capacity || !nodes) return tree.num_nodes();
     memcpy(nodes, tree.nodes.data(), tree.nodes.size() * 4);
     if (order && count > 0) memcpy(order, tree.order.data(), (size_t)count * 4);
+    if (grid) { for (int a = 0; a < 3; ++a) { grid[a] = tree.origin[a]; grid[3 + a] = tree.step[a]; } grid[6] = tree.pad; grid[7] = tree.prune; }
     return tree.num_nodes();
 }
 

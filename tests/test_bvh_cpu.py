@@ -14,43 +14,57 @@ def pt():
 
 
 def _tree(pt, tris):
-    nodes, order = pt.binding.bvh_build(tris)
-    ints = nodes.view(np.int32)
-    return nodes, ints, order
+    """nodes (uint32 records), child boxes decoded to world space [n, 2, 2, 3] (child, lo/hi, xyz), order, grid"""
+    nodes, order, grid = pt.binding.bvh_build(tris)
+    w = nodes[:, 0:6].reshape(-1, 2, 3)
+    g = np.stack([w[:, :, 0] & 0xffff, w[:, :, 0] >> 16, w[:, :, 1] & 0xffff,
+                  w[:, :, 1] >> 16, w[:, :, 2] & 0xffff, w[:, :, 2] >> 16], axis=-1).reshape(-1, 2, 2, 3)
+    return nodes, g.astype(np.float64), order, grid
 
 
 LEAF = 8
 
 
-def _children(ints, k):
+def _children(nodes, k):
     """[(link, count, is_leaf)] of record k; split axis"""
-    kids = [(int(ints[k, 12 + 2 * c]), int(ints[k, 13 + 2 * c]) & 7, bool(ints[k, 13 + 2 * c] & LEAF)) for c in (0, 1)]
-    return kids, (int(ints[k, 13]) >> 4) & 3
+    kids = []
+    for c in (0, 1):
+        v = int(nodes[k, 6 + c])
+        kids.append((v & 0xffffff, (v >> 24) & 7, bool((v >> 24) & LEAF)))
+    return kids, (int(nodes[k, 6]) >> 28) & 3
+
+
+def _miss(nodes, k, octant):
+    return int(nodes[k, 8 + octant].astype(np.int32))
 
 
 @pytest.mark.parametrize("size", [(8, 16), (30, 60), (97, 521)])
 def test_tree_structure(pt, size):
     tris = pt.meshes.uv_sphere(n_lat=size[0], n_lon=size[1])
-    nodes, ints, order = _tree(pt, tris)
+    nodes, gbox, order, grid = _tree(pt, tris)
     n = len(nodes)
+    origin, step, pad = grid[0:3].astype(np.float64), grid[3:6].astype(np.float64), float(grid[6])
+    box = origin + gbox * step                                        # world-space planes
     assert sorted(order.tolist()) == list(range(len(tris)))          # every triangle in exactly one leaf slot
     verts = np.stack([tris["v0"], tris["v1"], tris["v2"]], axis=1)      # (T, 3, 3)
     leaves, parents = [], np.zeros(n, dtype=np.int32)
     for k in range(n):
-        kids, axis = _children(ints, k)
+        kids, axis = _children(nodes, k)
         assert axis <= 2
         for c, (link, count, is_leaf) in enumerate(kids):
-            lo, hi = nodes[k, 6 * c:6 * c + 3], nodes[k, 6 * c + 3:6 * c + 6]
+            lo, hi = box[k, c, 0], box[k, c, 1]
             if is_leaf:
                 assert 1 <= count <= 4
                 leaves.append((link, count))
                 v = verts[order[link:link + count]].reshape(-1, 3)
-                assert (v.min(axis=0) > lo).all() and (v.max(axis=0) < hi).all()
+                # the box holds its triangles with the padding to spare, and is not wastefully loose
+                assert (v.min(axis=0) - 0.9 * pad > lo).all() and (v.max(axis=0) + 0.9 * pad < hi).all()
+                assert (v.min(axis=0) - pad - 4 * step < lo).all() and (v.max(axis=0) + pad + 4 * step > hi).all()
             else:
                 assert k < link < n and count == 0                    # records are laid out parent first
                 parents[link] += 1
-                for cc in (0, 1):                                     # a child's boxes lie inside its own box
-                    assert (nodes[link, 6 * cc:6 * cc + 3] >= lo).all() and (nodes[link, 6 * cc + 3:6 * cc + 6] <= hi).all()
+                for cc in (0, 1):                                     # a child's boxes lie inside its own box (grid units)
+                    assert (gbox[link, cc, 0] >= gbox[k, c, 0]).all() and (gbox[link, cc, 1] <= gbox[k, c, 1]).all()
     assert parents[0] == 0 and (parents[1:] == 1).all()
     leaves.sort()
     assert leaves[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(leaves, leaves[1:]))
@@ -63,32 +77,36 @@ def test_tree_structure(pt, size):
             assert not seen[node]
             seen[node] = True
             steps += 1
-            kids, axis = _children(ints, node)
+            kids, axis = _children(nodes, node)
             inner = [link for link, _, is_leaf in kids if not is_leaf]
             if len(inner) == 2:
                 node = kids[(octant >> axis) & 1][0]
             elif inner:
                 node = inner[0]
             else:
-                node = int(ints[node, 16 + octant])
+                node = _miss(nodes, node, octant)
         assert seen.all() and steps == n
-        assert ints[0, 16 + octant] == -1
+        assert _miss(nodes, 0, octant) == -1
 
 
-def _walk(nodes, ints, order, tris, po, o, d, prune):
-    """The kernel's walk (pt_kernels.hpp: bvh_walk) for one ray; leaf tests through the oracle."""
-    o32, d32 = o.astype(np.float32), d.astype(np.float32)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        inv = (np.float32(1) / d32).astype(np.float32)
-        off = (-(o32 * inv)).astype(np.float32)
+def _walk(nodes, gbox, order, grid, tris, po, o, d):
+    """The kernel's walk (pt_kernels.hpp: bvh_ray / bvh_slab / bvh_step) for one ray; leaf tests through the oracle."""
+    f = np.float32
+    o32, d32 = o.astype(f), d.astype(f)
+    origin, step, prune = grid[0:3], grid[3:6], f(grid[7])
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        off_axis = np.where(np.abs(d32) < f(1e-20), np.copysign(f(1e-20), d32), d32).astype(f)
+        inv = (f(1) / off_axis).astype(f)
+        kk = (step * inv).astype(f)
+        bb = ((origin - o32).astype(f) * inv).astype(f)
     octant = int(d32[0] < 0) | (int(d32[1] < 0) << 1) | (int(d32[2] < 0) << 2)
-    state = {"best": np.float32(np.finfo(np.float32).max), "i": -1}
+    state = {"best": f(np.finfo(f).max), "i": -1}
     bary = po.Vec3()
 
     def hit(lo, hi):
         with np.errstate(invalid="ignore", over="ignore"):
-            t1, t2 = lo * inv + off, hi * inv + off
-            reach = state["best"] + np.float32(prune)
+            t1, t2 = lo * kk.astype(np.float64) + bb, hi * kk.astype(np.float64) + bb
+            reach = state["best"] + prune
         tn = max(np.fmax.reduce(np.fmin(t1, t2)), 0.0)
         tf = np.fmin.reduce(np.fmax(t1, t2))
         return tn <= tf and tn <= reach
@@ -99,17 +117,17 @@ def _walk(nodes, ints, order, tris, po, o, d, prune):
             T = tris[k]
             if po.lib().pto_ray_triangle(po.vec3(o32), po.vec3(d32), po.vec3(T["v0"]), po.vec3(T["v1"]),
                                          po.vec3(T["v2"]), bary):
-                tz = np.float32(bary.z)
+                tz = f(bary.z)
                 if tz > 0 and (state["best"] > tz or (state["best"] == tz and k < state["i"])):
                     state["best"], state["i"] = tz, k
 
     node, visited = 0, 0
     while node >= 0:
         visited += 1
-        kids, axis = _children(ints, node)
+        kids, axis = _children(nodes, node)
         go = []
         for c, (link, count, is_leaf) in enumerate(kids):
-            h = hit(nodes[node, 6 * c:6 * c + 3], nodes[node, 6 * c + 3:6 * c + 6])
+            h = hit(gbox[node, c, 0], gbox[node, c, 1])
             if h and is_leaf:
                 leaf(link, count)
             go.append(h and not is_leaf)
@@ -118,15 +136,15 @@ def _walk(nodes, ints, order, tris, po, o, d, prune):
         elif go[0] or go[1]:
             node = kids[1 if go[1] else 0][0]
         else:
-            node = int(ints[node, 16 + octant])
+            node = _miss(nodes, node, octant)
     return state["i"], state["best"], visited
 
 
 def test_walk_finds_the_naive_winner(pt, po):
     tris = pt.meshes.uv_sphere(n_lat=40, n_lon=80)                    # 6240 triangles
-    nodes, ints, order = _tree(pt, tris)
+    nodes, gbox, order, grid = _tree(pt, tris)
     amax = max(1.0, float(np.abs(np.stack([tris["v0"], tris["v1"], tris["v2"]])).max()))
-    prune = 16.0 * np.ldexp(np.float32(amax), -13)
+    assert grid[6] == np.ldexp(np.float32(amax), -13) and grid[7] == 16 * grid[6]      # pad, prune
     rng = np.random.default_rng(5)
     verts = np.stack([tris["v0"], tris["v1"], tris["v2"]], axis=1)
     rays = np.zeros(600, dtype=po.PATH_DT)
@@ -148,13 +166,20 @@ def test_walk_finds_the_naive_winner(pt, po):
             o = np.array([1.5, 3.0, 1.0]) + rng.normal(size=3) * 0.3  # from inside the sphere: back faces only
         d = target - o
         d /= np.linalg.norm(d)
+        if k % 8 == 5:                                                # exactly axis-parallel, through or past the mesh
+            ax = rng.integers(3)
+            d = np.zeros(3)
+            d[ax] = rng.choice([-1.0, 1.0])
+            if k % 16 == 5:
+                o = target - d * rng.uniform(2, 6)
         rays["origin"][k], rays["direction"][k] = o, d
     want_i, want_t = po.mesh_winners(tris.view(po.TRI_DT), rays)
     assert (want_i >= 0).sum() > 250 and (want_i < 0).sum() > 30
     total = 0
     for k in range(len(rays)):
-        gi, gt, visited = _walk(nodes, ints, order, tris, po, rays["origin"][k], rays["direction"][k], prune)
+        gi, gt, visited = _walk(nodes, gbox, order, grid, tris, po, rays["origin"][k], rays["direction"][k])
         total += visited
+        assert visited < 0.2 * len(nodes), k      # no ray degenerates into a sweep of the tree (axis-parallel ones included)
         assert gi == want_i[k], k
         if gi >= 0:
             assert np.float32(gt).tobytes() == np.float32(want_t[k]).tobytes()
@@ -164,19 +189,19 @@ def test_walk_finds_the_naive_winner(pt, po):
 
 def test_degenerate_inputs(pt):
     # empty mesh, one triangle, coincident triangles (no split separates them)
-    nodes, order = pt.binding.bvh_build(np.zeros(0, dtype=pt.TRI_DT))
-    ints = nodes.view(np.int32)
-    assert len(nodes) == 1 and (nodes[0, 0:3] > nodes[0, 3:6]).all() and (nodes[0, 6:9] > nodes[0, 9:12]).all()
-    assert ints[0, 13] == LEAF and ints[0, 15] == LEAF and (ints[0, 16:24] == -1).all()
+    nodes, gbox, order, grid = _tree(pt, np.zeros(0, dtype=pt.TRI_DT))
+    assert len(nodes) == 1 and (gbox[0, :, 0] > gbox[0, :, 1]).all()              # both boxes inverted
+    assert [c[1:] for c in _children(nodes, 0)[0]] == [(0, True), (0, True)]
+    assert all(_miss(nodes, 0, o) == -1 for o in range(8))
     one = np.zeros(1, dtype=pt.TRI_DT)
     one["v1"][0], one["v2"][0] = (1, 0, 0), (0, 1, 0)
-    nodes, order = pt.binding.bvh_build(one)
-    ints = nodes.view(np.int32)
-    assert len(nodes) == 1 and order.tolist() == [0] and ints[0, 13] == (LEAF | 1) and ints[0, 15] == LEAF
-    assert (nodes[0, 0:3] < 0).all() and (nodes[0, 3:6] > 0).all() and (nodes[0, 6:9] > nodes[0, 9:12]).all()
+    nodes, gbox, order, grid = _tree(pt, one)
+    assert len(nodes) == 1 and order.tolist() == [0]
+    assert [c[1:] for c in _children(nodes, 0)[0]] == [(1, True), (0, True)]
+    box = grid[0:3] + gbox[0, 0] * grid[3:6]
+    assert (box[0] < 0).all() and (box[1] > [1, 1, 0]).all() and (gbox[0, 1, 0] > gbox[0, 1, 1]).all()
     same = np.repeat(one, 37)
-    nodes, order = pt.binding.bvh_build(same)
-    ints = nodes.view(np.int32)
+    nodes, gbox, order, grid = _tree(pt, same)
     assert sorted(order.tolist()) == list(range(37))
-    counts = [(ints[k, 13 + 2 * c] & 7) for k in range(len(nodes)) for c in (0, 1) if ints[k, 13 + 2 * c] & LEAF]
+    counts = [c[1] for k in range(len(nodes)) for c in _children(nodes, k)[0] if c[2]]
     assert sum(counts) == 37 and max(counts) <= 4

@@ -392,6 +392,12 @@ def test_mesh_bvh_adversarial_rays(pt, po, scenes):
     o[inside] = np.array([1.5, 3.0, 1.0]) + rng.normal(size=(inside.sum(), 3)) * 0.3
     dvec = target - o
     dvec /= np.linalg.norm(dvec, axis=1, keepdims=True)
+    par = np.arange(n) % 8 == 5                                                  # exactly axis-parallel rays, half of them
+    axis = rng.integers(3, size=n)                                               # aimed at the chosen point
+    unit = np.eye(3)[axis] * rng.choice([-1.0, 1.0], size=(n, 1))
+    dvec[par] = unit[par]
+    aimed = par & (np.arange(n) % 16 == 5)
+    o[aimed] = target[aimed] - unit[aimed] * rng.uniform(2, 6, size=(aimed.sum(), 1))
     rays["origin"], rays["direction"] = o, dvec
     pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | pt.PT_MESH_BVH)
     got, _ = pt.intersect_once(rays)
