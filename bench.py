@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
                     help="c2: BASELINE configs[1] (the metric's workload); c3: glass ball 1280x720 depth 16; "
                          "c4: Cornell + 100k-triangle mesh (parity-test cases, selectable for measurement)")
-    ap.add_argument("--flags", default="compact", help="comma list: compact,sort,unfused,cache,bvh")
+    ap.add_argument("--flags", default="compact", help="comma list: compact,sort,unfused,cache,bvh,aa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--strip-rows", type=int, default=8)
@@ -105,7 +105,7 @@ def main():
     flags = 0
     for f in args.flags.split(","):
         flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED,
-                  "cache": pt.PT_CACHE_FIRST, "bvh": pt.PT_MESH_BVH, "": 0}[f]
+                  "cache": pt.PT_CACHE_FIRST, "bvh": pt.PT_MESH_BVH, "aa": pt.PT_AA_JITTER, "": 0}[f]
     per_step_iters = pt.sharding.step_iterations(0, args.batch, world)[1]     # = batch * world
 
     # an explicit (non-null) torch stream: the library launches on it, torch copies / RCCL order against it

@@ -9,16 +9,16 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k_bounce", "k_intersect", "k_raygen", "k_gather", "k_shade_fake", "k_tonemap", "k_sort"):
+    for k in ("k_bounce", "k_mesh", "k_intersect", "k_raygen", "k_gather", "k_shade_fake", "k_tonemap", "k_sort"):
         if k in name:
             tail = ""
             if "k_bounce" in name:
                 import re
-                m = re.search(r"k_bounce<(\d), (true|false)(?:, (true|false))?>", name)
+                m = re.search(r"k_bounce<(\d), (true|false)(?:, (true|false|\d))?>", name)
                 if m:
+                    mesh = {"true": ",mesh", "1": ",mesh-tiles", "2": ",mesh-bvh", "3": ",mesh-prepass"}.get(m.group(3), "")
                     tail = "<%s,%s%s>" % ("isect" if m.group(1) == "1" else "fused",
-                                          "compact" if m.group(2) == "true" else "inplace",
-                                          ",mesh" if m.group(3) == "true" else "")
+                                          "compact" if m.group(2) == "true" else "inplace", mesh)
             return k + tail
     return name[:60]
 
