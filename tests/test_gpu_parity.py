@@ -549,6 +549,41 @@ def test_ptbench_headless_host(pt, po, scenes, tmp_path):
     assert got.tobytes() == want.tobytes()
 
 
+def test_ptbench_mesh_scene_hierarchy_and_camera_options(pt, tmp_path):
+    """ptbench on a scene file with a `mesh file.obj` object: --bvh gives the PNG of the loop over every triangle,
+    byte for byte; --aa / --lens render (and change the image)."""
+    import os
+    import subprocess
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tris = pt.meshes.uv_sphere(center=(0.0, 0.0, 0.0), radius=1.0, n_lat=24, n_lon=48)
+    with open(tmp_path / "ball.obj", "w") as f:
+        for t in tris:
+            for k in ("v0", "v1", "v2"):
+                f.write("v %.9g %.9g %.9g\n" % tuple(t[k]))
+        for i in range(len(tris)):
+            f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    txt = open(os.path.join(root, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         96 96")
+    n_obj = sum(1 for line in txt.splitlines() if line.startswith("OBJECT "))
+    txt = txt.rstrip("\n") + "\n\nOBJECT %d\nmesh ball.obj\nmaterial 2\nTRANS 2 3 1\nROTAT 0 30 0\nSCALE 1.5 1.5 1.5\n" % n_obj
+    scene_file = tmp_path / "cornell_mesh.txt"
+    scene_file.write_text(txt)
+    exe = pt.build_ptbench()
+
+    def render(tag, *opts):
+        p = subprocess.run([exe, str(scene_file), "--iters", "4", "--batch", "2", "--out", str(tmp_path / tag)] + list(opts),
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "%d triangles" % len(tris) in p.stdout
+        return np.asarray(Image.open(str(tmp_path / (tag + ".4samp.png"))).convert("RGB"), dtype=np.uint8)
+
+    loop, bvh = render("loop"), render("bvh", "--bvh")
+    assert loop.tobytes() == bvh.tobytes()
+    assert (loop[30:70, 55:90] != loop[0, 0]).any()
+    dof = render("dof", "--bvh", "--aa", "--lens", "0.3", "9")
+    assert dof.shape == loop.shape and (dof != loop).any()
+
+
 def test_first_bounce_cache_follows_camera(pt, po, scenes):
     """PT_CACHE_FIRST (INSTRUCTION.md:87-89): batches reuse the cached bounce-0 intersections; a camera
     change through pathtrace()'s per-call re-read invalidates them."""
