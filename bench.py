@@ -193,6 +193,9 @@ def main():
                     "algorithmic_bytes_per_launch": int(algo_bytes / max(1, launches)),
                     "stage_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]},
                     "grays_per_s_in_kernel": round(rank_rays / (ms * 1e-3) / 1e9, 3) if ms > 0 else 0.0}
+        valu = measured_valu(args, world, ms * 1e-3 / max(1, launches), rank_rays / max(1, launches))
+        if valu:
+            roofline["valu"] = valu
 
     # ---- CPU baseline: the oracle (plain-C port) on this host, rank 0, N = 1 only ----
     cpu = None
@@ -247,6 +250,29 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_valu(args, world, avg_launch_s, rays_per_launch):
+    """VALU issue rate of k_bounce from the SQ_INSTS_VALU pass of THIS command line (profiles/traffic.json):
+    the kernel is bound by FP32 vector issue, so this is the utilisation that matters beside the HBM figure.
+    Peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-operations/s (157.3 TFLOP/s = that x 2 for FMA x 2 packed)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if world != 1 or not os.path.exists(path) or avg_launch_s <= 0:
+        return None
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    if t.get("config") != args.config or t.get("batch") != args.batch or t.get("flags") != args.flags:
+        return None
+    insts = t.get("valu_wave_insts_per_launch")
+    if not insts:
+        return None
+    peak = 256 * 4 * 16 * 2.4e9
+    rate = insts * 64 / avg_launch_s
+    return {"wave_insts_per_launch": int(insts), "insts_per_ray": round(insts * 64 / max(1.0, rays_per_launch), 1),
+            "lane_ops_per_s": round(rate / 1e12, 2), "peak_lane_ops_per_s": round(peak / 1e12, 2), "unit": "T/s",
+            "frac": round(rate / peak, 3)}
 
 
 def measured_traffic(args, world):

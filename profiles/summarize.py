@@ -64,8 +64,15 @@ def traffic_json(d, out_path, meta):
                     vals.append(float(r["Counter_Value"]))
         if vals:
             tot[name] = sum(vals) / len(vals)
+    valu = []
+    for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == "SQ_INSTS_VALU" and "k_bounce" in r["Kernel_Name"]:
+                valu.append(float(r["Counter_Value"]))
     if len(tot) == 2:
         meta = dict(meta)
+        if valu:
+            meta["valu_wave_insts_per_launch"] = sum(valu) / len(valu)
         meta.update({"fetch_kib_per_launch_raw": tot["FETCH_SIZE"], "write_kib_per_launch": tot["WRITE_SIZE"],
                      "bytes_per_launch": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024),
                      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 "

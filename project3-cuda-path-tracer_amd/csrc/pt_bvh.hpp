@@ -42,7 +42,10 @@ namespace ptbvh {
 constexpr int NODE_WORDS = 16;
 constexpr int GRID_MAX = 65535;
 constexpr int LINK_BITS = 24;
-constexpr int LEAF_MAX = 4;
+#ifndef PT_LEAF_MAX
+#define PT_LEAF_MAX 4
+#endif
+constexpr int LEAF_MAX = PT_LEAF_MAX;    // triangles per leaf (the count field has 3 bits)
 constexpr int SAH_BINS = 16;
 constexpr int INFO_LEAF = 8;         // bit 3 of an info word
 

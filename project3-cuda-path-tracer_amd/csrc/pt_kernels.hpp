@@ -156,38 +156,57 @@ __device__ __forceinline__ void bvh_slab(const BvhRay &r, uint32_t w0, uint32_t 
     tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
                          __builtin_fmaxf(t1z, t2z));
 }
-// one step at record `node` (>= 0); returns the record to continue with, < 0 when the walk is over
-__device__ __forceinline__ int bvh_step(const float *__restrict__ nodes, const float *__restrict__ btris,
-                                        float prune, const BvhRay &r, int node, float &best, int &best_i) {
-    auto leaf = [&](int first, int cnt) {
-        const float4 *t4 = reinterpret_cast<const float4 *>(btris + (size_t)first * TRI_WORDS);
-#pragma unroll 1
-        for (int k = 0; k < cnt; ++k) {
-            const float4 P = t4[3 * k], Q = t4[3 * k + 1], S = t4[3 * k + 2];
-            float tz;
-            if (ptd::ray_triangle(r.ro, r.rd, ptd::mk(P.x, P.y, P.z), ptd::mk(P.w, Q.x, Q.y), ptd::mk(Q.z, Q.w, S.x), tz)) {
-                const int orig = __float_as_int(S.y);                    // index in the caller's triangle array
-                if (tz > 0.0f && (best > tz || (best == tz && orig < best_i))) { best = tz; best_i = orig; }
-            }
-        }
-    };
+struct BvhRec { uint4 a, b; int miss; };   // the three loads of one record: boxes, boxes + links, miss[octant]
+__device__ __forceinline__ BvhRec bvh_fetch(const float *__restrict__ nodes, int node, int oct) {
     const uint4 *n4 = reinterpret_cast<const uint4 *>(nodes + (size_t)node * BVH_NODE_WORDS);
-    const uint4 A = n4[0], B = n4[1];
-    int next = reinterpret_cast<const int *>(n4)[8 + r.oct];
-    const int link_l = (int)(B.z & 0xffffffu), info_l = (int)(B.z >> 24);
-    const int link_r = (int)(B.w & 0xffffffu), info_r = (int)(B.w >> 24);
+    BvhRec rec;
+    rec.a = n4[0]; rec.b = n4[1];
+    rec.miss = reinterpret_cast<const int *>(n4)[8 + oct];
+    return rec;
+}
+// box tests of a fetched record: the record to continue with (< 0: the walk is over) and the hit leaf
+// children as first | count << 24 (-1: none), to be tested by bvh_leaf
+__device__ __forceinline__ int bvh_decide(const BvhRec &rec, const BvhRay &r, float reach, int &leaf_l, int &leaf_r) {
+    const int link_l = (int)(rec.b.z & 0xffffffu), info_l = (int)(rec.b.z >> 24);
+    const int link_r = (int)(rec.b.w & 0xffffffu), info_r = (int)(rec.b.w >> 24);
     float tn_l, tf_l, tn_r, tf_r;
-    bvh_slab(r, A.x, A.y, A.z, tn_l, tf_l);
-    bvh_slab(r, A.w, B.x, B.y, tn_r, tf_r);
-    const bool hit_l = tn_l <= tf_l && tn_l <= best + prune;
-    if (hit_l && (info_l & 8)) leaf(link_l, info_l & 7);
-    const bool hit_r = tn_r <= tf_r && tn_r <= best + prune;
-    if (hit_r && (info_r & 8)) leaf(link_r, info_r & 7);
+    bvh_slab(r, rec.a.x, rec.a.y, rec.a.z, tn_l, tf_l);
+    bvh_slab(r, rec.a.w, rec.b.x, rec.b.y, tn_r, tf_r);
+    const bool hit_l = tn_l <= tf_l && tn_l <= reach;
+    const bool hit_r = tn_r <= tf_r && tn_r <= reach;
+    leaf_l = (hit_l && (info_l & 8)) ? (link_l | ((info_l & 7) << 24)) : -1;
+    leaf_r = (hit_r && (info_r & 8)) ? (link_r | ((info_r & 7) << 24)) : -1;
     const bool go_l = hit_l && !(info_l & 8), go_r = hit_r && !(info_r & 8);
     const bool right_near = (r.oct >> ((info_l >> 4) & 3)) & 1;
+    int next = rec.miss;
     if (go_l && go_r) next = right_near ? link_r : link_l;             // the far one follows through the near one's miss link
     else if (go_l) next = link_l;
     else if (go_r) next = link_r;
+    return next;
+}
+__device__ __forceinline__ void bvh_leaf(const float *__restrict__ btris, const BvhRay &r, int leaf, float &best, int &best_i) {
+    const float4 *t4 = reinterpret_cast<const float4 *>(btris + (size_t)(leaf & 0xffffff) * TRI_WORDS);
+    const int cnt = leaf >> 24;
+#ifdef PT_LEAF_UNROLL
+#pragma unroll PT_LEAF_UNROLL
+#endif
+    for (int k = 0; k < cnt; ++k) {
+        const float4 P = t4[3 * k], Q = t4[3 * k + 1], S = t4[3 * k + 2];
+        float tz;
+        if (ptd::ray_triangle(r.ro, r.rd, ptd::mk(P.x, P.y, P.z), ptd::mk(P.w, Q.x, Q.y), ptd::mk(Q.z, Q.w, S.x), tz)) {
+            const int orig = __float_as_int(S.y);                        // index in the caller's triangle array
+            if (tz > 0.0f && (best > tz || (best == tz && orig < best_i))) { best = tz; best_i = orig; }
+        }
+    }
+}
+// one step at record `node` (>= 0); returns the record to continue with, < 0 when the walk is over
+__device__ __forceinline__ int bvh_step(const float *__restrict__ nodes, const float *__restrict__ btris,
+                                        float prune, const BvhRay &r, int node, float &best, int &best_i) {
+    const BvhRec rec = bvh_fetch(nodes, node, r.oct);
+    int leaf_l, leaf_r;
+    const int next = bvh_decide(rec, r, best + prune, leaf_l, leaf_r);
+    if (leaf_l >= 0) bvh_leaf(btris, r, leaf_l, best, best_i);
+    if (leaf_r >= 0) bvh_leaf(btris, r, leaf_r, best, best_i);
     return next;
 }
 // `grid`: origin xyz, step xyz of the mesh (six floats of its geom record)
@@ -913,9 +932,15 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 // go to mesh_hit[slot] = {t, geom, triangle} and one bit per path in mesh_mask[tile]; k_bounce
 // <MESH_PRE> folds them with the geom-index tie-break of pathtrace.cu:192.
 // ---------------------------------------------------------------------------
+#ifndef PT_MESH_PREFETCH
+#define PT_MESH_PREFETCH 0                   // 1: fetch the next record before testing the current leaves (measured: no gain)
+#endif
+#ifndef PT_MESH_WAVES
+#define PT_MESH_WAVES 5                      // waves per SIMD k_mesh is register-budgeted for
+#endif
 constexpr int MQ_SLOTS = 128;                 // ring entries per wave (a tile adds <= 64 while < 64 wait)
 constexpr int MQ_WORDS = 8 * MQ_SLOTS;        // src, path, origin xyz, direction xyz
-constexpr int MQ_STEPS = 4;                   // walk steps between two looks at the ring
+constexpr int MQ_STEPS = 4;                   // walk steps between two looks at the ring (8: same speed)
 constexpr int MQ_LEAVE = 24;                  // lanes still walking when the wave goes back to scanning
 
 // per-lane state of a walk in flight; it survives across the scanning of further tiles
@@ -924,6 +949,8 @@ struct MeshWalker {
     uint32_t src, path;
     BvhRay ray;
     int mesh, node, steps;            // position in SceneDev::bvh_meshes, record in that mesh's tree
+    int geom, root;                   // of the current mesh
+    BvhRec rec;                       // record `node`, fetched one step ahead
     float tz; int tri;                // best of the current mesh (bary.z order)
     float best_t; int best_geom, best_tri;   // best over the meshes finished so far (world distance, geom order)
 };
@@ -949,10 +976,14 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, const float *mq, uint3
             const uint32_t rank = (uint32_t)__popcll((unsigned long long)(idle & ((1ull << lane) - 1)));
             if (!w.have && rank < avail) {
                 const uint32_t s = (q_head + rank) & (MQ_SLOTS - 1);
+                const int4 m = meshes[0];                               // {geom, root record, triangles, -}
                 w.src = mi[0 * MQ_SLOTS + s]; w.path = mi[1 * MQ_SLOTS + s];
-                w.ray = mesh_ray(a.scene, meshes[0].x, ptd::mk(mq[2 * MQ_SLOTS + s], mq[3 * MQ_SLOTS + s], mq[4 * MQ_SLOTS + s]),
+                w.ray = mesh_ray(a.scene, m.x, ptd::mk(mq[2 * MQ_SLOTS + s], mq[3 * MQ_SLOTS + s], mq[4 * MQ_SLOTS + s]),
                                  ptd::mk(mq[5 * MQ_SLOTS + s], mq[6 * MQ_SLOTS + s], mq[7 * MQ_SLOTS + s]));
-                w.mesh = 0; w.node = 0; w.steps = 0; w.tz = FLT_MAX; w.tri = -1;
+                w.mesh = 0; w.geom = m.x; w.root = m.y; w.node = 0; w.steps = 0; w.tz = FLT_MAX; w.tri = -1;
+#if PT_MESH_PREFETCH
+                w.rec = bvh_fetch(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, 0, w.ray.oct);
+#endif
                 w.best_t = FLT_MAX; w.best_geom = -1; w.best_tri = -1;
                 w.have = true;
             }
@@ -971,29 +1002,38 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, const float *mq, uint3
             }
 #endif
             if (w.have) {
-                const int4 m = meshes[w.mesh];                         // {geom, root record, triangles, -}
                 if (w.node >= 0) {
-                    w.node = bvh_step(a.scene.bvh_nodes + (size_t)m.y * BVH_NODE_WORDS, a.scene.bvh_tris, a.scene.bvh_prune,
-                                      w.ray, w.node, w.tz, w.tri);
-#ifdef PT_MESH_STATS
-                    if (w.steps == 5000) {
-                        atomicAdd(&a.ctl->keep[3], 1u);
-                        a.ctl->keep[4] = __float_as_uint(w.ray.ro.x); a.ctl->keep[5] = __float_as_uint(w.ray.ro.y); a.ctl->keep[6] = __float_as_uint(w.ray.ro.z);
-                        a.ctl->keep[7] = __float_as_uint(w.ray.rd.x); a.ctl->keep[8] = __float_as_uint(w.ray.rd.y); a.ctl->keep[9] = __float_as_uint(w.ray.rd.z);
-                        a.ctl->keep[10] = __float_as_uint(w.tz); a.ctl->keep[11] = (uint32_t)a.depth;
-                    }
+                    // decide on the record fetched last step, start fetching the next one, and only then test the
+                    // triangles of the hit leaves: the two round trips overlap instead of following each other
+                    int leaf_l, leaf_r;
+#if !PT_MESH_PREFETCH
+                    w.rec = bvh_fetch(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, w.node, w.ray.oct);
 #endif
+                    w.node = bvh_decide(w.rec, w.ray, w.tz + a.scene.bvh_prune, leaf_l, leaf_r);
                     if (++w.steps > a.scene.bvh_guard) w.node = -1;    // NaN rays: every record is "hit"
+#if PT_MESH_PREFETCH
+                    if (w.node >= 0) w.rec = bvh_fetch(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, w.node, w.ray.oct);
+#endif
+                    if (leaf_l >= 0) bvh_leaf(a.scene.bvh_tris, w.ray, leaf_l, w.tz, w.tri);
+                    if (leaf_r >= 0) bvh_leaf(a.scene.bvh_tris, w.ray, leaf_r, w.tz, w.tri);
+#ifdef PT_MESH_STATS
+                    atomicMax(&a.ctl->keep[14], (uint32_t)w.steps);
+#endif
                 }
                 if (w.node < 0) {                                      // this mesh is done
                     if (w.tri >= 0) {                                  // completion spec 8.0: distance to origin + dir * bary.z
                         const f3 p = ptd::add(w.ray.ro, ptd::scale(w.ray.rd, w.tz));
                         const float t = ptd::length(ptd::sub(w.ray.ro, p));
-                        if (t > 0.0f && w.best_t > t) { w.best_t = t; w.best_geom = m.x; w.best_tri = w.tri; }
+                        if (t > 0.0f && w.best_t > t) { w.best_t = t; w.best_geom = w.geom; w.best_tri = w.tri; }
                     }
                     if (++w.mesh < a.scene.bvh_nmesh) {
-                        w.ray = mesh_ray(a.scene, meshes[w.mesh].x, w.ray.ro, w.ray.rd);
+                        const int4 m = meshes[w.mesh];
+                        w.geom = m.x; w.root = m.y;
+                        w.ray = mesh_ray(a.scene, m.x, w.ray.ro, w.ray.rd);
                         w.node = 0; w.steps = 0; w.tz = FLT_MAX; w.tri = -1;
+#if PT_MESH_PREFETCH
+                        w.rec = bvh_fetch(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, 0, w.ray.oct);
+#endif
                     } else {
                         if (w.best_geom >= 0) {
                             a.mesh_hit[w.src] = make_float4(w.best_t, __int_as_float(w.best_geom), __int_as_float(w.best_tri), 0.0f);
@@ -1008,7 +1048,7 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, const float *mq, uint3
 }
 
 template <bool COMPACT>
-__global__ __launch_bounds__(BLOCK, 5) void k_mesh(BounceArgs a) {
+__global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     float *mq = lds_raw + (threadIdx.x >> 6) * MQ_WORDS;
     uint32_t *mi = reinterpret_cast<uint32_t *>(mq);
@@ -1023,17 +1063,20 @@ __global__ __launch_bounds__(BLOCK, 5) void k_mesh(BounceArgs a) {
     const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
     const uint32_t Wd = a.dir_in.W;                               // waves of the grid that packed the pool
     const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], Wd) * TILE : 0;
-    uint32_t cur = 0;
-    if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), Wd, wid * R * TILE);
     uint32_t q_head = 0, q_total = 0;                             // wave-uniform
     MeshWalker w;
     w.have = false; w.src = 0; w.path = 0; w.ray = bvh_ray(ptd::mk(0, 0, 0), ptd::mk(0, 0, 1), ptd::mk(0, 0, 0), ptd::mk(1, 1, 1));
     w.mesh = 0; w.node = -1; w.steps = 0; w.tz = FLT_MAX; w.tri = -1; w.best_t = FLT_MAX; w.best_geom = -1; w.best_tri = -1;
+    w.geom = 0; w.root = 0; w.rec.a = make_uint4(0, 0, 0, 0); w.rec.b = make_uint4(0, 0, 0, 0); w.rec.miss = -1;
     for (uint32_t r = 0; r < R; ++r) {
-        // a packed pool is read run by run (the source cursor advances with it); a dense one -- bounce 0, where
-        // neighbouring camera rays reach a mesh together -- is dealt tile by tile so every wave gets its share
-        const uint32_t tile = packed_in ? wid * R + r : r * W + wid;
+        // Tiles are dealt round-robin, not in runs: the pool keeps pixel order through every (stable) compaction,
+        // so the rays that reach a mesh -- and the ones that leave its surface -- sit in neighbouring tiles; a run
+        // of them would keep one wave walking long after the others are done (measured: waves alive 15 % of the
+        // launch on average).  The price is one directory search per tile instead of a cursor.
+        const uint32_t tile = r * W + wid;
         if (tile >= tiles) break;
+        uint32_t cur = 0;
+        if (packed_in) cur = find_range(a.dir_in.base(), Wd, tile * TILE);
         const uint32_t i = tile * TILE + lane;
         bool active = i < n;
         uint32_t src = i;
