@@ -321,13 +321,6 @@ template <typename P> PTD float world_distance(P fwd, f3 ro, f3 qo, f3 qd, float
     return length_gated(sub(ro, mv_point(fwd, obj_p)));
 }
 
-template <typename P> PTD float box_test(P g, f3 ro, f3 rd, f3 &face_n, int &outside) {
-    f3 qo, qd, obj_p; float t_obj; int code;
-    if (!box_slab(g, ro, rd, qo, qd, t_obj, code, outside)) return -1.0f;
-    face_n = mk(__int_as_float(code), 0.0f, 0.0f);                        // decoded by cube_normal
-    return world_distance(g + G_FWD, ro, qo, qd, t_obj, obj_p);
-}
-
 // object-space part of sphereIntersectionTest (intersections.h:102-134)
 template <typename P> PTD bool sphere_quad(P g, f3 ro, f3 rd, f3 &o, f3 &d, float &t_obj, int &outside) {
     o = mv_point(g + G_INV, ro);
@@ -351,11 +344,6 @@ template <typename P> PTD bool sphere_quad(P g, f3 ro, f3 rd, f3 &o, f3 &d, floa
     return true;
 }
 
-template <typename P> PTD float sphere_test(P g, f3 ro, f3 rd, f3 &obj_p, int &outside) {
-    f3 o, d; float t_obj;
-    if (!sphere_quad(g, ro, rd, o, d, t_obj, outside)) return -1.0f;
-    return world_distance(g + G_FWD, ro, o, d, t_obj, obj_p);
-}
 
 // surface normal of the winning primitive (the part of the two tests above
 // that the reference evaluates for every candidate)

@@ -40,17 +40,16 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, Lens le
 constexpr int LDS_CTL_WORDS = 16;    // [0] last-block flag, [2..5] scan scratch
 constexpr int GF_WORDS = 32;         // staged per geom for per-lane gathers: transform[12], type, materialid, 2 pad,
                                      // invTranspose[12], 4 pad
-// per-wave candidate queue (PT_QUEUE): ring of 128 slots, SoA: qo.xyz qd.xyz t_obj (7 planes), meta, and
+// per-wave candidate queue: ring of 128 slots, SoA: qo.xyz qd.xyz t_obj (7 planes), meta, and
 // the 64 per-lane best keys (u64)
 constexpr int Q_SLOTS = 128;
 constexpr int Q_WORDS = 7 * Q_SLOTS + Q_SLOTS + 2 * 64;
 __host__ __device__ constexpr int scene_lds_words(int nmats, int ngeoms) {
-    return ((nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * ngeoms * GF_WORDS + PT_GEOM_LDS * ngeoms * ptd::GEOM_WORDS;
+    return ((nmats * ptd::MAT_WORDS + 3) & ~3) + ngeoms * GF_WORDS;
 }
 __device__ __forceinline__ void stage_scene(float *lds_mats, const SceneDev &sc) {
     const int mw = sc.nmats * ptd::MAT_WORDS;
     for (int k = threadIdx.x; k < mw; k += BLOCK) lds_mats[k] = sc.mats[k];
-#if PT_QUEUE
     {   // per-lane gathers of the tail: forward transform (12) + type + material per geom
         float *gf = lds_mats + ((mw + 3) & ~3);
         for (int k = threadIdx.x; k < sc.ngeoms * GF_WORDS; k += BLOCK) {
@@ -62,11 +61,6 @@ __device__ __forceinline__ void stage_scene(float *lds_mats, const SceneDev &sc)
             gf[k] = v;
         }
     }
-#endif
-#if PT_GEOM_LDS
-    float *lds_geoms = lds_mats + ((mw + 3) & ~3) + PT_QUEUE * sc.ngeoms * GF_WORDS;
-    for (int k = threadIdx.x; k < sc.ngeoms * ptd::GEOM_WORDS; k += BLOCK) lds_geoms[k] = sc.geoms[k];
-#endif
     __syncthreads();
 }
 
@@ -80,7 +74,6 @@ __device__ __forceinline__ cfloat *as_const(const float *p) {
     return (cfloat *)(unsigned long long)p;
 }
 
-#if PT_QUEUE
 // One lane-dense pass over up to 64 queued candidates [head, head+count): lane k evaluates the
 // shared tail of candidate head+k for whichever lane queued it and folds the distance into that
 // lane's best key with an LDS 64-bit min.  key = (bits(t) << 32) | absolute slot: positive floats
@@ -112,7 +105,6 @@ __device__ __forceinline__ void queue_pass(float *wq, const float *gf, uint32_t 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
-#endif
 
 // Stackless walk of one mesh's hierarchy (record layout and link construction: pt_bvh.hpp).
 // Per lane and step: fetch one 128-B record (both child boxes + links as four 16-B loads, the
@@ -226,9 +218,6 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
     h.t = FLT_MAX; h.geom = -1; h.outside = 1; h.aux = ptd::mk(0, 0, 0);
     const int ngeoms = sc.ngeoms;
     const float *__restrict__ tris = sc.tris;
-    int outside = 1;                                    // shared across tests, pathtrace.cu:169
-    (void)outside;
-#if PT_QUEUE
     const int lane_q = threadIdx.x & 63;
     float *qf = wq;
     uint32_t *qi = reinterpret_cast<uint32_t *>(wq + 7 * Q_SLOTS);
@@ -250,18 +239,9 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
-#endif
-#ifdef PT_GEOM_UNROLL
-#pragma unroll PT_GEOM_UNROLL
-#endif
     for (int g = 0; g < ngeoms; ++g) {
-#if PT_GEOM_LDS
-        const float *rec = geoms + g * ptd::GEOM_WORDS;                // LDS broadcast
-        const int type = __builtin_amdgcn_readfirstlane(__float_as_int(rec[0]));
-#else
         cfloat *rec = as_const(geoms) + g * ptd::GEOM_WORDS;           // wave-uniform address -> s_load
         const int type = __float_as_int(rec[0]);
-#endif
         if (MESH == MESH_PRE && type == PT_TRIANGLE_MESH) continue;        // k_mesh already walked every mesh
         if (MESH == MESH_BVH && type == PT_TRIANGLE_MESH) {
             // same winner as the loop below (smallest bary.z, lowest triangle index on ties), found by
@@ -330,7 +310,6 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
             }
             continue;
         }
-#if PT_QUEUE
         {   // object-space test per lane; hits are queued and their tails run lane-dense (queue_pass)
             f3 qo = ptd::mk(0, 0, 0), qd = ptd::mk(0, 0, 1);
             float t_obj = 0.0f;
@@ -360,19 +339,7 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
             }
             continue;
         }
-#endif
-        {   // monolithic reference-shaped tests (object-space test + world-distance tail in one body)
-            float t = -1.0f;
-            f3 aux = ptd::mk(0, 0, 0);
-            if (type == PT_CUBE) { if (active) t = ptd::box_test(rec, ro, rd, aux, outside); }
-            else if (type == PT_SPHERE) { if (active) t = ptd::sphere_test(rec, ro, rd, aux, outside); }
-            if (t > 0.0f && h.t > t) {                  // pathtrace.cu:192 (first geom wins ties)
-                h.t = t; h.geom = g; h.outside = outside; h.aux = aux;
-            }
-            continue;
-        }
     }
-#if PT_QUEUE
     if (q_total > q_head) {
         queue_pass(wq, gf, q_head, q_total - q_head, ro);
         latch();
@@ -390,28 +357,19 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
             h.aux = (type == PT_CUBE) ? ptd::mk(__int_as_float((w_meta >> 7) & 7), 0.0f, 0.0f) : w_objp;
         }
     }
-#endif
 }
 
 // normal + materialId of the winning primitive: a per-lane gather from the records staged in LDS
-// (gf, PT_QUEUE) -- ~100 cycles instead of an L2 round trip -- or from the global record array
+// (gf) -- ~100 cycles instead of an L2 round trip -- or from the global record array
 __device__ __forceinline__ void resolve_hit(const float *__restrict__ geoms, const float *gf,
                                             const float *__restrict__ tris, const ptd::Hit &h, float &t, f3 &n,
                                             int &mat) {
     if (h.geom < 0) { t = -1.0f; n = ptd::mk(0, 0, 0); mat = 0; return; }
-#if PT_QUEUE
     (void)geoms;
     const float *rec = gf + h.geom * GF_WORDS;
     const int type = __float_as_int(rec[12]);
     mat = __float_as_int(rec[13]);
     const float *fwd = rec, *invt = rec + 16;
-#else
-    (void)gf;
-    const float *rec = geoms + h.geom * ptd::GEOM_WORDS;
-    const int type = __float_as_int(rec[0]);
-    mat = __float_as_int(rec[1]);
-    const float *fwd = rec + ptd::G_FWD, *invt = rec + ptd::G_INVT;
-#endif
     t = h.t;
     if (type == PT_CUBE) n = ptd::cube_normal(fwd, h.aux);
     else if (type == PT_SPHERE) n = ptd::sphere_normal(invt, h.aux, h.outside);
@@ -487,15 +445,9 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isec
     float *mats_lds = lds_raw + LDS_CTL_WORDS;
     const float *gf = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
     float *wq = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
-    float *tri_lds = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + PT_QUEUE * WAVES * Q_WORDS;
-#if PT_GEOM_LDS || PT_QUEUE
+    float *tri_lds = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + WAVES * Q_WORDS;
     stage_scene(mats_lds, sc);
-#endif
-#if PT_GEOM_LDS
-    const float *gsrc = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * sc.ngeoms * GF_WORDS;
-#else
     const float *gsrc = sc.geoms;
-#endif
     const int lane = threadIdx.x & 63;
     const uint32_t W = gridDim.x * WAVES;
     const uint32_t wid = run_id();
@@ -763,7 +715,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     float *mats = lds_raw + LDS_CTL_WORDS;
     const float *gf = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
     float *wq = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
-    float *tri_lds = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + PT_QUEUE * WAVES * Q_WORDS;
+    float *tri_lds = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + WAVES * Q_WORDS;
 #ifdef PT_STAMPS
 #define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.depth == PT_STAMPS) a.ctl->stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -825,11 +777,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
         float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
         if (MODE == MODE_FUSED) {
             ptd::Hit h;
-#if PT_GEOM_LDS
-            const float *gsrc = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * a.scene.ngeoms * GF_WORDS;
-#else
             const float *gsrc = a.scene.geoms;
-#endif
             const float4 *pre_hit = nullptr;
             if (MESH == MESH_PRE) {
                 // lanes of this tile for which k_mesh found a mesh hit; the mask is consumed (cleared) here
@@ -1142,15 +1090,9 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache
     float *mats_lds = lds_raw + LDS_CTL_WORDS;
     const float *gf = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
     float *wq = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
-    float *tri_lds = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + PT_QUEUE * WAVES * Q_WORDS;
-#if PT_GEOM_LDS || PT_QUEUE
+    float *tri_lds = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + WAVES * Q_WORDS;
     stage_scene(mats_lds, sc);
-#endif
-#if PT_GEOM_LDS
-    const float *gsrc = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3) + PT_QUEUE * sc.ngeoms * GF_WORDS;
-#else
     const float *gsrc = sc.geoms;
-#endif
     const uint32_t n = (uint32_t)map.tile_pixels;
     const uint32_t tiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {

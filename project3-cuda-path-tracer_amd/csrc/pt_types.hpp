@@ -9,12 +9,6 @@ namespace {
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4                     // waves per SIMD the bounce kernels are register-budgeted for
 #endif
-#ifndef PT_GEOM_LDS
-#define PT_GEOM_LDS 0                      // 1: broadcast geom records from LDS, 0: scalar loads (SGPRs)
-#endif
-#ifndef PT_QUEUE
-#define PT_QUEUE 1                         // evaluate the world-distance tails lane-dense from a per-wave LDS queue
-#endif
 constexpr int BLOCK = 256;                 // 4 waves of 64
 constexpr int WAVES = BLOCK / 64;
 constexpr int TILE = 64;                   // paths per tile = one wave64

@@ -708,7 +708,7 @@ static int init_impl(const pt_scene_desc *d) {
         HIPCHK(hipMemcpy(R.d_geoms, grec.data(), grec.size() * 4, hipMemcpyHostToDevice));   // records now name tree roots
     }
     R.lds_bytes = ((size_t)LDS_CTL_WORDS + (size_t)scene_lds_words(d->num_materials, d->num_geoms) +
-                   (size_t)PT_QUEUE * WAVES * Q_WORDS) * 4;
+                   (size_t)WAVES * Q_WORDS) * 4;
     R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
     if (const char *pad = getenv("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
     if (R.mesh_mode == MESH_TILES) R.lds_bytes += (size_t)TRI_TILE * TRI_WORDS * 4;
