@@ -43,7 +43,7 @@ constexpr int NODE_WORDS = 16;
 constexpr int GRID_MAX = 65535;
 constexpr int LINK_BITS = 24;
 #ifndef PT_LEAF_MAX
-#define PT_LEAF_MAX 4
+#define PT_LEAF_MAX 2
 #endif
 constexpr int LEAF_MAX = PT_LEAF_MAX;    // triangles per leaf (the count field has 3 bits)
 constexpr int SAH_BINS = 16;

@@ -178,7 +178,11 @@ __device__ __forceinline__ int bvh_decide(const BvhRec &rec, const BvhRay &r, fl
 }
 __device__ __forceinline__ void bvh_leaf(const float *__restrict__ btris, const BvhRay &r, int leaf, float &best, int &best_i) {
     const float4 *t4 = reinterpret_cast<const float4 *>(btris + (size_t)(leaf & 0xffffff) * TRI_WORDS);
+#ifdef PT_EXPERIMENT_NO_TRIS
+    const int cnt = 0;
+#else
     const int cnt = leaf >> 24;
+#endif
 #ifdef PT_LEAF_UNROLL
 #pragma unroll PT_LEAF_UNROLL
 #endif
@@ -880,16 +884,17 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 // go to mesh_hit[slot] = {t, geom, triangle} and one bit per path in mesh_mask[tile]; k_bounce
 // <MESH_PRE> folds them with the geom-index tie-break of pathtrace.cu:192.
 // ---------------------------------------------------------------------------
-#ifndef PT_MESH_PREFETCH
-#define PT_MESH_PREFETCH 0                   // 1: fetch the next record before testing the current leaves (measured: no gain)
-#endif
 #ifndef PT_MESH_WAVES
 #define PT_MESH_WAVES 5                      // waves per SIMD k_mesh is register-budgeted for
 #endif
-constexpr int MQ_SLOTS = 128;                 // ring entries per wave (a tile adds <= 64 while < 64 wait)
-constexpr int MQ_WORDS = 8 * MQ_SLOTS;        // src, path, origin xyz, direction xyz
-constexpr int MQ_STEPS = 4;                   // walk steps between two looks at the ring (8: same speed)
-constexpr int MQ_LEAVE = 24;                  // lanes still walking when the wave goes back to scanning
+constexpr int MQ_SLOTS = 128;                 // ray ring entries per wave (a tile adds <= 64 while < 64 wait)
+constexpr int TQ_SLOTS = 512;                 // triangle ring entries per wave (a step adds <= 64 * 2 * LEAF_MAX while < 64 wait)
+constexpr int MQ_RAY_WORDS = 8 * MQ_SLOTS;    // src, path, origin xyz, direction xyz
+constexpr int MQ_WORDS = MQ_RAY_WORDS + TQ_SLOTS + 2 * 64;   // + triangle ring + the 64 per-lane best keys (u64)
+constexpr int MQ_STEPS = 4;                   // walk steps between two looks at the ray ring (8: same speed)
+constexpr int MQ_LEAVE = 24;                  // lanes still busy when the wave goes back to scanning
+constexpr unsigned long long TRI_KEY_NONE = (0x7f7fffffull << 32) | 0xffffffffull;   // bary.z = FLT_MAX, no triangle
+static_assert(2 * PT_LEAF_MAX * 64 + 63 <= TQ_SLOTS, "a step's triangles must fit beside the waiting ones");
 
 // per-lane state of a walk in flight; it survives across the scanning of further tiles
 struct MeshWalker {
@@ -898,10 +903,10 @@ struct MeshWalker {
     BvhRay ray;
     int mesh, node, steps;            // position in SceneDev::bvh_meshes, record in that mesh's tree
     int geom, root;                   // of the current mesh
-    BvhRec rec;                       // record `node`, fetched one step ahead
-    float tz; int tri;                // best of the current mesh (bary.z order)
+    uint32_t ticket;                  // triangle-ring index past this lane's last queued triangle
     float best_t; int best_geom, best_tri;   // best over the meshes finished so far (world distance, geom order)
 };
+struct MeshRings { uint32_t q_head, q_total, t_head, t_total; };   // wave-uniform ring cursors
 
 // the ray in the grid of mesh geom `g` (origin / step sit in the inverse-transform words of its record)
 __device__ __forceinline__ BvhRay mesh_ray(const SceneDev &sc, int g, f3 ro, f3 rd) {
@@ -909,86 +914,128 @@ __device__ __forceinline__ BvhRay mesh_ray(const SceneDev &sc, int g, f3 ro, f3 
     return bvh_ray(ro, rd, ptd::mk(q[0], q[1], q[2]), ptd::mk(q[3], q[4], q[5]));
 }
 
-// Lanes without a walk take the next ring entries; every lane with one advances MQ_STEPS records, moving
-// on to the next mesh / publishing its result as it finishes.  Returns when the ring is empty and fewer
-// than `leave` lanes are still walking (0: run dry).
-__device__ __forceinline__ void mesh_drain(MeshWalker &w, const float *mq, uint32_t &q_head, uint32_t q_total,
-                                           const BounceArgs &a, int leave) {
+// One lane-dense pass over up to 64 queued triangle tests [head, head + count): lane k tests triangle slot
+// e >> 6 against the ray of lane e & 63 (fetched from that lane's registers) and folds a hit into the owner's
+// best key with an LDS 64-bit min.  key = (bits(bary.z) << 32) | original triangle index: the smallest bary.z,
+// the lowest index on ties -- the order of the loop over every triangle (completion spec 8.0).
+__device__ __forceinline__ void tri_pass(float *mq, uint32_t head, uint32_t count, const MeshWalker &w, const BounceArgs &a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t *tq = reinterpret_cast<const uint32_t *>(mq + MQ_RAY_WORDS);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(mq + MQ_RAY_WORDS + TQ_SLOTS);
+    const bool on = (uint32_t)lane < count;
+    const uint32_t e = on ? tq[(head + (uint32_t)lane) & (TQ_SLOTS - 1)] : 0u;
+    const int owner = (int)(e & 63u);
+    const f3 ro = ptd::mk(__shfl(w.ray.ro.x, owner), __shfl(w.ray.ro.y, owner), __shfl(w.ray.ro.z, owner));
+    const f3 rd = ptd::mk(__shfl(w.ray.rd.x, owner), __shfl(w.ray.rd.y, owner), __shfl(w.ray.rd.z, owner));
+    if (on) {
+        const float4 *t4 = reinterpret_cast<const float4 *>(a.scene.bvh_tris + (size_t)(e >> 6) * TRI_WORDS);
+        const float4 P = t4[0], Q = t4[1], S = t4[2];
+        float tz;
+        if (ptd::ray_triangle(ro, rd, ptd::mk(P.x, P.y, P.z), ptd::mk(P.w, Q.x, Q.y), ptd::mk(Q.z, Q.w, S.x), tz) && tz > 0.0f)
+            __hip_atomic_fetch_min(&keys[owner], ((unsigned long long)__float_as_uint(tz) << 32) | __float_as_uint(S.y),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// Lanes without a walk take the next ray-ring entries; every lane with one advances MQ_STEPS records.  The
+// triangles of the leaves a step reaches are not tested by the lane that found them -- a handful of lanes
+// would each run the 65-instruction test while the rest of the wave waits -- but queued and tested 64 at a
+// time (tri_pass).  A lane whose walk of a mesh is over waits until its last queued triangle has been tested,
+// then folds the mesh's winner and moves on to the next mesh or publishes its result.  Returns when the ray
+// ring is empty and fewer than `leave` lanes are still busy (0: run dry).
+__device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &rg, const BounceArgs &a, int leave) {
     const int lane = threadIdx.x & 63;
     const uint32_t *mi = reinterpret_cast<const uint32_t *>(mq);
+    uint32_t *tq = reinterpret_cast<uint32_t *>(mq + MQ_RAY_WORDS);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(mq + MQ_RAY_WORDS + TQ_SLOTS);
     const int4 *meshes = a.scene.bvh_meshes;
+    const uint64_t below = (1ull << lane) - 1;
     for (;;) {
         const uint64_t idle = __ballot(!w.have);
-        const uint32_t avail = q_total - q_head;
+        const uint32_t avail = rg.q_total - rg.q_head;
         if (idle && avail) {
-            const uint32_t rank = (uint32_t)__popcll((unsigned long long)(idle & ((1ull << lane) - 1)));
+            const uint32_t rank = (uint32_t)__popcll((unsigned long long)(idle & below));
             if (!w.have && rank < avail) {
-                const uint32_t s = (q_head + rank) & (MQ_SLOTS - 1);
+                const uint32_t s = (rg.q_head + rank) & (MQ_SLOTS - 1);
                 const int4 m = meshes[0];                               // {geom, root record, triangles, -}
                 w.src = mi[0 * MQ_SLOTS + s]; w.path = mi[1 * MQ_SLOTS + s];
                 w.ray = mesh_ray(a.scene, m.x, ptd::mk(mq[2 * MQ_SLOTS + s], mq[3 * MQ_SLOTS + s], mq[4 * MQ_SLOTS + s]),
                                  ptd::mk(mq[5 * MQ_SLOTS + s], mq[6 * MQ_SLOTS + s], mq[7 * MQ_SLOTS + s]));
-                w.mesh = 0; w.geom = m.x; w.root = m.y; w.node = 0; w.steps = 0; w.tz = FLT_MAX; w.tri = -1;
-#if PT_MESH_PREFETCH
-                w.rec = bvh_fetch(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, 0, w.ray.oct);
-#endif
+                w.mesh = 0; w.geom = m.x; w.root = m.y; w.node = 0; w.steps = 0; w.ticket = rg.t_head;
                 w.best_t = FLT_MAX; w.best_geom = -1; w.best_tri = -1;
+                keys[lane] = TRI_KEY_NONE;
                 w.have = true;
             }
-            q_head += min((uint32_t)__popcll((unsigned long long)idle), avail);
+            rg.q_head += min((uint32_t)__popcll((unsigned long long)idle), avail);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         const uint64_t busy = __ballot(w.have);
         if (!busy) return;
-        if (q_total == q_head && (int)__popcll((unsigned long long)busy) < leave) return;
+        if (rg.q_total == rg.q_head && (int)__popcll((unsigned long long)busy) < leave) return;
 #pragma unroll 1
         for (int k = 0; k < MQ_STEPS; ++k) {
+            int leaf_l = -1, leaf_r = -1;
+            if (w.have && w.node >= 0) {
+                const BvhRec rec = bvh_fetch(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, w.node, w.ray.oct);
+                // prune against the best bary.z the tested triangles have produced so far (it may lag: conservative)
+                const float best = __uint_as_float((uint32_t)(keys[lane] >> 32));
+                w.node = bvh_decide(rec, w.ray, best + a.scene.bvh_prune, leaf_l, leaf_r);
+                if (++w.steps > a.scene.bvh_guard) w.node = -1;        // NaN rays: every record is "hit"
+            }
 #ifdef PT_MESH_STATS
             {
-                const uint64_t bb = __ballot(w.have && w.node >= 0);
+                const uint64_t bb = __ballot(w.have && (w.node >= 0 || leaf_l >= 0 || leaf_r >= 0));
                 if (lane == 0 && bb) { atomicAdd(&a.ctl->keep[1], (uint32_t)__popcll((unsigned long long)bb)); atomicAdd(&a.ctl->keep[2], 1u); }
+                atomicMax(&a.ctl->keep[14], (uint32_t)w.steps);
             }
 #endif
-            if (w.have) {
-                if (w.node >= 0) {
-                    // decide on the record fetched last step, start fetching the next one, and only then test the
-                    // triangles of the hit leaves: the two round trips overlap instead of following each other
-                    int leaf_l, leaf_r;
-#if !PT_MESH_PREFETCH
-                    w.rec = bvh_fetch(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, w.node, w.ray.oct);
-#endif
-                    w.node = bvh_decide(w.rec, w.ray, w.tz + a.scene.bvh_prune, leaf_l, leaf_r);
-                    if (++w.steps > a.scene.bvh_guard) w.node = -1;    // NaN rays: every record is "hit"
-#if PT_MESH_PREFETCH
-                    if (w.node >= 0) w.rec = bvh_fetch(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, w.node, w.ray.oct);
-#endif
-                    if (leaf_l >= 0) bvh_leaf(a.scene.bvh_tris, w.ray, leaf_l, w.tz, w.tri);
-                    if (leaf_r >= 0) bvh_leaf(a.scene.bvh_tris, w.ray, leaf_r, w.tz, w.tri);
-#ifdef PT_MESH_STATS
-                    atomicMax(&a.ctl->keep[14], (uint32_t)w.steps);
-#endif
+            // queue this step's triangles: slot order = lane order (any order gives the same minimum)
+            const int nl = leaf_l >= 0 ? (leaf_l >> 24) : 0, nr = leaf_r >= 0 ? (leaf_r >> 24) : 0;
+            const int nt = nl + nr;
+            if (__ballot(nt > 0)) {
+                uint32_t pre = 0, tot = 0;
+#pragma unroll
+                for (int bit = 0; bit < 4; ++bit) {                      // exclusive prefix of nt (< 16) over the lanes
+                    const uint64_t bm = __ballot((nt >> bit) & 1);
+                    pre += (uint32_t)__popcll((unsigned long long)(bm & below)) << bit;
+                    tot += (uint32_t)__popcll((unsigned long long)bm) << bit;
                 }
-                if (w.node < 0) {                                      // this mesh is done
-                    if (w.tri >= 0) {                                  // completion spec 8.0: distance to origin + dir * bary.z
-                        const f3 p = ptd::add(w.ray.ro, ptd::scale(w.ray.rd, w.tz));
-                        const float t = ptd::length(ptd::sub(w.ray.ro, p));
-                        if (t > 0.0f && w.best_t > t) { w.best_t = t; w.best_geom = w.geom; w.best_tri = w.tri; }
+                const uint32_t pos = rg.t_total + pre;
+                for (int j = 0; j < nl; ++j)
+                    tq[(pos + (uint32_t)j) & (TQ_SLOTS - 1)] = (uint32_t)lane | ((uint32_t)((leaf_l & 0xffffff) + j) << 6);
+                for (int j = 0; j < nr; ++j)
+                    tq[(pos + (uint32_t)(nl + j)) & (TQ_SLOTS - 1)] = (uint32_t)lane | ((uint32_t)((leaf_r & 0xffffff) + j) << 6);
+                if (nt > 0) w.ticket = pos + (uint32_t)nt;
+                rg.t_total += tot;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                while (rg.t_total - rg.t_head >= 64) { tri_pass(mq, rg.t_head, 64, w, a); rg.t_head += 64; }
+            }
+            // nobody is walking any more but triangles are still queued: test them now, their owners are waiting
+            if (rg.t_total != rg.t_head && !__ballot(w.have && w.node >= 0)) {
+                tri_pass(mq, rg.t_head, rg.t_total - rg.t_head, w, a);
+                rg.t_head = rg.t_total;
+            }
+            if (w.have && w.node < 0 && (int32_t)(rg.t_head - w.ticket) >= 0) {    // this mesh is done and fully tested
+                const unsigned long long key = keys[lane];
+                if ((uint32_t)key != 0xffffffffu) {                      // completion spec 8.0: distance to origin + dir * bary.z
+                    const float tz = __uint_as_float((uint32_t)(key >> 32));
+                    const f3 p = ptd::add(w.ray.ro, ptd::scale(w.ray.rd, tz));
+                    const float t = ptd::length(ptd::sub(w.ray.ro, p));
+                    if (t > 0.0f && w.best_t > t) { w.best_t = t; w.best_geom = w.geom; w.best_tri = (int)(uint32_t)key; }
+                }
+                if (++w.mesh < a.scene.bvh_nmesh) {
+                    const int4 m = meshes[w.mesh];
+                    w.geom = m.x; w.root = m.y;
+                    w.ray = mesh_ray(a.scene, m.x, w.ray.ro, w.ray.rd);
+                    w.node = 0; w.steps = 0;
+                    keys[lane] = TRI_KEY_NONE;
+                } else {
+                    if (w.best_geom >= 0) {
+                        a.mesh_hit[w.src] = make_float4(w.best_t, __int_as_float(w.best_geom), __int_as_float(w.best_tri), 0.0f);
+                        atomicOr(&a.mesh_mask[w.path >> 6], 1ull << (w.path & 63u));
                     }
-                    if (++w.mesh < a.scene.bvh_nmesh) {
-                        const int4 m = meshes[w.mesh];
-                        w.geom = m.x; w.root = m.y;
-                        w.ray = mesh_ray(a.scene, m.x, w.ray.ro, w.ray.rd);
-                        w.node = 0; w.steps = 0; w.tz = FLT_MAX; w.tri = -1;
-#if PT_MESH_PREFETCH
-                        w.rec = bvh_fetch(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, 0, w.ray.oct);
-#endif
-                    } else {
-                        if (w.best_geom >= 0) {
-                            a.mesh_hit[w.src] = make_float4(w.best_t, __int_as_float(w.best_geom), __int_as_float(w.best_tri), 0.0f);
-                            atomicOr(&a.mesh_mask[w.path >> 6], 1ull << (w.path & 63u));
-                        }
-                        w.have = false;
-                    }
+                    w.have = false;
                 }
             }
         }
@@ -1011,11 +1058,11 @@ __global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
     const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
     const uint32_t Wd = a.dir_in.W;                               // waves of the grid that packed the pool
     const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], Wd) * TILE : 0;
-    uint32_t q_head = 0, q_total = 0;                             // wave-uniform
+    MeshRings rg{0, 0, 0, 0};
     MeshWalker w;
     w.have = false; w.src = 0; w.path = 0; w.ray = bvh_ray(ptd::mk(0, 0, 0), ptd::mk(0, 0, 1), ptd::mk(0, 0, 0), ptd::mk(1, 1, 1));
-    w.mesh = 0; w.node = -1; w.steps = 0; w.tz = FLT_MAX; w.tri = -1; w.best_t = FLT_MAX; w.best_geom = -1; w.best_tri = -1;
-    w.geom = 0; w.root = 0; w.rec.a = make_uint4(0, 0, 0, 0); w.rec.b = make_uint4(0, 0, 0, 0); w.rec.miss = -1;
+    w.mesh = 0; w.node = -1; w.steps = 0; w.ticket = 0; w.best_t = FLT_MAX; w.best_geom = -1; w.best_tri = -1;
+    w.geom = 0; w.root = 0;
     for (uint32_t r = 0; r < R; ++r) {
         // Tiles are dealt round-robin, not in runs: the pool keeps pixel order through every (stable) compaction,
         // so the rays that reach a mesh -- and the ones that leave its surface -- sit in neighbouring tiles; a run
@@ -1062,22 +1109,22 @@ __global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
         const uint64_t m = __ballot(cand);
         if (m) {
             if (cand) {
-                const uint32_t s = (q_total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))) & (MQ_SLOTS - 1);
+                const uint32_t s = (rg.q_total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))) & (MQ_SLOTS - 1);
                 mi[0 * MQ_SLOTS + s] = src; mi[1 * MQ_SLOTS + s] = i;
                 mq[2 * MQ_SLOTS + s] = ro.x; mq[3 * MQ_SLOTS + s] = ro.y; mq[4 * MQ_SLOTS + s] = ro.z;
                 mq[5 * MQ_SLOTS + s] = rd.x; mq[6 * MQ_SLOTS + s] = rd.y; mq[7 * MQ_SLOTS + s] = rd.z;
             }
-            q_total += (uint32_t)__popcll((unsigned long long)m);
+            rg.q_total += (uint32_t)__popcll((unsigned long long)m);
 #ifdef PT_MESH_STATS
             if (lane == 0) atomicAdd(&a.ctl->keep[0], (uint32_t)__popcll((unsigned long long)m));
 #endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // keep the ring below 64 waiting entries so the next tile always fits
-            if (q_total - q_head >= 64 - (uint32_t)__popcll((unsigned long long)__ballot(w.have)) || q_total - q_head >= 64)
-                mesh_drain(w, mq, q_head, q_total, a, MQ_LEAVE);
+            if (rg.q_total - rg.q_head >= 64 - (uint32_t)__popcll((unsigned long long)__ballot(w.have)))
+                mesh_drain(w, mq, rg, a, MQ_LEAVE);
         }
     }
-    mesh_drain(w, mq, q_head, q_total, a, 0);
+    mesh_drain(w, mq, rg, a, 0);
 }
 
 // First-bounce cache (INSTRUCTION.md:87-89): camera rays do not depend on the iteration (no

@@ -53,8 +53,8 @@ static_assert(sizeof(pt_triangle) == 36, "triangle ABI");
 using ptd::f3;
 
 #include "pt_types.hpp"
-#include "pt_kernels.hpp"
 #include "pt_bvh.hpp"
+#include "pt_kernels.hpp"
 
 namespace {
 
