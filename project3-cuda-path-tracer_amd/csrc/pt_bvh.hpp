@@ -2,7 +2,7 @@
 // (the assignment's "hierarchical spatial data structure", INSTRUCTION.md:129-139,
 // 218-240 -- the reference has none).  Included by ptmi355.hip only; no device code here.
 //
-// Layout: a binary tree (binned surface-area splits, leaves of 1..4
+// Layout: a binary tree (binned surface-area splits, leaves of 1..LEAF_MAX = 2
 // triangles) stored as one 64-byte record per INTERNAL node that carries the boxes of BOTH
 // children, so one fetch per step decides two boxes.  A walk is bound by how many address-divergent
 // vector loads the texture path can take, so the record is made small: box planes are 16-bit
@@ -12,7 +12,7 @@
 //   [3..5]   right child box, same packing
 //   [6]      left link  | info << 24      [7] right link | info << 24
 //              info = count | leaf << 3 | split axis of THIS node << 4   (axis only in the left info)
-//              leaf child: link = first record in the leaf-ordered triangle array, count = 0..4
+//              leaf child: link = first record in the leaf-ordered triangle array, count = 0..LEAF_MAX
 //              internal child: link = record index of that child                    (links < 2^24)
 //   [8..15]  miss link per ray-direction octant (bit k set when dir[k] < 0): the record to continue
 //            with when this subtree is finished; -1 ends the walk

@@ -885,7 +885,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 // <MESH_PRE> folds them with the geom-index tie-break of pathtrace.cu:192.
 // ---------------------------------------------------------------------------
 #ifndef PT_MESH_WAVES
-#define PT_MESH_WAVES 5                      // waves per SIMD k_mesh is register-budgeted for
+#define PT_MESH_WAVES 4                      // waves per SIMD k_mesh is register-budgeted for
 #endif
 constexpr int MQ_SLOTS = 128;                 // ray ring entries per wave (a tile adds <= 64 while < 64 wait)
 constexpr int TQ_SLOTS = 512;                 // triangle ring entries per wave (a step adds <= 64 * 2 * LEAF_MAX while < 64 wait)
