@@ -158,7 +158,8 @@ __device__ __forceinline__ BvhRec bvh_fetch(const float *__restrict__ nodes, int
 }
 // box tests of a fetched record: the record to continue with (< 0: the walk is over) and the hit leaf
 // children as first | count << 24 (-1: none), to be tested by bvh_leaf
-__device__ __forceinline__ int bvh_decide(const BvhRec &rec, const BvhRay &r, float reach, int &leaf_l, int &leaf_r) {
+__device__ __forceinline__ int bvh_decide(const BvhRec &rec, const BvhRay &r, float reach, int &leaf_l, int &leaf_r,
+                                          int *skip = nullptr) {
     const int link_l = (int)(rec.b.z & 0xffffffu), info_l = (int)(rec.b.z >> 24);
     const int link_r = (int)(rec.b.w & 0xffffffu), info_r = (int)(rec.b.w >> 24);
     float tn_l, tf_l, tn_r, tf_r;
@@ -174,6 +175,16 @@ __device__ __forceinline__ int bvh_decide(const BvhRec &rec, const BvhRay &r, fl
     if (go_l && go_r) next = right_near ? link_r : link_l;             // the far one follows through the near one's miss link
     else if (go_l) next = link_l;
     else if (go_r) next = link_r;
+    if (skip) {
+        // the walk enters one internal child while its internal sibling was missed: that sibling is where the
+        // entered subtree's miss links lead if it is the far one -- the caller may skip it (straight to rec.miss)
+        *skip = -1;
+        const bool inner_l = !(info_l & 8), inner_r = !(info_r & 8);
+        if (inner_l && inner_r && (go_l != go_r)) {
+            const bool entered_right = go_r;
+            if (entered_right == right_near) *skip = entered_right ? link_l : link_r;   // the missed one is the far child
+        }
+    }
     return next;
 }
 __device__ __forceinline__ void bvh_leaf(const float *__restrict__ btris, const BvhRay &r, int leaf, float &best, int &best_i) {
@@ -713,7 +724,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
 enum { MODE_FUSED = 0, MODE_ISECT = 1, MODE_CACHE0 = 2 };
 
 template <int MODE, bool COMPACT, int MESH>
-__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
+__global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
     float *mats = lds_raw + LDS_CTL_WORDS;
@@ -884,6 +895,9 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 // go to mesh_hit[slot] = {t, geom, triangle} and one bit per path in mesh_mask[tile]; k_bounce
 // <MESH_PRE> folds them with the geom-index tie-break of pathtrace.cu:192.
 // ---------------------------------------------------------------------------
+#ifndef PT_SKIP_PAIRS
+#define PT_SKIP_PAIRS 2                      // missed-sibling pairs remembered per walk (registers)
+#endif
 #ifndef PT_MESH_WAVES
 #define PT_MESH_WAVES 4                      // waves per SIMD k_mesh is register-budgeted for
 #endif
@@ -891,8 +905,14 @@ constexpr int MQ_SLOTS = 128;                 // ray ring entries per wave (a ti
 constexpr int TQ_SLOTS = 512;                 // triangle ring entries per wave (a step adds <= 64 * 2 * LEAF_MAX while < 64 wait)
 constexpr int MQ_RAY_WORDS = 8 * MQ_SLOTS;    // src, path, origin xyz, direction xyz
 constexpr int MQ_WORDS = MQ_RAY_WORDS + TQ_SLOTS + 2 * 64;   // + triangle ring + the 64 per-lane best keys (u64)
-constexpr int MQ_STEPS = 4;                   // walk steps between two looks at the ray ring (8: same speed)
-constexpr int MQ_LEAVE = 24;                  // lanes still busy when the wave goes back to scanning
+#ifndef PT_MQ_STEPS
+#define PT_MQ_STEPS 8
+#endif
+#ifndef PT_MQ_LEAVE
+#define PT_MQ_LEAVE 56
+#endif
+constexpr int MQ_STEPS = PT_MQ_STEPS;         // walk steps between two looks at the ray ring
+constexpr int MQ_LEAVE = PT_MQ_LEAVE;         // lanes still busy when the wave goes back to scanning
 constexpr unsigned long long TRI_KEY_NONE = (0x7f7fffffull << 32) | 0xffffffffull;   // bary.z = FLT_MAX, no triangle
 static_assert(2 * PT_LEAF_MAX * 64 + 63 <= TQ_SLOTS, "a step's triangles must fit beside the waiting ones");
 
@@ -904,6 +924,7 @@ struct MeshWalker {
     int mesh, node, steps;            // position in SceneDev::bvh_meshes, record in that mesh's tree
     int geom, root;                   // of the current mesh
     uint32_t ticket;                  // triangle-ring index past this lane's last queued triangle
+    int skip[PT_SKIP_PAIRS], to[PT_SKIP_PAIRS];   // newest (missed far sibling -> where its miss link leads) pairs, newest first
     float best_t; int best_geom, best_tri;   // best over the meshes finished so far (world distance, geom order)
 };
 struct MeshRings { uint32_t q_head, q_total, t_head, t_total; };   // wave-uniform ring cursors
@@ -927,7 +948,11 @@ __device__ __forceinline__ void tri_pass(float *mq, uint32_t head, uint32_t coun
     const int owner = (int)(e & 63u);
     const f3 ro = ptd::mk(__shfl(w.ray.ro.x, owner), __shfl(w.ray.ro.y, owner), __shfl(w.ray.ro.z, owner));
     const f3 rd = ptd::mk(__shfl(w.ray.rd.x, owner), __shfl(w.ray.rd.y, owner), __shfl(w.ray.rd.z, owner));
+#ifdef PT_EXPERIMENT_NO_TRIS
+    if (false) {
+#else
     if (on) {
+#endif
         const float4 *t4 = reinterpret_cast<const float4 *>(a.scene.bvh_tris + (size_t)(e >> 6) * TRI_WORDS);
         const float4 P = t4[0], Q = t4[1], S = t4[2];
         float tz;
@@ -963,6 +988,8 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &
                 w.ray = mesh_ray(a.scene, m.x, ptd::mk(mq[2 * MQ_SLOTS + s], mq[3 * MQ_SLOTS + s], mq[4 * MQ_SLOTS + s]),
                                  ptd::mk(mq[5 * MQ_SLOTS + s], mq[6 * MQ_SLOTS + s], mq[7 * MQ_SLOTS + s]));
                 w.mesh = 0; w.geom = m.x; w.root = m.y; w.node = 0; w.steps = 0; w.ticket = rg.t_head;
+#pragma unroll
+                for (int u = 0; u < PT_SKIP_PAIRS; ++u) { w.skip[u] = -1; w.to[u] = -1; }
                 w.best_t = FLT_MAX; w.best_geom = -1; w.best_tri = -1;
                 keys[lane] = TRI_KEY_NONE;
                 w.have = true;
@@ -980,7 +1007,30 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &
                 const BvhRec rec = bvh_fetch(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, w.node, w.ray.oct);
                 // prune against the best bary.z the tested triangles have produced so far (it may lag: conservative)
                 const float best = __uint_as_float((uint32_t)(keys[lane] >> 32));
-                w.node = bvh_decide(rec, w.ray, best + a.scene.bvh_prune, leaf_l, leaf_r);
+                int skip;
+                w.node = bvh_decide(rec, w.ray, best + a.scene.bvh_prune, leaf_l, leaf_r, &skip);
+                // A missed far sibling would still be entered through the miss links of the subtree walked first,
+                // only to fail both of its box tests.  Its own miss link equals this record's, which is known here:
+                // remember the pair and jump over the sibling when the walk arrives at it.  PT_SKIP_PAIRS pairs are kept
+                // in registers (the deepest ones, where most visits happen); a forgotten pair only costs the visit.
+                if (skip >= 0) {
+#pragma unroll
+                    for (int u = PT_SKIP_PAIRS - 1; u > 0; --u) { w.skip[u] = w.skip[u - 1]; w.to[u] = w.to[u - 1]; }
+                    w.skip[0] = skip; w.to[0] = rec.miss;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PT_SKIP_PAIRS; ++u)
+                        if (w.node >= 0 && w.node == w.skip[0]) {
+                            w.node = w.to[0];
+#pragma unroll
+                            for (int v = 0; v + 1 < PT_SKIP_PAIRS; ++v) { w.skip[v] = w.skip[v + 1]; w.to[v] = w.to[v + 1]; }
+                            w.skip[PT_SKIP_PAIRS - 1] = -1;
+                        }
+                }
+#ifdef PT_MESH_STATS
+                if (leaf_l < 0 && leaf_r < 0 && w.node == rec.miss) atomicAdd(&a.ctl->keep[12], 1u);   // nothing hit
+                if (leaf_l >= 0 || leaf_r >= 0) atomicAdd(&a.ctl->keep[13], 1u);                        // a leaf hit
+#endif
                 if (++w.steps > a.scene.bvh_guard) w.node = -1;        // NaN rays: every record is "hit"
             }
 #ifdef PT_MESH_STATS
@@ -1029,6 +1079,8 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &
                     w.geom = m.x; w.root = m.y;
                     w.ray = mesh_ray(a.scene, m.x, w.ray.ro, w.ray.rd);
                     w.node = 0; w.steps = 0;
+#pragma unroll
+                    for (int u = 0; u < PT_SKIP_PAIRS; ++u) w.skip[u] = -1;
                     keys[lane] = TRI_KEY_NONE;
                 } else {
                     if (w.best_geom >= 0) {
@@ -1063,6 +1115,8 @@ __global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
     w.have = false; w.src = 0; w.path = 0; w.ray = bvh_ray(ptd::mk(0, 0, 0), ptd::mk(0, 0, 1), ptd::mk(0, 0, 0), ptd::mk(1, 1, 1));
     w.mesh = 0; w.node = -1; w.steps = 0; w.ticket = 0; w.best_t = FLT_MAX; w.best_geom = -1; w.best_tri = -1;
     w.geom = 0; w.root = 0;
+#pragma unroll
+    for (int u = 0; u < PT_SKIP_PAIRS; ++u) { w.skip[u] = -1; w.to[u] = -1; }
     for (uint32_t r = 0; r < R; ++r) {
         // Tiles are dealt round-robin, not in runs: the pool keeps pixel order through every (stable) compaction,
         // so the rays that reach a mesh -- and the ones that leave its surface -- sit in neighbouring tiles; a run
@@ -1106,6 +1160,9 @@ __global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
             cand |= tn <= tf;
         }
         cand = cand && active;
+#ifdef PT_EXPERIMENT_SCAN_ONLY
+        cand = false;
+#endif
         const uint64_t m = __ballot(cand);
         if (m) {
             if (cand) {

@@ -9,6 +9,9 @@ namespace {
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4                     // waves per SIMD the bounce kernels are register-budgeted for
 #endif
+#ifndef PT_PRE_WAVES
+#define PT_PRE_WAVES 5                       // k_bounce<MESH_PRE>: 97 VGPRs unconstrained; budgeted for 5 waves per SIMD (+6 %)
+#endif
 constexpr int BLOCK = 256;                 // 4 waves of 64
 constexpr int WAVES = BLOCK / 64;
 constexpr int TILE = 64;                   // paths per tile = one wave64

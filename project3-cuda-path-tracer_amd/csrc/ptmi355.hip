@@ -454,7 +454,7 @@ int collect_stats(void) {
             c.keep[0], c.keep[1], c.keep[2], c.keep[2] ? (double)c.keep[1] / c.keep[2] : 0.0);
     {
         float f[7]; memcpy(f, &c.keep[4], sizeof f);
-        fprintf(stderr, "[ptmi355] longest walk %u records\n", c.keep[14]);
+        fprintf(stderr, "[ptmi355] longest walk %u records; records where nothing was hit: %u, with a leaf hit: %u\n", c.keep[14], c.keep[12], c.keep[13]);
         fprintf(stderr, "[ptmi355] walks past 5000 steps: %u; last: o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) tz=%g depth %u\n", c.keep[3],
                 f[0], f[1], f[2], f[3], f[4], f[5], f[6], c.keep[11]);
     }
