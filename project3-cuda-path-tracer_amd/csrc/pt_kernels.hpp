@@ -64,8 +64,6 @@ __device__ __forceinline__ void stage_scene(float *lds_mats, const SceneDev &sc)
     __syncthreads();
 }
 
-// `uniform_trips` != 0: every wave of the block executes the same geom sequence (needed when
-// meshes stage triangle tiles through LDS with block barriers); `active` masks idle lanes.
 // Geom records are read through the CONSTANT address space: the array is immutable for the
 // lifetime of the launch and the address is wave-uniform, so the loads become s_load_dwordxN
 // (scalar cache -> SGPRs) instead of per-lane vector loads.

@@ -272,6 +272,63 @@ def test_lifecycle_and_errors(pt, scenes):
     pt.pathtraceFree()
 
 
+def _resized(cam, w, h):
+    """The reference camera at another resolution: pixelLength follows scene.cpp:131-135 (2 * tan(fov) / resolution)."""
+    c = cam.copy()
+    c["resolution"][0] = (w, h)
+    yscaled = np.tan(np.float32(c["fov"][0][1]) * np.float32(np.pi / 180))
+    xscaled = np.float32(yscaled * np.float32(w) / np.float32(h))
+    c["pixelLength"][0] = (np.float32(2 * xscaled / np.float32(w)), np.float32(2 * yscaled / np.float32(h)))
+    return c
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (65, 1), (63, 2), (1, 130)])
+def test_ragged_frames(pt, po, scenes, shape):
+    """Frames that are not a multiple of the 64-path tile (down to one pixel), depth 1 and the full depth,
+    every pipeline: live counts and image equal the oracle's."""
+    s = scenes["cornell_glass_64"]
+    cam = _resized(s["camera"], *shape)
+    for depth in (1, s["depth"]):
+        scene = pt.Scene(s["geoms"], s["materials"], cam, depth)
+        for flags, oflags in ((pt.PT_COMPACT, po.F_COMPACT), (0, 0), (pt.PT_COMPACT | pt.PT_SORT_MATERIAL, po.F_COMPACT | po.F_SORT),
+                              (pt.PT_COMPACT | pt.PT_CACHE_FIRST, po.F_COMPACT)):
+            ref = po.Tracer(s["geoms"], s["materials"], cam, depth, flags=oflags, trig=po.TRIG_SHARED)
+            pt.pathtraceInit(scene, flags=flags, max_batch=3)
+            n = shape[0] * shape[1]
+            img = np.zeros((n, 3), dtype=np.float32)
+            for it in (1, 2):
+                img = pt.pathtrace(None, 0, it)
+                st = ref.iterate(it)
+                assert list(pt.get_stats().live[:depth]) == list(st.live[:depth])
+            pt.trace_batch(3, 3, img)
+            for it in (3, 4, 5):
+                ref.iterate(it)
+            assert img.tobytes() == ref.image.tobytes()
+            pt.pathtraceFree()
+
+
+def test_degenerate_scenes(pt, po, scenes):
+    """No geometry at all (every ray misses), a lone light, and a scene whose only object is behind the camera."""
+    s = scenes["cornell_64"]
+    light = s["geoms"][:1].copy()
+    behind = s["geoms"][6:7].copy()
+    behind["translation"][0] = (0, 5, 30)
+    behind["transform"][0][3][:3] = (0, 5, 30)
+    inv = np.linalg.inv(behind["transform"][0].T.astype(np.float64))
+    behind["inverseTransform"][0] = inv.T.astype(np.float32)
+    behind["invTranspose"][0] = inv.astype(np.float32)
+    for geoms in (s["geoms"][:0], light, behind):
+        scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"])
+        ref = po.Tracer(np.ascontiguousarray(geoms).view(po.GEOM_DT), s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
+        for it in (1, 2):
+            img = pt.pathtrace(None, 0, it)
+            st = ref.iterate(it)
+            assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
+            assert img.tobytes() == ref.image.tobytes()
+        pt.pathtraceFree()
+
+
 def test_pbo_device_pointer(pt, scenes, golden):
     """pathtrace() writes the tonemapped RGBA8 into a device buffer (the mapped PBO)."""
     import torch
