@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s of the wavefront path tracer on the BASELINE.json workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config c2|c3|c5tile]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config c2|c3|c4|c5]
 
 A *step* is one pass of the hot path over one batch of synthetic input: B
 iterations (samples per pixel) of the 800x800 depth-8 Cornell box with the
@@ -50,9 +50,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="iterations (spp) per step per full frame")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2: BASELINE configs[1] (the metric's workload); c3: glass ball 1280x720 depth 16; "
-                         "c4: Cornell + 100k-triangle mesh (parity-test cases, selectable for measurement)")
+                         "c4: Cornell + 100k-triangle mesh; c5: 3840x2160 Cornell (parity-test cases, selectable for measurement)")
     ap.add_argument("--flags", default="compact", help="comma list: compact,sort,unfused,cache,bvh,aa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -92,7 +92,7 @@ def main():
 
     pt = ge.load_package()
     pt.library()
-    scene_name = {"c2": "cornell", "c3": "cornell_glass", "c4": "cornell"}[args.config]
+    scene_name = {"c2": "cornell", "c3": "cornell_glass", "c4": "cornell", "c5": "cornell_4k"}[args.config]
     scene = load_scene(pt, scene_name)
     if args.config == "c4":       # BASELINE configs[3]: naive loop over a 100 032-triangle UV sphere, material 1
         tris = pt.meshes.uv_sphere(n_lat=97, n_lon=521)

@@ -23,3 +23,4 @@ b c3_nosort --config c3 --flags compact --no-cpu-baseline
 b c4_bvh --config c4 --flags compact,bvh --steps 10 --warmup 2 --no-cpu-baseline
 b c4_loop --config c4 --flags compact --steps 2 --warmup 1 --batch 1 --no-cpu-baseline
 b c2_aa --config c2 --flags compact,aa --no-cpu-baseline
+b c5 --config c5 --batch 4 --steps 5 --warmup 1 --no-cpu-baseline
