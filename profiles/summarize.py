@@ -83,4 +83,4 @@ def traffic_json(d, out_path, meta):
 if __name__ == "__main__":
     main(sys.argv[1])
     if len(sys.argv) > 2:
-        traffic_json(sys.argv[1], sys.argv[2], {"config": "c2", "batch": 16, "flags": "compact"})
+        traffic_json(sys.argv[1], sys.argv[2], {"config": "c2", "batch": 64, "flags": "compact"})   # bench.py defaults
