@@ -422,6 +422,33 @@ def test_mesh_bvh_vs_oracle(pt, po, scenes, size):
         pt.pathtraceFree()
 
 
+def test_mesh_bvh_two_meshes_fused(pt, po, scenes):
+    """Two meshes (one nested inside the glass ball's silhouette, one overlapping the first) through the mesh
+    pre-pass: every walk visits both trees and keeps the nearer hit, geom order on ties."""
+    s = scenes["cornell_glass_64"]
+    a = pt.meshes.uv_sphere(center=(1.5, 3.0, 1.0), radius=1.5, n_lat=20, n_lon=40)
+    b = pt.meshes.uv_sphere(center=(2.2, 3.5, 1.5), radius=1.2, n_lat=14, n_lon=24)
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], a, material_id=1)
+    geoms, tris, meshes = pt.meshes.add_mesh(geoms, b, material_id=4, existing_triangles=tris, existing_meshes=meshes)
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
+    for flags, oflags in ((pt.PT_COMPACT, po.F_COMPACT), (0, 0)):
+        ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], s["depth"], flags=oflags, trig=po.TRIG_SHARED,
+                        tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
+        pt.pathtraceInit(scene, flags=flags | pt.PT_MESH_BVH, max_batch=3)
+        n = scene.resolution[0] * scene.resolution[1]
+        img = np.zeros((n, 3), dtype=np.float32)
+        for it in (1, 2):
+            img = pt.pathtrace(None, 0, it)
+            st = ref.iterate(it)
+            assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
+            assert img.tobytes() == ref.image.tobytes()
+        pt.trace_batch(3, 3, img)
+        for it in (3, 4, 5):
+            ref.iterate(it)
+        assert img.tobytes() == ref.image.tobytes()
+        pt.pathtraceFree()
+
+
 def test_mesh_bvh_adversarial_rays(pt, po, scenes):
     """Rays aimed exactly at vertices and edges (where several triangles tie or just miss), from outside and
     from inside the mesh, plus two meshes in one scene: winner index and distance come out as the oracle's loop
