@@ -721,14 +721,106 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
 // MODE_CACHE0  : bounce 0 with PT_CACHE_FIRST: the per-pixel intersection cache (INSTRUCTION.md:87-89)
 enum { MODE_FUSED = 0, MODE_ISECT = 1, MODE_CACHE0 = 2 };
 
+// per-launch constants of a wave for bounce_tile
+struct TileCtx {
+    float *mats; const float *gf; float *wq; float *tri_lds;   // LDS carve: materials, per-geom gather records, hit-tail ring, triangle tile
+    int lane, iter0;
+};
+
+// One 64-path tile of one bounce: load (or generate) the paths, intersect, shade / scatter, write the final
+// colour of the paths that end here and append the survivors at dst_base + packed (wave64 ballot + popcount
+// rank).  `i` = logical path index (what MODE_ISECT planes and the mesh mask are keyed by), `src` = pool slot.
+template <int MODE, bool COMPACT, int MESH>
+__device__ __forceinline__ void bounce_tile(const BounceArgs &a, const TileCtx &c, const Pool &in, const Pool &out, int depth,
+                                            bool gen_rays, uint32_t tile, uint32_t i, uint32_t src, bool have, bool active,
+                                            uint32_t n, uint32_t dst_base, uint32_t &packed, uint32_t &traced) {
+    const int lane = c.lane;
+    uint32_t pid = DEAD_PID;
+    f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1), col = ptd::mk(1.0f, 1.0f, 1.0f);
+    if (active) {
+        if (gen_rays) {
+            pid = i;
+        } else {
+            // all ten fields of the slot in one burst of loads (one memory latency per tile)
+            char *q = in.slot(src);
+            pid = ppid(q);
+            ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
+            rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
+            col = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8));
+            if (pid == DEAD_PID) active = false;
+        }
+    }
+    uint32_t smp = 0;
+    int pixel = 0;
+    if (active) {
+        smp = sample_of(a.map, pid);
+        pixel = local_to_pixel(a.map, (int)(pid - smp * (uint32_t)a.map.tile_pixels));
+        if (gen_rays) camera_ray(a.cam, a.lens, a.trace_depth, c.iter0 + (int)smp, pixel, a.map.W, ro, rd);
+    }
+    float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
+    if (MODE == MODE_FUSED) {
+        ptd::Hit h;
+        const float *gsrc = a.scene.geoms;
+        const float4 *pre_hit = nullptr;
+        if (MESH == MESH_PRE) {
+            // lanes of this tile for which k_mesh found a mesh hit; the mask is consumed (cleared) here
+            const unsigned long long mm = a.mesh_mask[tile];
+            if (mm) {
+                if (lane == 0) a.mesh_mask[tile] = 0ull;
+                if (active && ((mm >> lane) & 1ull)) pre_hit = a.mesh_hit + src;
+            }
+        }
+        intersect_scene<MESH>(gsrc, a.scene, c.tri_lds, active, ro, rd, h, c.wq, c.gf, pre_hit);
+        if (active) { resolve_hit(gsrc, c.gf, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
+    } else if (active) {
+        // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
+        const uint32_t q = (MODE == MODE_CACHE0) ? pid - smp * (uint32_t)a.map.tile_pixels : i;
+        t = at(a.isect.plane(0), q);
+        nrm = ptd::mk(at(a.isect.plane(1), q), at(a.isect.plane(2), q), at(a.isect.plane(3), q));
+        const int m = at(a.isect.mat(), q);
+        mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
+    }
+    bool alive = false;
+    ptd::PathState ps;
+    ps.o = ro; ps.d = rd; ps.c = col;
+    if (active) {
+        alive = ptd::shade_scatter(ps, t, nrm, mat, outside, c.mats, c.iter0 + (int)smp, pixel, depth,
+                                   depth == a.trace_depth - 1);
+        if (!alive) {
+            at(a.fin, pid) = ps.c.x; at(a.fin + (size_t)in.cap, pid) = ps.c.y;
+            at(a.fin + 2 * (size_t)in.cap, pid) = ps.c.z;
+        }
+    }
+    // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
+    const uint64_t bal = __ballot(alive);
+    const uint64_t act = __ballot(active);
+    traced += (uint32_t)__popcll((unsigned long long)act);
+    uint32_t dst = i;
+    if (COMPACT) {
+        dst = dst_base + packed + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
+        packed += (uint32_t)__popcll((unsigned long long)bal);
+    }
+    if (alive) {
+        char *q = out.slot(dst);
+        pf(q, 0) = ps.o.x; pf(q, 1) = ps.o.y; pf(q, 2) = ps.o.z;
+        pf(q, 3) = ps.d.x; pf(q, 4) = ps.d.y; pf(q, 5) = ps.d.z;
+        pf(q, 6) = ps.c.x; pf(q, 7) = ps.c.y; pf(q, 8) = ps.c.z;
+        ppid(q) = pid;
+    } else if (!COMPACT && have && i < n) {
+        out.pid(dst) = DEAD_PID;
+    }
+}
+
 template <int MODE, bool COMPACT, int MESH>
 __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
     float *mats = lds_raw + LDS_CTL_WORDS;
-    const float *gf = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
-    float *wq = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
-    float *tri_lds = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + WAVES * Q_WORDS;
+    TileCtx c;
+    c.mats = mats;
+    c.gf = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
+    c.wq = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
+    c.tri_lds = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + WAVES * Q_WORDS;
 #ifdef PT_STAMPS
 #define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.depth == PT_STAMPS) a.ctl->stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -738,15 +830,15 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
     stage_scene(mats, a.scene);
     STAMP(1);
     const int lane = threadIdx.x & 63;
+    c.lane = lane;
     const uint32_t W = gridDim.x * WAVES;
     const uint32_t wid = run_id();
-    const int iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;       // graph replay: arguments are frozen
+    c.iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;       // graph replay: arguments are frozen
     const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);                        // logical tiles per wave (one contiguous run)
     const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
     const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
-    const bool last_bounce = (a.depth == a.trace_depth - 1);
     uint32_t traced = 0;
     uint32_t packed = 0;                                         // survivors this wave has written (wave-uniform)
     uint32_t cur = 0;                                            // source range of the run's current position
@@ -761,86 +853,11 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
         if (MESH != MESH_TILES && tile >= tiles) break;
         const bool have = tile < tiles;
         const uint32_t i = tile * TILE + lane;                    // logical path index
-        bool active = have && i < n;
+        const bool active = have && i < n;
         uint32_t src = i;
         if (packed_in && have) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
-        uint32_t pid = DEAD_PID;
-        f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1), col = ptd::mk(1.0f, 1.0f, 1.0f);
-        if (active) {
-            if (a.gen_rays) {
-                pid = i;
-            } else {
-                // all ten fields of the slot in one burst of loads (one memory latency per tile)
-                char *q = a.in.slot(src);
-                pid = ppid(q);
-                ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
-                rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
-                col = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8));
-                if (pid == DEAD_PID) active = false;
-            }
-        }
-        uint32_t smp = 0;
-        int pixel = 0;
-        if (active) {
-            smp = sample_of(a.map, pid);
-            pixel = local_to_pixel(a.map, (int)(pid - smp * (uint32_t)a.map.tile_pixels));
-            if (a.gen_rays) camera_ray(a.cam, a.lens, a.trace_depth, iter0 + (int)smp, pixel, a.map.W, ro, rd);
-        }
-        if (r == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(3); }
-        float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
-        if (MODE == MODE_FUSED) {
-            ptd::Hit h;
-            const float *gsrc = a.scene.geoms;
-            const float4 *pre_hit = nullptr;
-            if (MESH == MESH_PRE) {
-                // lanes of this tile for which k_mesh found a mesh hit; the mask is consumed (cleared) here
-                const unsigned long long mm = a.mesh_mask[tile];
-                if (mm) {
-                    if (lane == 0) a.mesh_mask[tile] = 0ull;
-                    if (active && ((mm >> lane) & 1ull)) pre_hit = a.mesh_hit + src;
-                }
-            }
-            intersect_scene<MESH>(gsrc, a.scene, tri_lds, active, ro, rd, h, wq, gf, pre_hit);
-            if (active) { resolve_hit(gsrc, gf, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
-        } else if (active) {
-            // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
-            const uint32_t q = (MODE == MODE_CACHE0) ? pid - smp * (uint32_t)a.map.tile_pixels : i;
-            t = at(a.isect.plane(0), q);
-            nrm = ptd::mk(at(a.isect.plane(1), q), at(a.isect.plane(2), q), at(a.isect.plane(3), q));
-            const int m = at(a.isect.mat(), q);
-            mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
-        }
-        if (r == 0) STAMP(4);
-        bool alive = false;
-        ptd::PathState ps;
-        ps.o = ro; ps.d = rd; ps.c = col;
-        if (active) {
-            alive = ptd::shade_scatter(ps, t, nrm, mat, outside, mats, iter0 + (int)smp, pixel, a.depth,
-                                       last_bounce);
-            if (!alive) {
-                at(a.fin, pid) = ps.c.x; at(a.fin + (size_t)a.in.cap, pid) = ps.c.y;
-                at(a.fin + 2 * (size_t)a.in.cap, pid) = ps.c.z;
-            }
-        }
-        if (r == 0) STAMP(5);
-        // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
-        const uint64_t bal = __ballot(alive);
-        const uint64_t act = __ballot(active);
-        traced += (uint32_t)__popcll((unsigned long long)act);
-        uint32_t dst = i;
-        if (COMPACT) {
-            dst = wid * R * TILE + packed + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
-            packed += (uint32_t)__popcll((unsigned long long)bal);
-        }
-        if (alive) {
-            char *q = a.out.slot(dst);
-            pf(q, 0) = ps.o.x; pf(q, 1) = ps.o.y; pf(q, 2) = ps.o.z;
-            pf(q, 3) = ps.d.x; pf(q, 4) = ps.d.y; pf(q, 5) = ps.d.z;
-            pf(q, 6) = ps.c.x; pf(q, 7) = ps.c.y; pf(q, 8) = ps.c.z;
-            ppid(q) = pid;
-        } else if (!COMPACT && have && i < n) {
-            a.out.pid(dst) = DEAD_PID;
-        }
+        bounce_tile<MODE, COMPACT, MESH>(a, c, a.in, a.out, a.depth, a.gen_rays != 0, tile, i, src, have, active, n,
+                                         wid * R * TILE, packed, traced);
     }
     STAMP(6);
     // paths traced this bounce: with compaction it is simply the live count; otherwise count the alive
@@ -880,6 +897,65 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
             if (threadIdx.x == 0 && a.depth == PT_STAMPS) { a.ctl->stamp[8] = t0; a.ctl->stamp[9] = __builtin_amdgcn_s_memrealtime(); }
 #endif
         }
+    }
+}
+
+// A whole batch in ONE launch, for small batches (the reference's calling pattern is one iteration per
+// call): at 1 spp every bounce kernel is ~20 us of fixed cost (launch, scene staging, directory search,
+// last-workgroup scan) around a few microseconds of work.  Here every wave generates the camera rays of its
+// run of tiles and then keeps ITS OWN survivors through all the bounces: bounce d+1 reads the span the wave
+// packed at bounce d (the two pools ping-pong inside the launch), so there is no exchange between waves, no
+// directory and no barrier.  The concatenation of the spans is still the stable partition's order; the paths
+// just are not dealt out again after every bounce, which costs load balance (a wave whose pixels live long
+// works longer) -- the price that makes this the small-batch path only.  Traced counts go to 32 partial sums
+// per bounce (Control::bucket[d][1]; a same-address atomic per wave would serialise), folded by k_gather.
+__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    float *mats = lds_raw + LDS_CTL_WORDS;
+    TileCtx c;
+    c.mats = mats;
+    c.gf = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
+    c.wq = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
+    c.tri_lds = nullptr;
+    stage_scene(mats, a.scene);
+    const int lane = threadIdx.x & 63;
+    c.lane = lane;
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t wid = run_id();
+    c.iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;
+    const uint32_t n = a.pool_n;
+    const uint32_t tiles = (n + TILE - 1) / TILE;
+    const uint32_t R = range_tiles(n, W);
+    const uint32_t base = wid * R * TILE;                         // this wave's span in both pools
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = n;
+    Pool in = a.in, out = a.out;
+    uint32_t count = 0;                                           // paths of this wave entering the bounce (d > 0)
+    for (int d = 0; d < a.trace_depth; ++d) {
+        uint32_t traced = 0, packed = 0;
+        if (d == 0) {
+            for (uint32_t r = 0; r < R; ++r) {
+                const uint32_t tile = wid * R + r;
+                if (tile >= tiles) break;
+                const uint32_t i = tile * TILE + lane;
+                bounce_tile<MODE_FUSED, true, MESH_NONE>(a, c, in, out, 0, true, tile, i, i, true, i < n, n, base, packed, traced);
+            }
+        } else {
+            for (uint32_t t = 0; t * TILE < count; ++t) {
+                const uint32_t k = t * TILE + lane;
+                bounce_tile<MODE_FUSED, true, MESH_NONE>(a, c, in, out, d, false, 0, base + k, base + k, true, k < count, n, base,
+                                                         packed, traced);
+            }
+        }
+        if (lane == 0 && traced)
+            atomicAdd(&a.ctl->bucket[d][1][(wid % ELECT_BUCKETS) * 16], traced);
+        count = packed;
+        if (count == 0) break;
+        const Pool tmp = in; in = out; out = tmp;
+        // the span this wave just wrote is read back by its own (other) lanes.  Workgroup scope is enough -- the
+        // wave stays on its CU, whose vector L1 sees its own write-through stores -- and costs only the wait; an
+        // agent-scope fence writes back / invalidates the L2 and made the launch 4x slower.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
@@ -1247,10 +1323,16 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const fl
 // finalGather (pathtrace.cu:269-278): image[pixelIndex] += colour, one add per
 // pixel per iteration, samples added in iteration order
 __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin, uint32_t cap, TileMap map,
-                                                  int count, const Control *ctl, Persist *per, int depths,
-                                                  uint32_t fake_rays) {
+                                                  int count, Control *ctl, Persist *per, int depths,
+                                                  uint32_t fake_rays, int partial_counts) {
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
     if (j == 0) {                    // fold this batch's ray count into the persistent counter
+        if (partial_counts)          // k_iteration left 32 partial sums per bounce
+            for (int d = 0; d < depths; ++d) {
+                uint32_t s = 0;
+                for (int k = 0; k < ELECT_BUCKETS; ++k) s += ctl->bucket[d][1][k * 16];
+                ctl->alive[d] = s;
+            }
         unsigned long long r = fake_rays;
         for (int d = 0; d < depths; ++d) r += ctl->alive[d];
         per->rays += r;

@@ -20,6 +20,17 @@ def pt():
     p.pathtraceFree()
 
 
+@pytest.fixture(autouse=True, params=["one launch per bounce", "small batches in one launch"])
+def launch_plan(request, monkeypatch):
+    """Every test runs under both launch plans: a kernel per bounce for every batch (PTMI355_WHOLE_MAX=0), and
+    the default, where batches of up to 3 M paths run all their bounces in one launch (k_iteration)."""
+    if request.param == "one launch per bounce":
+        monkeypatch.setenv("PTMI355_WHOLE_MAX", "0")
+    else:
+        monkeypatch.delenv("PTMI355_WHOLE_MAX", raising=False)
+    return request.param
+
+
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
