@@ -182,6 +182,28 @@ def test_c2_full_iteration(pt, po, scenes, golden, flags_name):
     pt.pathtraceFree()
 
 
+def test_c2_forty_iterations_in_batches(pt, po, scenes):
+    """The bench workload at length: 40 iterations of C2 traced as batches of 16 + 16 + 8 paths pools against the
+    oracle's 40 sequential iterations (all host threads): total rays and every pixel of the running sum."""
+    import os
+    s = scenes["cornell"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=16)
+    img = np.zeros((n, 3), dtype=np.float32)
+    pt.trace_batch(1, 16, None)
+    pt.trace_batch(17, 16, None)
+    pt.trace_batch(33, 8, img)
+    rays = pt.get_stats().total_rays
+    pt.pathtraceFree()
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED)
+    want = 0
+    for it in range(1, 41):
+        want += ref.iterate(it, threads=os.cpu_count() or 8).rays
+    assert rays == want
+    assert img.tobytes() == ref.image.tobytes()
+
+
 def test_c2_compaction_order_hash(pt, po, scenes, golden):
     z = golden["completion"]
     s = scenes["cornell"]
