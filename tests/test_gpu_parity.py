@@ -530,6 +530,46 @@ def test_mesh_bvh_two_meshes_fused(pt, po, scenes):
         pt.pathtraceFree()
 
 
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_mesh_bvh_triangle_soup(pt, po, scenes, seed):
+    """Random triangle soups -- slivers, zero-area and very large triangles, heavy overlap, coplanar duplicates
+    (exact ties between triangles) -- through the hierarchy and the mesh pre-pass vs the oracle's loop."""
+    rng = np.random.default_rng(7000 + seed)
+    s = scenes["cornell_64"]
+    n = int(rng.integers(200, 2500))
+    c = rng.uniform(-3, 3, (n, 3)) + (0, 5, 0)
+    size = 10 ** rng.uniform(-2.5, 0.6, (n, 1))
+    v0 = c + rng.normal(size=(n, 3)) * size
+    v1 = c + rng.normal(size=(n, 3)) * size
+    v2 = c + rng.normal(size=(n, 3)) * size
+    sl = rng.random(n) < 0.1
+    v2[sl] = v1[sl] + (v1[sl] - v0[sl]) * 1e-4 + rng.normal(size=(sl.sum(), 3)) * 1e-6        # slivers
+    dg = rng.random(n) < 0.03
+    v2[dg] = v1[dg]                                                                          # zero area
+    tris = np.zeros(n + 40, dtype=pt.TRI_DT)
+    tris["v0"][:n], tris["v1"][:n], tris["v2"][:n] = v0, v1, v2
+    dup = rng.integers(n, size=40)                                                           # exact duplicates: ties
+    tris[n:] = tris[dup]
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"][:6], tris, material_id=int(rng.integers(1, 5)))
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
+    ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED,
+                    tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_MESH_BVH, max_batch=2)
+    for it in (1, 2):
+        img = pt.pathtrace(None, 0, it)
+        st = ref.iterate(it)
+        assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
+        assert img.tobytes() == ref.image.tobytes()
+    pt.pathtraceFree()
+    # the camera rays' winners themselves (inline walk of the unfused path)
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | pt.PT_MESH_BVH)
+    rays = po.generate_rays(s["camera"], s["depth"])
+    got, _ = pt.intersect_once(rays.view(pt.PATH_DT))
+    want, _ = po.compute_intersections(rays, geoms.view(po.GEOM_DT), tris.view(po.TRI_DT), meshes.view(po.MESH_DT))
+    assert got.tobytes() == want.tobytes()
+    pt.pathtraceFree()
+
+
 def test_mesh_bvh_adversarial_rays(pt, po, scenes):
     """Rays aimed exactly at vertices and edges (where several triangles tie or just miss), from outside and
     from inside the mesh, plus two meshes in one scene: winner index and distance come out as the oracle's loop
