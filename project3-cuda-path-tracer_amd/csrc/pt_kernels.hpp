@@ -187,11 +187,7 @@ __device__ __forceinline__ int bvh_decide(const BvhRec &rec, const BvhRay &r, fl
 }
 __device__ __forceinline__ void bvh_leaf(const float *__restrict__ btris, const BvhRay &r, int leaf, float &best, int &best_i) {
     const float4 *t4 = reinterpret_cast<const float4 *>(btris + (size_t)(leaf & 0xffffff) * TRI_WORDS);
-#ifdef PT_EXPERIMENT_NO_TRIS
-    const int cnt = 0;
-#else
     const int cnt = leaf >> 24;
-#endif
 #ifdef PT_LEAF_UNROLL
 #pragma unroll PT_LEAF_UNROLL
 #endif
@@ -1022,11 +1018,7 @@ __device__ __forceinline__ void tri_pass(float *mq, uint32_t head, uint32_t coun
     const int owner = (int)(e & 63u);
     const f3 ro = ptd::mk(__shfl(w.ray.ro.x, owner), __shfl(w.ray.ro.y, owner), __shfl(w.ray.ro.z, owner));
     const f3 rd = ptd::mk(__shfl(w.ray.rd.x, owner), __shfl(w.ray.rd.y, owner), __shfl(w.ray.rd.z, owner));
-#ifdef PT_EXPERIMENT_NO_TRIS
-    if (false) {
-#else
     if (on) {
-#endif
         const float4 *t4 = reinterpret_cast<const float4 *>(a.scene.bvh_tris + (size_t)(e >> 6) * TRI_WORDS);
         const float4 P = t4[0], Q = t4[1], S = t4[2];
         float tz;
@@ -1234,9 +1226,6 @@ __global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
             cand |= tn <= tf;
         }
         cand = cand && active;
-#ifdef PT_EXPERIMENT_SCAN_ONLY
-        cand = false;
-#endif
         const uint64_t m = __ballot(cand);
         if (m) {
             if (cand) {
