@@ -1,0 +1,17 @@
+#!/bin/bash
+# CPU-side sanitizer pass (GPU AddressSanitizer is not available on this pool): the host code -- oracle, scene
+# loader / image writer, hierarchy builder -- under ASan + UBSan.  Usage: bash tests/tools/run_sanitizers.sh
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+T=$(mktemp -d)
+SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
+g++ -std=c++17 $SAN -o "$T/bvh_harness" "$ROOT/tests/tools/bvh_harness.cpp" && "$T/bvh_harness"
+gcc -std=c11 $SAN -fPIC -ffp-contract=off -fno-fast-math -pthread -shared -o "$T/libptoracle.so" "$ROOT/oracle/ptoracle.c" -lm -lpthread
+g++ -std=c++17 $SAN -fPIC -ffp-contract=off -shared -I"$ROOT/include" -o "$T/libpthost.so" "$ROOT/project3-cuda-path-tracer_amd/host/pthost.cpp"
+cp "$ROOT/oracle/libptoracle.so" "$T/keep_oracle.so"; cp "$ROOT/project3-cuda-path-tracer_amd/libpthost.so" "$T/keep_host.so"
+restore() { cp "$T/keep_oracle.so" "$ROOT/oracle/libptoracle.so"; cp "$T/keep_host.so" "$ROOT/project3-cuda-path-tracer_amd/libpthost.so"; }
+trap restore EXIT
+cp "$T/libptoracle.so" "$ROOT/oracle/libptoracle.so"; cp "$T/libpthost.so" "$ROOT/project3-cuda-path-tracer_amd/libpthost.so"
+cd "$ROOT"
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
+    python -m pytest tests/test_oracle_golden.py tests/test_host_loader.py tests/test_camera_ext_cpu.py -x -q
