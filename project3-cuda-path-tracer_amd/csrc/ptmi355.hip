@@ -199,6 +199,13 @@ int tile_rows(int tile_index, int tile_count, int strip_rows, int H) {
     return rows;
 }
 
+int ensure_isect(void) {
+    if (R.isect_mem) return PT_OK;
+    HIPCHK(hipMalloc(&R.isect_mem, (size_t)R.cap * 5 * 4));
+    R.isect = Isect{R.isect_mem, R.cap};
+    return PT_OK;
+}
+
 int ensure_scratch(size_t bytes) {
     if (bytes <= R.scratch_bytes) return PT_OK;
     if (R.scratch) (void)hipFree(R.scratch);
@@ -735,8 +742,12 @@ static int init_impl(const pt_scene_desc *d) {
         HIPCHK(hipMalloc(&R.pool_mem[k], (((capz + 63) / 64) * 64) * 10 * 4));     // whole 64-path tiles
         R.pool[k] = carve_pool(R.pool_mem[k], R.cap);
     }
-    HIPCHK(hipMalloc(&R.isect_mem, capz * 5 * 4));
-    R.isect = Isect{R.isect_mem, R.cap};
+    // the ShadeableIntersection planes exist only where a pipeline materialises them (the fused path keeps them
+    // in registers): unfused / sorted / fake-shader pipelines now, pt_intersect_once on first use
+    if (R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER)) {
+        const int rc = ensure_isect();
+        if (rc != PT_OK) return rc;
+    }
     HIPCHK(hipMalloc(&R.final_mem, capz * 3 * 4));
     if (d->device_image) { R.image = d->device_image; R.own_image = false; }
     else {
@@ -953,6 +964,8 @@ int pt_intersect_once(const pt_path_segment *host_paths, int n, pt_shadeable_int
     if (n == 0) return PT_OK;
     if (!host_paths || !host_isects) return fail(PT_ERR_INVALID, "pt_intersect_once: null buffer");
     int rc = ensure_scratch((size_t)n * (sizeof(pt_path_segment) + 1) + 64);
+    if (rc) return rc;
+    rc = ensure_isect();
     if (rc) return rc;
     R.in_step = false;
     HIPCHK(hipMemcpyAsync(R.scratch, host_paths, (size_t)n * sizeof(pt_path_segment), hipMemcpyHostToDevice, R.stream));
