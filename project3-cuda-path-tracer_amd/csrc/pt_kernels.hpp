@@ -105,14 +105,14 @@ __device__ __forceinline__ void queue_pass(float *wq, const float *gf, uint32_t 
 }
 
 // Stackless walk of one mesh's hierarchy (record layout and link construction: pt_bvh.hpp).
-// Per lane and step: fetch one 128-B record (both child boxes + links as four 16-B loads, the
-// octant's miss link as a fifth), slab-test both boxes against [0, best + prune], intersect the
-// triangles of hit leaf children, then continue with a hit internal child (the nearer one when
-// both are hit) or follow the miss link.  The box test only has to be conservative (it decides
-// which exact triangle tests run, never their outcome), so it uses v_rcp and fused multiply-adds;
-// NaNs from 0 * inf drop out of v_min/v_max, which errs towards visiting.  Every link points
-// forward in the octant's depth-first order, so the walk ends after at most `guard` records; the
-// guard also bounds it for NaN rays.
+// Per lane and step: fetch one 64-B record (both child boxes on a 16-bit grid + both links as two
+// 16-B loads, the octant's miss link as a third), slab-test both boxes against [0, best + prune],
+// intersect the triangles of hit leaf children, then continue with a hit internal child (the nearer
+// one when both are hit) or follow the miss link.  The box test only has to be conservative (it
+// decides which exact triangle tests run, never their outcome), so it uses v_rcp and fused
+// multiply-adds; NaNs drop out of v_min/v_max, which errs towards visiting.  For a fixed octant the
+// links spell out one depth-first order, so a walk visits a record at most once; `guard` bounds it
+// for NaN rays all the same.
 struct BvhRay {                       // what a walk keeps per (ray, mesh)
     f3 ro, rd;
     float kx, ky, kz, bx, by, bz;     // slab form over the mesh's grid: t = grid * k + b
@@ -958,11 +958,12 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a)
 // ---------------------------------------------------------------------------
 // Mesh pre-pass (PT_MESH_BVH, fused path).  Walking a hierarchy inside k_bounce keeps a whole
 // wave waiting on the few lanes whose rays reach a mesh (a mesh covers a few per cent of the
-// directions) while each of their steps is a dependent 128-B fetch.  k_mesh runs first instead:
-// every wave scans its run of tiles, tests each ray against the root record of every mesh (two
+// directions) while each of their steps is a dependent fetch.  k_mesh runs first instead: every
+// wave scans tiles dealt round-robin, tests each ray against the root record of every mesh (two
 // boxes, wave-uniform scalar loads) and appends the candidates {slot, path, ray} to a per-wave
-// LDS ring; whenever 64 are waiting they are walked lane-dense, one candidate per lane.  Results
-// go to mesh_hit[slot] = {t, geom, triangle} and one bit per path in mesh_mask[tile]; k_bounce
+// LDS ring; lanes without a walk take ring entries, all lanes walk together, and the triangles of
+// the leaves they reach are queued and tested 64 at a time.  Results go
+// to mesh_hit[slot] = {t, geom, triangle} and one bit per path in mesh_mask[tile]; k_bounce
 // <MESH_PRE> folds them with the geom-index tie-break of pathtrace.cu:192.
 // ---------------------------------------------------------------------------
 #ifndef PT_SKIP_PAIRS
