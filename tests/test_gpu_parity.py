@@ -410,6 +410,27 @@ def test_random_scenes(pt, po, scenes, seed):
     assert np.isfinite(ref.image).all() and ref.image.max() > 0
 
 
+def test_trace_depth_reread_every_call(pt, po, scenes):
+    """pathtrace() re-reads traceDepth from the scene on every call (pathtrace.cu:286): a smaller depth set after
+    init takes effect at once (and back), like the camera."""
+    s = scenes["cornell_glass_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
+    total = np.zeros((scene.resolution[0] * scene.resolution[1], 3), dtype=np.float32)
+    for it, depth in ((1, s["depth"]), (2, 3), (3, 1), (4, s["depth"])):
+        scene.traceDepth = depth
+        img = pt.pathtrace(None, 0, it)
+        ref = po.Tracer(s["geoms"], s["materials"], s["camera"], depth, trig=po.TRIG_SHARED)
+        st = ref.iterate(it)
+        assert list(pt.get_stats().live[:depth]) == list(st.live[:depth])
+        total += ref.image                                   # the running sum adds each iteration's contribution
+        assert np.array_equal(img, total)
+    with pytest.raises(pt.PtError):
+        scene.traceDepth = s["depth"] + 1                    # deeper than what pathtraceInit sized for
+        pt.pathtrace(None, 0, 5)
+    pt.pathtraceFree()
+
+
 def test_pbo_device_pointer(pt, scenes, golden):
     """pathtrace() writes the tonemapped RGBA8 into a device buffer (the mapped PBO)."""
     import torch
