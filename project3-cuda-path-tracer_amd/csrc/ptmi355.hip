@@ -734,7 +734,7 @@ static int init_impl(const pt_scene_desc *d) {
     R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
     if (const char *pad = getenv("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
     if (R.mesh_mode == MESH_TILES) R.lds_bytes += (size_t)TRI_TILE * TRI_WORDS * 4;
-    if (R.lds_bytes > 60 * 1024) return fail(PT_ERR_INVALID, "pt_init: material records need %zu B of LDS (> 60 KiB)", R.lds_bytes);
+    if (R.lds_bytes > 60 * 1024) return fail(PT_ERR_INVALID, "pt_init: the scene records staged per workgroup (12 B per material word, 128 B per geom) need %zu B of LDS (> 60 KiB)", R.lds_bytes);
 
     // pools, intersections, final colours, image, control
     const size_t capz = R.cap;
