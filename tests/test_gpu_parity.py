@@ -431,6 +431,40 @@ def test_trace_depth_reread_every_call(pt, po, scenes):
     pt.pathtraceFree()
 
 
+def test_many_primitives(pt, po, scenes):
+    """150 cubes / spheres (19 KB of per-geom gather records in LDS, every ray loops over all of them) and the
+    LDS limit: 600 are refused with a message instead of a bad launch."""
+    rng = np.random.default_rng(4242)
+    s = scenes["cornell_64"]
+    H = pt.host_binding.host_library()
+
+    def make(ng):
+        geoms = np.zeros(ng, dtype=pt.GEOM_DT)
+        for g in geoms:
+            g["type"] = rng.integers(2)
+            g["materialid"] = rng.integers(len(s["materials"]))
+            g["translation"] = rng.uniform(-4.5, 4.5, 3) + (0, 5, 0)
+            g["rotation"] = rng.uniform(-180, 180, 3)
+            g["scale"] = rng.uniform(0.2, 1.2, 3)
+        geoms[0] = s["geoms"][0]                                         # the light
+        for k in range(1, ng):
+            H.pth_build_geom_matrices(geoms.ctypes.data + k * pt.GEOM_DT.itemsize)
+        return geoms
+
+    geoms = make(150)
+    scene = pt.Scene(geoms, s["materials"], s["camera"], 4)
+    ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], 4, trig=po.TRIG_SHARED)
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
+    for it in (1, 2):
+        img = pt.pathtrace(None, 0, it)
+        st = ref.iterate(it)
+        assert list(pt.get_stats().live[:4]) == list(st.live[:4])
+    assert img.tobytes() == ref.image.tobytes()
+    pt.pathtraceFree()
+    with pytest.raises(pt.PtError, match="LDS"):
+        pt.pathtraceInit(pt.Scene(make(600), s["materials"], s["camera"], 4), flags=pt.PT_COMPACT)
+
+
 def test_pbo_device_pointer(pt, scenes, golden):
     """pathtrace() writes the tonemapped RGBA8 into a device buffer (the mapped PBO)."""
     import torch
