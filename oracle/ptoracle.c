@@ -700,6 +700,68 @@ void pto_sort_by_material(int n, pto_path *paths, pto_isect *isects, uint8_t *ou
     free(items);
 }
 
+/* ---- iteration-parallel driver: the CPU baseline of bench.py ------------------------------------------
+ * Iterations are independent (the RNG is keyed by the iteration number), so the natural way to use every host
+ * core is one whole iteration per thread -- what the GPU's batch mode does with samples.  Each iteration goes to
+ * its own image and the images are added in iteration order, so the sum equals `count` sequential calls of
+ * pto_trace_iteration bit for bit. */
+typedef struct {
+    const pto_scene *sc;
+    int iter0, count, N;
+    pto_vec3 *images;              /* count * N */
+    int next;                      /* next iteration to hand out */
+    int64_t rays;
+    pthread_mutex_t lock;
+} par_job;
+
+static void *par_worker(void *arg) {
+    par_job *j = (par_job *)arg;
+    pto_path *paths = (pto_path *)malloc((size_t)j->N * sizeof(pto_path));
+    pto_isect *isects = (pto_isect *)malloc((size_t)j->N * sizeof(pto_isect));
+    for (;;) {
+        pthread_mutex_lock(&j->lock);
+        const int k = j->next < j->count ? j->next++ : -1;
+        pthread_mutex_unlock(&j->lock);
+        if (k < 0) break;
+        pto_stats st;
+        pto_trace_iteration(j->sc, j->iter0 + k, j->images + (size_t)k * j->N, paths, isects, &st, NULL, NULL);
+        pthread_mutex_lock(&j->lock);
+        j->rays += st.rays;
+        pthread_mutex_unlock(&j->lock);
+    }
+    free(paths);
+    free(isects);
+    return NULL;
+}
+
+int64_t pto_trace_iterations_parallel(const pto_scene *sc, int iter0, int count, pto_vec3 *image_sum, int nthreads) {
+    par_job j;
+    j.sc = sc; j.iter0 = iter0; j.count = count; j.next = 0; j.rays = 0;
+    j.N = sc->camera.resolution[0] * sc->camera.resolution[1];
+    j.images = (pto_vec3 *)calloc((size_t)count * j.N, sizeof(pto_vec3));
+    if (!j.images) return -1;
+    pthread_mutex_init(&j.lock, NULL);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > count) nthreads = count;
+    if (nthreads > 1024) nthreads = 1024;
+    pthread_t *th = (pthread_t *)malloc((size_t)nthreads * sizeof(pthread_t));
+    int started = 0;
+    for (int t = 0; t < nthreads; ++t)
+        if (pthread_create(&th[started], NULL, par_worker, &j) == 0) ++started;
+    if (started == 0) par_worker(&j);
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    for (int k = 0; k < count; ++k) {                       /* iteration order: the running sum of the reference */
+        const pto_vec3 *im = j.images + (size_t)k * j.N;
+        for (int p = 0; p < j.N; ++p) {
+            image_sum[p].x += im[p].x; image_sum[p].y += im[p].y; image_sum[p].z += im[p].z;
+        }
+    }
+    free(th);
+    free(j.images);
+    pthread_mutex_destroy(&j.lock);
+    return j.rays;
+}
+
 uint64_t pto_fnv1a_i32(const int32_t *v, int stride_bytes, int n) {
     uint64_t h = 1469598103934665603ull;
     const uint8_t *p = (const uint8_t *)v;

@@ -178,6 +178,11 @@ void pto_trace_iteration_mt(const pto_scene *sc, int iter, pto_vec3 *image,
                             pto_path *paths, pto_isect *isects, pto_stats *stats,
                             int nthreads);
 
+/* `count` iterations iter0 .. iter0+count-1, one whole iteration per thread, images added in iteration order
+ * (== sequential pto_trace_iteration calls, bit for bit); returns rays traced, -1 when out of memory.  This is
+ * bench.py's CPU baseline: ~85 MB of scratch per thread + 12 B per pixel per iteration. */
+int64_t pto_trace_iterations_parallel(const pto_scene *sc, int iter0, int count, pto_vec3 *image_sum, int nthreads);
+
 uint64_t pto_fnv1a_i32(const int32_t *v, int stride_bytes, int n);
 
 /* The host-side rows (scene loader, camera set-up, image writer) have no oracle

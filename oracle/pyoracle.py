@@ -128,6 +128,8 @@ def lib():
                                           C.c_void_p, C.POINTER(Stats), C.c_void_p, C.c_void_p]
         L.pto_trace_iteration_mt.argtypes = [C.POINTER(Scene), C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.POINTER(Stats), C.c_int]
+        L.pto_trace_iterations_parallel.restype = C.c_int64
+        L.pto_trace_iterations_parallel.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.pto_fnv1a_i32.restype = C.c_uint64
         L.pto_fnv1a_i32.argtypes = [C.c_void_p, C.c_int, C.c_int]
         _lib = L
@@ -256,6 +258,13 @@ class Tracer:
         self.image = np.zeros((self.n, 3), dtype=np.float32)
         self.paths = np.zeros(self.n, dtype=PATH_DT)
         self.isects = np.zeros(self.n, dtype=ISECT_DT)
+
+    def iterate_parallel(self, iter0, count, threads):
+        """`count` iterations, one whole iteration per thread; adds them to self.image in iteration order."""
+        rays = lib().pto_trace_iterations_parallel(C.byref(self.scene), iter0, count, _p(self.image), threads)
+        if rays < 0:
+            raise MemoryError("pto_trace_iterations_parallel")
+        return rays
 
     def iterate(self, it, snapshots=None, threads=0):
         """Run iteration `it` (1-based). If `snapshots` is a list, append per-bounce

@@ -216,3 +216,14 @@ def test_png_statistic(po, golden, scenes):
     num = np.sqrt(((pooled - want)[mask] ** 2).sum())
     den = np.sqrt((want[mask] ** 2).sum())
     assert num / den < 0.12, num / den                                 # 6 spp noise floor ~0.08; 0.05 at >=256 spp
+
+
+def test_iteration_parallel_driver_equals_sequential(po, scenes):
+    """bench.py's CPU baseline runs one whole iteration per thread and adds the images in iteration order: the
+    same bits as sequential iterations."""
+    s = scenes["cornell_glass_64"]
+    a = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED)
+    b = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED)
+    want = sum(a.iterate(it).rays for it in range(3, 14))
+    got = b.iterate_parallel(3, 11, 4)
+    assert got == want and a.image.tobytes() == b.image.tobytes()
