@@ -263,6 +263,32 @@ def test_tiles_equal_whole_frame(pt, scenes):
         assert acc.tobytes() == whole.tobytes(), (tiles, strip)
 
 
+def test_tiles_equal_whole_frame_with_mesh_jitter_and_lens(pt, scenes):
+    """The same for everything that is keyed by pixel or path index: a mesh through the hierarchy (mesh pre-pass
+    masks and records), pixel jitter and the lens (random engine keyed by the GLOBAL pixel index), batches."""
+    s = scenes["cornell_glass_64"]
+    tris = pt.meshes.uv_sphere(center=(1.5, 3.0, 1.0), radius=1.5, n_lat=16, n_lon=32)
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=2)
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
+    n = scene.resolution[0] * scene.resolution[1]
+    kw = dict(flags=pt.PT_COMPACT | pt.PT_MESH_BVH | pt.PT_AA_JITTER, lens=(0.2, 9.0), max_batch=3)
+    whole = np.zeros((n, 3), dtype=np.float32)
+    pt.pathtraceInit(scene, **kw)
+    pt.trace_batch(1, 3, whole)
+    pt.pathtraceFree()
+    assert np.isfinite(whole).all() and whole.max() > 0
+    for tiles, strip in ((2, 8), (5, 3)):
+        acc = np.zeros((n, 3), dtype=np.float32)
+        for k in range(tiles):
+            img = np.zeros((n, 3), dtype=np.float32)
+            pt.pathtraceInit(scene, tile=(k, tiles, strip), **kw)
+            pt.trace_batch(1, 3, img)
+            pt.pathtraceFree()
+            assert ((acc != 0) & (img != 0)).sum() == 0
+            acc += img
+        assert acc.tobytes() == whole.tobytes(), (tiles, strip)
+
+
 def test_fake_shader_as_is(pt, scenes, golden):
     """The reference exactly as shipped: one bounce + shadeFakeMaterial + sendImageToPBO."""
     z = golden["fakeshade"]
