@@ -491,6 +491,40 @@ def test_many_primitives(pt, po, scenes):
         pt.pathtraceInit(pt.Scene(make(600), s["materials"], s["camera"], 4), flags=pt.PT_COMPACT)
 
 
+def test_singular_and_extreme_transforms(pt, po, scenes):
+    """Geoms whose matrices hold inf / NaN (zero scale -> singular inverse), denormal and 1e18 scales: whatever the
+    reference arithmetic makes of them (mostly misses, some NaN distances), the GPU makes the same of them."""
+    s = scenes["cornell_64"]
+    H = pt.host_binding.host_library()
+    geoms = s["geoms"].copy()
+    extra = np.zeros(6, dtype=pt.GEOM_DT)
+    scales = [(0.0, 1.0, 1.0), (1e-30, 1e-30, 1e-30), (1e18, 1e18, 1e18), (1.0, 0.0, 0.0), (1e-20, 2.0, 2.0), (3e10, 1e-10, 1.0)]
+    for k, g in enumerate(extra):
+        g["type"] = k % 2
+        g["materialid"] = 1 + k % 4
+        g["translation"] = (0.5 * k - 1, 5, 0)
+        g["rotation"] = (10 * k, 20, 0)
+        g["scale"] = scales[k]
+        H.pth_build_geom_matrices(extra.ctypes.data + k * pt.GEOM_DT.itemsize)
+    geoms = np.concatenate([geoms, extra])
+    assert not np.isfinite(geoms["inverseTransform"]).all()              # the singular ones really are inf / NaN
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"])
+    rays = po.generate_rays(s["camera"], s["depth"])
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED)
+    got, got_out = pt.intersect_once(rays.view(pt.PATH_DT))
+    pt.pathtraceFree()
+    want, want_out = po.compute_intersections(rays, geoms.view(po.GEOM_DT))
+    assert got.tobytes() == want.tobytes()
+    ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED)
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
+    for it in (1, 2):
+        img = pt.pathtrace(None, 0, it)
+        st = ref.iterate(it)
+        assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
+    assert img.tobytes() == ref.image.tobytes()
+    pt.pathtraceFree()
+
+
 def test_pbo_device_pointer(pt, scenes, golden):
     """pathtrace() writes the tonemapped RGBA8 into a device buffer (the mapped PBO)."""
     import torch
