@@ -525,6 +525,25 @@ def test_singular_and_extreme_transforms(pt, po, scenes):
     pt.pathtraceFree()
 
 
+def test_nan_camera(pt, po, scenes):
+    """Scene::loadCamera leaves camera.right NaN (scene.cpp:138) until runCuda recomputes it; a host that skips the
+    recompute traces NaN rays.  They take the reference's paths through the tests (every comparison false) and so
+    does the GPU: same live counts, same (NaN-laden) image bits."""
+    s = scenes["cornell_64"]
+    cam = s["camera"].copy()
+    cam["right"][0] = np.nan
+    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
+    ref = po.Tracer(s["geoms"], s["materials"], cam, s["depth"], trig=po.TRIG_SHARED)
+    for flags in (pt.PT_COMPACT, pt.PT_COMPACT | pt.PT_UNFUSED):
+        pt.pathtraceInit(scene, flags=flags)
+        img = pt.pathtrace(None, 0, 1)
+        if flags == pt.PT_COMPACT:
+            st = ref.iterate(1)
+        assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
+        assert img.tobytes() == ref.image.tobytes()
+        pt.pathtraceFree()
+
+
 def test_pbo_device_pointer(pt, scenes, golden):
     """pathtrace() writes the tonemapped RGBA8 into a device buffer (the mapped PBO)."""
     import torch
