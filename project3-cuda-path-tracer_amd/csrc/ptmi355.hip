@@ -244,8 +244,10 @@ BounceArgs bounce_args(int depth) {
 int enqueue_begin(int iter0, int count, bool stepping) {
     if (count < 1 || count > R.max_batch)
         return fail(PT_ERR_INVALID, "batch count %d outside [1, max_batch=%d]", count, R.max_batch);
-    if (iter0 < 1 || (int64_t)iter0 + count - 1 >= (1 << 22))
-        return fail(PT_ERR_INVALID, "iteration %d outside [1, 2^22): makeSeededRandomEngine packs iter in 22 bits", iter0);
+    // makeSeededRandomEngine ORs the iteration into a word that holds the depth from bit 22 up (pathtrace.cu:41-45);
+    // past 2^22 iterations the streams of different depths collide in the reference too -- reproduced, not refused
+    if (iter0 < 0 || (int64_t)iter0 + count - 1 > 0x7fffffff)
+        return fail(PT_ERR_INVALID, "iteration %d (+%d) outside [0, 2^31)", iter0, count);
     R.step_iter0 = iter0; R.step_count = count; R.step_depth = 0; R.cur = 0; R.cur_dir = -1;
     R.sorted_isects = false;
     HIPCHK(hipMemsetAsync(&R.ctl->stamp, 0, R.ctl_bytes, R.stream));      // everything but Control::iter0
@@ -417,8 +419,10 @@ int enqueue_batch(int iter0, int count) {
     if (!graphable) return enqueue_batch_direct(iter0, count);
     if (count < 1 || count > R.max_batch)
         return fail(PT_ERR_INVALID, "batch count %d outside [1, max_batch=%d]", count, R.max_batch);
-    if (iter0 < 1 || (int64_t)iter0 + count - 1 >= (1 << 22))
-        return fail(PT_ERR_INVALID, "iteration %d outside [1, 2^22): makeSeededRandomEngine packs iter in 22 bits", iter0);
+    // makeSeededRandomEngine ORs the iteration into a word that holds the depth from bit 22 up (pathtrace.cu:41-45);
+    // past 2^22 iterations the streams of different depths collide in the reference too -- reproduced, not refused
+    if (iter0 < 0 || (int64_t)iter0 + count - 1 > 0x7fffffff)
+        return fail(PT_ERR_INVALID, "iteration %d (+%d) outside [0, 2^31)", iter0, count);
     auto it = R.graphs.find(count);
     if (it == R.graphs.end()) {
         hipGraph_t graph = nullptr;

@@ -544,6 +544,28 @@ def test_nan_camera(pt, po, scenes):
         pt.pathtraceFree()
 
 
+def test_large_iteration_numbers(pt, po, scenes):
+    """Iteration numbers past 2^22 spill into the depth bits of the seed word (pathtrace.cu:41-45); the reference
+    keeps going with colliding streams and so do the oracle and the GPU, identically.  Iteration 0 too."""
+    s = scenes["cornell_glass_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED)
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=3)
+    img = np.zeros((n, 3), dtype=np.float32)
+    for it in (0, (1 << 22) - 1, 1 << 22, 5000000, (1 << 31) - 3):
+        img = pt.pathtrace(None, 0, it)
+        st = ref.iterate(it)
+        assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]]), it
+    pt.trace_batch((1 << 22) - 1, 3, img)                    # a batch that straddles the boundary
+    for it in range((1 << 22) - 1, (1 << 22) + 2):
+        ref.iterate(it)
+    assert img.tobytes() == ref.image.tobytes()
+    with pytest.raises(pt.PtError):
+        pt.trace_batch((1 << 31) - 2, 3, img)                # would overflow int
+    pt.pathtraceFree()
+
+
 def test_pbo_device_pointer(pt, scenes, golden):
     """pathtrace() writes the tonemapped RGBA8 into a device buffer (the mapped PBO)."""
     import torch
