@@ -446,7 +446,7 @@ __device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t sp
 // standalone computeIntersections: materialises the ShadeableIntersection planes
 // (indexed by LOGICAL path index)
 template <int MESH>
-__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc,
+__global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc,
                                                                     const uint32_t *n_ptr, uint32_t n_fixed,
                                                                     RangeDir dir_in, const uint32_t *nprev_ptr,
                                                                     Control *ctl) {

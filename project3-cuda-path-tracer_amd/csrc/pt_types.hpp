@@ -9,6 +9,9 @@ namespace {
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4                     // waves per SIMD the bounce kernels are register-budgeted for
 #endif
+#ifndef PT_ISECT_WAVES
+#define PT_ISECT_WAVES 4                     // k_intersect (unfused / sorted pipelines)
+#endif
 #ifndef PT_PRE_WAVES
 #define PT_PRE_WAVES 5                       // k_bounce<MESH_PRE>: 97 VGPRs unconstrained; budgeted for 5 waves per SIMD (+6 %)
 #endif
