@@ -214,6 +214,11 @@ int pt_get_bvh_info(pt_bvh_info *out);
  * optional): origin xyz, step xyz of the 16-bit box grid, box padding, prune margin. */
 int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node_capacity,
                  int32_t *order, float *grid);
+/* host-only (no GPU): the world-space cull boxes pt_init derives for `count` primitives seen from `eye` (3 floats,
+ * may be NULL): boxes = count x {lo.xyz, hi.xyz}; *origin_bound = the |origin|_1 up to which they hold.  A ray
+ * outside a primitive's box is never handed to the exact test (csrc/pt_cull.hpp has the error bound that makes
+ * this identical to the reference's loop over every primitive, pathtrace.cu:176-199). */
+int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound);
 const char *pt_last_error(void);
 const char *pt_version(void);
 

@@ -138,6 +138,7 @@ def library():
         L.pt_get_profile.argtypes = [C.POINTER(Profile)]
         L.pt_get_bvh_info.argtypes = [C.POINTER(BvhInfo)]
         L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.pt_cull_boxes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.pt_free.restype = None
         _lib = L
     return _lib
@@ -309,6 +310,16 @@ def bvh_build(triangles):
     grid = np.zeros(8, dtype=np.float32)
     _chk(min(0, L.pt_bvh_build(_p(tris), len(tris), _p(nodes), need, _p(order), _p(grid))))
     return nodes, order[:len(tris)], grid
+
+
+def cull_boxes(geoms, eye=(0.0, 0.0, 0.0)):
+    """Host-only: (boxes[n, 2, 3] float32 = lo / hi, origin bound) pt_init derives for the cull stage."""
+    g = np.ascontiguousarray(geoms, dtype=GEOM_DT)
+    e = np.asarray(eye, dtype=np.float32)
+    out = np.zeros((len(g), 2, 3), dtype=np.float32)
+    r = C.c_float(0.0)
+    _chk(library().pt_cull_boxes(_p(g), len(g), _p(e), _p(out), C.byref(r)))
+    return out, r.value
 
 
 def total_rays():

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libptmi355.so")
-SOURCES = [os.path.join(HERE, "csrc", f) for f in ("ptmi355.hip", "pt_device.hpp", "pt_types.hpp", "pt_kernels.hpp", "pt_bvh.hpp")] + \
+SOURCES = [os.path.join(HERE, "csrc", f) for f in ("ptmi355.hip", "pt_device.hpp", "pt_types.hpp", "pt_kernels.hpp", "pt_bvh.hpp", "pt_cull.hpp")] + \
           [os.path.join(ROOT, "include", "ptmi355.h")]
 # -ffp-contract=off: the reference arithmetic (GLM, no FMA) must be reproduced bit for bit.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]

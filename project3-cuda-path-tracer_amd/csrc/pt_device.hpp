@@ -237,6 +237,14 @@ PTD f3 normalize_normal_range(f3 a, float dt) {
 //   min(v_k^2) >= 2^-78 x                  -> every normalised component is at least 2^-40 (and <= 1+),
 //   max|qo_k| < 2^54                       -> numerators (+-0.5 - qo) are +0 or in [2^-25, 2^55).
 // NaNs fail the ordered compares.  Inactive lanes do not vote.
+PTD bool norm_fast_ok(float x) {
+#if PT_FASTDIV
+    return __all(x >= 8.271806125530277e-25f && x <= 1.2089258196146292e24f);
+#else
+    (void)x;
+    return false;
+#endif
+}
 PTD bool cube_fast_ok(f3 qo, f3 v, float x) {
 #if PT_FASTDIV
     const float sq_min = __builtin_fminf(__builtin_fminf(v.x * v.x, v.y * v.y), v.z * v.z);
@@ -251,16 +259,26 @@ PTD bool cube_fast_ok(f3 qo, f3 v, float x) {
 #endif
 }
 
-// object-space part of boxIntersectionTest (intersections.h:48-84): true when the slab test passes;
-// qo/qd = object-space ray, t_obj = the parameter the test settles on, code = face normal code.
-template <typename P> PTD bool box_slab(P g, f3 ro, f3 rd, f3 &qo, f3 &qd, float &t_obj, int &code_out, int &outside) {
-    qo = mv_point(g + G_INV, ro);
-    const f3 v = mv_dir(g + G_INV, rd);
-    const float x = dot(v, v);
+// The object-space ray both tests start from (intersections.h:50-52,105-107): qo = M^-1 * (ro, 1),
+// v = M^-1 * (rd, 0), x = dot(v, v); q.direction = glm::normalize(v) = v * (1 / sqrt(x)).
+template <typename P> PTD void object_ray(P inv, f3 ro, f3 rd, f3 &qo, f3 &v, float &x) {
+    qo = mv_point(inv, ro);
+    v = mv_dir(inv, rd);
+    x = dot(v, v);
+}
+// glm::normalize(v) given x = dot(v, v); `fast` = norm_fast_ok(x) (wave-uniform)
+PTD f3 normalize_with(f3 v, float x, bool fast) {
+    if (fast) return normalize_normal_range(v, x);
+    return scale(v, 1.0f / __builtin_sqrtf(x));
+}
+
+// slab part of boxIntersectionTest (intersections.h:54-84) on the object-space ray (qo, qd): true when the
+// test passes; t_obj = the parameter it settles on, code = face normal code.  `fast` = cube_fast_ok(...) of
+// the lanes that run this (wave-uniform among them): the rescale-free divides.
+PTD bool cube_slabs(f3 qo, f3 qd, bool fast, float &t_obj, int &code_out, int &outside) {
     float t1x, t2x, t1y, t2y, t1z, t2z;
     float tax, tbx, tay, tby, taz, tbz;
-    if (cube_fast_ok(qo, v, x)) {                                         // wave-uniform
-        qd = normalize_normal_range(v, x);
+    if (fast) {                                                           // wave-uniform
         const float rx = rcp_refined(qd.x), ry = rcp_refined(qd.y), rz = rcp_refined(qd.z);
         t1x = div_by_rcp(-0.5f - qo.x, qd.x, rx); t2x = div_by_rcp(+0.5f - qo.x, qd.x, rx);
         t1y = div_by_rcp(-0.5f - qo.y, qd.y, ry); t2y = div_by_rcp(+0.5f - qo.y, qd.y, ry);
@@ -272,7 +290,6 @@ template <typename P> PTD bool box_slab(P g, f3 ro, f3 rd, f3 &qo, f3 &qd, float
         tay = __builtin_fminf(t1y, t2y); tby = __builtin_fmaxf(t1y, t2y);
         taz = __builtin_fminf(t1z, t2z); tbz = __builtin_fmaxf(t1z, t2z);
     } else {
-        qd = scale(v, 1.0f / __builtin_sqrtf(x));                         // glm normalize
         t1x = (-0.5f - qo.x) / qd.x; t2x = (+0.5f - qo.x) / qd.x;
         t1y = (-0.5f - qo.y) / qd.y; t2y = (+0.5f - qo.y) / qd.y;
         t1z = (-0.5f - qo.z) / qd.z; t2z = (+0.5f - qo.z) / qd.z;
@@ -321,10 +338,8 @@ template <typename P> PTD float world_distance(P fwd, f3 ro, f3 qo, f3 qd, float
     return length_gated(sub(ro, mv_point(fwd, obj_p)));
 }
 
-// object-space part of sphereIntersectionTest (intersections.h:102-134)
-template <typename P> PTD bool sphere_quad(P g, f3 ro, f3 rd, f3 &o, f3 &d, float &t_obj, int &outside) {
-    o = mv_point(g + G_INV, ro);
-    d = normalize_gated(mv_dir(g + G_INV, rd));
+// root part of sphereIntersectionTest (intersections.h:110-134) on the object-space ray (o, d)
+PTD bool sphere_roots(f3 o, f3 d, float &t_obj, int &outside) {
     float vDotDirection = dot(o, d);
     float radicand = vDotDirection * vDotDirection - (dot(o, o) - (0.5f * 0.5f));
     if (radicand < 0) return false;

@@ -33,38 +33,63 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, Lens le
 // scene staging + intersection (computeIntersections, pathtrace.cu:149-213)
 // ---------------------------------------------------------------------------
 // Dynamic LDS carve (no static __shared__: the dynamic base stays 16-B aligned, guide G17):
-// [ctl: 16 dwords][mats: nmats*12 dwords][tri tile: TRI_TILE*9 dwords (if any)]
-// Geom records are NOT staged: every lane of every wave reads the same record, so they are
-// fetched with wave-uniform (scalar, SGPR) loads straight from the 1-KB record array, which
-// costs no VGPRs and no LDS bandwidth; materials are per-lane gathers and live in LDS.
-constexpr int LDS_CTL_WORDS = 16;    // [0] last-block flag, [2..5] scan scratch
-constexpr int GF_WORDS = 32;         // staged per geom for per-lane gathers: transform[12], type, materialid, 2 pad,
-                                     // invTranspose[12], 4 pad
-// per-wave candidate queue: ring of 128 slots, SoA: qo.xyz qd.xyz t_obj (7 planes), meta, and
-// the 64 per-lane best keys (u64)
-constexpr int Q_SLOTS = 128;
-constexpr int Q_WORDS = 7 * Q_SLOTS + Q_SLOTS + 2 * 64;
+//   [ctl: 16 dwords]
+//   [scene block, SLDS only: materials nmats*12 | ginfo ngeoms (padded to 4) | gather records ngeoms*36]
+//   [per wave: PW_WORDS]  [triangle tile: TRI_TILE*12 dwords (MESH_TILES only)]
+// What every lane of a wave reads alike (the cull boxes, mesh records) comes through wave-uniform scalar
+// loads from global memory; what lanes gather individually (the matrices of the primitive a candidate names,
+// the material of a winner) is staged in LDS when the scene fits (SLDS) and read from global memory through
+// the vector cache when it does not (any number of primitives / materials).
+constexpr int LDS_CTL_WORDS = 16;    // [0] last-block flag, [2..5] scan scratch, [8..11] traced counts
+constexpr int GREC_WORDS = 36;       // gather record per geom: inverseTransform[12] transform[12] invTranspose[12], each
+                                     // 4 columns x 3 rows.  Stride 36 words: records of 16 consecutive geoms start in
+                                     // distinct 4-bank slots, so a ds_read_b128 by 64 lanes naming different geoms does
+                                     // not conflict (the r01 layout, stride 32, put every geom on the same banks: 24 %
+                                     // of the LDS cycles were bank conflicts)
+// per-wave block: candidate ring + two tiles in flight (rays, best keys, winner records)
+constexpr int Q_SLOTS = 128;         // candidate ring entries (a tile's cull adds <= 64 per geom while < 64 wait)
+constexpr int PW_RING = 0;                               // u32[128]: lane | parity << 6 | type << 7 | geom << 9
+constexpr int PW_BEST = PW_RING + Q_SLOTS;               // u64[2][64]: (bits(t) << 32) | geom, ~0 = nothing hit
+constexpr int PW_WIN = PW_BEST + 2 * 64 * 2;             // float4[2][64]: winner's normal xyz, outside flag
+constexpr int PW_RAYS = PW_WIN + 2 * 64 * 4;             // float[2][6][64]: ro.xyz rd.xyz of the tile's paths
+constexpr int PW_WORDS = PW_RAYS + 2 * 6 * 64;           // 1664 dwords = 6.5 KiB per wave
+constexpr int CULL_WORDS = 8;        // per geom, scalar-loaded: lo.x hi.x lo.y hi.y lo.z hi.z type spare
+
 __host__ __device__ constexpr int scene_lds_words(int nmats, int ngeoms) {
-    return ((nmats * ptd::MAT_WORDS + 3) & ~3) + ngeoms * GF_WORDS;
-}
-__device__ __forceinline__ void stage_scene(float *lds_mats, const SceneDev &sc) {
-    const int mw = sc.nmats * ptd::MAT_WORDS;
-    for (int k = threadIdx.x; k < mw; k += BLOCK) lds_mats[k] = sc.mats[k];
-    {   // per-lane gathers of the tail: forward transform (12) + type + material per geom
-        float *gf = lds_mats + ((mw + 3) & ~3);
-        for (int k = threadIdx.x; k < sc.ngeoms * GF_WORDS; k += BLOCK) {
-            const int g = k / GF_WORDS, w = k - g * GF_WORDS;
-            float v = 0.0f;
-            if (w < 12) v = sc.geoms[g * ptd::GEOM_WORDS + ptd::G_FWD + w];
-            else if (w < 16) v = sc.geoms[g * ptd::GEOM_WORDS + (w - 12)];          // type, materialid, mesh range
-            else if (w < 28) v = sc.geoms[g * ptd::GEOM_WORDS + ptd::G_INVT + (w - 16)];
-            gf[k] = v;
-        }
-    }
-    __syncthreads();
+    return ((nmats * ptd::MAT_WORDS + 3) & ~3) + ((ngeoms + 3) & ~3) + ngeoms * GREC_WORDS;
 }
 
-// Geom records are read through the CONSTANT address space: the array is immutable for the
+// where the per-lane gathers of a kernel read from
+struct SceneAcc {
+    const float *mats;        // MAT_WORDS per material
+    const uint32_t *ginfo;    // per geom: materialid | type << 28
+    const float *grec;        // GREC_WORDS per geom, 16-B aligned
+};
+
+template <bool SLDS>
+__device__ __forceinline__ SceneAcc stage_scene(float *lds_scene, const SceneDev &sc) {
+    SceneAcc acc;
+    if (!SLDS) {
+        acc.mats = sc.mats; acc.ginfo = sc.ginfo; acc.grec = sc.grec;
+        return acc;
+    }
+    const int mw = sc.nmats * ptd::MAT_WORDS;
+    float *mats = lds_scene;
+    uint32_t *ginfo = reinterpret_cast<uint32_t *>(lds_scene + ((mw + 3) & ~3));
+    float *grec = lds_scene + ((mw + 3) & ~3) + ((sc.ngeoms + 3) & ~3);
+    for (int k = threadIdx.x; k < mw; k += BLOCK) mats[k] = sc.mats[k];
+    for (int k = threadIdx.x; k < sc.ngeoms; k += BLOCK) ginfo[k] = sc.ginfo[k];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(sc.grec);
+        float4 *dst = reinterpret_cast<float4 *>(grec);
+        for (int k = threadIdx.x; k < sc.ngeoms * (GREC_WORDS / 4); k += BLOCK) dst[k] = src[k];
+    }
+    __syncthreads();
+    acc.mats = mats; acc.ginfo = ginfo; acc.grec = grec;
+    return acc;
+}
+
+// Geom-uniform records are read through the CONSTANT address space: the arrays are immutable for the
 // lifetime of the launch and the address is wave-uniform, so the loads become s_load_dwordxN
 // (scalar cache -> SGPRs) instead of per-lane vector loads.
 typedef const __attribute__((address_space(4))) float cfloat;
@@ -72,34 +97,135 @@ __device__ __forceinline__ cfloat *as_const(const float *p) {
     return (cfloat *)(unsigned long long)p;
 }
 
-// One lane-dense pass over up to 64 queued candidates [head, head+count): lane k evaluates the
-// shared tail of candidate head+k for whichever lane queued it and folds the distance into that
-// lane's best key with an LDS 64-bit min.  key = (bits(t) << 32) | absolute slot: positive floats
-// order like their bit patterns and slots are issued in geom order, so the minimum key is the
-// smallest t with the lowest geom index on ties -- pathtrace.cu:192's strict `t_min > t` scan.
-__device__ __forceinline__ void queue_pass(float *wq, const float *gf, uint32_t head, uint32_t count, f3 ro) {
+// ---------------------------------------------------------------------------
+// Intersection of one wave's paths with the scene, in three lane-dense stages.
+//
+// The reference tests every ray against every primitive in object space (pathtrace.cu:176-199): per cube two
+// mat4 * vec4, a normalise, six IEEE divides, then for a hit the shared tail (getPointOnRay, transform back,
+// length) and the normal -- ~1550 instructions per ray on Cornell although only ~1.25 primitives per ray are hit.
+//
+//  1. CULL.  Per primitive a world-space box, computed at pt_init, that contains every ray the reference's own
+//     float arithmetic could report a hit for (ptmi355.hip: make_cull_boxes, with the error bound).  All lanes
+//     test their ray against it with one v_rcp per axis per RAY and six fused multiply-adds + min/max per
+//     primitive (the box comes from wave-uniform scalar loads).  This test only decides which exact tests run,
+//     never their outcome, so it may be approximate as long as it errs towards "candidate": rays outside the
+//     range the bound was derived for (huge or non-finite origins, odd direction magnitudes) are candidates of
+//     everything (`wild`); for the others every slab parameter is finite (cull_ray).
+//  2. CANDIDATE RING.  Lanes whose ray reaches the box append (lane, primitive) to a per-wave LDS ring (slot =
+//     running total + ballot rank).
+//  3. PASS.  Whenever 64 candidates wait, lane k takes candidate k: it fetches that path's ray from the wave's
+//     LDS copy, gathers the primitive's matrices (LDS or vector cache), runs the reference's object-space test
+//     operation for operation and, on a hit, the tail and the surface normal, and folds the world distance into
+//     the owning path's best key with an LDS 64-bit min on (bits(t) << 32) | geom -- positive floats order like
+//     their bit patterns, so the minimum is the smallest t with the lowest geom index on ties, exactly
+//     pathtrace.cu:192's strict `t_min > t` scan.  The lane whose key is the path's minimum after the pass
+//     writes the winner record (normal, outside flag).
+//
+// A tile's last candidates rarely fill a pass, so two tiles are in flight per wave (parity 0/1 of the per-wave
+// LDS block): the leftovers of tile T are tested together with the first candidates of tile T+1, and T is
+// shaded after T+1's cull.  Passes therefore run full: ~1.3 per 64 paths on Cornell instead of 2.
+// ---------------------------------------------------------------------------
+struct CullRay {                      // per path, for stage 1
+    float ix, iy, iz, nx, ny, nz;     // slab form: t = plane * i + n   (i = 1/d, n = -o/d)
+    bool wild;                        // outside the range the cull bound was derived for: candidate of everything
+};
+__device__ __forceinline__ CullRay cull_ray(f3 ro, f3 rd, float rmax) {
+    CullRay c;
+    const float os = (__builtin_fabsf(ro.x) + __builtin_fabsf(ro.y)) + __builtin_fabsf(ro.z);
+    const float ds = (__builtin_fabsf(rd.x) + __builtin_fabsf(rd.y)) + __builtin_fabsf(rd.z);
+    c.wild = !(os <= rmax) || !(ds >= 9.5367431640625e-07f && ds <= 1048576.0f);      // NaN / inf fail the compares
+    // 1/d clamped to +-2^100: a direction component of (nearly) zero would make the planes +-inf and, in the fused
+    // form plane * i + n, inf - inf = NaN for every plane on the origin's side of zero -- v_min(NaN, +inf) = +inf
+    // would then reject a ray that runs INSIDE the slab.  With the clamp every t of a non-wild ray is finite, an
+    // axis-parallel ray inside a slab sees (-huge, +huge), outside it (+-huge, +-huge): the slab test of a ray that
+    // is parallel for all purposes (it would need t > 2^46 to cross a pad, far beyond the other axes' exits).
+    c.ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(rd.x), -0x1p100f, 0x1p100f);
+    c.iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(rd.y), -0x1p100f, 0x1p100f);
+    c.iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(rd.z), -0x1p100f, 0x1p100f);
+    c.nx = -ro.x * c.ix; c.ny = -ro.y * c.iy; c.nz = -ro.z * c.iz;
+    return c;
+}
+// true unless the ray certainly misses the box [lo, hi] (scalar operands).  NaN-safe towards "true".
+__device__ __forceinline__ bool cull_box(const CullRay &c, float lox, float hix, float loy, float hiy, float loz, float hiz) {
+    const float t1x = __builtin_fmaf(lox, c.ix, c.nx), t2x = __builtin_fmaf(hix, c.ix, c.nx);
+    const float t1y = __builtin_fmaf(loy, c.iy, c.ny), t2y = __builtin_fmaf(hiy, c.iy, c.ny);
+    const float t1z = __builtin_fmaf(loz, c.iz, c.nz), t2z = __builtin_fmaf(hiz, c.iz, c.nz);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
+                                     __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+                                     __builtin_fmaxf(t1z, t2z));
+    return !(tn > tf);
+}
+
+struct WaveQ {                        // wave-uniform ring cursors + the wave's LDS block
+    float *pw;
+    uint32_t head, total;
+    __device__ __forceinline__ uint32_t *ring() const { return reinterpret_cast<uint32_t *>(pw + PW_RING); }
+    __device__ __forceinline__ unsigned long long *best(int par) const {
+        return reinterpret_cast<unsigned long long *>(pw + PW_BEST) + par * 64;
+    }
+    __device__ __forceinline__ float4 *win(int par) const { return reinterpret_cast<float4 *>(pw + PW_WIN) + par * 64; }
+    __device__ __forceinline__ float *rays(int par) const { return pw + PW_RAYS + par * 6 * 64; }
+};
+
+// stage 3: candidates [head, head + count), count <= 64
+__device__ __forceinline__ void cand_pass(const WaveQ &q, const SceneAcc &acc, uint32_t head, uint32_t count) {
     const int lane = threadIdx.x & 63;
-    float *qf = wq;
-    uint32_t *qi = reinterpret_cast<uint32_t *>(wq + 7 * Q_SLOTS);
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(wq + 8 * Q_SLOTS);
-    const bool on = (uint32_t)lane < count;
-    const uint32_t abs_slot = head + (uint32_t)lane;
-    const uint32_t s = abs_slot & (Q_SLOTS - 1);
-    const uint32_t meta = on ? qi[s] : 0u;
-    const int origin = (int)(meta & 63u);
-    // the queued lane's world-space ray origin
-    const f3 oro = ptd::mk(__shfl(ro.x, origin), __shfl(ro.y, origin), __shfl(ro.z, origin));
-    if (on) {
-        const f3 qo = ptd::mk(qf[0 * Q_SLOTS + s], qf[1 * Q_SLOTS + s], qf[2 * Q_SLOTS + s]);
-        const f3 qd = ptd::mk(qf[3 * Q_SLOTS + s], qf[4 * Q_SLOTS + s], qf[5 * Q_SLOTS + s]);
-        const float t_obj = qf[6 * Q_SLOTS + s];
-        const float *fwd = gf + (meta >> 10) * GF_WORDS;                  // per-lane gather of the transform
-        f3 obj_p;
-        const float t = ptd::world_distance(fwd, oro, qo, qd, t_obj, obj_p);
-        qf[0 * Q_SLOTS + s] = obj_p.x; qf[1 * Q_SLOTS + s] = obj_p.y; qf[2 * Q_SLOTS + s] = obj_p.z;
-        if (t > 0.0f)
-            __hip_atomic_fetch_min(&best[origin], ((unsigned long long)__float_as_uint(t) << 32) | abs_slot,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if ((uint32_t)lane < count) {
+        const uint32_t e = q.ring()[(head + (uint32_t)lane) & (Q_SLOTS - 1)];
+        const int origin = (int)(e & 63u), par = (int)((e >> 6) & 1u), type = (int)((e >> 7) & 3u);
+        const uint32_t g = e >> 9;
+        const float *ry = q.rays(par) + origin;
+        const f3 ro = ptd::mk(ry[0], ry[64], ry[128]);
+        const f3 rd = ptd::mk(ry[192], ry[256], ry[320]);
+        const float4 *rec4 = reinterpret_cast<const float4 *>(acc.grec + (size_t)g * GREC_WORDS);
+        float m[12];
+        {
+            const float4 a = rec4[0], b = rec4[1], c = rec4[2];
+            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+            m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+        }
+        f3 qo, v;
+        float x;
+        ptd::object_ray(m, ro, rd, qo, v, x);
+        const f3 qd = ptd::normalize_with(v, x, ptd::norm_fast_ok(x));
+        float t_obj = 0.0f;
+        int code = 7, outside = 1;
+        bool hit = false;
+        if (type == PT_CUBE) {
+            hit = ptd::cube_slabs(qo, qd, ptd::cube_fast_ok(qo, v, x), t_obj, code, outside);
+        } else {
+            hit = ptd::sphere_roots(qo, qd, t_obj, outside);
+        }
+        if (hit) {
+            // shared tail of both tests (intersections.h:85-87,136-143)
+            {
+                const float4 a = rec4[3], b = rec4[4], c = rec4[5];
+                m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+                m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+            }
+            f3 obj_p;
+            const float t = ptd::world_distance(m, ro, qo, qd, t_obj, obj_p);
+            // normal: cube = normalize(transform * (face, 0)), sphere = +-normalize(invTranspose * (objP, 0))
+            f3 nv = obj_p;
+            if (type == PT_CUBE) {
+                nv = ptd::face_from_code(code);
+            } else {
+                const float4 a = rec4[6], b = rec4[7], c = rec4[8];
+                m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+                m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+            }
+            f3 n = ptd::normalize(ptd::mv_dir(m, nv));
+            if (type != PT_CUBE && !outside) n = ptd::neg(n);
+            if (t > 0.0f) {                                                // pathtrace.cu:192
+                const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | g;
+                unsigned long long *bk = q.best(par) + origin;
+                __hip_atomic_fetch_min(bk, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // LDS operations of one wave execute in order: every min of this pass precedes this read
+                if (*bk == key) q.win(par)[origin] = make_float4(n.x, n.y, n.z, __int_as_float(outside));
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
@@ -219,91 +345,77 @@ __device__ __forceinline__ void bvh_walk(const float *__restrict__ nodes, const 
     for (int it = 0; it < guard && node >= 0; ++it) node = bvh_step(nodes, btris, prune, r, node, best, best_i);
 }
 
+// nearest mesh hit of a path so far (meshes fold in geom order: strict `>` keeps the first on ties)
+struct MeshBest { float t; int geom, tri; };
+
+// Stages 1 + 2 for one tile (parity `par` of the wave's LDS block): store the rays, reset the best keys, test every
+// primitive's cull box and queue the candidates; passes run as the ring fills.  Triangle meshes keep their own
+// paths (every triangle through LDS tiles / the hierarchy inline / the k_mesh pre-pass) and fold into `mb`.
 template <int MESH>
-__device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms, const SceneDev &sc,
-                                                float *tri_lds, bool active,
-                                                f3 ro, f3 rd, ptd::Hit &h, float *wq = nullptr,
-                                                const float *gf = nullptr, const float4 *pre_hit = nullptr) {
-    h.t = FLT_MAX; h.geom = -1; h.outside = 1; h.aux = ptd::mk(0, 0, 0);
+__device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &acc, WaveQ &q, int par, float *tri_lds,
+                                           bool active, f3 ro, f3 rd, MeshBest &mb, const float4 *pre_hit) {
+    const int lane = threadIdx.x & 63;
+    {
+        float *ry = q.rays(par) + lane;
+        ry[0] = ro.x; ry[64] = ro.y; ry[128] = ro.z; ry[192] = rd.x; ry[256] = rd.y; ry[320] = rd.z;
+        q.best(par)[lane] = ~0ull;
+    }
+    mb.t = FLT_MAX; mb.geom = -1; mb.tri = -1;
+    if (MESH == MESH_PRE && pre_hit) {                           // this lane's nearest mesh hit, found by k_mesh
+        const float4 m = *pre_hit;
+        mb.t = m.x; mb.geom = __float_as_int(m.y); mb.tri = __float_as_int(m.z);
+    }
+    const CullRay cr = cull_ray(ro, rd, sc.rmax);
+    const uint32_t tag = (uint32_t)lane | ((uint32_t)par << 6);
     const int ngeoms = sc.ngeoms;
     const float *__restrict__ tris = sc.tris;
-    const int lane_q = threadIdx.x & 63;
-    float *qf = wq;
-    uint32_t *qi = reinterpret_cast<uint32_t *>(wq + 7 * Q_SLOTS);
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(wq + 8 * Q_SLOTS);
-    best[lane_q] = ~0ull;
-    unsigned long long seen = ~0ull;
-    uint32_t q_head = 0, q_total = 0;                   // wave-uniform
-    int w_geom = -1, w_meta = 0;
-    f3 w_objp = ptd::mk(0, 0, 0);
-    // after a pass: lanes whose best key changed latch the winner's record while it is still intact
-    auto latch = [&]() {
-        const unsigned long long key = best[lane_q];
-        if (key != seen) {
-            seen = key;
-            const uint32_t s = (uint32_t)key & (Q_SLOTS - 1);
-            w_meta = (int)qi[s];
-            w_geom = w_meta >> 10;
-            w_objp = ptd::mk(qf[0 * Q_SLOTS + s], qf[1 * Q_SLOTS + s], qf[2 * Q_SLOTS + s]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
     for (int g = 0; g < ngeoms; ++g) {
-        cfloat *rec = as_const(geoms) + g * ptd::GEOM_WORDS;           // wave-uniform address -> s_load
-        const int type = __float_as_int(rec[0]);
-        if (MESH == MESH_PRE && type == PT_TRIANGLE_MESH) continue;        // k_mesh already walked every mesh
-        if (MESH == MESH_BVH && type == PT_TRIANGLE_MESH) {
-            // same winner as the loop below (smallest bary.z, lowest triangle index on ties), found by
-            // walking the mesh's bounding-volume hierarchy instead of testing every triangle
-            const int root = __float_as_int(rec[2]);
-            const int count = __float_as_int(rec[3]);
+        cfloat *cb = as_const(sc.cull) + g * CULL_WORDS;               // wave-uniform address -> s_load_dwordx8
+        const int type = __float_as_int(cb[6]);
+        if (MESH != MESH_NONE && type == PT_TRIANGLE_MESH) {
+            if (MESH == MESH_PRE) continue;                             // k_mesh already walked every mesh
+            cfloat *rec = as_const(sc.geoms) + g * ptd::GEOM_WORDS;
             float best = FLT_MAX;
             int best_i = -1;
-            if (active && count > 0)
-                bvh_walk(sc.bvh_nodes + (size_t)root * BVH_NODE_WORDS, sc.bvh_tris, rec + ptd::G_INV, sc.bvh_prune,
-                         sc.bvh_guard, ro, rd, best, best_i);
-            if (active && best_i >= 0) {
-                f3 p = ptd::add(ro, ptd::scale(rd, best));
-                const float t = ptd::length(ptd::sub(ro, p));
-                if (t > 0.0f && h.t > t) {
-                    h.t = t; h.geom = g; h.outside = 1;
-                    h.aux = ptd::mk(__int_as_float(best_i), 0.0f, 0.0f);
-                }
-            }
-            continue;
-        }
-        if (MESH == MESH_TILES && type == PT_TRIANGLE_MESH) {
-            // completion spec 8.0: nearest triangle by strictly smaller bary.z, first wins ties
-            const int first = __float_as_int(rec[2]);
-            const int count = __float_as_int(rec[3]);
-            float best = FLT_MAX;
-            int best_i = -1;
-            for (int base = 0; base < count; base += TRI_TILE) {
-                const int nt = min(TRI_TILE, count - base);
-                const int nt4 = (nt + 3) & ~3;                   // the tile is zero-padded to a multiple of 4
-                __syncthreads();
-                {   // global -> LDS, 16 B per thread per step; zero triangles (a = 0 < eps: never hit) as padding
-                    const float4 *src = reinterpret_cast<const float4 *>(tris + (size_t)(first + base) * TRI_WORDS);
-                    float4 *dst = reinterpret_cast<float4 *>(tri_lds);
-                    for (int k = threadIdx.x; k < nt4 * 3; k += BLOCK)
-                        dst[k] = k < nt * 3 ? src[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-                __syncthreads();
-                if (active) {
-                    // four triangles per step: their twelve ds_read_b128 (wave-uniform addresses, LDS
-                    // broadcasts) are issued together so the LDS latency is paid once per four tests
-                    const float4 *tl = reinterpret_cast<const float4 *>(tri_lds);
-                    for (int k = 0; k < nt4; k += 4) {
-                        float4 w[12];
+            if (MESH == MESH_BVH) {
+                // same winner as the loop below (smallest bary.z, lowest triangle index on ties), found by
+                // walking the mesh's bounding-volume hierarchy instead of testing every triangle
+                const int root = __float_as_int(rec[2]);
+                const int count = __float_as_int(rec[3]);
+                if (active && count > 0)
+                    bvh_walk(sc.bvh_nodes + (size_t)root * BVH_NODE_WORDS, sc.bvh_tris, rec + ptd::G_INV, sc.bvh_prune,
+                             sc.bvh_guard, ro, rd, best, best_i);
+            } else {
+                // completion spec 8.0: nearest triangle by strictly smaller bary.z, first wins ties
+                const int first = __float_as_int(rec[2]);
+                const int count = __float_as_int(rec[3]);
+                for (int base = 0; base < count; base += TRI_TILE) {
+                    const int nt = min(TRI_TILE, count - base);
+                    const int nt4 = (nt + 3) & ~3;                   // the tile is zero-padded to a multiple of 4
+                    __syncthreads();
+                    {   // global -> LDS, 16 B per thread per step; zero triangles (a = 0 < eps: never hit) as padding
+                        const float4 *src = reinterpret_cast<const float4 *>(tris + (size_t)(first + base) * TRI_WORDS);
+                        float4 *dst = reinterpret_cast<float4 *>(tri_lds);
+                        for (int k = threadIdx.x; k < nt4 * 3; k += BLOCK)
+                            dst[k] = k < nt * 3 ? src[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+                    __syncthreads();
+                    if (active) {
+                        // four triangles per step: their twelve ds_read_b128 (wave-uniform addresses, LDS
+                        // broadcasts) are issued together so the LDS latency is paid once per four tests
+                        const float4 *tl = reinterpret_cast<const float4 *>(tri_lds);
+                        for (int k = 0; k < nt4; k += 4) {
+                            float4 w[12];
 #pragma unroll
-                        for (int j = 0; j < 12; ++j) w[j] = tl[k * 3 + j];
+                            for (int j = 0; j < 12; ++j) w[j] = tl[k * 3 + j];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float4 A = w[3 * j], B = w[3 * j + 1], C = w[3 * j + 2];
-                            float tz;
-                            if (ptd::ray_triangle(ro, rd, ptd::mk(A.x, A.y, A.z), ptd::mk(A.w, B.x, B.y),
-                                                  ptd::mk(B.z, B.w, C.x), tz)) {
-                                if (tz > 0.0f && best > tz) { best = tz; best_i = first + base + k + j; }
+                            for (int j = 0; j < 4; ++j) {
+                                const float4 A = w[3 * j], B = w[3 * j + 1], C = w[3 * j + 2];
+                                float tz;
+                                if (ptd::ray_triangle(ro, rd, ptd::mk(A.x, A.y, A.z), ptd::mk(A.w, B.x, B.y),
+                                                      ptd::mk(B.z, B.w, C.x), tz)) {
+                                    if (tz > 0.0f && best > tz) { best = tz; best_i = first + base + k + j; }
+                                }
                             }
                         }
                     }
@@ -312,80 +424,54 @@ __device__ __forceinline__ void intersect_scene(const float *__restrict__ geoms,
             if (active && best_i >= 0) {
                 f3 p = ptd::add(ro, ptd::scale(rd, best));
                 const float t = ptd::length(ptd::sub(ro, p));
-                if (t > 0.0f && h.t > t) {
-                    h.t = t; h.geom = g; h.outside = 1;
-                    h.aux = ptd::mk(__int_as_float(best_i), 0.0f, 0.0f);
-                }
+                if (t > 0.0f && mb.t > t) { mb.t = t; mb.geom = g; mb.tri = best_i; }
             }
             continue;
         }
-        {   // object-space test per lane; hits are queued and their tails run lane-dense (queue_pass)
-            f3 qo = ptd::mk(0, 0, 0), qd = ptd::mk(0, 0, 1);
-            float t_obj = 0.0f;
-            int code = 7, cand_outside = 1;
-            bool hit = false;
-            if (active) {
-                if (type == PT_CUBE) hit = ptd::box_slab(rec, ro, rd, qo, qd, t_obj, code, cand_outside);
-                else if (type == PT_SPHERE) hit = ptd::sphere_quad(rec, ro, rd, qo, qd, t_obj, cand_outside);
+        const bool cand = active && (cr.wild || cull_box(cr, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5]));
+        const uint64_t m = __ballot(cand);
+        if (m) {
+            if (cand) {
+                const uint32_t s = (q.total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))) & (Q_SLOTS - 1);
+                q.ring()[s] = tag | ((uint32_t)type << 7) | ((uint32_t)g << 9);
             }
-            const uint64_t m = __ballot(hit);
-            if (m) {
-                if (hit) {
-                    const uint32_t s = (q_total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane_q) - 1)))) &
-                                       (Q_SLOTS - 1);
-                    qf[0 * Q_SLOTS + s] = qo.x; qf[1 * Q_SLOTS + s] = qo.y; qf[2 * Q_SLOTS + s] = qo.z;
-                    qf[3 * Q_SLOTS + s] = qd.x; qf[4 * Q_SLOTS + s] = qd.y; qf[5 * Q_SLOTS + s] = qd.z;
-                    qf[6 * Q_SLOTS + s] = t_obj;
-                    qi[s] = (uint32_t)lane_q | ((uint32_t)cand_outside << 6) | ((uint32_t)code << 7) | ((uint32_t)g << 10);
-                }
-                q_total += (uint32_t)__popcll((unsigned long long)m);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (q_total - q_head >= 64) {            // a full wave of tails is waiting
-                    queue_pass(wq, gf, q_head, 64, ro);
-                    q_head += 64;
-                    latch();
-                }
+            q.total += (uint32_t)__popcll((unsigned long long)m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (q.total - q.head >= 64) {                // a full wave of candidates is waiting
+                cand_pass(q, acc, q.head, 64);
+                q.head += 64;
             }
-            continue;
-        }
-    }
-    if (q_total > q_head) {
-        queue_pass(wq, gf, q_head, q_total - q_head, ro);
-        latch();
-    }
-    if (MESH == MESH_PRE && pre_hit) {                           // this lane's nearest mesh hit, found by k_mesh
-        const float4 m = *pre_hit;
-        h.t = m.x; h.geom = __float_as_int(m.y); h.outside = 1; h.aux = ptd::mk(m.z, 0.0f, 0.0f);
-    }
-    if (w_geom >= 0) {
-        const unsigned long long key = seen;
-        const float t = __uint_as_float((uint32_t)(key >> 32));
-        if (h.t > t || (h.t == t && w_geom < h.geom)) {      // meshes fold straight into h: keep geom order on ties
-            h.t = t; h.geom = w_geom; h.outside = (w_meta >> 6) & 1;
-            const int type = __float_as_int(gf[w_geom * GF_WORDS + 12]);
-            h.aux = (type == PT_CUBE) ? ptd::mk(__int_as_float((w_meta >> 7) & 7), 0.0f, 0.0f) : w_objp;
         }
     }
 }
 
-// normal + materialId of the winning primitive: a per-lane gather from the records staged in LDS
-// (gf) -- ~100 cycles instead of an L2 round trip -- or from the global record array
-__device__ __forceinline__ void resolve_hit(const float *__restrict__ geoms, const float *gf,
-                                            const float *__restrict__ tris, const ptd::Hit &h, float &t, f3 &n,
-                                            int &mat) {
-    if (h.geom < 0) { t = -1.0f; n = ptd::mk(0, 0, 0); mat = 0; return; }
-    (void)geoms;
-    const float *rec = gf + h.geom * GF_WORDS;
-    const int type = __float_as_int(rec[12]);
-    mat = __float_as_int(rec[13]);
-    const float *fwd = rec, *invt = rec + 16;
-    t = h.t;
-    if (type == PT_CUBE) n = ptd::cube_normal(fwd, h.aux);
-    else if (type == PT_SPHERE) n = ptd::sphere_normal(invt, h.aux, h.outside);
-    else {
-        const float *tv = tris + (size_t)__float_as_int(h.aux.x) * TRI_WORDS;
+// every candidate queued before `ticket` has been tested when this returns
+__device__ __forceinline__ void drain_to(WaveQ &q, const SceneAcc &acc, uint32_t ticket) {
+    while ((int32_t)(ticket - q.head) > 0) {
+        const uint32_t cnt = min(64u, q.total - q.head);
+        cand_pass(q, acc, q.head, cnt);
+        q.head += cnt;
+    }
+}
+
+// the winner of lane's path of the tile with parity `par`: t (-1: miss), normal, materialId, outside flag
+__device__ __forceinline__ void tile_result(const WaveQ &q, int par, const SceneAcc &acc, const float *__restrict__ tris,
+                                            const MeshBest &mb, float &t, f3 &n, int &mat, int &outside) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long key = q.best(par)[lane];
+    t = -1.0f; n = ptd::mk(0, 0, 0); mat = 0; outside = 1;
+    int geom = -1;
+    if (key != ~0ull) {
+        const float4 w = q.win(par)[lane];
+        t = __uint_as_float((uint32_t)(key >> 32)); geom = (int)(uint32_t)key;
+        n = ptd::mk(w.x, w.y, w.z); outside = __float_as_int(w.w);
+    }
+    if (mb.geom >= 0 && (geom < 0 || t > mb.t || (t == mb.t && mb.geom < geom))) {     // pathtrace.cu:192 across all geoms
+        const float *tv = tris + (size_t)mb.tri * TRI_WORDS;
+        t = mb.t; geom = mb.geom; outside = 1;
         n = ptd::normalize(ptd::cross(ptd::mk(tv[3], tv[4], tv[5]), ptd::mk(tv[6], tv[7], tv[8])));
     }
+    if (geom >= 0) mat = (int)(acc.ginfo[geom] & 0x0fffffffu);
 }
 
 // ---- reading a range-packed pool -------------------------------------------------------
@@ -443,20 +529,28 @@ __device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t sp
     return src;
 }
 
+// the LDS carve of a kernel that intersects
+struct LdsCarve { float *scene, *pw, *tri; };
+__device__ __forceinline__ LdsCarve carve_lds(float *lds_raw, const SceneDev &sc, bool slds) {
+    LdsCarve c;
+    c.scene = lds_raw + LDS_CTL_WORDS;
+    float *after = c.scene + (slds ? scene_lds_words(sc.nmats, sc.ngeoms) : 0);
+    c.pw = after + (threadIdx.x >> 6) * PW_WORDS;
+    c.tri = after + WAVES * PW_WORDS;
+    return c;
+}
+
 // standalone computeIntersections: materialises the ShadeableIntersection planes
-// (indexed by LOGICAL path index)
-template <int MESH>
+// (indexed by LOGICAL path index).  Two tiles in flight per wave, as in k_bounce.
+template <int MESH, bool SLDS>
 __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc,
                                                                     const uint32_t *n_ptr, uint32_t n_fixed,
                                                                     RangeDir dir_in, const uint32_t *nprev_ptr,
                                                                     Control *ctl) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    float *mats_lds = lds_raw + LDS_CTL_WORDS;
-    const float *gf = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
-    float *wq = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
-    float *tri_lds = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + WAVES * Q_WORDS;
-    stage_scene(mats_lds, sc);
-    const float *gsrc = sc.geoms;
+    const LdsCarve lc = carve_lds(lds_raw, sc, SLDS);
+    const SceneAcc acc = stage_scene<SLDS>(lc.scene, sc);
+    WaveQ q{lc.pw, 0, 0};
     const int lane = threadIdx.x & 63;
     const uint32_t W = gridDim.x * WAVES;
     const uint32_t wid = run_id();
@@ -467,6 +561,19 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
     const uint32_t span = packed ? range_tiles(*nprev_ptr, W) * TILE : 0;
     uint32_t cur = 0;
     if (packed && wid * R < tiles) cur = find_range(dir_in.base(), W, wid * R * TILE);
+    auto finish = [&](uint32_t i, int par, const MeshBest &mb) {
+        if (i < n) {
+            float t; f3 nrm; int mat, outside;
+            tile_result(q, par, acc, sc.tris, mb, t, nrm, mat, outside);
+            // a miss writes only t; the other fields read as the zeros of pathtrace.cu:343's memset
+            out.plane(0)[i] = t; out.plane(1)[i] = nrm.x; out.plane(2)[i] = nrm.y; out.plane(3)[i] = nrm.z;
+            out.mat()[i] = mat | (outside ? 0 : (int)0x80000000u);
+        }
+    };
+    bool pending = false;
+    uint32_t prev_i = 0, prev_ticket = 0;
+    MeshBest prev_mb{FLT_MAX, -1, -1};
+    int par = 0;
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t tile = wid * R + r;
         if (MESH != MESH_TILES && tile >= tiles) break;
@@ -477,21 +584,18 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
         if (packed && have) src = resolve_src(dir_in, span, cur, i, active, ctl);
         f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
         if (active) {
-            char *q = in.slot(src);
-            if (ppid(q) == DEAD_PID) active = false;
-            ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
-            rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
+            char *p = in.slot(src);
+            if (ppid(p) == DEAD_PID) active = false;
+            ro = ptd::mk(pf(p, 0), pf(p, 1), pf(p, 2));
+            rd = ptd::mk(pf(p, 3), pf(p, 4), pf(p, 5));
         }
-        ptd::Hit h;
-        intersect_scene<MESH>(gsrc, sc, tri_lds, active, ro, rd, h, wq, gf);
-        if (have && i < n) {
-            float t; f3 nrm; int mat;
-            resolve_hit(gsrc, gf, sc.tris, h, t, nrm, mat);
-            // a miss writes only t; the other fields read as the zeros of pathtrace.cu:343's memset
-            out.plane(0)[i] = t; out.plane(1)[i] = nrm.x; out.plane(2)[i] = nrm.y; out.plane(3)[i] = nrm.z;
-            out.mat()[i] = mat | (h.outside ? 0 : (int)0x80000000u);
-        }
+        MeshBest mb;
+        cull_scene<MESH>(sc, acc, q, par, lc.tri, active, ro, rd, mb, nullptr);
+        const uint32_t ticket = q.total;
+        if (pending) { drain_to(q, acc, prev_ticket); finish(prev_i, par ^ 1, prev_mb); }
+        prev_i = have ? i : 0xffffffffu; prev_mb = mb; prev_ticket = ticket; pending = true; par ^= 1;
     }
+    if (pending) { drain_to(q, acc, prev_ticket); finish(prev_i, par ^ 1, prev_mb); }
 }
 
 // ---------------------------------------------------------------------------
@@ -561,15 +665,20 @@ __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t 
 // ---------------------------------------------------------------------------
 // Pass 1 (k_sort_hist): every wave histograms the keys of its run of R tiles (wave64
 // match-ballot, per-wave bins in LDS) into table[bin][wave]; the last workgroup out scans the
-// bin-major table (nbins * W words) in place into start offsets.  Pass 2 (k_sort_scatter):
-// every wave walks its run again and moves path state + intersection to
-// offset[key][wave] + (same-key paths already seen in the run) + (same-key lanes below it),
-// which is the stable order.  The sorted pool is dense.
-constexpr int SORT_MAX_BINS = 256;
+// bin-major table (nbins * W words) in place into start offsets.  Pass 2 (k_sort_perm):
+// every wave walks its run again and computes where each path goes,
+// offset[key][wave] + (same-key paths already seen in the run) + (same-key lanes below it) -- the stable
+// order -- but moves nothing: it scatters two words, perm[dst] = {pool slot, logical index}.  The shading
+// kernel (k_bounce<MODE_ISECT>) then walks the SORTED order and gathers path state and intersection through
+// the permutation.  Inside one material's segment the sources are still in increasing order, so the gathers of
+// a tile touch a few source tiles' rows, most of whose lanes are used; r01 moved the 60 B of state +
+// intersection per path with 15 scattered 4-B stores instead (2.5 TB/s, 212 of 494 ms on C3).
+constexpr int SORT_MAX_BINS = 2048;    // per-wave bins live in LDS: 8 KiB per wave at the limit
 
 struct SortArgs {
-    Pool in, out;            // out: dense, sorted
-    Isect isect, isect_out;  // logical order in, sorted order out
+    Isect isect;             // logical order
+    uint32_t *perm;          // out: [0, cap) pool slot, [cap, 2 cap) logical index, both in sorted order
+    uint32_t cap;
     RangeDir dir_in;
     Control *ctl;
     uint32_t *table;         // nbins * W words
@@ -623,7 +732,7 @@ __device__ __forceinline__ void scan_words_inplace(uint32_t *w, uint32_t total, 
 __global__ __launch_bounds__(BLOCK) void k_sort_hist(SortArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
-    uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * SORT_MAX_BINS;   // per-wave bins
+    uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * ((a.nbins + 3) & ~3);   // per-wave bins
     const int lane = threadIdx.x & 63;
     const uint32_t W = gridDim.x * WAVES;
     const uint32_t wid = run_id();
@@ -663,10 +772,10 @@ __global__ __launch_bounds__(BLOCK) void k_sort_hist(SortArgs a) {
     if (sctl[0]) scan_words_inplace(a.table, (uint32_t)a.nbins * W, sctl + 2);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
+__global__ __launch_bounds__(BLOCK) void k_sort_perm(SortArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
-    uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * SORT_MAX_BINS;   // per-wave running offsets
+    uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * ((a.nbins + 3) & ~3);   // per-wave running offsets
     const int lane = threadIdx.x & 63;
     const uint32_t W = gridDim.x * WAVES;
     const uint32_t wid = run_id();
@@ -697,15 +806,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
             if (lane == 0) bins[k] = base + (uint32_t)__popcll((unsigned long long)m);
             rem &= ~m;
         }
-        if (valid) {
-            char *qs = a.in.slot(src), *qd = a.out.slot(dst);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) pf(qd, k) = pf(qs, k);
-            ppid(qd) = ppid(qs);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a.isect_out.plane(k)[dst] = a.isect.plane(k)[i];
-            a.isect_out.mat()[dst] = a.isect.mat()[i];
-        }
+        if (valid) { at(a.perm, dst) = src; at(a.perm + a.cap, dst) = i; }
     }
 }
 
@@ -717,114 +818,191 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(SortArgs a) {
 // MODE_CACHE0  : bounce 0 with PT_CACHE_FIRST: the per-pixel intersection cache (INSTRUCTION.md:87-89)
 enum { MODE_FUSED = 0, MODE_ISECT = 1, MODE_CACHE0 = 2 };
 
-// per-launch constants of a wave for bounce_tile
+// per-launch constants of a wave
 struct TileCtx {
-    float *mats; const float *gf; float *wq; float *tri_lds;   // LDS carve: materials, per-geom gather records, hit-tail ring, triangle tile
+    SceneAcc acc;               // per-lane gathers: materials, geom info, matrices (LDS or global)
+    float *tri_lds;             // triangle tile (MESH_TILES)
     int lane, iter0;
 };
 
-// One 64-path tile of one bounce: load (or generate) the paths, intersect, shade / scatter, write the final
-// colour of the paths that end here and append the survivors at dst_base + packed (wave64 ballot + popcount
-// rank).  `i` = logical path index (what MODE_ISECT planes and the mesh mask are keyed by), `src` = pool slot.
-template <int MODE, bool COMPACT, int MESH>
-__device__ __forceinline__ void bounce_tile(const BounceArgs &a, const TileCtx &c, const Pool &in, const Pool &out, int depth,
-                                            bool gen_rays, uint32_t tile, uint32_t i, uint32_t src, bool have, bool active,
-                                            uint32_t n, uint32_t dst_base, uint32_t &packed, uint32_t &traced) {
-    const int lane = c.lane;
-    uint32_t pid = DEAD_PID;
-    f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1), col = ptd::mk(1.0f, 1.0f, 1.0f);
+// a tile in flight: what its shading needs besides the wave's LDS block (rays, best keys, winner records)
+struct TileRegs {
+    bool have, active;
+    uint32_t i, src, tile, pid, smp;
+    int pixel;
+    f3 col;
+    MeshBest mb;
+};
+
+// First half of one 64-path tile of one bounce: load (or generate) the paths.  `i` = logical path index (what
+// MODE_ISECT planes and the mesh mask are keyed by), `src` = pool slot.
+__device__ __forceinline__ void tile_load(const BounceArgs &a, const TileCtx &c, const Pool &in, bool gen_rays,
+                                          uint32_t tile, uint32_t i, uint32_t src, bool have, bool active,
+                                          TileRegs &tr, f3 &ro, f3 &rd) {
+    tr.have = have; tr.i = i; tr.src = src; tr.tile = tile;
+    tr.pid = DEAD_PID; tr.smp = 0; tr.pixel = 0;
+    tr.col = ptd::mk(1.0f, 1.0f, 1.0f);
+    tr.mb.t = FLT_MAX; tr.mb.geom = -1; tr.mb.tri = -1;
+    ro = ptd::mk(0, 0, 0); rd = ptd::mk(0, 0, 1);
     if (active) {
         if (gen_rays) {
-            pid = i;
+            tr.pid = i;
         } else {
             // all ten fields of the slot in one burst of loads (one memory latency per tile)
-            char *q = in.slot(src);
-            pid = ppid(q);
-            ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
-            rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
-            col = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8));
-            if (pid == DEAD_PID) active = false;
+            char *p = in.slot(src);
+            tr.pid = ppid(p);
+            ro = ptd::mk(pf(p, 0), pf(p, 1), pf(p, 2));
+            rd = ptd::mk(pf(p, 3), pf(p, 4), pf(p, 5));
+            tr.col = ptd::mk(pf(p, 6), pf(p, 7), pf(p, 8));
+            if (tr.pid == DEAD_PID) active = false;
         }
     }
-    uint32_t smp = 0;
-    int pixel = 0;
     if (active) {
-        smp = sample_of(a.map, pid);
-        pixel = local_to_pixel(a.map, (int)(pid - smp * (uint32_t)a.map.tile_pixels));
-        if (gen_rays) camera_ray(a.cam, a.lens, a.trace_depth, c.iter0 + (int)smp, pixel, a.map.W, ro, rd);
+        tr.smp = sample_of(a.map, tr.pid);
+        tr.pixel = local_to_pixel(a.map, (int)(tr.pid - tr.smp * (uint32_t)a.map.tile_pixels));
+        if (gen_rays) camera_ray(a.cam, a.lens, a.trace_depth, c.iter0 + (int)tr.smp, tr.pixel, a.map.W, ro, rd);
     }
-    float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0; int outside = 1;
-    if (MODE == MODE_FUSED) {
-        ptd::Hit h;
-        const float *gsrc = a.scene.geoms;
-        const float4 *pre_hit = nullptr;
-        if (MESH == MESH_PRE) {
-            // lanes of this tile for which k_mesh found a mesh hit; the mask is consumed (cleared) here
-            const unsigned long long mm = a.mesh_mask[tile];
-            if (mm) {
-                if (lane == 0) a.mesh_mask[tile] = 0ull;
-                if (active && ((mm >> lane) & 1ull)) pre_hit = a.mesh_hit + src;
-            }
-        }
-        intersect_scene<MESH>(gsrc, a.scene, c.tri_lds, active, ro, rd, h, c.wq, c.gf, pre_hit);
-        if (active) { resolve_hit(gsrc, c.gf, a.scene.tris, h, t, nrm, mat); outside = h.outside; }
-    } else if (active) {
-        // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
-        const uint32_t q = (MODE == MODE_CACHE0) ? pid - smp * (uint32_t)a.map.tile_pixels : i;
-        t = at(a.isect.plane(0), q);
-        nrm = ptd::mk(at(a.isect.plane(1), q), at(a.isect.plane(2), q), at(a.isect.plane(3), q));
-        const int m = at(a.isect.mat(), q);
-        mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
-    }
+    tr.active = active;
+}
+
+// Second half: shade / scatter with the intersection (t, nrm, mat, outside), write the final colour of the paths
+// that end here and append the survivors at dst_base + packed (wave64 ballot + popcount rank).
+template <bool COMPACT>
+__device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c, const Pool &in, const Pool &out, int depth,
+                                           const TileRegs &tr, f3 ro, f3 rd, float t, f3 nrm, int mat, int outside,
+                                           uint32_t n, uint32_t dst_base, uint32_t &packed, uint32_t &traced) {
+    const int lane = c.lane;
     bool alive = false;
     ptd::PathState ps;
-    ps.o = ro; ps.d = rd; ps.c = col;
-    if (active) {
-        alive = ptd::shade_scatter(ps, t, nrm, mat, outside, c.mats, c.iter0 + (int)smp, pixel, depth,
+    ps.o = ro; ps.d = rd; ps.c = tr.col;
+    if (tr.active) {
+        alive = ptd::shade_scatter(ps, t, nrm, mat, outside, c.acc.mats, c.iter0 + (int)tr.smp, tr.pixel, depth,
                                    depth == a.trace_depth - 1);
         if (!alive) {
-            at(a.fin, pid) = ps.c.x; at(a.fin + (size_t)in.cap, pid) = ps.c.y;
-            at(a.fin + 2 * (size_t)in.cap, pid) = ps.c.z;
+            at(a.fin, tr.pid) = ps.c.x; at(a.fin + (size_t)in.cap, tr.pid) = ps.c.y;
+            at(a.fin + 2 * (size_t)in.cap, tr.pid) = ps.c.z;
         }
     }
     // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
     const uint64_t bal = __ballot(alive);
-    const uint64_t act = __ballot(active);
+    const uint64_t act = __ballot(tr.active);
     traced += (uint32_t)__popcll((unsigned long long)act);
-    uint32_t dst = i;
+    uint32_t dst = tr.i;
     if (COMPACT) {
         dst = dst_base + packed + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
         packed += (uint32_t)__popcll((unsigned long long)bal);
     }
     if (alive) {
-        char *q = out.slot(dst);
-        pf(q, 0) = ps.o.x; pf(q, 1) = ps.o.y; pf(q, 2) = ps.o.z;
-        pf(q, 3) = ps.d.x; pf(q, 4) = ps.d.y; pf(q, 5) = ps.d.z;
-        pf(q, 6) = ps.c.x; pf(q, 7) = ps.c.y; pf(q, 8) = ps.c.z;
-        ppid(q) = pid;
-    } else if (!COMPACT && have && i < n) {
+        char *p = out.slot(dst);
+        pf(p, 0) = ps.o.x; pf(p, 1) = ps.o.y; pf(p, 2) = ps.o.z;
+        pf(p, 3) = ps.d.x; pf(p, 4) = ps.d.y; pf(p, 5) = ps.d.z;
+        pf(p, 6) = ps.c.x; pf(p, 7) = ps.c.y; pf(p, 8) = ps.c.z;
+        ppid(p) = tr.pid;
+    } else if (!COMPACT && tr.have && tr.i < n) {
         out.pid(dst) = DEAD_PID;
     }
 }
 
+// the tile with parity `par` has been fully tested: read its rays back from the wave's LDS block, fold the
+// winner and shade
+template <bool COMPACT>
+__device__ __forceinline__ void tile_finish(const BounceArgs &a, const TileCtx &c, const WaveQ &q, int par, const Pool &in,
+                                            const Pool &out, int depth, const TileRegs &tr, uint32_t n, uint32_t dst_base,
+                                            uint32_t &packed, uint32_t &traced) {
+    const float *ry = q.rays(par) + c.lane;
+    const f3 ro = ptd::mk(ry[0], ry[64], ry[128]);
+    const f3 rd = ptd::mk(ry[192], ry[256], ry[320]);
+    float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0, outside = 1;
+    if (tr.active) tile_result(q, par, c.acc, a.scene.tris, tr.mb, t, nrm, mat, outside);
+    tile_shade<COMPACT>(a, c, in, out, depth, tr, ro, rd, t, nrm, mat, outside, n, dst_base, packed, traced);
+}
+
+// The tiles [first, first + count) of one wave's run at one bounce, two in flight (see the intersection stages
+// above): tile T+1 is loaded and culled before tile T is shaded, so T's last candidates share a pass with T+1's
+// first.  `logical0` = logical index of the run's first path; with `own_span` (k_iteration) the paths sit densely
+// in the wave's own span and `live` of them exist.
 template <int MODE, bool COMPACT, int MESH>
+__device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c, WaveQ &q, const Pool &in, const Pool &out,
+                                          int depth, bool gen_rays, uint32_t first_tile, uint32_t count, uint32_t tiles,
+                                          uint32_t n, bool packed_in, uint32_t span_in, uint32_t &cur, uint32_t dst_base,
+                                          bool own_span, uint32_t live, uint32_t &packed, uint32_t &traced) {
+    const int lane = c.lane;
+    bool pending = false;
+    TileRegs prev{};
+    uint32_t prev_ticket = 0;
+    int par = 0;
+    for (uint32_t r = 0; r < count; ++r) {
+        const uint32_t tile = first_tile + r;
+        if (MESH != MESH_TILES && !own_span && tile >= tiles) break;
+        bool have, active;
+        uint32_t i, src;
+        if (own_span) {                                   // k_iteration: the wave's own packed span
+            const uint32_t k = r * TILE + lane;
+            have = true; active = k < live; i = dst_base + k; src = i;
+        } else {
+            have = tile < tiles;
+            i = tile * TILE + lane;                        // logical path index
+            active = have && i < n;
+            src = i;
+            if (MODE == MODE_ISECT && a.perm) { if (active) src = at(a.perm, i); }        // material sort: gather through the permutation
+            else if (packed_in && have) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
+        }
+        TileRegs tr;
+        f3 ro, rd;
+        tile_load(a, c, in, gen_rays, tile, i, src, have, active, tr, ro, rd);
+        if (MODE == MODE_FUSED) {
+            const float4 *pre_hit = nullptr;
+            if (MESH == MESH_PRE) {
+                // lanes of this tile for which k_mesh found a mesh hit; the mask is consumed (cleared) here
+                const unsigned long long mm = a.mesh_mask[tile];
+                if (mm) {
+                    if (lane == 0) a.mesh_mask[tile] = 0ull;
+                    if (tr.active && ((mm >> lane) & 1ull)) pre_hit = a.mesh_hit + src;
+                }
+            }
+            cull_scene<MESH>(a.scene, c.acc, q, par, c.tri_lds, tr.active, ro, rd, tr.mb, pre_hit);
+            const uint32_t ticket = q.total;
+            if (pending) {
+                drain_to(q, c.acc, prev_ticket);
+                tile_finish<COMPACT>(a, c, q, par ^ 1, in, out, depth, prev, n, dst_base, packed, traced);
+            }
+            prev = tr; prev_ticket = ticket; pending = true; par ^= 1;
+        } else {
+            // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
+            float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0, outside = 1;
+            if (tr.active) {
+                const uint32_t k = (MODE == MODE_CACHE0) ? tr.pid - tr.smp * (uint32_t)a.map.tile_pixels
+                                                         : (a.perm ? at(a.perm + in.cap, i) : i);
+                t = at(a.isect.plane(0), k);
+                nrm = ptd::mk(at(a.isect.plane(1), k), at(a.isect.plane(2), k), at(a.isect.plane(3), k));
+                const int m = at(a.isect.mat(), k);
+                mat = m & 0x7fffffff; outside = (m < 0) ? 0 : 1;
+            }
+            tile_shade<COMPACT>(a, c, in, out, depth, tr, ro, rd, t, nrm, mat, outside, n, dst_base, packed, traced);
+        }
+    }
+    if (pending) {
+        drain_to(q, c.acc, prev_ticket);
+        tile_finish<COMPACT>(a, c, q, par ^ 1, in, out, depth, prev, n, dst_base, packed, traced);
+    }
+}
+
+template <int MODE, bool COMPACT, int MESH, bool SLDS>
 __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
-    float *mats = lds_raw + LDS_CTL_WORDS;
+    const LdsCarve lc = carve_lds(lds_raw, a.scene, SLDS);
     TileCtx c;
-    c.mats = mats;
-    c.gf = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
-    c.wq = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
-    c.tri_lds = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + WAVES * Q_WORDS;
+    c.tri_lds = lc.tri;
 #ifdef PT_STAMPS
 #define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.depth == PT_STAMPS) a.ctl->stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define STAMP(k) do {} while (0)
 #endif
     STAMP(0);
-    stage_scene(mats, a.scene);
+    c.acc = stage_scene<SLDS>(lc.scene, a.scene);
     STAMP(1);
+    WaveQ q{lc.pw, 0, 0};
     const int lane = threadIdx.x & 63;
     c.lane = lane;
     const uint32_t W = gridDim.x * WAVES;
@@ -833,7 +1011,7 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
     const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);                        // logical tiles per wave (one contiguous run)
-    const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
+    const bool packed_in = COMPACT && a.dir_in.mem != nullptr && !(MODE == MODE_ISECT && a.perm);
     const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
     uint32_t traced = 0;
     uint32_t packed = 0;                                         // survivors this wave has written (wave-uniform)
@@ -844,17 +1022,8 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
 
     // every wave walks its own run of R consecutive 64-path tiles; no workgroup barrier inside
     // the loop unless a mesh needs block-wide triangle staging (then all waves run R iterations)
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t tile = wid * R + r;
-        if (MESH != MESH_TILES && tile >= tiles) break;
-        const bool have = tile < tiles;
-        const uint32_t i = tile * TILE + lane;                    // logical path index
-        const bool active = have && i < n;
-        uint32_t src = i;
-        if (packed_in && have) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
-        bounce_tile<MODE, COMPACT, MESH>(a, c, a.in, a.out, a.depth, a.gen_rays != 0, tile, i, src, have, active, n,
-                                         wid * R * TILE, packed, traced);
-    }
+    run_tiles<MODE, COMPACT, MESH>(a, c, q, a.in, a.out, a.depth, a.gen_rays != 0, wid * R, R, tiles, n, packed_in, span_in,
+                                   cur, wid * R * TILE, false, 0, packed, traced);
     STAMP(6);
     // paths traced this bounce: with compaction it is simply the live count; otherwise count the alive
     // slots, one atomic per workgroup (summed through LDS) rather than one per wave on a single address
@@ -905,15 +1074,19 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
 // just are not dealt out again after every bounce, which costs load balance (a wave whose pixels live long
 // works longer) -- the price that makes this the small-batch path only.  Traced counts go to 32 partial sums
 // per bounce (Control::bucket[d][1]; a same-address atomic per wave would serialise), folded by k_gather.
+//
+// The wave's stores of bounce d are read back by its own (other) lanes at bounce d+1 through the CU's vector
+// L1, which its own write-through stores update: workgroup scope is enough for that, on the condition that the
+// workgroup runs in CU mode (not tgsplit: a workgroup's waves then share one CU and one L1) -- the mode hipcc
+// compiles for by default and the only one this library is built in (build.py passes no -mtgsplit).
+template <bool SLDS>
 __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    float *mats = lds_raw + LDS_CTL_WORDS;
+    const LdsCarve lc = carve_lds(lds_raw, a.scene, SLDS);
     TileCtx c;
-    c.mats = mats;
-    c.gf = mats + ((a.scene.nmats * ptd::MAT_WORDS + 3) & ~3);
-    c.wq = mats + scene_lds_words(a.scene.nmats, a.scene.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
     c.tri_lds = nullptr;
-    stage_scene(mats, a.scene);
+    c.acc = stage_scene<SLDS>(lc.scene, a.scene);
+    WaveQ q{lc.pw, 0, 0};
     const int lane = threadIdx.x & 63;
     c.lane = lane;
     const uint32_t W = gridDim.x * WAVES;
@@ -926,30 +1099,22 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a)
     if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = n;
     Pool in = a.in, out = a.out;
     uint32_t count = 0;                                           // paths of this wave entering the bounce (d > 0)
+    uint32_t cur = 0;
     for (int d = 0; d < a.trace_depth; ++d) {
         uint32_t traced = 0, packed = 0;
-        if (d == 0) {
-            for (uint32_t r = 0; r < R; ++r) {
-                const uint32_t tile = wid * R + r;
-                if (tile >= tiles) break;
-                const uint32_t i = tile * TILE + lane;
-                bounce_tile<MODE_FUSED, true, MESH_NONE>(a, c, in, out, 0, true, tile, i, i, true, i < n, n, base, packed, traced);
-            }
-        } else {
-            for (uint32_t t = 0; t * TILE < count; ++t) {
-                const uint32_t k = t * TILE + lane;
-                bounce_tile<MODE_FUSED, true, MESH_NONE>(a, c, in, out, d, false, 0, base + k, base + k, true, k < count, n, base,
-                                                         packed, traced);
-            }
-        }
+        if (d == 0)
+            run_tiles<MODE_FUSED, true, MESH_NONE>(a, c, q, in, out, 0, true, wid * R, R, tiles, n, false, 0, cur, base, false, 0,
+                                                   packed, traced);
+        else
+            run_tiles<MODE_FUSED, true, MESH_NONE>(a, c, q, in, out, d, false, 0, (count + TILE - 1) / TILE, tiles, n, false, 0, cur,
+                                                   base, true, count, packed, traced);
         if (lane == 0 && traced)
             atomicAdd(&a.ctl->bucket[d][1][(wid % ELECT_BUCKETS) * 16], traced);
         count = packed;
         if (count == 0) break;
         const Pool tmp = in; in = out; out = tmp;
-        // the span this wave just wrote is read back by its own (other) lanes.  Workgroup scope is enough -- the
-        // wave stays on its CU, whose vector L1 sees its own write-through stores -- and costs only the wait; an
-        // agent-scope fence writes back / invalidates the L2 and made the launch 4x slower.
+        // the span this wave just wrote is read back by its own (other) lanes; an agent-scope fence writes back /
+        // invalidates the L2 and made the launch 4x slower
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1251,16 +1416,13 @@ __global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
 // First-bounce cache (INSTRUCTION.md:87-89): camera rays do not depend on the iteration (no
 // jitter, pathtrace.cu:134), so computeIntersections of bounce 0 is evaluated once per pixel and
 // camera and reused by every sample.
-template <int MESH>
+template <int MESH, bool SLDS>
 __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache, SceneDev sc, pt_camera cam,
                                                                       TileMap map) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    float *mats_lds = lds_raw + LDS_CTL_WORDS;
-    const float *gf = mats_lds + ((sc.nmats * ptd::MAT_WORDS + 3) & ~3);
-    float *wq = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + (threadIdx.x >> 6) * Q_WORDS;
-    float *tri_lds = mats_lds + scene_lds_words(sc.nmats, sc.ngeoms) + WAVES * Q_WORDS;
-    stage_scene(mats_lds, sc);
-    const float *gsrc = sc.geoms;
+    const LdsCarve lc = carve_lds(lds_raw, sc, SLDS);
+    const SceneAcc acc = stage_scene<SLDS>(lc.scene, sc);
+    WaveQ q{lc.pw, 0, 0};
     const uint32_t n = (uint32_t)map.tile_pixels;
     const uint32_t tiles = (n + BLOCK - 1) / BLOCK;
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -1268,13 +1430,14 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache
         const bool active = j < n;
         f3 ro = ptd::mk(cam.position.x, cam.position.y, cam.position.z), rd = ptd::mk(0, 0, 1);
         if (active) camera_ray(cam, Lens{0, 0.0f, 0.0f}, 0, 0, local_to_pixel(map, (int)j), map.W, ro, rd);   // pinhole only (pt_init)
-        ptd::Hit h;
-        intersect_scene<MESH>(gsrc, sc, tri_lds, active, ro, rd, h, wq, gf);
+        MeshBest mb;
+        cull_scene<MESH>(sc, acc, q, 0, lc.tri, active, ro, rd, mb, nullptr);
+        drain_to(q, acc, q.total);
         if (active) {
-            float t; f3 nrm; int mat;
-            resolve_hit(gsrc, gf, sc.tris, h, t, nrm, mat);
+            float t; f3 nrm; int mat, outside;
+            tile_result(q, 0, acc, sc.tris, mb, t, nrm, mat, outside);
             cache.plane(0)[j] = t; cache.plane(1)[j] = nrm.x; cache.plane(2)[j] = nrm.y; cache.plane(3)[j] = nrm.z;
-            cache.mat()[j] = mat | (h.outside ? 0 : (int)0x80000000u);
+            cache.mat()[j] = mat | (outside ? 0 : (int)0x80000000u);
         }
     }
 }
@@ -1394,16 +1557,17 @@ __global__ void k_import_paths(Pool p, const pt_path_segment *in, uint32_t n) {
     p.pid(i) = i;
 }
 
-__global__ void k_export_isects(Isect is, uint32_t n, pt_shadeable_intersection *out, uint8_t *outside) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ void k_export_isects(Isect is, uint32_t n, pt_shadeable_intersection *out, uint8_t *outside, const uint32_t *perm_i) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    const uint32_t i = perm_i ? perm_i[o] : o;               // material sort: records in sorted order
     pt_shadeable_intersection s;
     const int m = is.mat()[i];
     s.t = is.plane(0)[i];
     if (s.t > 0.0f) { s.surfaceNormal = {is.plane(1)[i], is.plane(2)[i], is.plane(3)[i]}; s.materialId = m & 0x7fffffff; }
     else { s.surfaceNormal = {0, 0, 0}; s.materialId = 0; }      // memset(0) + t = -1 only
-    out[i] = s;
-    if (outside) outside[i] = (m < 0) ? 0 : 1;
+    out[o] = s;
+    if (outside) outside[o] = (m < 0) ? 0 : 1;
 }
 
 

@@ -153,7 +153,11 @@ struct Lens {
 };
 
 struct SceneDev {
-    const float *geoms;  int ngeoms;       // GEOM_WORDS dwords each
+    const float *geoms;  int ngeoms;       // GEOM_WORDS dwords each (mesh ranges / grids; scalar loads)
+    const float *cull;                     // CULL_WORDS per geom: padded world box + type (scalar loads)
+    const float *grec;                     // GREC_WORDS per geom: the three matrices (per-lane gathers)
+    const uint32_t *ginfo;                 // per geom: materialid | type << 28
+    float rmax;                            // |origin|_1 bound the cull boxes were derived for
     const float *mats;   int nmats;        // MAT_WORDS dwords each
     const float *tris;   int ntris;        // v0, e1, e2 + pad (12 dwords each)
     const float *bvh_nodes;                // PT_MESH_BVH: all meshes' trees, BVH_NODE_WORDS per node
@@ -180,6 +184,8 @@ struct BounceArgs {
     // and, per logical 64-path tile, the lanes that have one
     float4 *mesh_hit;
     unsigned long long *mesh_mask;
+    // material sort: [0, cap) pool slot and [cap, 2 cap) logical index of the path at each sorted position
+    const uint32_t *perm;
 };
 
 __device__ __forceinline__ int local_to_pixel(const TileMap &m, int j) {

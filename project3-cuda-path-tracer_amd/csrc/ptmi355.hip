@@ -1,26 +1,18 @@
 // ptmi355.hip -- libptmi355.so: kernels + C-ABI (include/ptmi355.h).
 //
-// MI355X-native replacement for the hot path of the reference's
-// src/pathtrace.cu (pathtraceInit / pathtrace / pathtraceFree and its five
-// kernels).  Design:
-//   * path state lives in SoA planes (ox..oz, dx..dz, cr..cb, pid) of a pool
-//     that holds `batch` iterations of the tile's pixels; two pools ping-pong;
-//   * one fused kernel per bounce: intersect (scene records broadcast from
-//     LDS) -> shade/scatter -> stable compaction -> write survivors;
-//   * compaction is tile-local and wait-free: a 256-path tile packs its
-//     survivors (wave64 ballot + popcount rank, 4 wave counts through LDS) to
-//     the front of its own 256-slot span and publishes its count; the last
-//     workgroup to finish the launch (one agent-scope atomic per workgroup)
-//     scans the tile counts into tile bases; the next bounce reads logical
-//     path i through those bases (64-entry window in LDS + binary search), so
-//     the logical order is exactly the stable partition's while no workgroup
-//     ever waits on another (round-1 look-back version: 81 % of wave time
-//     parked, profiles/r01a);
-//   * the live count stays on the device: the next bounce reads it from HBM,
-//     no host round trip inside an iteration;
-//   * terminated paths drop their final colour into final[sample][pixel];
-//     one gather kernel adds the samples into the float3 accumulation buffer
-//     in iteration order (bit-identical to sequential iterations).
+// MI355X-native replacement for the hot path of the reference's src/pathtrace.cu (pathtraceInit / pathtrace /
+// pathtraceFree and its five kernels).  Design:
+//   * path state lives in a pool that is SoA per 64-path tile (ten 256-B rows: ox..oz dx..dz cr..cb pid) and holds
+//     `batch` iterations of the tile's pixels; two pools ping-pong;
+//   * a persistent grid; every WAVE owns one contiguous run of 64-path tiles per bounce and walks it with two
+//     tiles in flight: cull against per-primitive world boxes -> candidate ring in LDS -> lane-dense exact
+//     object-space tests (64 candidates per pass) -> shade / scatter in registers (pt_kernels.hpp);
+//   * stable compaction without cross-wave communication: survivors are ranked with a wave64 ballot and appended
+//     to the front of the wave's own span; each wave publishes its count, the last workgroup out of the launch
+//     scans the <= 8192 counts into bases (range directory) and the next bounce maps logical index -> slot;
+//   * the live count stays on the device: the next bounce reads it from HBM, no host round trip inside a batch;
+//   * terminated paths drop their final colour into final[sample][pixel]; one gather kernel adds the samples into
+//     the float3 accumulation buffer in iteration order (bit-identical to sequential iterations).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction:
 // parity with the reference arithmetic is bit-exact, tests/test_gpu_parity.py).
@@ -28,6 +20,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +47,7 @@ using ptd::f3;
 
 #include "pt_types.hpp"
 #include "pt_bvh.hpp"
+#include "pt_cull.hpp"
 #include "pt_kernels.hpp"
 
 namespace {
@@ -105,6 +99,12 @@ struct Renderer {
     float *image = nullptr;
     bool own_image = false;
     float *d_geoms = nullptr, *d_mats = nullptr, *d_tris = nullptr;
+    float *d_cull = nullptr, *d_grec = nullptr;
+    uint32_t *d_ginfo = nullptr;
+    double cull_eye_reach = 0.0;  // |camera position|_1 the cull boxes were made for
+    std::vector<pt_geom> geoms_keep;   // host copies (pt_set_camera may have to remake the cull boxes)
+    std::vector<pt_triangle> tris_keep;
+    bool scene_lds = true;        // gather records + materials staged in LDS (else read through the vector cache)
     SceneDev scene{};
     size_t lds_bytes = 0;
     Control *ctl = nullptr;
@@ -262,28 +262,44 @@ int enqueue_begin(int iter0, int count, bool stepping) {
     return PT_OK;
 }
 
-// the mesh mode is a template switch of every kernel that intersects: pick the instantiation
+// the mesh mode and where the per-lane scene gathers come from (LDS / vector cache) are template switches of
+// every kernel that intersects: pick the instantiation
 #define PT_MESH_DISPATCH(CALL)                                          \
     do {                                                                \
-        if (R.mesh_mode == MESH_BVH) { constexpr int MESH = MESH_BVH; CALL; }            \
-        else if (R.mesh_mode == MESH_TILES) { constexpr int MESH = MESH_TILES; CALL; }   \
-        else { constexpr int MESH = MESH_NONE; CALL; }                  \
+        if (R.scene_lds) {                                              \
+            constexpr bool SLDS = true;                                 \
+            if (R.mesh_mode == MESH_BVH) { constexpr int MESH = MESH_BVH; CALL; }            \
+            else if (R.mesh_mode == MESH_TILES) { constexpr int MESH = MESH_TILES; CALL; }   \
+            else { constexpr int MESH = MESH_NONE; CALL; }              \
+        } else {                                                        \
+            constexpr bool SLDS = false;                                \
+            if (R.mesh_mode == MESH_BVH) { constexpr int MESH = MESH_BVH; CALL; }            \
+            else if (R.mesh_mode == MESH_TILES) { constexpr int MESH = MESH_TILES; CALL; }   \
+            else { constexpr int MESH = MESH_NONE; CALL; }              \
+        }                                                               \
     } while (0)
 
 void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, const RangeDir &dir,
                       const uint32_t *nprev) {
-    PT_MESH_DISPATCH(hipLaunchKernelGGL((k_intersect<MESH>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, in,
+    PT_MESH_DISPATCH(hipLaunchKernelGGL((k_intersect<MESH, SLDS>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, in,
                                         R.isect, R.scene, n_ptr, n_fixed, dir, nprev, R.ctl));
 }
 
 template <int MODE, bool COMPACT>
 void launch_bounce(const BounceArgs &a) {
-    if (MODE == MODE_FUSED && R.mesh_mode == MESH_BVH) {
-        // meshes were walked by the pre-pass (enqueue_bounce); this launch reads its results
-        hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH_PRE>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+    if (MODE != MODE_FUSED) {
+        // nothing is intersected: one instantiation serves every mesh mode
+        if (R.scene_lds) hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH_NONE, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        else hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH_NONE, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
         return;
     }
-    PT_MESH_DISPATCH(hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH>), dim3(R.grid), dim3(BLOCK), R.lds_bytes,
+    if (R.mesh_mode == MESH_BVH) {
+        // meshes were walked by the pre-pass (enqueue_bounce); this launch reads its results
+        if (R.scene_lds) hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH_PRE, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        else hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH_PRE, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        return;
+    }
+    PT_MESH_DISPATCH(hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH, SLDS>), dim3(R.grid), dim3(BLOCK), R.lds_bytes,
                                         R.stream, a));
 }
 
@@ -321,7 +337,7 @@ int enqueue_bounce(int depth) {
         StageTimer tm(PT_STAGE_INTERSECT);
         const Isect cache{R.cache_mem, (uint32_t)R.map.tile_pixels};
         const int blocks = std::min(R.grid, (R.map.tile_pixels + BLOCK - 1) / BLOCK);
-        PT_MESH_DISPATCH(hipLaunchKernelGGL((k_cache_first<MESH>), dim3(blocks), dim3(BLOCK), R.lds_bytes, R.stream,
+        PT_MESH_DISPATCH(hipLaunchKernelGGL((k_cache_first<MESH, SLDS>), dim3(blocks), dim3(BLOCK), R.lds_bytes, R.stream,
                                             cache, R.scene, R.cam, R.map));
         HIPCHK(hipGetLastError());
         R.cache_valid = true;
@@ -388,7 +404,8 @@ int enqueue_batch_direct(int iter0, int count) {
         // small batch: every bounce in one launch (k_iteration)
         StageTimer tm(PT_STAGE_BOUNCE);
         BounceArgs a = bounce_args(0);
-        hipLaunchKernelGGL(k_iteration, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        if (R.scene_lds) hipLaunchKernelGGL(k_iteration<true>, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        else hipLaunchKernelGGL(k_iteration<false>, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
         HIPCHK(hipGetLastError());
         R.step_depth = R.trace_depth;
         R.whole = true;
@@ -447,6 +464,43 @@ int enqueue_batch(int iter0, int count) {
     R.step_iter0 = iter0; R.step_count = count;
     R.cur = g.cur; R.cur_dir = g.cur_dir; R.step_depth = g.step_depth;
     R.sorted_isects = g.sorted_isects; R.gen_fused = g.gen_fused;
+    return PT_OK;
+}
+
+// per-primitive cull boxes (pt_cull.hpp) for the scene of R.desc as seen from camera `cam`: the |origin|_1 bound
+// they are derived for covers the scene and the camera; a camera that later moves beyond it gets new boxes
+int upload_cull(const pt_scene_desc *d, const pt_camera &cam) {
+    const int n = d->num_geoms;
+    std::vector<const float *> inv((size_t)std::max(1, n));
+    std::vector<char> sph((size_t)std::max(1, n)), skip((size_t)std::max(1, n));
+    for (int i = 0; i < n; ++i) {
+        inv[(size_t)i] = &d->geoms[i].inverseTransform.m[0][0];
+        sph[(size_t)i] = d->geoms[i].type == PT_SPHERE;
+        skip[(size_t)i] = d->geoms[i].type == PT_TRIANGLE_MESH;
+    }
+    const double eye[3] = {(double)cam.position.x, (double)cam.position.y, (double)cam.position.z};
+    std::vector<ptcull::Box> boxes;
+    std::vector<double> pts(eye, eye + 3);
+    // triangle meshes are world-space soups: their vertices bound where rays can start as well
+    for (int t = 0; t < d->num_triangles; ++t) {
+        const pt_vec3 *v = &d->triangles[t].v0;
+        double m = 0.0;
+        for (int k = 0; k < 3; ++k) m = std::max(m, (double)std::fabs(v[k].x) + std::fabs(v[k].y) + std::fabs(v[k].z));
+        if (t == 0 || m > pts[3]) { if (pts.size() < 6) pts.resize(6, 0.0); pts[3] = m; pts[4] = 0.0; pts[5] = 0.0; }
+    }
+    R.scene.rmax = ptcull::make_boxes(inv.data(), reinterpret_cast<const bool *>(sph.data()),
+                                      reinterpret_cast<const bool *>(skip.data()), n, pts.data(), (int)(pts.size() / 3), boxes);
+    std::vector<float> rec((size_t)std::max(1, n) * CULL_WORDS, 0.0f);
+    for (int i = 0; i < n; ++i) {
+        float *r = rec.data() + (size_t)i * CULL_WORDS;
+        for (int k = 0; k < 3; ++k) { r[2 * k] = boxes[(size_t)i].lo[k]; r[2 * k + 1] = boxes[(size_t)i].hi[k]; }
+        memcpy(&r[6], &d->geoms[i].type, 4);
+    }
+    if (!R.d_cull) HIPCHK(hipMalloc(&R.d_cull, rec.size() * 4));
+    HIPCHK(hipMemcpyAsync(R.d_cull, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, R.stream));
+    HIPCHK(hipStreamSynchronize(R.stream));            // `rec` is pageable host memory about to go out of scope
+    R.scene.cull = R.d_cull;
+    R.cull_eye_reach = std::fabs(eye[0]) + std::fabs(eye[1]) + std::fabs(eye[2]);
     return PT_OK;
 }
 
@@ -516,6 +570,9 @@ void pt_free(void) {
     if (R.d_geoms) (void)hipFree(R.d_geoms);
     if (R.d_mats) (void)hipFree(R.d_mats);
     if (R.d_tris) (void)hipFree(R.d_tris);
+    if (R.d_cull) (void)hipFree(R.d_cull);
+    if (R.d_grec) (void)hipFree(R.d_grec);
+    if (R.d_ginfo) (void)hipFree(R.d_ginfo);
     drop_graphs();
     if (R.mesh_hit) (void)hipFree(R.mesh_hit);
     if (R.mesh_mask) (void)hipFree(R.mesh_mask);
@@ -725,6 +782,33 @@ static int init_impl(const pt_scene_desc *d) {
     R.scene.geoms = R.d_geoms; R.scene.ngeoms = d->num_geoms;
     R.scene.mats = R.d_mats; R.scene.nmats = d->num_materials;
     R.scene.tris = R.d_tris; R.scene.ntris = d->num_triangles;
+    {   // per-lane gather records (the three matrices, 4 columns x 3 rows each) and geom info words
+        std::vector<float> gath((size_t)std::max(1, d->num_geoms) * GREC_WORDS, 0.0f);
+        std::vector<uint32_t> ginfo((size_t)std::max(1, d->num_geoms), 0u);
+        for (int i = 0; i < d->num_geoms; ++i) {
+            const pt_geom &g = d->geoms[i];
+            float *r = gath.data() + (size_t)i * GREC_WORDS;
+            const pt_mat4 *ms[3] = {&g.inverseTransform, &g.transform, &g.invTranspose};
+            for (int m = 0; m < 3; ++m)
+                for (int c = 0; c < 4; ++c)
+                    for (int rr = 0; rr < 3; ++rr) r[m * 12 + c * 3 + rr] = ms[m]->m[c][rr];
+            ginfo[(size_t)i] = (uint32_t)g.materialid | ((uint32_t)g.type << 28);
+        }
+        if (d->num_materials >= (1 << 28)) return fail(PT_ERR_INVALID, "pt_init: at most 2^28 materials");
+        HIPCHK(hipMalloc(&R.d_grec, gath.size() * 4));
+        HIPCHK(hipMalloc((void **)&R.d_ginfo, ginfo.size() * 4));
+        HIPCHK(hipMemcpy(R.d_grec, gath.data(), gath.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(R.d_ginfo, ginfo.data(), ginfo.size() * 4, hipMemcpyHostToDevice));
+        R.scene.grec = R.d_grec; R.scene.ginfo = R.d_ginfo;
+    }
+    R.geoms_keep.assign(d->geoms, d->geoms + d->num_geoms);
+    if (d->num_triangles > 0) R.tris_keep.assign(d->triangles, d->triangles + d->num_triangles);
+    R.desc.geoms = R.geoms_keep.data();
+    R.desc.triangles = R.tris_keep.empty() ? nullptr : R.tris_keep.data();
+    {
+        const int rc = upload_cull(&R.desc, R.cam);
+        if (rc != PT_OK) return rc;
+    }
     R.mesh_mode = MESH_NONE;
     for (int i = 0; i < d->num_geoms; ++i)
         if (d->geoms[i].type == PT_TRIANGLE_MESH) R.mesh_mode = (d->flags & PT_MESH_BVH) ? MESH_BVH : MESH_TILES;
@@ -733,12 +817,19 @@ static int init_impl(const pt_scene_desc *d) {
         if (rc != PT_OK) return rc;
         HIPCHK(hipMemcpy(R.d_geoms, grec.data(), grec.size() * 4, hipMemcpyHostToDevice));   // records now name tree roots
     }
-    R.lds_bytes = ((size_t)LDS_CTL_WORDS + (size_t)scene_lds_words(d->num_materials, d->num_geoms) +
-                   (size_t)WAVES * Q_WORDS) * 4;
-    R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
-    if (const char *pad = getenv("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
-    if (R.mesh_mode == MESH_TILES) R.lds_bytes += (size_t)TRI_TILE * TRI_WORDS * 4;
-    if (R.lds_bytes > 60 * 1024) return fail(PT_ERR_INVALID, "pt_init: the scene records staged per workgroup (12 B per material word, 128 B per geom) need %zu B of LDS (> 60 KiB)", R.lds_bytes);
+    // LDS per workgroup: control words + (scene block, when it is small enough to leave room for five workgroups
+    // per CU) + the four per-wave blocks (+ the triangle tile).  A scene that does not fit is gathered from global
+    // memory through the vector cache instead: any number of primitives / materials runs.
+    {
+        const size_t base = ((size_t)LDS_CTL_WORDS + (size_t)WAVES * PW_WORDS) * 4 +
+                            (R.mesh_mode == MESH_TILES ? (size_t)TRI_TILE * TRI_WORDS * 4 : 0);
+        const size_t scene = (size_t)scene_lds_words(d->num_materials, d->num_geoms) * 4;
+        R.scene_lds = base + scene <= 32 * 1024 || (R.mesh_mode == MESH_TILES && base + scene <= 64 * 1024);
+        if (const char *e = getenv("PTMI355_SCENE_LDS")) R.scene_lds = atoi(e) != 0 && base + scene <= 64 * 1024;   // tests force the global path
+        R.lds_bytes = base + (R.scene_lds ? scene : 0);
+        R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
+        if (const char *pad = getenv("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
+    }
 
     // pools, intersections, final colours, image, control
     const size_t capz = R.cap;
@@ -775,10 +866,10 @@ static int init_impl(const pt_scene_desc *d) {
     int per_cu = 0;
     if (R.mesh_mode == MESH_BVH)
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH_PRE>, BLOCK, R.lds_bytes));
+            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH_PRE, true>, BLOCK, R.lds_bytes));
     else
         PT_MESH_DISPATCH(HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH>, BLOCK, R.lds_bytes)));
+            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH, SLDS>, BLOCK, R.lds_bytes)));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
@@ -820,6 +911,15 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
     if (trace_depth < 1 || trace_depth > R.desc.trace_depth)
         return fail(PT_ERR_INVALID, "pt_set_camera: trace_depth %d outside [1, %d]", trace_depth, R.desc.trace_depth);
     if (memcmp(&R.cam, camera, sizeof R.cam) != 0) { R.cache_valid = false; drop_graphs(); }   // refill the bounce-0 cache
+    {   // the cull boxes hold for ray origins within R.scene.rmax (1-norm); a camera outside that range would only
+        // make its rays candidates of every primitive (correct, slow): remake the boxes around the new position
+        const double reach = (double)std::fabs(camera->position.x) + std::fabs(camera->position.y) + std::fabs(camera->position.z);
+        if (std::isfinite(reach) && reach > (double)R.scene.rmax && reach != R.cull_eye_reach) {
+            const int rc = upload_cull(&R.desc, *camera);
+            if (rc != PT_OK) return rc;
+            drop_graphs();
+        }
+    }
     if (trace_depth != R.trace_depth) drop_graphs();
     R.cam = *camera;
     R.trace_depth = trace_depth;
@@ -1043,6 +1143,25 @@ int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node
     if (order && count > 0) memcpy(order, tree.order.data(), (size_t)count * 4);
     if (grid) { for (int a = 0; a < 3; ++a) { grid[a] = tree.origin[a]; grid[3 + a] = tree.step[a]; } grid[6] = tree.pad; grid[7] = tree.prune; }
     return tree.num_nodes();
+}
+
+int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound) {
+    if (count < 0 || (count > 0 && !geoms) || !boxes) return fail(PT_ERR_INVALID, "pt_cull_boxes: bad argument");
+    std::vector<const float *> inv((size_t)std::max(1, count));
+    std::vector<char> sph((size_t)std::max(1, count)), skip((size_t)std::max(1, count));
+    for (int i = 0; i < count; ++i) {
+        inv[(size_t)i] = &geoms[i].inverseTransform.m[0][0];
+        sph[(size_t)i] = geoms[i].type == PT_SPHERE;
+        skip[(size_t)i] = geoms[i].type == PT_TRIANGLE_MESH;
+    }
+    const double e[3] = {eye ? (double)eye[0] : 0.0, eye ? (double)eye[1] : 0.0, eye ? (double)eye[2] : 0.0};
+    std::vector<ptcull::Box> bx;
+    const float r = ptcull::make_boxes(inv.data(), reinterpret_cast<const bool *>(sph.data()),
+                                       reinterpret_cast<const bool *>(skip.data()), count, e, 1, bx);
+    for (int i = 0; i < count; ++i)
+        for (int k = 0; k < 3; ++k) { boxes[6 * i + k] = bx[(size_t)i].lo[k]; boxes[6 * i + 3 + k] = bx[(size_t)i].hi[k]; }
+    if (origin_bound) *origin_bound = r;
+    return PT_OK;
 }
 
 int pt_get_counters(int64_t *rays, int64_t *first_bounce_rays, int64_t *iterations) {

@@ -1,0 +1,70 @@
+"""The cull stage may only drop (ray, primitive) pairs the reference's own float arithmetic misses: for rays that
+stress the boxes of pt_cull.hpp (faces, edges, corners, grazing, inside, behind, axis-parallel, non-finite), every
+pair the ORACLE reports as a hit must be a candidate of the numpy model of the kernel's test.  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import cull_model  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def pt():
+    import __graft_entry__ as ge
+    ge.build()
+    return ge.load_package()
+
+
+def _check(pt, po, geoms, eye, rng, per_geom):
+    boxes, rmax = pt.cull_boxes(geoms, eye)
+    rays = cull_model.stress_rays(geoms, rng, per_geom=per_geom)
+    paths = np.zeros(len(rays), dtype=po.PATH_DT)
+    paths["origin"], paths["direction"] = rays[:, :3], rays[:, 3:]
+    total_hits = total_cand = 0
+    for gi in range(len(geoms)):
+        want, _ = po.compute_intersections(paths, geoms[gi:gi + 1].view(po.GEOM_DT))
+        # any t the loop of pathtrace.cu:176-199 would take (t > 0), and NaN distances (they come from a passed test)
+        hit = (want["t"] > 0) | np.isnan(want["t"])
+        cand, _wild = cull_model.candidates(rays, boxes[gi], rmax)
+        lost = hit & ~cand
+        assert not lost.any(), "geom %d: %d hits outside the box, e.g. ray %s" % (gi, lost.sum(), rays[np.nonzero(lost)[0][0]])
+        total_hits += int(hit.sum()); total_cand += int(cand.sum())
+    return total_hits, total_cand, len(rays) * len(geoms)
+
+
+def test_cornell_boxes(pt, po, scenes):
+    s = scenes["cornell"]
+    eye = s["camera"].view(pt.CAMERA_DT)[0]["position"]
+    hits, cand, pairs = _check(pt, po, s["geoms"], eye, np.random.default_rng(7), 6000)
+    assert hits > 20000 and cand < pairs                   # the rays do hit, and the boxes do cull
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_transforms(pt, po, scenes, seed):
+    """Rotated, non-uniformly scaled (thin slabs, 1000:1), tiny and huge primitives; singular ones get no box."""
+    rng = np.random.default_rng(100 + seed)
+    H = pt.host_binding.host_library()
+    ng = 10
+    geoms = np.zeros(ng, dtype=pt.GEOM_DT)
+    for k, g in enumerate(geoms):
+        g["type"] = rng.integers(2)
+        g["translation"] = rng.uniform(-4, 4, 3) + (0, 5, 0)
+        g["rotation"] = rng.uniform(-180, 180, 3) * (rng.random() < 0.8)
+        sc = rng.uniform(0.3, 3.0, 3)
+        if k % 3 == 0:
+            sc[rng.integers(3)] = rng.choice([0.02, 0.003])
+        if k == 1:
+            sc = np.array([25.0, 25.0, 25.0])
+        if k == 2:
+            sc = np.array([1e-3, 1e-3, 1e-3])
+        if k == 4:
+            sc = np.array([0.0, 1.0, 1.0])                 # singular: inverse holds inf / NaN
+        g["scale"] = sc
+        H.pth_build_geom_matrices(geoms.ctypes.data + k * pt.GEOM_DT.itemsize)
+    boxes, _ = pt.cull_boxes(geoms, (0.0, 5.0, 10.5))
+    assert np.isinf(boxes[4]).all()                        # no culling for the singular one
+    assert np.isfinite(boxes[0]).all()
+    _check(pt, po, geoms, (0.0, 5.0, 10.5), rng, 2500)

@@ -3,9 +3,13 @@ the same inputs.  Everything here is bit-exact (float radiance included: the
 library is built without FMA contraction and shares the oracle's sin/cos
 definition), which is stricter than the north star's 1e-4 relative L2."""
 import hashlib
+import os
+import sys
 
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import __graft_entry__ as ge
 
@@ -457,38 +461,96 @@ def test_trace_depth_reread_every_call(pt, po, scenes):
     pt.pathtraceFree()
 
 
-def test_many_primitives(pt, po, scenes):
-    """150 cubes / spheres (19 KB of per-geom gather records in LDS, every ray loops over all of them) and the
-    LDS limit: 600 are refused with a message instead of a bad launch."""
-    rng = np.random.default_rng(4242)
+@pytest.mark.parametrize("ng,nm", [(150, 5), (1000, 300)])
+def test_many_primitives(pt, po, scenes, ng, nm):
+    """150 cubes / spheres (gather records staged in LDS) and 1000 with 300 materials (too large for LDS: matrices and
+    materials are gathered through the vector cache; the reference's loop has no limit, pathtrace.cu:176): live counts
+    and image equal the oracle's, fused, with the material sort (> 255 materials) and without compaction."""
+    rng = np.random.default_rng(4242 + ng)
     s = scenes["cornell_64"]
     H = pt.host_binding.host_library()
+    mats = np.zeros(nm, dtype=pt.MATERIAL_DT)
+    mats[:len(s["materials"])] = s["materials"]
+    for m in mats[len(s["materials"]):]:
+        m["color"] = rng.uniform(0.2, 1.0, 3)
+        m["spec_color"] = rng.uniform(0.5, 1.0, 3)
+        kind = rng.integers(5)
+        m["hasReflective"], m["hasRefractive"] = (1.0, 0.0) if kind == 1 else ((0.0, 1.0) if kind == 2 else (0.0, 0.0))
+        m["indexOfRefraction"] = rng.uniform(1.1, 2.0)
+    geoms = np.zeros(ng, dtype=pt.GEOM_DT)
+    for g in geoms:
+        g["type"] = rng.integers(2)
+        g["materialid"] = rng.integers(nm)
+        g["translation"] = rng.uniform(-4.5, 4.5, 3) + (0, 5, 0)
+        g["rotation"] = rng.uniform(-180, 180, 3)
+        g["scale"] = rng.uniform(0.2, 1.2, 3) * (0.5 if ng > 500 else 1.0)
+    geoms[0] = s["geoms"][0]                                         # the light
+    for k in range(1, ng):
+        H.pth_build_geom_matrices(geoms.ctypes.data + k * pt.GEOM_DT.itemsize)
+    scene = pt.Scene(geoms, mats, s["camera"], 4)
+    for flags, oflags in ((pt.PT_COMPACT, po.F_COMPACT), (pt.PT_COMPACT | pt.PT_SORT_MATERIAL, po.F_COMPACT | po.F_SORT), (0, 0)):
+        ref = po.Tracer(geoms.view(po.GEOM_DT), mats.view(po.MATERIAL_DT), s["camera"], 4, flags=oflags, trig=po.TRIG_SHARED)
+        pt.pathtraceInit(scene, flags=flags)
+        for it in (1, 2):
+            img = pt.pathtrace(None, 0, it)
+            st = ref.iterate(it)
+            assert list(pt.get_stats().live[:4]) == list(st.live[:4]), (flags, it)
+        assert img.tobytes() == ref.image.tobytes(), flags
+        pt.pathtraceFree()
 
-    def make(ng):
-        geoms = np.zeros(ng, dtype=pt.GEOM_DT)
-        for g in geoms:
-            g["type"] = rng.integers(2)
-            g["materialid"] = rng.integers(len(s["materials"]))
-            g["translation"] = rng.uniform(-4.5, 4.5, 3) + (0, 5, 0)
-            g["rotation"] = rng.uniform(-180, 180, 3)
-            g["scale"] = rng.uniform(0.2, 1.2, 3)
-        geoms[0] = s["geoms"][0]                                         # the light
-        for k in range(1, ng):
-            H.pth_build_geom_matrices(geoms.ctypes.data + k * pt.GEOM_DT.itemsize)
-        return geoms
 
-    geoms = make(150)
-    scene = pt.Scene(geoms, s["materials"], s["camera"], 4)
-    ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], 4, trig=po.TRIG_SHARED)
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
-    for it in (1, 2):
-        img = pt.pathtrace(None, 0, it)
-        st = ref.iterate(it)
-        assert list(pt.get_stats().live[:4]) == list(st.live[:4])
-    assert img.tobytes() == ref.image.tobytes()
-    pt.pathtraceFree()
-    with pytest.raises(pt.PtError, match="LDS"):
-        pt.pathtraceInit(pt.Scene(make(600), s["materials"], s["camera"], 4), flags=pt.PT_COMPACT)
+def test_scene_gathers_from_global_memory(pt, po, scenes, monkeypatch):
+    """The Cornell scenes with the LDS staging of matrices / materials switched off (PTMI355_SCENE_LDS=0, the path
+    large scenes take): same bits."""
+    monkeypatch.setenv("PTMI355_SCENE_LDS", "0")
+    for name in ("cornell_64", "cornell_glass_64"):
+        s = scenes[name]
+        scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+        ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
+        for it in (1, 2, 3):
+            img = pt.pathtrace(None, 0, it)
+            st = ref.iterate(it)
+            assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
+        assert img.tobytes() == ref.image.tobytes()
+        pt.pathtraceFree()
+
+
+def test_cull_box_gates(pt, po, scenes):
+    """The cull stage (csrc/pt_cull.hpp, pt_kernels.hpp stage 1) never changes an intersection: rays aimed at the
+    faces / edges / corners of every primitive from 1e-7 to 1 object units off the surface, from on the surface, from
+    inside, from beyond the origin bound (`wild`), with axis-parallel, zero, un-normalised, NaN / inf components --
+    t, normal, material and the outside flag equal the oracle's loop over every primitive, bit for bit; for the
+    Cornell box and for rotated / thin / huge / tiny / singular primitives."""
+    import cull_model
+    H = pt.host_binding.host_library()
+    s = scenes["cornell"]
+    rng = np.random.default_rng(99)
+    extra = np.zeros(8, dtype=pt.GEOM_DT)
+    scales = [(2.0, 0.004, 3.0), (0.5, 0.5, 0.5), (25.0, 25.0, 25.0), (1e-3, 1e-3, 1e-3), (0.0, 1.0, 1.0), (3.0, 0.3, 0.03),
+              (1.0, 1.0, 1.0), (0.7, 2.0, 0.7)]
+    for k, g in enumerate(extra):
+        g["type"] = k % 2
+        g["materialid"] = 1 + k % 4
+        g["translation"] = rng.uniform(-3, 3, 3) + (0, 5, 0)
+        g["rotation"] = rng.uniform(-180, 180, 3)
+        g["scale"] = scales[k]
+        H.pth_build_geom_matrices(extra.ctypes.data + k * pt.GEOM_DT.itemsize)
+    for geoms in (s["geoms"], np.concatenate([s["geoms"], extra])):
+        rays = cull_model.stress_rays(geoms, rng, per_geom=3000)
+        paths = np.zeros(len(rays), dtype=pt.PATH_DT)
+        paths["origin"], paths["direction"] = rays[:, :3], rays[:, 3:]
+        scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"])
+        pt.pathtraceInit(scene, max_batch=1 + len(rays) // (800 * 800))
+        got, got_out = pt.intersect_once(paths)
+        pt.pathtraceFree()
+        want, want_out = po.compute_intersections(paths.view(po.PATH_DT), geoms.view(po.GEOM_DT))
+        assert (bits(got["t"]) == bits(want["t"])).all()
+        assert (bits(got["normal"]) == bits(want["normal"])).all()
+        assert (got["materialId"] == want["materialId"]).all()
+        hit = want["t"] > 0
+        assert hit.sum() > 5000 and (~hit).sum() > 1000
+        assert (got_out[hit] == want_out[hit]).all()
 
 
 def test_singular_and_extreme_transforms(pt, po, scenes):
