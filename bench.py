@@ -38,6 +38,18 @@ BYTES_PER_RAY = 44 + 104 + 4
 BYTES_PER_SURVIVOR = 88
 
 
+def csrc_digest():
+    """sha256 (first 16 hex digits) over the kernel sources: counter profiles are only valid for the build they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "project3-cuda-path-tracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hpp", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_scene(pt, name):
     z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
     g = lambda k: z["%s__%s" % (name, k)]

@@ -660,41 +660,42 @@ __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t 
 }
 
 // ---------------------------------------------------------------------------
-// material sort (INSTRUCTION.md:78-86; spec 8.0): stable counting sort of the live paths and
-// their intersections by key = materialId (misses last), before shading
+// material sort (INSTRUCTION.md:78-86; spec 8.0): stable sort of the live paths and their
+// intersections by key = materialId (misses last) before shading; the pool order after the
+// bounce is the stable partition of that sorted order
 // ---------------------------------------------------------------------------
-// Pass 1 (k_sort_hist): every wave histograms the keys of its run of R tiles (wave64
-// match-ballot, per-wave bins in LDS) into table[bin][wave]; the last workgroup out scans the
-// bin-major table (nbins * W words) in place into start offsets.  Pass 2 (k_sort_perm):
-// every wave walks its run again and computes where each path goes,
-// offset[key][wave] + (same-key paths already seen in the run) + (same-key lanes below it) -- the stable
-// order -- but moves nothing: it scatters two words, perm[dst] = {pool slot, logical index}.  The shading
-// kernel (k_bounce<MODE_ISECT>) then walks the SORTED order and gathers path state and intersection through
-// the permutation.  Inside one material's segment the sources are still in increasing order, so the gathers of
-// a tile touch a few source tiles' rows, most of whose lanes are used; r01 moved the 60 B of state +
-// intersection per path with 15 scattered 4-B stores instead (2.5 TB/s, 212 of 494 ms on C3).
-constexpr int SORT_MAX_BINS = 2048;    // per-wave bins live in LDS: 8 KiB per wave at the limit
-
-struct SortArgs {
-    Isect isect;             // logical order
-    uint32_t *perm;          // out: [0, cap) pool slot, [cap, 2 cap) logical index, both in sorted order
-    uint32_t cap;
-    RangeDir dir_in;
-    Control *ctl;
-    uint32_t *table;         // nbins * W words
-    int depth, nbins;        // nbins = nmats + 1 (misses)
-    uint32_t pool_n;
-    int compact;
-};
+// k_intersect materialises the intersections of the (dense) pool.  Then
+//   k_sort_hist   : every WORKGROUP histograms the keys of its contiguous run of 512-path chunks into
+//                   table[key][workgroup] -- only the keys whose paths go on (with compaction a key either survives
+//                   as a whole or not at all: miss, emissive material and the last bounce end a path, nothing
+//                   else does); the last workgroup out scans the table in place: table[key][g] becomes the position
+//                   in the OUTPUT pool of workgroup g's first path with that key.
+//   k_shade_sorted: every workgroup walks its run again, chunk by chunk: a stable counting sort of the chunk's 512
+//                   keys in LDS (per-wave counts -> starts, no data moves), then each wave takes 128 consecutive
+//                   SORTED positions, gathers their state and intersection from the chunk's 30 KB of pool rows (every
+//                   line the gathers touch is consumed by the same workgroup), shades them -- lanes of a wave run the
+//                   same material's code except where two keys meet -- and writes the survivors straight to their
+//                   place in the globally sorted, compacted output pool (runs of consecutive slots per key).
+// The sort therefore costs one extra read of the keys (8 B per path); nothing is moved to be sorted.  r01 moved
+// state + intersection (60 B per path) with fifteen scattered 4-B stores, then read them back: 2.5 TB/s, 43 % of
+// the time of a C3 step.
+constexpr int SORT_MAX_BINS = 2048;          // one bin per material + misses; per-wave chunk counts live in LDS (32 KiB at the limit)
+constexpr int SORT_CHUNK_TILES = 2 * WAVES;  // two 64-path tiles per wave and chunk
+constexpr int SORT_CHUNK = SORT_CHUNK_TILES * TILE;
 
 __device__ __forceinline__ uint32_t sort_key(const Isect &is, uint32_t i, int nbins) {
     const float t = is.plane(0)[i];
     const int m = is.mat()[i] & 0x7fffffff;
     return t > 0.0f ? (uint32_t)m : (uint32_t)(nbins - 1);
 }
+// does a path whose intersection has this key go on to the next bounce?  (ptd::shade_scatter's three exits)
+__device__ __forceinline__ bool key_survives(const float *__restrict__ mats, uint32_t key, int nbins, bool last_bounce) {
+    if (last_bounce || key >= (uint32_t)(nbins - 1)) return false;
+    return !(mats[key * ptd::MAT_WORDS + 9] > 0.0f);
+}
 
-// in-place exclusive scan of `total` words by one workgroup (1024 words per step)
-__device__ __forceinline__ void scan_words_inplace(uint32_t *w, uint32_t total, uint32_t *lds_scan) {
+// in-place exclusive scan of `total` words by one workgroup (1024 words per step); returns the sum
+__device__ __forceinline__ uint32_t scan_words_inplace(uint32_t *w, uint32_t total, uint32_t *lds_scan) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t steps = (total + 4 * BLOCK - 1) / (4 * BLOCK);
     uint32_t carry = 0;
@@ -727,37 +728,60 @@ __device__ __forceinline__ void scan_words_inplace(uint32_t *w, uint32_t total, 
         }
         carry += tot;
     }
+    return carry;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_sort_hist(SortArgs a) {
+// chunks of the pool a workgroup owns in the sort kernels: [first, first + count)
+__device__ __forceinline__ void sort_run(uint32_t n, uint32_t &first, uint32_t &count) {
+    const uint32_t chunks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
+    const uint32_t per = (chunks + gridDim.x - 1) / gridDim.x;
+    first = min(chunks, blockIdx.x * per);
+    count = min(chunks - first, per);
+}
+
+// one round per distinct key among the valid lanes: f(key, ballot of the lanes holding it)
+template <typename F>
+__device__ __forceinline__ void for_each_key(bool valid, uint32_t key, F f) {
+    uint64_t rem = __ballot(valid);
+    while (rem) {
+        const int l = __ffsll((unsigned long long)rem) - 1;
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
+        const uint64_t m = __ballot(valid && key == k);
+        f(k, m);
+        rem &= ~m;
+    }
+}
+
+template <bool COMPACT>
+__global__ __launch_bounds__(BLOCK) void k_sort_hist(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
-    uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * ((a.nbins + 3) & ~3);   // per-wave bins
-    const int lane = threadIdx.x & 63;
-    const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = run_id();
-    const uint32_t n = a.compact ? a.ctl->nlive[a.depth] : a.pool_n;
-    const uint32_t tiles = (n + TILE - 1) / TILE;
-    const uint32_t R = range_tiles(n, W);
-    for (int b = lane; b < a.nbins; b += 64) bins[b] = 0;
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t tile = wid * R + r;
-        if (tile >= tiles) break;
-        const uint32_t i = tile * TILE + lane;
-        const bool valid = i < n;
-        const uint32_t key = valid ? sort_key(a.isect, i, a.nbins) : 0u;
-        uint64_t rem = __ballot(valid);
-        while (rem) {                                           // one round per distinct key in the tile
-            const int l = __ffsll((unsigned long long)rem) - 1;
-            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
-            const uint64_t m = __ballot(valid && key == k);
-            if (lane == 0) bins[k] += (uint32_t)__popcll((unsigned long long)m);
-            rem &= ~m;
+    uint32_t *bins = sctl + LDS_CTL_WORDS;                            // the workgroup's bins
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr bool compact = COMPACT;
+    const uint32_t n = (compact && a.depth > 0) ? a.ctl->nlive[a.depth] : a.pool_n;
+    uint32_t first, count;
+    sort_run(n, first, count);
+    for (int b = threadIdx.x; b < a.nbins; b += BLOCK) bins[b] = 0;
+    __syncthreads();
+    for (uint32_t c = 0; c < count; ++c) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t i = ((first + c) * SORT_CHUNK_TILES + wave * 2 + s) * TILE + lane;
+            const bool valid = i < n;
+            const uint32_t key = valid ? sort_key(a.isect, i, a.nbins) : 0u;
+            for_each_key(valid, key, [&](uint32_t k, uint64_t m) {
+                if (lane == 0) atomicAdd(&bins[k], (uint32_t)__popcll((unsigned long long)m));
+            });
         }
     }
-    // publish table[bin][wave] (write-through), then elect the last workgroup to scan it
-    for (int b = lane; b < a.nbins; b += 64)
-        __hip_atomic_store(&a.table[(size_t)b * W + wid], bins[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // publish table[bin][workgroup] (write-through), then elect the last workgroup to scan it
+    const bool last_bounce = a.depth == a.trace_depth - 1;
+    for (int b = threadIdx.x; b < a.nbins; b += BLOCK) {
+        const uint32_t cnt = (!compact || key_survives(a.scene.mats, (uint32_t)b, a.nbins, last_bounce)) ? bins[b] : 0u;
+        __hip_atomic_store(&a.sort_table[(size_t)b * gridDim.x + blockIdx.x], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -769,44 +793,153 @@ __global__ __launch_bounds__(BLOCK) void k_sort_hist(SortArgs a) {
         sctl[0] = last ? 1u : 0u;
     }
     __syncthreads();
-    if (sctl[0]) scan_words_inplace(a.table, (uint32_t)a.nbins * W, sctl + 2);
+    if (sctl[0]) {
+        const uint32_t total = scan_words_inplace(a.sort_table, (uint32_t)a.nbins * gridDim.x, sctl + 2);
+        if (threadIdx.x == 0) {
+            if (compact) a.ctl->nlive[a.depth + 1] = total;
+            if (a.depth == 0) a.ctl->nlive[0] = a.pool_n;
+        }
+    }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_sort_perm(SortArgs a) {
+template <bool COMPACT>
+__global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
-    uint32_t *bins = sctl + LDS_CTL_WORDS + (threadIdx.x >> 6) * ((a.nbins + 3) & ~3);   // per-wave running offsets
-    const int lane = threadIdx.x & 63;
-    const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = run_id();
-    const uint32_t n = a.compact ? a.ctl->nlive[a.depth] : a.pool_n;
-    const uint32_t tiles = (n + TILE - 1) / TILE;
-    const uint32_t R = range_tiles(n, W);
-    const bool packed = a.compact && a.dir_in.mem != nullptr;
-    const uint32_t span = packed ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
-    uint32_t cur = 0;
-    if (packed && wid * R < tiles) cur = find_range(a.dir_in.base(), W, wid * R * TILE);
-    for (int b = lane; b < a.nbins; b += 64) bins[b] = a.table[(size_t)b * W + wid];
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t tile = wid * R + r;
-        if (tile >= tiles) break;
-        const uint32_t i = tile * TILE + lane;
-        const bool valid = i < n;
-        uint32_t src = i;
-        if (packed) src = resolve_src(a.dir_in, span, cur, i, valid, a.ctl);
-        const uint32_t key = valid ? sort_key(a.isect, i, a.nbins) : 0u;
-        uint32_t dst = 0;
-        uint64_t rem = __ballot(valid);
-        while (rem) {
-            const int l = __ffsll((unsigned long long)rem) - 1;
-            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
-            const uint64_t m = __ballot(valid && key == k);
-            const uint32_t base = bins[k];                          // same address for the whole wave
-            if (valid && key == k) dst = base + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)));
-            if (lane == 0) bins[k] = base + (uint32_t)__popcll((unsigned long long)m);
-            rem &= ~m;
+    const int nb = (a.nbins + 3) & ~3;
+    uint32_t *gbase = sctl + LDS_CTL_WORDS;          // [nb] output position of this workgroup's next path per key
+    uint32_t *ktot = gbase + nb;                     // [nb] paths per key in the chunk
+    uint32_t *kstart = ktot + nb;                    // [nb] first sorted position of the key in the chunk
+    uint32_t *wcount = kstart + nb;                  // [WAVES][nb] per-wave counts, then running sorted positions
+    uint32_t *order = wcount + WAVES * nb;           // [SORT_CHUNK] sorted position -> element of the chunk
+    uint32_t *keyl = order + SORT_CHUNK;             // [SORT_CHUNK] element -> key
+    float *mats = reinterpret_cast<float *>(keyl + SORT_CHUNK);       // materials (when they fit: a.nbins <= 64)
+    const bool mats_lds = a.nbins <= 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;
+    const uint32_t n = (COMPACT && a.depth > 0) ? a.ctl->nlive[a.depth] : a.pool_n;
+    const bool last_bounce = a.depth == a.trace_depth - 1;
+    uint32_t first, count;
+    sort_run(n, first, count);
+    for (int b = threadIdx.x; b < a.nbins; b += BLOCK) gbase[b] = a.sort_table[(size_t)b * gridDim.x + blockIdx.x];
+    if (mats_lds)
+        for (int k = threadIdx.x; k < a.scene.nmats * ptd::MAT_WORDS; k += BLOCK) mats[k] = a.scene.mats[k];
+    const float *mat_src = mats_lds ? mats : a.scene.mats;
+    uint32_t traced = 0;
+    for (uint32_t c = 0; c < count; ++c) {
+        const uint32_t chunk_base = (first + c) * SORT_CHUNK;
+        // ---- A: keys of the wave's two tiles, per-wave counts ----
+        for (int b = lane; b < a.nbins; b += 64) wcount[wave * nb + b] = 0;
+        uint32_t key2[2];
+        bool valid2[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t e = (uint32_t)(wave * 2 + s) * TILE + lane;
+            const uint32_t i = chunk_base + e;
+            valid2[s] = i < n;
+            key2[s] = valid2[s] ? sort_key(a.isect, i, a.nbins) : 0u;
+            keyl[e] = key2[s];
+            for_each_key(valid2[s], key2[s], [&](uint32_t k, uint64_t m) {
+                if (lane == 0) wcount[wave * nb + k] += (uint32_t)__popcll((unsigned long long)m);
+            });
         }
-        if (valid) { at(a.perm, dst) = src; at(a.perm + a.cap, dst) = i; }
+        __syncthreads();
+        // ---- B: per key, counts -> starts of each wave's share; chunk totals; starts of the keys ----
+        for (int b = threadIdx.x; b < a.nbins; b += BLOCK) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { const uint32_t v = wcount[w * nb + b]; wcount[w * nb + b] = run; run += v; }
+            ktot[b] = run;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t carry = 0;
+            for (int base = 0; base < a.nbins; base += 64) {
+                const uint32_t v = (base + lane < a.nbins) ? ktot[base + lane] : 0u;
+                uint32_t incl = v;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t u = __shfl_up(incl, off);
+                    if (lane >= off) incl += u;
+                }
+                if (base + lane < a.nbins) kstart[base + lane] = carry + incl - v;
+                carry += (uint32_t)__shfl((int)incl, 63);
+            }
+        }
+        __syncthreads();
+        // ---- C: sorted position of every element (stable: tiles in order, lanes in order) ----
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t e = (uint32_t)(wave * 2 + s) * TILE + lane;
+            for_each_key(valid2[s], key2[s], [&](uint32_t k, uint64_t m) {
+                const uint32_t base = kstart[k] + wcount[wave * nb + k];           // same address for the whole wave
+                if (valid2[s] && key2[s] == k) order[base + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))] = e;
+                if (lane == 0) wcount[wave * nb + k] += (uint32_t)__popcll((unsigned long long)m);
+            });
+        }
+        __syncthreads();
+        // ---- D: shade 128 consecutive sorted positions per wave ----
+        const uint32_t chunk_n = min((uint32_t)SORT_CHUNK, n - chunk_base);
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t p = (uint32_t)(wave * 2 + s) * TILE + lane;
+            bool active = p < chunk_n;
+            uint32_t key = 0, i = 0, pid = DEAD_PID, dst = 0;
+            f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1), col = ptd::mk(1, 1, 1);
+            if (active) {
+                const uint32_t e = order[p];
+                key = keyl[e];
+                i = chunk_base + e;
+                dst = gbase[key] + (p - kstart[key]);
+                char *q = a.in.slot(i);
+                pid = ppid(q);
+                ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
+                rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
+                col = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8));
+            }
+            const bool have = active;
+            if (pid == DEAD_PID) active = false;
+            bool alive = false;
+            ptd::PathState ps;
+            ps.o = ro; ps.d = rd; ps.c = col;
+            if (active) {
+                const float t = at(a.isect.plane(0), i);
+                const f3 nrm = ptd::mk(at(a.isect.plane(1), i), at(a.isect.plane(2), i), at(a.isect.plane(3), i));
+                const int m = at(a.isect.mat(), i);
+                const uint32_t smp = sample_of(a.map, pid);
+                const int pixel = local_to_pixel(a.map, (int)(pid - smp * (uint32_t)a.map.tile_pixels));
+                alive = ptd::shade_scatter(ps, t, nrm, m & 0x7fffffff, (m < 0) ? 0 : 1, mat_src, iter0 + (int)smp, pixel,
+                                           a.depth, last_bounce);
+                if (!alive) {
+                    at(a.fin, pid) = ps.c.x; at(a.fin + (size_t)a.in.cap, pid) = ps.c.y;
+                    at(a.fin + 2 * (size_t)a.in.cap, pid) = ps.c.z;
+                }
+            }
+            traced += (uint32_t)__popcll((unsigned long long)__ballot(active));
+            if (alive) {
+                char *q = a.out.slot(dst);
+                pf(q, 0) = ps.o.x; pf(q, 1) = ps.o.y; pf(q, 2) = ps.o.z;
+                pf(q, 3) = ps.d.x; pf(q, 4) = ps.d.y; pf(q, 5) = ps.d.z;
+                pf(q, 6) = ps.c.x; pf(q, 7) = ps.c.y; pf(q, 8) = ps.c.z;
+                ppid(q) = pid;
+            } else if (!COMPACT && have) {
+                a.out.pid(dst) = DEAD_PID;
+            }
+        }
+        __syncthreads();
+        // ---- E: this workgroup's output positions move on ----
+        for (int b = threadIdx.x; b < a.nbins; b += BLOCK)
+            if (!COMPACT || key_survives(mat_src, (uint32_t)b, a.nbins, last_bounce)) gbase[b] += ktot[b];
+        __syncthreads();
+    }
+    if (COMPACT) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->alive[a.depth] = n;
+    } else {
+        if (lane == 0) sctl[8 + wave] = traced;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tb = sctl[8] + sctl[9] + sctl[10] + sctl[11];
+            if (tb) atomicAdd(&a.ctl->alive[a.depth], tb);
+        }
     }
 }
 
@@ -944,8 +1077,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
             i = tile * TILE + lane;                        // logical path index
             active = have && i < n;
             src = i;
-            if (MODE == MODE_ISECT && a.perm) { if (active) src = at(a.perm, i); }        // material sort: gather through the permutation
-            else if (packed_in && have) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
+            if (packed_in && have) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
         }
         TileRegs tr;
         f3 ro, rd;
@@ -971,8 +1103,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
             // MODE_ISECT: planes in logical order; MODE_CACHE0: one record per pixel of the tile
             float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0, outside = 1;
             if (tr.active) {
-                const uint32_t k = (MODE == MODE_CACHE0) ? tr.pid - tr.smp * (uint32_t)a.map.tile_pixels
-                                                         : (a.perm ? at(a.perm + in.cap, i) : i);
+                const uint32_t k = (MODE == MODE_CACHE0) ? tr.pid - tr.smp * (uint32_t)a.map.tile_pixels : i;
                 t = at(a.isect.plane(0), k);
                 nrm = ptd::mk(at(a.isect.plane(1), k), at(a.isect.plane(2), k), at(a.isect.plane(3), k));
                 const int m = at(a.isect.mat(), k);
@@ -1011,7 +1142,7 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
     const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);                        // logical tiles per wave (one contiguous run)
-    const bool packed_in = COMPACT && a.dir_in.mem != nullptr && !(MODE == MODE_ISECT && a.perm);
+    const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
     const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
     uint32_t traced = 0;
     uint32_t packed = 0;                                         // survivors this wave has written (wave-uniform)
@@ -1557,17 +1688,16 @@ __global__ void k_import_paths(Pool p, const pt_path_segment *in, uint32_t n) {
     p.pid(i) = i;
 }
 
-__global__ void k_export_isects(Isect is, uint32_t n, pt_shadeable_intersection *out, uint8_t *outside, const uint32_t *perm_i) {
-    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n) return;
-    const uint32_t i = perm_i ? perm_i[o] : o;               // material sort: records in sorted order
+__global__ void k_export_isects(Isect is, uint32_t n, pt_shadeable_intersection *out, uint8_t *outside) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
     pt_shadeable_intersection s;
     const int m = is.mat()[i];
     s.t = is.plane(0)[i];
     if (s.t > 0.0f) { s.surfaceNormal = {is.plane(1)[i], is.plane(2)[i], is.plane(3)[i]}; s.materialId = m & 0x7fffffff; }
     else { s.surfaceNormal = {0, 0, 0}; s.materialId = 0; }      // memset(0) + t = -1 only
-    out[o] = s;
-    if (outside) outside[o] = (m < 0) ? 0 : 1;
+    out[i] = s;
+    if (outside) outside[i] = (m < 0) ? 0 : 1;
 }
 
 

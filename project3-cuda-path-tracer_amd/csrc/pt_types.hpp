@@ -184,8 +184,9 @@ struct BounceArgs {
     // and, per logical 64-path tile, the lanes that have one
     float4 *mesh_hit;
     unsigned long long *mesh_mask;
-    // material sort: [0, cap) pool slot and [cap, 2 cap) logical index of the path at each sorted position
-    const uint32_t *perm;
+    // material sort: table[key][workgroup] of k_sort_hist / k_shade_sorted; keys = materials + 1 (misses)
+    uint32_t *sort_table;
+    int nbins;
 };
 
 __device__ __forceinline__ int local_to_pixel(const TileMap &m, int j) {

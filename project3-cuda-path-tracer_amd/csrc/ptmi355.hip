@@ -90,7 +90,6 @@ struct Renderer {
     Pool pool[2]{};
     int cur = 0;                  // pool holding the current live prefix
     float *isect_mem = nullptr;
-    float *isect2_mem = nullptr;  // sorted intersections (PT_SORT_MATERIAL)
     uint32_t *sort_table = nullptr;
     float *cache_mem = nullptr;   // first-bounce cache: 5 planes of tile_pixels (PT_CACHE_FIRST)
     bool cache_valid = false;
@@ -115,7 +114,7 @@ struct Renderer {
     uint32_t max_tiles = 0;
     size_t ctl_bytes = 0;         // Control, zeroed per batch
     int grid = 0;                 // persistent grid size
-    bool sorted_isects = false;   // the last bounce's intersections live in isect2 (sorted order)
+    bool sorted_isects = false;   // the last bounce was shaded in material order (the intersection planes keep the order the bounce received)
     bool gen_fused = false;       // bounce 0 of the current batch generates its own rays
     Lens lens{0, 0.0f, 0.0f};     // PT_AA_JITTER / thin lens (pt_scene_desc, pt_set_lens)
     // one captured graph per batch size: memset + every launch of a batch replayed with one hipGraphLaunch
@@ -315,22 +314,28 @@ int enqueue_bounce(int depth) {
         HIPCHK(hipGetLastError());
     }
     if (R.flags & PT_SORT_MATERIAL) {
-        // intersections (logical order) -> histogram + scan -> scatter into the other pool, dense and
-        // sorted; the shade/compact kernel then reads that pool and writes back into the first one
-        StageTimer tm(PT_STAGE_SORT);
-        SortArgs sa{};
-        sa.in = a.in; sa.out = R.pool[R.cur ^ 1];
-        sa.isect = R.isect; sa.isect_out = Isect{R.isect2_mem, R.cap};
-        sa.dir_in = a.dir_in; sa.ctl = R.ctl; sa.table = R.sort_table;
-        sa.depth = depth; sa.nbins = R.scene.nmats + 1; sa.pool_n = a.pool_n; sa.compact = compact ? 1 : 0;
-        const size_t lds = ((size_t)LDS_CTL_WORDS + (size_t)WAVES * SORT_MAX_BINS) * 4;
-        hipLaunchKernelGGL(k_sort_hist, dim3(R.grid), dim3(BLOCK), lds, R.stream, sa);
+        // intersections of the (dense) pool -> per-workgroup key histogram + scan -> chunk-local counting sort fused
+        // with shading: survivors land in the other pool in globally sorted, compacted order (pt_kernels.hpp)
+        a.in = R.pool[R.cur]; a.out = R.pool[R.cur ^ 1];
+        a.sort_table = R.sort_table; a.nbins = R.scene.nmats + 1;
+        {
+            StageTimer tm(PT_STAGE_SORT);
+            const size_t lds = ((size_t)LDS_CTL_WORDS + (size_t)((a.nbins + 3) & ~3)) * 4;
+            if (compact) hipLaunchKernelGGL(k_sort_hist<true>, dim3(R.grid), dim3(BLOCK), lds, R.stream, a);
+            else hipLaunchKernelGGL(k_sort_hist<false>, dim3(R.grid), dim3(BLOCK), lds, R.stream, a);
+            HIPCHK(hipGetLastError());
+        }
+        StageTimer tm(PT_STAGE_BOUNCE);
+        const size_t nb = (size_t)((a.nbins + 3) & ~3);
+        const size_t lds = ((size_t)LDS_CTL_WORDS + (3 + WAVES) * nb + 2 * SORT_CHUNK +
+                            (a.nbins <= 64 ? (size_t)R.scene.nmats * ptd::MAT_WORDS : 0)) * 4;
+        if (compact) hipLaunchKernelGGL(k_shade_sorted<true>, dim3(R.grid), dim3(BLOCK), lds, R.stream, a);
+        else hipLaunchKernelGGL(k_shade_sorted<false>, dim3(R.grid), dim3(BLOCK), lds, R.stream, a);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_sort_scatter, dim3(R.grid), dim3(BLOCK), lds, R.stream, sa);
-        HIPCHK(hipGetLastError());
-        a.in = sa.out; a.out = R.pool[R.cur];
-        a.isect = sa.isect_out;
-        a.dir_in = tile_dir(-1);                         // the sorted pool is dense
+        R.cur ^= 1; R.cur_dir = -1;                      // the sorted pool is dense
+        R.sorted_isects = true;
+        R.step_depth = depth + 1;
+        return PT_OK;
     }
     const bool cached0 = depth == 0 && !unfused && (R.flags & PT_CACHE_FIRST);
     if (cached0 && !R.cache_valid) {
@@ -359,12 +364,7 @@ int enqueue_bounce(int depth) {
         if (compact) launch_bounce<MODE_FUSED, true>(a); else launch_bounce<MODE_FUSED, false>(a);
     }
     HIPCHK(hipGetLastError());
-    if (R.flags & PT_SORT_MATERIAL) {
-        // pool[cur] was rewritten in place of the pre-sort state; without compaction the survivors
-        // stay where the sorted pass put them, i.e. in pool[cur] as well
-        if (compact) R.cur_dir = depth;
-        R.sorted_isects = true;
-    } else if (compact) { R.cur ^= 1; R.cur_dir = depth; }
+    if (compact) { R.cur ^= 1; R.cur_dir = depth; }
     R.step_depth = depth + 1;
     return PT_OK;
 }
@@ -562,7 +562,6 @@ void pt_free(void) {
     if (R.stream) (void)hipStreamSynchronize(R.stream);
     for (int k = 0; k < 2; ++k) if (R.pool_mem[k]) (void)hipFree(R.pool_mem[k]);
     if (R.isect_mem) (void)hipFree(R.isect_mem);
-    if (R.isect2_mem) (void)hipFree(R.isect2_mem);
     if (R.sort_table) (void)hipFree(R.sort_table);
     if (R.cache_mem) (void)hipFree(R.cache_mem);
     if (R.final_mem) (void)hipFree(R.final_mem);
@@ -888,9 +887,8 @@ static int init_impl(const pt_scene_desc *d) {
     if (R.flags & PT_CACHE_FIRST) HIPCHK(hipMalloc(&R.cache_mem, (size_t)R.map.tile_pixels * 5 * 4));
     if (R.flags & PT_SORT_MATERIAL) {
         if (d->num_materials + 1 > SORT_MAX_BINS)
-            return fail(PT_ERR_INVALID, "pt_init: PT_SORT_MATERIAL supports at most %d materials", SORT_MAX_BINS - 1);
-        HIPCHK(hipMalloc(&R.isect2_mem, capz * 5 * 4));
-        HIPCHK(hipMalloc((void **)&R.sort_table, (size_t)(d->num_materials + 1) * R.grid * WAVES * sizeof(uint32_t)));
+            return fail(PT_ERR_INVALID, "pt_init: PT_SORT_MATERIAL keeps one bin per material in LDS: at most %d materials", SORT_MAX_BINS - 1);
+        HIPCHK(hipMalloc((void **)&R.sort_table, (size_t)(d->num_materials + 1) * R.grid * sizeof(uint32_t)));
     }
     {   // range directory: one count + one base per wave of the persistent grid, per bounce
         const size_t Wp = ((size_t)R.grid * WAVES + 3) & ~(size_t)3;
@@ -1051,8 +1049,7 @@ int pt_export_intersections(pt_shadeable_intersection *host_isects, uint8_t *hos
     uint8_t *d_out = (uint8_t *)R.scratch + (size_t)n * sizeof(pt_shadeable_intersection);
     if (n) {
         hipLaunchKernelGGL(k_export_isects, dim3((n + 255) / 256), dim3(256), 0, R.stream,
-                           R.sorted_isects ? Isect{R.isect2_mem, R.cap} : R.isect, n,
-                           (pt_shadeable_intersection *)R.scratch, host_outside ? d_out : (uint8_t *)nullptr);
+                           R.isect, n, (pt_shadeable_intersection *)R.scratch, host_outside ? d_out : (uint8_t *)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(host_isects, R.scratch, (size_t)n * sizeof(pt_shadeable_intersection), hipMemcpyDeviceToHost, R.stream));
         if (host_outside) HIPCHK(hipMemcpyAsync(host_outside, d_out, n, hipMemcpyDeviceToHost, R.stream));
