@@ -1,7 +1,7 @@
 # Convenience targets; `python -c "import __graft_entry__ as g; g.build()"` does the same from Python.
 HIPCC ?= /opt/rocm/bin/hipcc
 PKG   := project3-cuda-path-tracer_amd
-HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17
+HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17
 
 all: lib host oracle
 

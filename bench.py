@@ -2,22 +2,27 @@
 """bench.py -- Mrays/s of the wavefront path tracer on the BASELINE.json workload.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config c2|c3|c4|c5]
+                    [--scaling weak|strong] [--reduce-every I] [--collective gather|reduce]
 
-A *step* is one pass of the hot path over one batch of synthetic input: B
-iterations (samples per pixel) of the 800x800 depth-8 Cornell box with the
-mirror ball (BASELINE.json configs[1], "c2"), traced as one path pool through
-ray generation, the fused intersect/shade/compact bounce kernels and the final
-gather, with every buffer resident in HBM.  value = rays traced (sum over
-bounces of live paths, counted on the device) / wall time, in Mrays/s.
+A *step* is one pass of the hot path over one batch of synthetic input: B iterations (samples per pixel) of the
+800x800 depth-8 Cornell box with the mirror ball (BASELINE.json configs[1], "c2"), traced as one path pool through
+ray generation, the fused intersect / shade / compact bounce kernels and the final gather, with every buffer
+resident in HBM.  value = rays traced (sum over bounces of live paths, counted on the device) / wall time, in Mrays/s.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is tiled
-across the ranks in interleaved row strips, every rank traces B*N iterations of
-its tile per step (per-GPU work fixed -> weak scaling) and the float3
-accumulation buffers are summed onto rank 0 with one RCCL reduce per step.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is tiled across the ranks in interleaved row
+strips.  --scaling weak (default; the contract's definition: per-GPU work fixed): every rank traces B*N iterations
+of its tile per step.  --scaling strong: the frame gets B iterations per step whatever N (total work fixed).  The
+tiles' running sums travel to rank 0 once per --reduce-every iterations (default: once per step; 1 = the per-iteration
+exchange of BASELINE.json's north_star) as a gather of the packed tile rows (N/k*12 B per rank) or, with
+--collective reduce, as a sum of the zero-padded full frames; either overlaps the next batch's tracing.
 
-Extra JSON objects (see the task statement): `roofline` for the dominant kernel
-(k_bounce: algorithmic bytes / HIP-event time on the launch stream) and
-`cpu_baseline` (the plain-C oracle on this host's cores, rank 0, N = 1 only).
+Extra JSON objects (see the task statement): `roofline` for the dominant kernel and `cpu_baseline` (the plain-C
+oracle on this host's cores, rank 0, N = 1 only).  The kernel is bound by vector-instruction issue, not by HBM:
+`roofline.frac` is the issue utilisation (instruction counts per class from the committed rocprofv3 PMC passes of THIS
+build x the per-class issue costs measured by profiles/microbench/valu_peak.hip, over the launch time measured here
+with HIP events); the HBM figures (algorithmic bytes, and measured FETCH/WRITE_SIZE traffic) ride along.  The counter
+profile is keyed by a hash of the kernel sources: after any kernel change it is dropped (fields null) until
+profiles/run_rocprof.sh has been re-run.
 """
 import argparse
 import json
@@ -32,6 +37,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
+PEAK_CLOCK_GHZ = 2.4           # MI355X_MICROARCH.md: max clock
 # SURVEY 8(d) algorithmic bytes: intersect 44 B/ray + shade/scatter 104 B/ray +
 # compaction 4 B/ray, + 88 B per surviving path -- all done by the fused k_bounce launch
 BYTES_PER_RAY = 44 + 104 + 4
@@ -71,6 +78,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--strip-rows", type=int, default=8)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank traces batch*N iterations of its tile per step (per-GPU work fixed); "
+                         "strong = the frame gets `batch` iterations per step whatever N (total work fixed)")
+    ap.add_argument("--reduce-every", type=int, default=0,
+                    help="N > 1: iterations between two exchanges of the tiles' running sums (0 = once per step; "
+                         "1 = once per iteration, the north-star semantics)")
+    ap.add_argument("--collective", default="gather", choices=["gather", "reduce"],
+                    help="N > 1: gather the packed tile rows onto rank 0 (N/k*12 B per rank) or reduce(SUM) the zero-padded full frames")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device exercises the N>1 code path on a single GPU (debug)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
@@ -81,6 +96,9 @@ def main():
                          "config.pcie_inclusive_mrays_per_s, never as value")
     args = ap.parse_args()
 
+    # dmabuf IPC (the pool's driver has no legacy IPC): must be in the environment BEFORE the HIP runtime initialises,
+    # i.e. before torch is imported; launchers normally export it already
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -97,7 +115,6 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":      # "nccl" is RCCL on ROCm
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -120,32 +137,49 @@ def main():
     for f in args.flags.split(","):
         flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED,
                   "cache": pt.PT_CACHE_FIRST, "bvh": pt.PT_MESH_BVH, "aa": pt.PT_AA_JITTER, "": 0}[f]
-    per_step_iters = pt.sharding.step_iterations(0, args.batch, world)[1]     # = batch * world
+    per_step_iters = pt.sharding.step_iterations(0, args.batch, world, args.scaling)[1]
+    every = per_step_iters if (args.reduce_every <= 0 or world == 1) else min(args.reduce_every, per_step_iters)
 
     # an explicit (non-null) torch stream: the library launches on it, torch copies / RCCL order against it
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     image = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")     # accumulation buffer (torch-owned)
-    frame = torch.zeros_like(image) if world > 1 else None                # reduce target / staging
+    frame = torch.zeros_like(image) if world > 1 else None                # rank 0: the assembled frame / reduce staging
     torch.cuda.synchronize()
     pt.pathtraceInit(scene, flags=flags, device=local_rank, stream=stream.cuda_stream,
-                     tile=(rank, world, args.strip_rows), max_batch=per_step_iters,
+                     tile=(rank, world, args.strip_rows), max_batch=every,
                      device_image=image.data_ptr())
+    gather = None
+    if world > 1 and args.collective == "gather":
+        gather = pt.sharding.TileGather(torch, dist, rank, world, args.strip_rows, W, H, torch.device("cuda"),
+                                        via_host=(args.backend == "gloo"))
     pending = [None]
+    exchanges = [0]
 
-    def step(i):
-        iter0, count = pt.sharding.step_iterations(i, args.batch, world)
-        pt.trace_batch_async(iter0, count)                   # enqueue only
-        if world > 1:
-            # the reduce of step i runs on RCCL's stream while step i+1 traces; only the staging
-            # buffer hand-over is ordered
+    def exchange():
+        """tiles' running sums -> rank 0, overlapped with whatever is traced next"""
+        k = exchanges[0]
+        exchanges[0] += 1
+        if gather is not None:
+            gather.finish(frame, k & 1)                       # the gather issued two exchanges ago used this slot
+            gather.start(image, k & 1)
+        else:
             if pending[0] is not None:
                 pending[0].wait()
             frame.copy_(image)
-            pending[0] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)   # once per step, over xGMI
+            pending[0] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+
+    def step(i):
+        iter0, count = pt.sharding.step_iterations(i, args.batch, world, args.scaling)
+        for j in range(0, count, every):
+            pt.trace_batch_async(iter0 + j, min(every, count - j))          # enqueue only
+            if world > 1:
+                exchange()
 
     def barrier():
         if world > 1:
+            if gather is not None:
+                gather.drain(frame)
             if pending[0] is not None:
                 pending[0].wait()
                 pending[0] = None
@@ -198,18 +232,43 @@ def main():
         per_ray = BYTES_PER_RAY if fused else (104 + 4)
         algo_bytes = rank_rays * per_ray + survivors * BYTES_PER_SURVIVOR
         achieved = algo_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": "k_bounce<fused,compact>" if args.flags == "compact" else
-                    "k_bounce (" + args.flags + ")", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": measured_traffic(args, world), "launches": int(launches),
-                    "pass": "the %d timed steps repeated with per-launch HIP events" % args.steps,
-                    "avg_launch_us": round(ms * 1e3 / max(1, launches), 2),
-                    "algorithmic_bytes_per_launch": int(algo_bytes / max(1, launches)),
-                    "stage_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]},
-                    "grays_per_s_in_kernel": round(rank_rays / (ms * 1e-3) / 1e9, 3) if ms > 0 else 0.0}
-        valu = measured_valu(args, world, ms * 1e-3 / max(1, launches), rank_rays / max(1, launches))
-        if valu:
-            roofline["valu"] = valu
+        avg_s = ms * 1e-3 / max(1, launches)
+        kernel = "k_bounce<fused,compact>" if args.flags == "compact" else "k_bounce (" + args.flags + ")"
+        hbm_algo = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "bytes_per_launch": int(algo_bytes / max(1, launches)),
+                    "note": "SURVEY 8(d) algorithmic bytes of the unfused reference pipeline (152 B per ray + 88 B per "
+                            "survivor); the fused kernel never moves most of them"}
+        prof_json = counter_profile(args, world)
+        common = {"kernel": kernel, "launches": int(launches),
+                  "pass": "the %d timed steps repeated with per-launch HIP events" % args.steps,
+                  "avg_launch_us": round(avg_s * 1e6, 2),
+                  "stage_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]},
+                  "grays_per_s_in_kernel": round(rank_rays / (ms * 1e-3) / 1e9, 3) if ms > 0 else 0.0,
+                  "hbm_algorithmic": hbm_algo}
+        vm = prof_json.get("valu_model") if prof_json else None
+        if fused and vm and avg_s > 0:
+            # vector issue: counted instructions per class x measured cycles per class, over SIMDs x peak clock x time
+            used = vm["issue_cycles_per_launch"] / avg_s / 1e9                     # G SIMD-cycles of issue per second
+            peak = SIMDS * PEAK_CLOCK_GHZ
+            traffic = prof_json.get("bytes_per_launch")
+            roofline = dict(common, bound="valu-issue", achieved=round(used, 1), peak=round(peak, 1),
+                            unit="G SIMD issue-cycles/s", frac=round(used / peak, 4), traffic=traffic,
+                            source="profiles/traffic.json@csrc:%s (rocprofv3 --pmc passes of this build)" % prof_json.get("csrc_sha16"),
+                            valu={"wave_insts_per_launch": int(vm["wave_insts_per_launch"]),
+                                  "insts_per_ray": round(vm["wave_insts_per_launch"] * 64 / max(1.0, rank_rays / max(1, launches)), 1),
+                                  "issue_cycles_per_launch": int(vm["issue_cycles_per_launch"]), "mix": vm.get("mix"),
+                                  "issue_cost_table": "profiles/r02/valu_peak_r02.json",
+                                  "peak": "%d SIMDs x %.1f GHz (MI355X_MICROARCH.md max clock; ~2.1 GHz is what the chip "
+                                          "holds under this load)" % (SIMDS, PEAK_CLOCK_GHZ)})
+            if traffic:
+                roofline["hbm_measured"] = {"achieved": round(traffic / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                                            "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch (gfx950 correction)"}
+        else:
+            # no counter profile matches this build / command line: only the algorithmic HBM figure can be stated
+            roofline = dict(common, bound="hbm", achieved=hbm_algo["achieved"], peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=hbm_algo["frac"], traffic=None,
+                            source="no rocprofv3 counter profile for this build and command line (profiles/run_rocprof.sh)")
 
     # ---- CPU baseline: the oracle (plain-C port) on this host, rank 0, N = 1 only ----
     cpu = None
@@ -232,7 +291,8 @@ def main():
         barrier()
         final = image
         if world > 1:
-            final = pt.sharding.reduce_frame(dist, image, frame, dst=0)
+            # the frame rank 0 holds after the last exchange IS the result (gather: copies; reduce: sum with zeros)
+            final = frame
         torch.cuda.synchronize()
         if rank == 0:
             digest = hashlib.md5(final.cpu().numpy().tobytes()).hexdigest()
@@ -243,14 +303,18 @@ def main():
                       "Mrays/sec (live paths x bounces), config %s" % args.config,
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "scenes/cornell.txt (%s) %dx%d depth %d, compaction on, %d spp per step per GPU-tile"
                                    % (scene_name, W, H, scene.traceDepth, per_step_iters),
                        "batch_spp": args.batch, "flags": args.flags,
                        "sharding": "whole frame" if world == 1 else
-                       "interleaved %d-row strips over %d GPUs, RCCL reduce(SUM) of the float3 buffer per step"
-                       % (args.strip_rows, world),
+                       "interleaved %d-row strips over %d GPUs; %s scaling; tiles' running sums to rank 0 every %d "
+                       "iterations by %s, overlapped with the next batch"
+                       % (args.strip_rows, world, args.scaling, every,
+                          "a gather of the packed tile rows (%.2f MB per rank)" % (gather.bytes_per_rank / 1e6) if gather
+                          else "reduce(SUM) of the zero-padded frames (%.2f MB per rank)" % (npix * 12 / 1e6)),
+                       "exchanges_per_step": 0 if world == 1 else -(-per_step_iters // every),
                        "rays_per_step": int(rays / args.steps)},
         }
         if digest:
@@ -266,33 +330,9 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_valu(args, world, avg_launch_s, rays_per_launch):
-    """VALU issue rate of k_bounce from the SQ_INSTS_VALU pass of THIS command line (profiles/traffic.json):
-    the kernel is bound by FP32 vector issue, so this is the utilisation that matters beside the HBM figure.
-    Peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-operations/s (157.3 TFLOP/s = that x 2 for FMA x 2 packed)."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if world != 1 or not os.path.exists(path) or avg_launch_s <= 0:
-        return None
-    try:
-        t = json.load(open(path))
-    except Exception:
-        return None
-    if t.get("config") != args.config or t.get("batch") != args.batch or t.get("flags") != args.flags:
-        return None
-    insts = t.get("valu_wave_insts_per_launch")
-    if not insts:
-        return None
-    peak = 256 * 4 * 16 * 2.4e9
-    rate = insts * 64 / avg_launch_s
-    return {"wave_insts_per_launch": int(insts), "insts_per_ray": round(insts * 64 / max(1.0, rays_per_launch), 1),
-            "lane_ops_per_s": round(rate / 1e12, 2), "peak_lane_ops_per_s": round(peak / 1e12, 2), "unit": "T/s",
-            "frac": round(rate / peak, 3)}
-
-
-def measured_traffic(args, world):
-    """HBM bytes per k_bounce launch from the rocprofv3 PMC passes of THIS command line (FETCH_SIZE and
-    WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950;
-    profiles/traffic.json is written by profiles/summarize.py).  None when no matching profile exists."""
+def counter_profile(args, world):
+    """profiles/traffic.json (written by profiles/summarize.py from the rocprofv3 PMC passes) when it belongs to THIS
+    build (hash of the kernel sources) and THIS command line; None otherwise -- stale counters are never reported."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if world != 1 or not os.path.exists(path):
         return None
@@ -302,7 +342,9 @@ def measured_traffic(args, world):
         return None
     if t.get("config") != args.config or t.get("batch") != args.batch or t.get("flags") != args.flags:
         return None
-    return t.get("bytes_per_launch")
+    if t.get("csrc_sha16") != csrc_digest():
+        return None
+    return t
 
 
 def _total_rays(pt):

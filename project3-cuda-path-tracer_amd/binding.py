@@ -138,7 +138,7 @@ def library():
         L.pt_get_profile.argtypes = [C.POINTER(Profile)]
         L.pt_get_bvh_info.argtypes = [C.POINTER(BvhInfo)]
         L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        L.pt_cull_boxes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        L.pt_cull_boxes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
         L.pt_free.restype = None
         _lib = L
     return _lib
@@ -313,13 +313,15 @@ def bvh_build(triangles):
 
 
 def cull_boxes(geoms, eye=(0.0, 0.0, 0.0)):
-    """Host-only: (boxes[n, 2, 3] float32 = lo / hi, origin bound) pt_init derives for the cull stage."""
+    """Host-only: (boxes[n, 2, 3] float32 = lo / hi, origin bound, reject[n, 3] = axis / m_kk / m_k3) pt_init derives
+    for the cull stage."""
     g = np.ascontiguousarray(geoms, dtype=GEOM_DT)
     e = np.asarray(eye, dtype=np.float32)
     out = np.zeros((len(g), 2, 3), dtype=np.float32)
+    rej = np.zeros((len(g), 3), dtype=np.float32)
     r = C.c_float(0.0)
-    _chk(library().pt_cull_boxes(_p(g), len(g), _p(e), _p(out), C.byref(r)))
-    return out, r.value
+    _chk(library().pt_cull_boxes(_p(g), len(g), _p(e), _p(out), C.byref(r), _p(rej)))
+    return out, r.value, rej
 
 
 def total_rays():

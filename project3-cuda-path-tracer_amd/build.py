@@ -9,7 +9,9 @@ LIB = os.path.join(HERE, "libptmi355.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in ("ptmi355.hip", "pt_device.hpp", "pt_types.hpp", "pt_kernels.hpp", "pt_bvh.hpp", "pt_cull.hpp")] + \
           [os.path.join(ROOT, "include", "ptmi355.h")]
 # -ffp-contract=off: the reference arithmetic (GLM, no FMA) must be reproduced bit for bit.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+# -fno-slp-vectorize: the SLP vectoriser pairs fp32 multiplies / adds into v_pk_* and pays for it in register
+# shuffles; v_pk_mul_f32 issues in 4.3 cycles against 2 x 2.45 (profiles/r02/valu_peak_r02.json): +3 % without it.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17"]
 
 
 def hipcc():

@@ -165,4 +165,26 @@ inline float make_boxes(const float *const *inv16, const bool *is_sphere, const 
     return round_down(R);
 }
 
+// Axis along which the kernel's exact early miss may be evaluated for a CUBE (pt_kernels.hpp, cull_scene): a row k
+// of the inverseTransform's upper 3x3 whose off-diagonal entries are exactly zero, with every entry of the matrix
+// finite and bounded (so that v = A d is finite and dot(v, v) neither NaN nor a source of NaN for non-wild rays);
+// among several, the one with the largest |A_kk|, i.e. the thinnest world extent (the faces with the largest area).
+// Returns 3 when there is none; m_kk / m_k3 = the two floats the kernel needs.
+inline int reject_axis(const float *inv16, float &mkk, float &mk3) {
+    mkk = 0.0f; mk3 = 0.0f;
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 3; ++r)
+            if (!std::isfinite(inv16[c * 4 + r]) || std::fabs(inv16[c * 4 + r]) > 0x1p40f) return 3;
+    int best = 3;
+    for (int k = 0; k < 3; ++k) {
+        bool diag = true;
+        for (int j = 0; j < 3; ++j)
+            if (j != k && inv16[j * 4 + k] != 0.0f) diag = false;
+        const float d = inv16[k * 4 + k];
+        if (!diag || d == 0.0f) continue;
+        if (best == 3 || std::fabs(d) > std::fabs(mkk)) { best = k; mkk = d; mk3 = inv16[3 * 4 + k]; }
+    }
+    return best;
+}
+
 }  // namespace ptcull

@@ -217,10 +217,22 @@ PTD float sqrt_normal_range(float x) {
     r = (0.0f < e2) ? sp : r;
     return r;
 }
+// every active lane agrees: no lane votes against.  (__all() compiles to select 0/1 + compare + compare with exec;
+// the ballot of the NEGATED predicate is the two v_cmp themselves and one scalar compare with zero.)
+#ifndef PT_WAVE_ALL_BALLOT
+#define PT_WAVE_ALL_BALLOT 1
+#endif
+PTD bool wave_all(bool p) {
+#if PT_WAVE_ALL_BALLOT
+    return __builtin_amdgcn_ballot_w64(!p) == 0ull;
+#else
+    return __all(p);
+#endif
+}
 // wave-uniform gates for the two helpers below (NaN fails; inactive lanes do not vote)
 PTD bool all_in_range(float x, float lo, float hi) {
 #if PT_FASTDIV
-    return __all(x >= lo && x <= hi);
+    return wave_all(x >= lo && x <= hi);
 #else
     (void)x; (void)lo; (void)hi;
     return false;
@@ -239,7 +251,7 @@ PTD f3 normalize_normal_range(f3 a, float dt) {
 // NaNs fail the ordered compares.  Inactive lanes do not vote.
 PTD bool norm_fast_ok(float x) {
 #if PT_FASTDIV
-    return __all(x >= 8.271806125530277e-25f && x <= 1.2089258196146292e24f);
+    return wave_all(x >= 8.271806125530277e-25f && x <= 1.2089258196146292e24f);
 #else
     (void)x;
     return false;
@@ -252,7 +264,7 @@ PTD bool cube_fast_ok(f3 qo, f3 v, float x) {
     const bool finite = (qo.x + qo.y + qo.z) == (qo.x + qo.y + qo.z);          // fmax drops NaNs
     const bool ok = finite && x >= 8.271806125530277e-25f && x <= 1.2089258196146292e24f &&
                     sq_min >= x * 3.308722450212111e-24f && omax < 1.8014398509481984e16f;
-    return __all(ok);
+    return wave_all(ok);
 #else
     (void)qo; (void)v; (void)x;
     return false;

@@ -7,6 +7,9 @@
 
 namespace {
 
+// wave64 ballot straight from the compare (HIP's __ballot() goes through select 0/1 + compare-not-equal)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // ---------------------------------------------------------------------------
 // generateRayFromCamera -> SoA pool, `count` samples (stepping interface; the
 // batch path generates rays inside bounce 0)
@@ -53,7 +56,8 @@ constexpr int PW_BEST = PW_RING + Q_SLOTS;               // u64[2][64]: (bits(t)
 constexpr int PW_WIN = PW_BEST + 2 * 64 * 2;             // float4[2][64]: winner's normal xyz, outside flag
 constexpr int PW_RAYS = PW_WIN + 2 * 64 * 4;             // float[2][6][64]: ro.xyz rd.xyz of the tile's paths
 constexpr int PW_WORDS = PW_RAYS + 2 * 6 * 64;           // 1664 dwords = 6.5 KiB per wave
-constexpr int CULL_WORDS = 8;        // per geom, scalar-loaded: lo.x hi.x lo.y hi.y lo.z hi.z type spare
+constexpr int CULL_WORDS = 12;       // per geom, scalar-loaded: lo.x hi.x lo.y hi.y lo.z hi.z | type + (reject axis << 8), m_kk, m_k3, spare
+                                     //   | 2 spare (48 B: one s_load_dwordx8 + one s_load_dwordx4)
 
 __host__ __device__ constexpr int scene_lds_words(int nmats, int ngeoms) {
     return ((nmats * ptd::MAT_WORDS + 3) & ~3) + ((ngeoms + 3) & ~3) + ngeoms * GREC_WORDS;
@@ -168,9 +172,17 @@ struct WaveQ {                        // wave-uniform ring cursors + the wave's 
     __device__ __forceinline__ float *rays(int par) const { return pw + PW_RAYS + par * 6 * 64; }
 };
 
+#ifdef PT_CULL_STATS
+__device__ unsigned long long g_cull_stats[8];     // tiles, candidates, passes, pass lanes, hits, wild paths, active paths
+#define CULL_STAT(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_cull_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define CULL_STAT(k, v) do {} while (0)
+#endif
+
 // stage 3: candidates [head, head + count), count <= 64
 __device__ __forceinline__ void cand_pass(const WaveQ &q, const SceneAcc &acc, uint32_t head, uint32_t count) {
     const int lane = threadIdx.x & 63;
+    CULL_STAT(2, 1); CULL_STAT(3, count);
     if ((uint32_t)lane < count) {
         const uint32_t e = q.ring()[(head + (uint32_t)lane) & (Q_SLOTS - 1)];
         const int origin = (int)(e & 63u), par = (int)((e >> 6) & 1u), type = (int)((e >> 7) & 3u);
@@ -197,6 +209,7 @@ __device__ __forceinline__ void cand_pass(const WaveQ &q, const SceneAcc &acc, u
         } else {
             hit = ptd::sphere_roots(qo, qd, t_obj, outside);
         }
+        CULL_STAT(4, __popcll((unsigned long long)ballot64(hit)));
         if (hit) {
             // shared tail of both tests (intersections.h:85-87,136-143)
             {
@@ -366,12 +379,29 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
         mb.t = m.x; mb.geom = __float_as_int(m.y); mb.tri = __float_as_int(m.z);
     }
     const CullRay cr = cull_ray(ro, rd, sc.rmax);
+    CULL_STAT(0, 1); CULL_STAT(5, __popcll((unsigned long long)ballot64(active && cr.wild))); CULL_STAT(6, __popcll((unsigned long long)ballot64(active)));
     const uint32_t tag = (uint32_t)lane | ((uint32_t)par << 6);
     const int ngeoms = sc.ngeoms;
     const float *__restrict__ tris = sc.tris;
+    // the records come through wave-uniform scalar loads (s_load_dwordx8 + x4); the next primitive's is requested
+    // before this one's is used, so its latency overlaps the test instead of stalling every iteration
+    float nxt[9];
+    {
+        cfloat *c0 = as_const(sc.cull);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) nxt[k] = ngeoms > 0 ? c0[k] : 0.0f;
+    }
     for (int g = 0; g < ngeoms; ++g) {
-        cfloat *cb = as_const(sc.cull) + g * CULL_WORDS;               // wave-uniform address -> s_load_dwordx8
-        const int type = __float_as_int(cb[6]);
+        float cb[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cb[k] = nxt[k];
+        if (g + 1 < ngeoms) {
+            cfloat *cn = as_const(sc.cull) + (g + 1) * CULL_WORDS;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) nxt[k] = cn[k];
+        }
+        const int tw = __float_as_int(cb[6]);
+        const int type = tw & 0xff;
         if (MESH != MESH_NONE && type == PT_TRIANGLE_MESH) {
             if (MESH == MESH_PRE) continue;                             // k_mesh already walked every mesh
             cfloat *rec = as_const(sc.geoms) + g * ptd::GEOM_WORDS;
@@ -428,14 +458,32 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
             }
             continue;
         }
-        const bool cand = active && (cr.wild || cull_box(cr, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5]));
-        const uint64_t m = __ballot(cand);
+        bool keep = cull_box(cr, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5]);
+        // EXACT early miss along one axis (cubes whose inverseTransform row k has no off-diagonal entries, chosen at
+        // pt_init: the thinnest extent).  The reference's q.origin[k] is then fl(fl(m_kk o_k) + m_k3) -- the other
+        // products are exact zeros -- and q.direction[k] has the sign of fl(m_kk d_k), so "origin beyond the slab and
+        // heading away" ( |q_k| > 0.5 and q_k d_k > 0 ) makes both slab parameters of the axis negative: tmax < 0, a
+        // miss (intersections.h:56-77), whatever the other axes say.  This is what removes a path's OWN surface from
+        // its candidates: its origin sits 1e-6 above the wall it just left, well inside any box the float error
+        // allows, and would otherwise cost every bounce ray one object-space test.
+        const int rax = (tw >> 8) & 3;                                   // wave-uniform; 3 = none
+        if (rax != 3) {
+            const float mkk = cb[7], mk3 = cb[8];
+            const float ok = rax == 0 ? ro.x : (rax == 1 ? ro.y : ro.z);
+            const float dk = rax == 0 ? rd.x : (rax == 1 ? rd.y : rd.z);
+            const float qk = mkk * ok + mk3;
+            const float vk = mkk * dk;
+            if (__builtin_fabsf(qk) > 0.5f && qk * vk > 0.0f) keep = false;
+        }
+        const bool cand = active && (cr.wild || keep);
+        const uint64_t m = ballot64(cand);
         if (m) {
             if (cand) {
                 const uint32_t s = (q.total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))) & (Q_SLOTS - 1);
                 q.ring()[s] = tag | ((uint32_t)type << 7) | ((uint32_t)g << 9);
             }
             q.total += (uint32_t)__popcll((unsigned long long)m);
+            CULL_STAT(1, __popcll((unsigned long long)m));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (q.total - q.head >= 64) {                // a full wave of candidates is waiting
                 cand_pass(q, acc, q.head, 64);
@@ -483,7 +531,7 @@ __device__ __forceinline__ uint32_t find_range(const uint32_t *base, uint32_t W,
         const uint32_t step = (hi - lo + 63u) / 64u;
         const uint32_t idx = lo + (uint32_t)lane * step;
         const uint32_t v = idx < hi ? base[idx] : 0xffffffffu;
-        const uint64_t ok = __ballot(v <= P);       // base[] is non-decreasing: a prefix of the lanes
+        const uint64_t ok = ballot64(v <= P);       // base[] is non-decreasing: a prefix of the lanes
         const uint32_t k = (uint32_t)__popcll((unsigned long long)ok);
         const uint32_t nlo = lo + (k ? k - 1 : 0) * step;
         hi = min(hi, nlo + step);
@@ -524,7 +572,7 @@ __device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t sp
         s += 63;
     }
     // the highest active lane holds the tile's last path
-    const uint64_t act = __ballot(active);
+    const uint64_t act = ballot64(active);
     if (act) cur = (uint32_t)__builtin_amdgcn_readlane((int)rng, 63 - __builtin_clzll((unsigned long long)act));
     return src;
 }
@@ -742,11 +790,11 @@ __device__ __forceinline__ void sort_run(uint32_t n, uint32_t &first, uint32_t &
 // one round per distinct key among the valid lanes: f(key, ballot of the lanes holding it)
 template <typename F>
 __device__ __forceinline__ void for_each_key(bool valid, uint32_t key, F f) {
-    uint64_t rem = __ballot(valid);
+    uint64_t rem = ballot64(valid);
     while (rem) {
         const int l = __ffsll((unsigned long long)rem) - 1;
         const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
-        const uint64_t m = __ballot(valid && key == k);
+        const uint64_t m = ballot64(valid && key == k);
         f(k, m);
         rem &= ~m;
     }
@@ -914,7 +962,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
                     at(a.fin + 2 * (size_t)a.in.cap, pid) = ps.c.z;
                 }
             }
-            traced += (uint32_t)__popcll((unsigned long long)__ballot(active));
+            traced += (uint32_t)__popcll((unsigned long long)ballot64(active));
             if (alive) {
                 char *q = a.out.slot(dst);
                 pf(q, 0) = ps.o.x; pf(q, 1) = ps.o.y; pf(q, 2) = ps.o.z;
@@ -1017,8 +1065,8 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
         }
     }
     // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
-    const uint64_t bal = __ballot(alive);
-    const uint64_t act = __ballot(tr.active);
+    const uint64_t bal = ballot64(alive);
+    const uint64_t act = ballot64(tr.active);
     traced += (uint32_t)__popcll((unsigned long long)act);
     uint32_t dst = tr.i;
     if (COMPACT) {
@@ -1340,7 +1388,7 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &
     const int4 *meshes = a.scene.bvh_meshes;
     const uint64_t below = (1ull << lane) - 1;
     for (;;) {
-        const uint64_t idle = __ballot(!w.have);
+        const uint64_t idle = ballot64(!w.have);
         const uint32_t avail = rg.q_total - rg.q_head;
         if (idle && avail) {
             const uint32_t rank = (uint32_t)__popcll((unsigned long long)(idle & below));
@@ -1360,7 +1408,7 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &
             rg.q_head += min((uint32_t)__popcll((unsigned long long)idle), avail);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        const uint64_t busy = __ballot(w.have);
+        const uint64_t busy = ballot64(w.have);
         if (!busy) return;
         if (rg.q_total == rg.q_head && (int)__popcll((unsigned long long)busy) < leave) return;
 #pragma unroll 1
@@ -1398,7 +1446,7 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &
             }
 #ifdef PT_MESH_STATS
             {
-                const uint64_t bb = __ballot(w.have && (w.node >= 0 || leaf_l >= 0 || leaf_r >= 0));
+                const uint64_t bb = ballot64(w.have && (w.node >= 0 || leaf_l >= 0 || leaf_r >= 0));
                 if (lane == 0 && bb) { atomicAdd(&a.ctl->keep[1], (uint32_t)__popcll((unsigned long long)bb)); atomicAdd(&a.ctl->keep[2], 1u); }
                 atomicMax(&a.ctl->keep[14], (uint32_t)w.steps);
             }
@@ -1406,11 +1454,11 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &
             // queue this step's triangles: slot order = lane order (any order gives the same minimum)
             const int nl = leaf_l >= 0 ? (leaf_l >> 24) : 0, nr = leaf_r >= 0 ? (leaf_r >> 24) : 0;
             const int nt = nl + nr;
-            if (__ballot(nt > 0)) {
+            if (ballot64(nt > 0)) {
                 uint32_t pre = 0, tot = 0;
 #pragma unroll
                 for (int bit = 0; bit < 4; ++bit) {                      // exclusive prefix of nt (< 16) over the lanes
-                    const uint64_t bm = __ballot((nt >> bit) & 1);
+                    const uint64_t bm = ballot64((nt >> bit) & 1);
                     pre += (uint32_t)__popcll((unsigned long long)(bm & below)) << bit;
                     tot += (uint32_t)__popcll((unsigned long long)bm) << bit;
                 }
@@ -1425,7 +1473,7 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &
                 while (rg.t_total - rg.t_head >= 64) { tri_pass(mq, rg.t_head, 64, w, a); rg.t_head += 64; }
             }
             // nobody is walking any more but triangles are still queued: test them now, their owners are waiting
-            if (rg.t_total != rg.t_head && !__ballot(w.have && w.node >= 0)) {
+            if (rg.t_total != rg.t_head && !ballot64(w.have && w.node >= 0)) {
                 tri_pass(mq, rg.t_head, rg.t_total - rg.t_head, w, a);
                 rg.t_head = rg.t_total;
             }
@@ -1523,7 +1571,7 @@ __global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
             cand |= tn <= tf;
         }
         cand = cand && active;
-        const uint64_t m = __ballot(cand);
+        const uint64_t m = ballot64(cand);
         if (m) {
             if (cand) {
                 const uint32_t s = (rg.q_total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))) & (MQ_SLOTS - 1);
@@ -1537,7 +1585,7 @@ __global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
 #endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // keep the ring below 64 waiting entries so the next tile always fits
-            if (rg.q_total - rg.q_head >= 64 - (uint32_t)__popcll((unsigned long long)__ballot(w.have)))
+            if (rg.q_total - rg.q_head >= 64 - (uint32_t)__popcll((unsigned long long)ballot64(w.have)))
                 mesh_drain(w, mq, rg, a, MQ_LEAVE);
         }
     }

@@ -494,7 +494,11 @@ int upload_cull(const pt_scene_desc *d, const pt_camera &cam) {
     for (int i = 0; i < n; ++i) {
         float *r = rec.data() + (size_t)i * CULL_WORDS;
         for (int k = 0; k < 3; ++k) { r[2 * k] = boxes[(size_t)i].lo[k]; r[2 * k + 1] = boxes[(size_t)i].hi[k]; }
-        memcpy(&r[6], &d->geoms[i].type, 4);
+        int ax = 3;
+        if (d->geoms[i].type == PT_CUBE && !getenv("PTMI355_NO_AXIS_REJECT"))
+            ax = ptcull::reject_axis(&d->geoms[i].inverseTransform.m[0][0], r[7], r[8]);
+        const int tw = d->geoms[i].type | (ax << 8);
+        memcpy(&r[6], &tw, 4);
     }
     if (!R.d_cull) HIPCHK(hipMalloc(&R.d_cull, rec.size() * 4));
     HIPCHK(hipMemcpyAsync(R.d_cull, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, R.stream));
@@ -535,6 +539,16 @@ int collect_stats(void) {
         fprintf(stderr, "[ptmi355] longest walk %u records; records where nothing was hit: %u, with a leaf hit: %u\n", c.keep[14], c.keep[12], c.keep[13]);
         fprintf(stderr, "[ptmi355] walks past 5000 steps: %u; last: o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) tz=%g depth %u\n", c.keep[3],
                 f[0], f[1], f[2], f[3], f[4], f[5], f[6], c.keep[11]);
+    }
+#endif
+#ifdef PT_CULL_STATS
+    {
+        unsigned long long st[8] = {0};
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_cull_stats), sizeof st);
+        fprintf(stderr, "[ptmi355] cull since load: %llu tiles, %llu active paths (%.1f per tile), %llu wild, %llu candidates (%.3f per path), "
+                        "%llu passes (%.3f per tile, %.1f lanes each), %llu hits (%.3f per path)\n",
+                st[0], st[6], st[0] ? (double)st[6] / st[0] : 0.0, st[5], st[1], st[6] ? (double)st[1] / st[6] : 0.0, st[2],
+                st[0] ? (double)st[2] / st[0] : 0.0, st[2] ? (double)st[3] / st[2] : 0.0, st[4], st[6] ? (double)st[4] / st[6] : 0.0);
     }
 #endif
     if (getenv("PTMI355_DEBUG_SCAN")) {
@@ -1142,7 +1156,7 @@ int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node
     return tree.num_nodes();
 }
 
-int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound) {
+int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound, float *reject) {
     if (count < 0 || (count > 0 && !geoms) || !boxes) return fail(PT_ERR_INVALID, "pt_cull_boxes: bad argument");
     std::vector<const float *> inv((size_t)std::max(1, count));
     std::vector<char> sph((size_t)std::max(1, count)), skip((size_t)std::max(1, count));
@@ -1158,6 +1172,12 @@ int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxe
     for (int i = 0; i < count; ++i)
         for (int k = 0; k < 3; ++k) { boxes[6 * i + k] = bx[(size_t)i].lo[k]; boxes[6 * i + 3 + k] = bx[(size_t)i].hi[k]; }
     if (origin_bound) *origin_bound = r;
+    if (reject)
+        for (int i = 0; i < count; ++i) {
+            float mkk = 0.0f, mk3 = 0.0f;
+            const int ax = geoms[i].type == PT_CUBE ? ptcull::reject_axis(&geoms[i].inverseTransform.m[0][0], mkk, mk3) : 3;
+            reject[3 * i] = (float)ax; reject[3 * i + 1] = mkk; reject[3 * i + 2] = mk3;
+        }
     return PT_OK;
 }
 

@@ -3,7 +3,11 @@
 // pathtraceInit(); pathtrace() x ITERATIONS; saveImage(); pathtraceFree().
 //
 //   ptbench SCENEFILE.txt [--iters N] [--batch B] [--out BASENAME] [--sort] [--no-compact]
-//           [--cache-first] [--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D]
+//           [--cache-first] [--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D] [--tile R/K] [--strip-rows S]
+//
+// --tile R/K: this process renders only tile R of K (the rows y with (y / S) % K == R, global pixelIndex and RNG
+// keys unchanged), so K processes -- one per GPU, --device each -- render one frame between them; the other rows
+// of its image stay zero and the K raw sums (--pfm) add up, exactly, to the single-process image.
 //
 // Links libptmi355.so (the HIP library) and host/pthost.cpp.
 #include <chrono>
@@ -18,10 +22,10 @@
 int main(int argc, char **argv) {
     if (argc < 2) {
         printf("Usage: %s SCENEFILE.txt [--iters N] [--batch B] [--out BASE] [--sort] [--no-compact] [--cache-first] "
-               "[--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D]\n", argv[0]);
+               "[--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D] [--tile R/K] [--strip-rows S]\n", argv[0]);
         return 1;
     }
-    int iters = -1, batch = 1, device = 0;
+    int iters = -1, batch = 1, device = 0, tile_index = 0, tile_count = 1, strip_rows = 8;
     unsigned flags = PT_COMPACT;
     bool pfm = false;
     float lens_radius = 0.0f, focal_distance = 0.0f;
@@ -39,6 +43,13 @@ int main(int argc, char **argv) {
         else if (a == "--aa") flags |= PT_AA_JITTER;
         else if (a == "--lens" && i + 2 < argc) { lens_radius = (float)atof(argv[++i]); focal_distance = (float)atof(argv[++i]); }
         else if (a == "--pfm") pfm = true;
+        else if (a == "--tile" && i + 1 < argc) {
+            if (sscanf(argv[++i], "%d/%d", &tile_index, &tile_count) != 2 || tile_count < 1 || tile_index < 0 || tile_index >= tile_count) {
+                fprintf(stderr, "--tile wants R/K with 0 <= R < K\n");
+                return 1;
+            }
+        }
+        else if (a == "--strip-rows" && i + 1 < argc) strip_rows = atoi(argv[++i]);
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
     }
     pth_scene *sc = pth_load_scene(argv[1]);
@@ -56,7 +67,7 @@ int main(int argc, char **argv) {
     d.triangles = sc->triangles; d.num_triangles = sc->num_triangles;
     d.meshes = sc->meshes; d.num_meshes = sc->num_meshes;
     d.camera = sc->camera; d.trace_depth = sc->trace_depth; d.flags = flags; d.device = device;
-    d.tile_count = 1; d.strip_rows = 8; d.max_batch = batch;
+    d.tile_index = tile_index; d.tile_count = tile_count; d.strip_rows = strip_rows; d.max_batch = batch;
     d.lens_radius = lens_radius; d.focal_distance = focal_distance;
     pt_free();                                            // main.cpp:126
     if (pt_init(&d) != PT_OK) { fprintf(stderr, "pathtraceInit: %s\n", pt_last_error()); return 1; }

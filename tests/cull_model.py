@@ -7,8 +7,9 @@ F = np.float32
 BIG = F(2.0 ** 100)
 
 
-def candidates(rays, box, rmax):
-    """rays[n, 6] float32 (origin, direction); box[2, 3] (lo, hi); returns (candidate mask, wild mask)."""
+def candidates(rays, box, rmax, reject=None):
+    """rays[n, 6] float32 (origin, direction); box[2, 3] (lo, hi); reject = (axis, m_kk, m_k3) of the exact
+    one-axis early miss or None; returns (candidate mask, wild mask)."""
     o = rays[:, :3].astype(F)
     d = rays[:, 3:].astype(F)
     with np.errstate(all="ignore"):
@@ -23,6 +24,11 @@ def candidates(rays, box, rmax):
         tn = np.fmax(np.fmax(ta[:, 0], ta[:, 1]), np.fmax(ta[:, 2], F(0)))
         tf = np.fmin(np.fmin(tb[:, 0], tb[:, 1]), tb[:, 2])
         cand = ~(tn > tf)
+        if reject is not None and int(reject[0]) != 3:
+            k = int(reject[0])
+            qk = ((F(reject[1]) * o[:, k]).astype(F) + F(reject[2])).astype(F)
+            vk = (F(reject[1]) * d[:, k]).astype(F)
+            cand &= ~((np.abs(qk) > F(0.5)) & ((qk * vk).astype(F) > F(0)))
     return cand | wild, wild
 
 

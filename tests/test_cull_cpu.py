@@ -19,7 +19,7 @@ def pt():
 
 
 def _check(pt, po, geoms, eye, rng, per_geom):
-    boxes, rmax = pt.cull_boxes(geoms, eye)
+    boxes, rmax, rej = pt.cull_boxes(geoms, eye)
     rays = cull_model.stress_rays(geoms, rng, per_geom=per_geom)
     paths = np.zeros(len(rays), dtype=po.PATH_DT)
     paths["origin"], paths["direction"] = rays[:, :3], rays[:, 3:]
@@ -28,7 +28,7 @@ def _check(pt, po, geoms, eye, rng, per_geom):
         want, _ = po.compute_intersections(paths, geoms[gi:gi + 1].view(po.GEOM_DT))
         # any t the loop of pathtrace.cu:176-199 would take (t > 0), and NaN distances (they come from a passed test)
         hit = (want["t"] > 0) | np.isnan(want["t"])
-        cand, _wild = cull_model.candidates(rays, boxes[gi], rmax)
+        cand, _wild = cull_model.candidates(rays, boxes[gi], rmax, rej[gi])
         lost = hit & ~cand
         assert not lost.any(), "geom %d: %d hits outside the box, e.g. ray %s" % (gi, lost.sum(), rays[np.nonzero(lost)[0][0]])
         total_hits += int(hit.sum()); total_cand += int(cand.sum())
@@ -62,9 +62,12 @@ def test_random_transforms(pt, po, scenes, seed):
             sc = np.array([1e-3, 1e-3, 1e-3])
         if k == 4:
             sc = np.array([0.0, 1.0, 1.0])                 # singular: inverse holds inf / NaN
+        if k == 5:
+            g["type"], g["rotation"] = 1, 0.0              # an axis-aligned cube: has an exact early-miss axis
         g["scale"] = sc
         H.pth_build_geom_matrices(geoms.ctypes.data + k * pt.GEOM_DT.itemsize)
-    boxes, _ = pt.cull_boxes(geoms, (0.0, 5.0, 10.5))
+    boxes, _, rej = pt.cull_boxes(geoms, (0.0, 5.0, 10.5))
+    assert rej[5, 0] != 3 and rej[4, 0] == 3 and (rej[geoms["type"] == 0, 0] == 3).all()   # axis-aligned cubes only
     assert np.isinf(boxes[4]).all()                        # no culling for the singular one
     assert np.isfinite(boxes[0]).all()
     _check(pt, po, geoms, (0.0, 5.0, 10.5), rng, 2500)

@@ -213,16 +213,71 @@ def test_c2_compaction_order_hash(pt, po, scenes, golden):
     s = scenes["cornell"]
     scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
     pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
-    pt.trace_begin(1, 1)
-    for d in range(8):
-        live = pt.trace_bounce(d)
-        paths, n_live = pt.export_paths(640000)
-        assert n_live == live
-        seq = np.ascontiguousarray(paths["pixelIndex"])       # keep alive across the C call
-        h = po.lib().pto_fnv1a_i32(seq.ctypes.data, 4, live)
-        assert h == int(z["shared__cornell__seq_hash"][0][d]), "bounce %d" % d
-    pt.trace_end()
+    for it in (1, 2):                                             # the golden fixture holds both iterations
+        pt.trace_begin(it, 1)
+        for d in range(8):
+            live = pt.trace_bounce(d)
+            paths, n_live = pt.export_paths(640000)
+            assert n_live == live
+            seq = np.ascontiguousarray(paths["pixelIndex"])       # keep alive across the C call
+            h = po.lib().pto_fnv1a_i32(seq.ctypes.data, 4, live)
+            assert h == int(z["shared__cornell__seq_hash"][it - 1][d]), "iteration %d bounce %d" % (it, d)
+        pt.trace_end()
     pt.pathtraceFree()
+
+
+@pytest.mark.parametrize("flags_name", ["compact", "sort"])
+def test_c3_full_size(pt, po, scenes, flags_name):
+    """Config C3 at its full size -- glass ball, 1280x720, depth 16, material sort on / off: live counts, the
+    compacted pixelIndex sequence after every bounce (its hash) and the image of two iterations equal the oracle's
+    (threaded: one bounce of 921 600 paths at a time on 8 threads)."""
+    s = scenes["cornell_glass"]
+    cam = s["camera"]
+    assert tuple(cam[0]["resolution"]) == (1280, 720) and s["depth"] == 16
+    flags = pt.PT_COMPACT | (pt.PT_SORT_MATERIAL if flags_name == "sort" else 0)
+    oflags = po.F_COMPACT | (po.F_SORT if flags_name == "sort" else 0)
+    n = 1280 * 720
+    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
+    ref = po.Tracer(s["geoms"], s["materials"], cam, s["depth"], flags=oflags, trig=po.TRIG_SHARED)
+    pt.pathtraceInit(scene, flags=flags)
+    for it in (1, 2):
+        st = ref.iterate(it) if flags_name == "sort" else ref.iterate(it, threads=8)
+        pt.trace_begin(it, 1)
+        for d in range(s["depth"]):
+            live = pt.trace_bounce(d)
+            if d < st.bounces:
+                paths, n_live = pt.export_paths(n)
+                assert n_live == live
+                seq = np.ascontiguousarray(paths["pixelIndex"])
+                assert po.lib().pto_fnv1a_i32(seq.ctypes.data, 4, live) == st.seq_hash[d], "iteration %d bounce %d" % (it, d)
+        pt.trace_end()
+        gs = pt.get_stats()
+        assert list(gs.live[:16]) == list(st.live[:16]) and gs.rays == st.rays
+    assert pt.get_image(n).tobytes() == ref.image.tobytes()
+    pt.pathtraceFree()
+
+
+def test_statistical_tier_256spp(pt, golden, scenes):
+    """SURVEY section 4 / BASELINE section 5: 800x800 Cornell at 256 spp against the reference's only rendered
+    artefact (img/REFERENCE_cornell.5000samp.png, committed as 16x16-pooled means): x-flipped, clamped, quantised as
+    savePNG does, the ball and its reflection / shadow masked (the PNG's ball is matte), relative L2 <= 0.05."""
+    s = scenes["cornell"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = 800 * 800
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=64)
+    img = np.zeros((n, 3), dtype=np.float32)
+    for k in range(4):
+        pt.trace_batch(1 + 64 * k, 64, img)
+    pt.pathtraceFree()
+    img = (img / 256.0).reshape(800, 800, 3)[:, ::-1, :]               # saveImage x-flip (main.cpp:87)
+    img = np.floor(np.clip(img, 0, 1) * 255.0) / 255.0                 # savePNG (image.cpp:22-39)
+    pooled = img.reshape(50, 16, 50, 16, 3).mean(axis=(1, 3))
+    want = golden["png_stat"]["pooled"]
+    mask = np.ones((50, 50), dtype=bool)
+    mask[22:40, 12:32] = False
+    num = np.sqrt(((pooled - want)[mask] ** 2).sum())
+    den = np.sqrt((want[mask] ** 2).sum())
+    assert num / den <= 0.05, num / den
 
 
 def test_batch_equals_sequential(pt, scenes):
@@ -970,6 +1025,72 @@ def test_ptbench_headless_host(pt, po, scenes, tmp_path):
         ref.iterate(it)
     want = pt.image_to_rgb8(ref.image, 64, 64, 5.0)
     assert got.tobytes() == want.tobytes()
+
+
+def test_reference_host_through_the_shim(pt, po, scenes, tmp_path):
+    """The REFERENCE host -- its own scene.cpp / utilities.cpp / image.cpp / stb.cpp and the runCuda sequence of
+    main.cpp:101-147 (free before init, per-call camera re-read, scene->state.image refreshed by every pathtrace()) --
+    linked against host/pathtrace_shim.cpp + libptmi355.so (oracle/_ref/refhost, built in the build container by
+    oracle/Makefile, shipped with the snapshot): the PNG its saveImage() writes decodes to the pixels of ptbench's PNG
+    and of the oracle's image pushed through the same pipeline."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "refhost")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/refhost is built where /root/reference exists")
+    txt = open(os.path.join(root, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         64 64")
+    import re
+    txt = re.sub(r"(?m)^ITERATIONS\s+\d+", "ITERATIONS  5", txt)
+    txt = re.sub(r"(?m)^FILE\s+\S+", "FILE        %s" % str(tmp_path / "refhost"), txt)
+    scene_file = tmp_path / "cornell64.txt"
+    scene_file.write_text(txt)
+    p = subprocess.run([exe, str(scene_file), "T0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    from PIL import Image
+    got = np.asarray(Image.open(str(tmp_path / "refhost.T0.5samp.png")).convert("RGB"), dtype=np.uint8)
+    bench = pt.build_ptbench()
+    p = subprocess.run([bench, str(scene_file), "--out", str(tmp_path / "ptb")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    mine = np.asarray(Image.open(str(tmp_path / "ptb.5samp.png")).convert("RGB"), dtype=np.uint8)
+    assert got.tobytes() == mine.tobytes()
+    s = scenes["cornell_64"]
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
+    for it in range(1, 6):
+        ref.iterate(it)
+    assert got.tobytes() == pt.image_to_rgb8(ref.image, 64, 64, 5.0).tobytes()
+
+
+def _read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = [int(v) for v in f.readline().split()]
+        scale = float(f.readline())
+        data = np.frombuffer(f.read(), dtype="<f4" if scale < 0 else ">f4")
+    return data.reshape(h, w, 3)
+
+
+def test_ptbench_tiles(pt, tmp_path):
+    """`ptbench --tile R/K`: K host processes (one per GPU in production) render one frame between them; their raw
+    sums add up -- exactly, a sum with zeros -- to the single-process image."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         96 80")
+    scene_file = tmp_path / "c.txt"
+    scene_file.write_text(txt)
+    exe = pt.build_ptbench()
+
+    def render(name, *extra):
+        p = subprocess.run([exe, str(scene_file), "--iters", "3", "--batch", "2", "--pfm", "--out", str(tmp_path / name)] + list(extra),
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        return _read_pfm(str(tmp_path / (name + ".3samp.pfm")))
+
+    whole = render("whole")
+    parts = [render("t%d" % k, "--tile", "%d/3" % k, "--strip-rows", "8") for k in range(3)]
+    assert (parts[0] + parts[1] + parts[2]).tobytes() == whole.tobytes()
+    assert all((p != 0).any() and (p == 0).any() for p in parts)
 
 
 def test_ptbench_mesh_scene_hierarchy_and_camera_options(pt, tmp_path):

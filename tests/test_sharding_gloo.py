@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, strip_rows, out_path):
+def _worker(rank, world, port, strip_rows, out_path, mode):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -37,7 +37,8 @@ def _worker(rank, world, port, strip_rows, out_path):
     image = torch.zeros(W * H * 3, dtype=torch.float32)
     frame = torch.zeros_like(image)
     tr = po.Tracer(geoms, mats, cam, depth)
-    for step in range(2):
+    gather = None
+    for step in range(3):
         iter0, count = pt.sharding.step_iterations(step, batch, world)
         for it in range(iter0, iter0 + count):
             tr.iterate(it)
@@ -45,7 +46,15 @@ def _worker(rank, world, port, strip_rows, out_path):
         mine = np.zeros((W * H, 3), dtype=np.float32)
         mine[own] = tr.image[own]
         image.copy_(torch.from_numpy(mine.reshape(-1)))
-        pt.sharding.reduce_frame(dist, image, frame, dst=0)
+        if mode == "reduce":
+            pt.sharding.reduce_frame(dist, image, frame, dst=0)
+        else:                                    # the gather of packed tile rows, two slots in flight
+            if gather is None:
+                gather = pt.sharding.TileGather(torch, dist, rank, world, strip_rows, W, H, torch.device("cpu"), via_host=True)
+            gather.finish(frame, step & 1)
+            gather.start(image, step & 1)
+    if gather is not None:
+        gather.drain(frame)
     if rank == 0:
         np.save(out_path, frame.numpy().reshape(-1, 3))
         np.save(out_path + ".ref.npy", tr.image)
@@ -53,12 +62,13 @@ def _worker(rank, world, port, strip_rows, out_path):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["reduce", "gather"])
 @pytest.mark.parametrize("strip_rows", [4, 7])
-def test_two_rank_reduce_equals_single(tmp_path, strip_rows):
+def test_two_rank_reduce_equals_single(tmp_path, strip_rows, mode):
     import torch.multiprocessing as mp
     out = str(tmp_path / "frame.npy")
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, strip_rows, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, strip_rows, out, mode), nprocs=2, join=True)
     got, want = np.load(out), np.load(out + ".ref.npy")
     assert got.tobytes() == want.tobytes()
 
@@ -78,3 +88,4 @@ def test_tiles_partition_the_frame():
         assert (seen == 1).all()
         assert max(sizes) - min(sizes) <= strip * W    # balanced to within one strip
     assert sh.step_iterations(0, 16, 8) == (1, 128) and sh.step_iterations(2, 16, 8) == (257, 128)
+    assert sh.step_iterations(2, 16, 8, "strong") == (33, 16)
