@@ -98,9 +98,14 @@ enum pt_flags {
     PT_MESH_BVH      = 1u << 5,  /* cull triangle tests with a bounding-volume hierarchy built at
                                     pt_init (INSTRUCTION.md:129-139,218-240); same winner as the
                                     loop over every triangle */
-    PT_AA_JITTER     = 1u << 6   /* stochastic antialiasing: jitter each camera ray inside its
+    PT_AA_JITTER     = 1u << 6,  /* stochastic antialiasing: jitter each camera ray inside its
                                     pixel (the TODO at pathtrace.cu:134; INSTRUCTION.md:110).
                                     Excludes PT_CACHE_FIRST (INSTRUCTION.md:113). */
+    PT_ASYNC_IMAGE   = 1u << 7   /* opt-in: pt_trace / pt_trace_batch return without waiting; the copy of the
+                                    running sum into host_image_sum overlaps the NEXT call's tracing and is
+                                    complete when the next pt_trace / pt_trace_batch returns, or after
+                                    pt_synchronize, pt_get_image or pt_free (pt_get_stats needs pt_synchronize).  Off = the reference's synchronous pathtrace()
+                                    (pathtrace.cu:389-392), with the host buffer page-locked on first use. */
 };
 
 typedef struct pt_scene_desc {

@@ -32,7 +32,7 @@ ISECT_DT = np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("materialId", "<i4")])
 TRI_DT = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3)])
 MESH_DT = np.dtype([("geom_index", "<i4"), ("first_triangle", "<i4"), ("triangle_count", "<i4")])
 
-PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH, PT_AA_JITTER = 1, 2, 4, 8, 16, 32, 64
+PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH, PT_AA_JITTER, PT_ASYNC_IMAGE = 1, 2, 4, 8, 16, 32, 64, 128
 BVH_NODE_WORDS = 16
 
 

@@ -120,7 +120,7 @@ struct Renderer {
     // one captured graph per batch size: memset + every launch of a batch replayed with one hipGraphLaunch
     struct BatchGraph { hipGraphExec_t exec; int cur, cur_dir, step_depth; bool sorted_isects, gen_fused; };
     std::map<int, BatchGraph> graphs;
-    uint64_t whole_max_paths = 3000000;  // batches up to this many paths run as ONE launch (k_iteration); PTMI355_WHOLE_MAX
+    uint64_t whole_max_paths = 6000000;  // batches up to this many paths run as ONE launch (k_iteration); PTMI355_WHOLE_MAX
     bool whole = false;           // the current batch did
     bool use_graphs = false;      // PTMI355_GRAPH=1 turns replay on (measured slower than direct launches on ROCm 7.2: DESIGN.md 6.10)
     bool capturing = false;
@@ -131,6 +131,16 @@ struct Renderer {
     unsigned long long *mesh_mask = nullptr; // ... and which lanes of each logical tile have one
     int grid_mesh = 0;
     pt_bvh_info bvh_info{};
+    // host buffers the caller hands to pt_trace (scene->state.image): page-locked once so that the per-call copy of
+    // the running sum (pathtrace.cu:389-390) runs at PCIe speed instead of through the runtime's staging
+    struct HostReg { void *ptr; size_t bytes; };
+    std::vector<HostReg> host_regs;
+    // PT_ASYNC_IMAGE: snapshot of the running sum per call (device), copied out on a second stream while the next
+    // call traces
+    float *snap[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    uint64_t async_calls = 0;
     void *scratch = nullptr;      // export / import staging
     size_t scratch_bytes = 0;
     // stepping state
@@ -508,6 +518,60 @@ int upload_cull(const pt_scene_desc *d, const pt_camera &cam) {
     return PT_OK;
 }
 
+// page-lock a caller-owned host buffer (idempotent per pointer; failures are not errors: the copy then takes the
+// runtime's pageable path)
+void pin_host(void *ptr, size_t bytes) {
+    for (auto &h : R.host_regs)
+        if (h.ptr == ptr) {
+            if (h.bytes >= bytes) return;
+            (void)hipHostUnregister(h.ptr);
+            h = R.host_regs.back(); R.host_regs.pop_back();
+            break;
+        }
+    if (R.host_regs.size() >= 4) {                    // a host that keeps handing over new buffers: forget the oldest
+        (void)hipHostUnregister(R.host_regs.front().ptr);
+        R.host_regs.erase(R.host_regs.begin());
+    }
+    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) R.host_regs.push_back({ptr, bytes});
+    else (void)hipGetLastError();
+}
+
+// PT_ASYNC_IMAGE: the running sum after this call is snapshotted on the launch stream (device to device, microseconds)
+// and copied to the host on a second stream while the NEXT call traces; `host` is complete when the next
+// pt_trace / pt_trace_batch returns, or after pt_synchronize / pt_get_image / pt_free.
+int enqueue_async_image(float *host) {
+    const size_t bytes = (size_t)R.npix * 12;
+    const int k = (int)(R.async_calls & 1);
+    if (!R.copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&R.copy_stream, hipStreamNonBlocking));
+        for (int j = 0; j < 2; ++j) {
+            HIPCHK(hipMalloc(&R.snap[j], bytes));
+            HIPCHK(hipEventCreateWithFlags(&R.ev_snap[j], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&R.ev_copied[j], hipEventDisableTiming));
+        }
+    }
+    pin_host(host, bytes);
+    if (R.async_calls >= 2) HIPCHK(hipStreamWaitEvent(R.stream, R.ev_copied[k], 0));     // the copy that last read snap[k]
+    HIPCHK(hipMemcpyAsync(R.snap[k], R.image, bytes, hipMemcpyDeviceToDevice, R.stream));
+    HIPCHK(hipEventRecord(R.ev_snap[k], R.stream));
+    HIPCHK(hipStreamWaitEvent(R.copy_stream, R.ev_snap[k], 0));
+    HIPCHK(hipMemcpyAsync(host, R.snap[k], bytes, hipMemcpyDeviceToHost, R.copy_stream));
+    HIPCHK(hipEventRecord(R.ev_copied[k], R.copy_stream));
+    // the buffer handed over by the PREVIOUS call is complete when this call returns (its copy has been running
+    // beside this call's tracing, which is already enqueued)
+    if (R.async_calls >= 1) HIPCHK(hipEventSynchronize(R.ev_copied[k ^ 1]));
+    R.async_calls++;
+    return PT_OK;
+}
+
+// the synchronous copy of the running sum (the reference's semantics): on the launch stream, into a pinned buffer
+int enqueue_image_copy(float *host) {
+    const size_t bytes = (size_t)R.npix * 12;
+    pin_host(host, bytes);
+    HIPCHK(hipMemcpyAsync(host, R.image, bytes, hipMemcpyDeviceToHost, R.stream));
+    return PT_OK;
+}
+
 // reads the control block back (after a sync) and folds it into the stats
 int collect_stats(void) {
     Control c;
@@ -596,6 +660,14 @@ void pt_free(void) {
     if (R.dir_mem) (void)hipFree(R.dir_mem);
     if (R.persist) (void)hipFree(R.persist);
     if (R.scratch) (void)hipFree(R.scratch);
+    if (R.copy_stream) (void)hipStreamSynchronize(R.copy_stream);
+    for (auto &h : R.host_regs) (void)hipHostUnregister(h.ptr);
+    for (int j = 0; j < 2; ++j) {
+        if (R.snap[j]) (void)hipFree(R.snap[j]);
+        if (R.ev_snap[j]) (void)hipEventDestroy(R.ev_snap[j]);
+        if (R.ev_copied[j]) (void)hipEventDestroy(R.ev_copied[j]);
+    }
+    if (R.copy_stream) (void)hipStreamDestroy(R.copy_stream);
     for (hipEvent_t e : R.ev) (void)hipEventDestroy(e);
     if (R.stream && R.own_stream) (void)hipStreamDestroy(R.stream);
     R = Renderer{};
@@ -721,7 +793,7 @@ static int init_impl(const pt_scene_desc *d) {
     R.desc = *d; R.cam = d->camera; R.trace_depth = d->trace_depth; R.flags = d->flags; R.device = d->device;
     R.lens = Lens{(d->flags & PT_AA_JITTER) ? 1 : 0, d->lens_radius, d->focal_distance};
     if (const char *ug = getenv("PTMI355_GRAPH")) R.use_graphs = atoi(ug) != 0;
-    R.whole_max_paths = 3000000;     // measured at 800x800: 1 spp +13 %, 4 spp +8 %, 8 spp +1 %, 16 spp -8 %
+    R.whole_max_paths = 6000000;     // measured at 800x800 (r02): 1 spp +38 %, 4 spp +20 %, 8 spp +8 %, 16 spp -4 %
     if (const char *wm = getenv("PTMI355_WHOLE_MAX")) R.whole_max_paths = strtoull(wm, nullptr, 10);
     R.npix = W * H;
     R.map.W = W; R.map.H = H; R.map.tile_index = d->tile_index; R.map.tile_count = tile_count;
@@ -951,6 +1023,7 @@ int pt_set_lens(float lens_radius, float focal_distance) {
 int pt_synchronize(void) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_synchronize: not initialised");
     HIPCHK(hipStreamSynchronize(R.stream));
+    if (R.copy_stream) HIPCHK(hipStreamSynchronize(R.copy_stream));
     return PT_OK;
 }
 
@@ -965,10 +1038,12 @@ int pt_trace_batch(int iter0, int count, float *host_image_sum) {
     R.in_step = false;
     int rc = enqueue_batch(iter0, count);
     if (rc) return rc;
-    rc = collect_stats();
-    if (rc) return rc;
-    if (host_image_sum) HIPCHK(hipMemcpy(host_image_sum, R.image, (size_t)R.npix * 12, hipMemcpyDeviceToHost));
-    return PT_OK;
+    if (host_image_sum && (R.flags & PT_ASYNC_IMAGE)) return enqueue_async_image(host_image_sum);
+    if (host_image_sum) {
+        rc = enqueue_image_copy(host_image_sum);
+        if (rc) return rc;
+    }
+    return collect_stats();                               // one stream synchronisation covers the copy as well
 }
 
 int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
@@ -982,10 +1057,12 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
                            R.image, R.npix, iter);
         HIPCHK(hipGetLastError());
     }
-    rc = collect_stats();
-    if (rc) return rc;
-    if (host_image_sum) HIPCHK(hipMemcpy(host_image_sum, R.image, (size_t)R.npix * 12, hipMemcpyDeviceToHost));
-    return PT_OK;
+    if (host_image_sum && (R.flags & PT_ASYNC_IMAGE)) return enqueue_async_image(host_image_sum);
+    if (host_image_sum) {
+        rc = enqueue_image_copy(host_image_sum);
+        if (rc) return rc;
+    }
+    return collect_stats();                               // one stream synchronisation covers the copy as well
 }
 
 int pt_trace_begin(int iter0, int count) {
@@ -1103,6 +1180,7 @@ int pt_get_image(float *host_image_sum) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_get_image: not initialised");
     if (!host_image_sum) return fail(PT_ERR_INVALID, "pt_get_image: null buffer");
     HIPCHK(hipStreamSynchronize(R.stream));
+    if (R.copy_stream) HIPCHK(hipStreamSynchronize(R.copy_stream));
     HIPCHK(hipMemcpy(host_image_sum, R.image, (size_t)R.npix * 12, hipMemcpyDeviceToHost));
     return PT_OK;
 }

@@ -299,6 +299,29 @@ def test_batch_equals_sequential(pt, scenes):
     pt.pathtraceFree()
 
 
+def test_async_image_mode(pt, scenes):
+    """PT_ASYNC_IMAGE: pathtrace() returns without waiting for its own copy; the running sum reaches the host while
+    the next call traces.  When call i+1 returns the buffer of call i is complete; pt_synchronize completes the last
+    one; every sum equals the synchronous mode's."""
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
+    sums = [pt.pathtrace(None, 0, it).copy() for it in range(1, 7)]
+    pt.pathtraceFree()
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_ASYNC_IMAGE)
+    bufs = [np.zeros((n, 3), dtype=np.float32) for _ in range(3)]
+    L = pt.library()
+    for it in range(1, 7):
+        assert L.pt_trace(None, 0, it, bufs[it % 3].ctypes.data) == 0
+        if it >= 2:                               # the buffer of the previous call is complete when this one returns
+            assert bufs[(it - 1) % 3].tobytes() == sums[it - 2].tobytes()
+    pt.synchronize()
+    assert bufs[6 % 3].tobytes() == sums[5].tobytes()
+    assert pt.get_image(n).tobytes() == sums[5].tobytes()
+    pt.pathtraceFree()
+
+
 def test_tiles_equal_whole_frame(pt, scenes):
     """Interleaved row-strip tiles (multi-GPU sharding) reproduce the 1-tile image exactly:
     the RNG is keyed by the global pixelIndex."""
