@@ -728,7 +728,8 @@ __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t 
 // state + intersection (60 B per path) with fifteen scattered 4-B stores, then read them back: 2.5 TB/s, 43 % of
 // the time of a C3 step.
 constexpr int SORT_MAX_BINS = 2048;          // one bin per material + misses; per-wave chunk counts live in LDS (32 KiB at the limit)
-constexpr int SORT_CHUNK_TILES = 2 * WAVES;  // two 64-path tiles per wave and chunk
+constexpr int SORT_TPW = 2;                  // 64-path tiles per wave and chunk (1 and 4 measured: -2 % / -5 %)
+constexpr int SORT_CHUNK_TILES = SORT_TPW * WAVES;
 constexpr int SORT_CHUNK = SORT_CHUNK_TILES * TILE;
 
 __device__ __forceinline__ uint32_t sort_key(const Isect &is, uint32_t i, int nbins) {
@@ -814,8 +815,8 @@ __global__ __launch_bounds__(BLOCK) void k_sort_hist(BounceArgs a) {
     __syncthreads();
     for (uint32_t c = 0; c < count; ++c) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const uint32_t i = ((first + c) * SORT_CHUNK_TILES + wave * 2 + s) * TILE + lane;
+        for (int s = 0; s < SORT_TPW; ++s) {
+            const uint32_t i = ((first + c) * SORT_CHUNK_TILES + wave * SORT_TPW + s) * TILE + lane;
             const bool valid = i < n;
             const uint32_t key = valid ? sort_key(a.isect, i, a.nbins) : 0u;
             for_each_key(valid, key, [&](uint32_t k, uint64_t m) {
@@ -878,11 +879,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
         const uint32_t chunk_base = (first + c) * SORT_CHUNK;
         // ---- A: keys of the wave's two tiles, per-wave counts ----
         for (int b = lane; b < a.nbins; b += 64) wcount[wave * nb + b] = 0;
-        uint32_t key2[2];
-        bool valid2[2];
+        uint32_t key2[SORT_TPW];
+        bool valid2[SORT_TPW];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const uint32_t e = (uint32_t)(wave * 2 + s) * TILE + lane;
+        for (int s = 0; s < SORT_TPW; ++s) {
+            const uint32_t e = (uint32_t)(wave * SORT_TPW + s) * TILE + lane;
             const uint32_t i = chunk_base + e;
             valid2[s] = i < n;
             key2[s] = valid2[s] ? sort_key(a.isect, i, a.nbins) : 0u;
@@ -916,8 +917,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
         __syncthreads();
         // ---- C: sorted position of every element (stable: tiles in order, lanes in order) ----
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const uint32_t e = (uint32_t)(wave * 2 + s) * TILE + lane;
+        for (int s = 0; s < SORT_TPW; ++s) {
+            const uint32_t e = (uint32_t)(wave * SORT_TPW + s) * TILE + lane;
             for_each_key(valid2[s], key2[s], [&](uint32_t k, uint64_t m) {
                 const uint32_t base = kstart[k] + wcount[wave * nb + k];           // same address for the whole wave
                 if (valid2[s] && key2[s] == k) order[base + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))] = e;
@@ -927,9 +928,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
         __syncthreads();
         // ---- D: shade 128 consecutive sorted positions per wave ----
         const uint32_t chunk_n = min((uint32_t)SORT_CHUNK, n - chunk_base);
-#pragma unroll 1
-        for (int s = 0; s < 2; ++s) {
-            const uint32_t p = (uint32_t)(wave * 2 + s) * TILE + lane;
+#pragma unroll                       // both tiles' gathers in flight together: +5 % (profiles/r02/variants_sort.log)
+        for (int s = 0; s < SORT_TPW; ++s) {
+            const uint32_t p = (uint32_t)(wave * SORT_TPW + s) * TILE + lane;
             bool active = p < chunk_n;
             uint32_t key = 0, i = 0, pid = DEAD_PID, dst = 0;
             f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1), col = ptd::mk(1, 1, 1);

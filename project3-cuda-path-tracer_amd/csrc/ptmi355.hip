@@ -114,6 +114,7 @@ struct Renderer {
     uint32_t max_tiles = 0;
     size_t ctl_bytes = 0;         // Control, zeroed per batch
     int grid = 0;                 // persistent grid size
+    int grid_sort = 0;            // workgroups of the material-sort kernels (k_sort_hist / k_shade_sorted)
     bool sorted_isects = false;   // the last bounce was shaded in material order (the intersection planes keep the order the bounce received)
     bool gen_fused = false;       // bounce 0 of the current batch generates its own rays
     Lens lens{0, 0.0f, 0.0f};     // PT_AA_JITTER / thin lens (pt_scene_desc, pt_set_lens)
@@ -331,16 +332,16 @@ int enqueue_bounce(int depth) {
         {
             StageTimer tm(PT_STAGE_SORT);
             const size_t lds = ((size_t)LDS_CTL_WORDS + (size_t)((a.nbins + 3) & ~3)) * 4;
-            if (compact) hipLaunchKernelGGL(k_sort_hist<true>, dim3(R.grid), dim3(BLOCK), lds, R.stream, a);
-            else hipLaunchKernelGGL(k_sort_hist<false>, dim3(R.grid), dim3(BLOCK), lds, R.stream, a);
+            if (compact) hipLaunchKernelGGL(k_sort_hist<true>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+            else hipLaunchKernelGGL(k_sort_hist<false>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
             HIPCHK(hipGetLastError());
         }
         StageTimer tm(PT_STAGE_BOUNCE);
         const size_t nb = (size_t)((a.nbins + 3) & ~3);
         const size_t lds = ((size_t)LDS_CTL_WORDS + (3 + WAVES) * nb + 2 * SORT_CHUNK +
                             (a.nbins <= 64 ? (size_t)R.scene.nmats * ptd::MAT_WORDS : 0)) * 4;
-        if (compact) hipLaunchKernelGGL(k_shade_sorted<true>, dim3(R.grid), dim3(BLOCK), lds, R.stream, a);
-        else hipLaunchKernelGGL(k_shade_sorted<false>, dim3(R.grid), dim3(BLOCK), lds, R.stream, a);
+        if (compact) hipLaunchKernelGGL(k_shade_sorted<true>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+        else hipLaunchKernelGGL(k_shade_sorted<false>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
         HIPCHK(hipGetLastError());
         R.cur ^= 1; R.cur_dir = -1;                      // the sorted pool is dense
         R.sorted_isects = true;
@@ -974,12 +975,19 @@ static int init_impl(const pt_scene_desc *d) {
     if (R.flags & PT_SORT_MATERIAL) {
         if (d->num_materials + 1 > SORT_MAX_BINS)
             return fail(PT_ERR_INVALID, "pt_init: PT_SORT_MATERIAL keeps one bin per material in LDS: at most %d materials", SORT_MAX_BINS - 1);
-        HIPCHK(hipMalloc((void **)&R.sort_table, (size_t)(d->num_materials + 1) * R.grid * sizeof(uint32_t)));
+        {
+            int per_cu_sort = 8;                              // nothing in these kernels needs co-residency; 8 per CU measured best (5: -4 %)
+            if (const char *e = getenv("PTMI355_SORT_WGS")) per_cu_sort = std::max(1, atoi(e));
+            const uint32_t chunks = (R.cap + SORT_CHUNK - 1) / SORT_CHUNK;
+            R.grid_sort = (int)std::max<uint32_t>(1u, std::min<uint32_t>(chunks, (uint32_t)cus * (uint32_t)per_cu_sort));
+        }
+        HIPCHK(hipMalloc((void **)&R.sort_table, (size_t)(d->num_materials + 1) * R.grid_sort * sizeof(uint32_t)));
     }
     {   // range directory: one count + one base per wave of the persistent grid, per bounce
         const size_t Wp = ((size_t)R.grid * WAVES + 3) & ~(size_t)3;
         R.dir_stride = 2 * Wp + 8;
-        HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)R.trace_depth * R.dir_stride * sizeof(uint32_t)));
+        // one directory per bounce up to MAX_DEPTH: traceDepth is re-read on every call and may GROW (pathtrace.cu:286)
+        HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)MAX_DEPTH * R.dir_stride * sizeof(uint32_t)));
     }
     HIPCHK(hipStreamSynchronize(R.stream));
     g_err[0] = 0;
@@ -992,8 +1000,8 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
     if (camera->resolution[0] != R.map.W || camera->resolution[1] != R.map.H)
         return fail(PT_ERR_INVALID, "pt_set_camera: resolution changed (%dx%d -> %dx%d); re-init instead",
                     R.map.W, R.map.H, camera->resolution[0], camera->resolution[1]);
-    if (trace_depth < 1 || trace_depth > R.desc.trace_depth)
-        return fail(PT_ERR_INVALID, "pt_set_camera: trace_depth %d outside [1, %d]", trace_depth, R.desc.trace_depth);
+    if (trace_depth < 1 || trace_depth > MAX_DEPTH)
+        return fail(PT_ERR_INVALID, "pt_set_camera: trace_depth %d outside [1, %d]", trace_depth, MAX_DEPTH);
     if (memcmp(&R.cam, camera, sizeof R.cam) != 0) { R.cache_valid = false; drop_graphs(); }   // refill the bounce-0 cache
     {   // the cull boxes hold for ray origins within R.scene.rmax (1-norm); a camera outside that range would only
         // make its rays candidates of every primitive (correct, slow): remake the boxes around the new position
@@ -1004,7 +1012,12 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
             drop_graphs();
         }
     }
-    if (trace_depth != R.trace_depth) drop_graphs();
+    if (trace_depth != R.trace_depth) {
+        drop_graphs();
+        // the per-batch clear covers the election buckets of the bounces that can run
+        R.ctl_bytes = offsetof(Control, bucket) - offsetof(Control, stamp) +
+                      (size_t)trace_depth * sizeof(((Control *)nullptr)->bucket[0]);
+    }
     R.cam = *camera;
     R.trace_depth = trace_depth;
     return PT_OK;

@@ -519,13 +519,13 @@ def test_random_scenes(pt, po, scenes, seed):
 
 
 def test_trace_depth_reread_every_call(pt, po, scenes):
-    """pathtrace() re-reads traceDepth from the scene on every call (pathtrace.cu:286): a smaller depth set after
-    init takes effect at once (and back), like the camera."""
+    """pathtrace() re-reads traceDepth from the scene on every call (pathtrace.cu:286): a smaller OR LARGER depth set
+    after init takes effect at once (and back), like the camera."""
     s = scenes["cornell_glass_64"]
     scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
     pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
     total = np.zeros((scene.resolution[0] * scene.resolution[1], 3), dtype=np.float32)
-    for it, depth in ((1, s["depth"]), (2, 3), (3, 1), (4, s["depth"])):
+    for it, depth in ((1, s["depth"]), (2, 3), (3, 1), (4, s["depth"]), (5, s["depth"] + 7), (6, 2), (7, 40)):
         scene.traceDepth = depth
         img = pt.pathtrace(None, 0, it)
         ref = po.Tracer(s["geoms"], s["materials"], s["camera"], depth, trig=po.TRIG_SHARED)
@@ -534,8 +534,8 @@ def test_trace_depth_reread_every_call(pt, po, scenes):
         total += ref.image                                   # the running sum adds each iteration's contribution
         assert np.array_equal(img, total)
     with pytest.raises(pt.PtError):
-        scene.traceDepth = s["depth"] + 1                    # deeper than what pathtraceInit sized for
-        pt.pathtrace(None, 0, 5)
+        scene.traceDepth = 65                                # the control block holds 64 bounces
+        pt.pathtrace(None, 0, 8)
     pt.pathtraceFree()
 
 
