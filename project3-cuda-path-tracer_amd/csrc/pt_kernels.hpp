@@ -548,6 +548,16 @@ __device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t sp
                                                 bool active, Control *ctl) {
     const int lane = threadIdx.x & 63;
     const uint32_t *base = dir.base();
+#ifndef PT_NO_RESOLVE_FAST
+    {
+        // A range holds the survivors of a whole run of tiles (thousands of paths), so a tile almost always lies
+        // inside the range the previous tile ended in: two wave-uniform loads and one subtraction then replace the
+        // windowed search below.
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p) - (uint32_t)__builtin_amdgcn_readfirstlane(lane);
+        const uint32_t b0 = base[cur], b1 = base[cur + 1];              // cur < W always (base[] has W + 1 entries)
+        if (p0 >= b0 && p0 + 63u < b1) return cur * span + (p - b0);
+    }
+#endif
     bool resolved = !active;
     uint32_t src = 0, rng = cur;
     uint32_t s = cur;
