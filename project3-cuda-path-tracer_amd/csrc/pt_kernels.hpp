@@ -1059,7 +1059,28 @@ __device__ __forceinline__ void tile_load(const BounceArgs &a, const TileCtx &c,
 
 // Second half: shade / scatter with the intersection (t, nrm, mat, outside), write the final colour of the paths
 // that end here and append the survivors at dst_base + packed (wave64 ballot + popcount rank).
-template <bool COMPACT>
+// does the ray reach one of the two root boxes of some mesh?  (wave-uniform scalar loads of the roots; the same
+// conservative box arithmetic the walk uses)
+__device__ __forceinline__ bool mesh_root_candidate(const SceneDev &sc, f3 ro, f3 rd) {
+    bool cand = false;
+#pragma unroll 1
+    for (int k = 0; k < sc.bvh_nmesh; ++k) {
+        const __attribute__((address_space(4))) int *mrec =
+            (const __attribute__((address_space(4))) int *)(unsigned long long)(sc.bvh_meshes + k);
+        cfloat *grid = as_const(sc.geoms) + (size_t)mrec[0] * ptd::GEOM_WORDS + ptd::G_INV;
+        const __attribute__((address_space(4))) uint32_t *b =
+            (const __attribute__((address_space(4))) uint32_t *)(unsigned long long)(sc.bvh_nodes + (size_t)mrec[1] * BVH_NODE_WORDS);
+        const BvhRay br = bvh_ray(ro, rd, ptd::mk(grid[0], grid[1], grid[2]), ptd::mk(grid[3], grid[4], grid[5]));
+        float tn, tf;
+        bvh_slab(br, b[0], b[1], b[2], tn, tf);
+        cand |= tn <= tf;
+        bvh_slab(br, b[3], b[4], b[5], tn, tf);
+        cand |= tn <= tf;
+    }
+    return cand;
+}
+
+template <bool COMPACT, int MESH = MESH_NONE>
 __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c, const Pool &in, const Pool &out, int depth,
                                            const TileRegs &tr, f3 ro, f3 rd, float t, f3 nrm, int mat, int outside,
                                            uint32_t n, uint32_t dst_base, uint32_t &packed, uint32_t &traced) {
@@ -1090,6 +1111,10 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
         pf(p, 3) = ps.d.x; pf(p, 4) = ps.d.y; pf(p, 5) = ps.d.z;
         pf(p, 6) = ps.c.x; pf(p, 7) = ps.c.y; pf(p, 8) = ps.c.z;
         ppid(p) = tr.pid;
+        // mesh pre-pass of the NEXT bounce: flag the slot when the new ray can reach a mesh at all (~11 % of them on
+        // C4), so that k_mesh neither scans nor loads the other 89 %
+        if (MESH == MESH_PRE && mesh_root_candidate(a.scene, ps.o, ps.d))
+            atomicOr(&a.mesh_flags_out[dst >> 6], 1ull << (dst & 63u));
     } else if (!COMPACT && tr.have && tr.i < n) {
         out.pid(dst) = DEAD_PID;
     }
@@ -1097,7 +1122,7 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
 
 // the tile with parity `par` has been fully tested: read its rays back from the wave's LDS block, fold the
 // winner and shade
-template <bool COMPACT>
+template <bool COMPACT, int MESH>
 __device__ __forceinline__ void tile_finish(const BounceArgs &a, const TileCtx &c, const WaveQ &q, int par, const Pool &in,
                                             const Pool &out, int depth, const TileRegs &tr, uint32_t n, uint32_t dst_base,
                                             uint32_t &packed, uint32_t &traced) {
@@ -1106,7 +1131,7 @@ __device__ __forceinline__ void tile_finish(const BounceArgs &a, const TileCtx &
     const f3 rd = ptd::mk(ry[192], ry[256], ry[320]);
     float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0, outside = 1;
     if (tr.active) tile_result(q, par, c.acc, a.scene.tris, tr.mb, t, nrm, mat, outside);
-    tile_shade<COMPACT>(a, c, in, out, depth, tr, ro, rd, t, nrm, mat, outside, n, dst_base, packed, traced);
+    tile_shade<COMPACT, MESH>(a, c, in, out, depth, tr, ro, rd, t, nrm, mat, outside, n, dst_base, packed, traced);
 }
 
 // The tiles [first, first + count) of one wave's run at one bounce, two in flight (see the intersection stages
@@ -1143,19 +1168,15 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
         tile_load(a, c, in, gen_rays, tile, i, src, have, active, tr, ro, rd);
         if (MODE == MODE_FUSED) {
             const float4 *pre_hit = nullptr;
-            if (MESH == MESH_PRE) {
-                // lanes of this tile for which k_mesh found a mesh hit; the mask is consumed (cleared) here
-                const unsigned long long mm = a.mesh_mask[tile];
-                if (mm) {
-                    if (lane == 0) a.mesh_mask[tile] = 0ull;
-                    if (tr.active && ((mm >> lane) & 1ull)) pre_hit = a.mesh_hit + src;
-                }
+            if (MESH == MESH_PRE && tr.active) {
+                // slots whose flag is set carry a mesh result from k_mesh (a hit, or "walked, nothing hit")
+                if ((a.mesh_flags_in[src >> 6] >> (src & 63u)) & 1ull) pre_hit = a.mesh_hit + src;
             }
             cull_scene<MESH>(a.scene, c.acc, q, par, c.tri_lds, tr.active, ro, rd, tr.mb, pre_hit);
             const uint32_t ticket = q.total;
             if (pending) {
                 drain_to(q, c.acc, prev_ticket);
-                tile_finish<COMPACT>(a, c, q, par ^ 1, in, out, depth, prev, n, dst_base, packed, traced);
+                tile_finish<COMPACT, MESH>(a, c, q, par ^ 1, in, out, depth, prev, n, dst_base, packed, traced);
             }
             prev = tr; prev_ticket = ticket; pending = true; par ^= 1;
         } else {
@@ -1173,7 +1194,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
     }
     if (pending) {
         drain_to(q, c.acc, prev_ticket);
-        tile_finish<COMPACT>(a, c, q, par ^ 1, in, out, depth, prev, n, dst_base, packed, traced);
+        tile_finish<COMPACT, MESH>(a, c, q, par ^ 1, in, out, depth, prev, n, dst_base, packed, traced);
     }
 }
 
@@ -1318,8 +1339,9 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a)
 // boxes, wave-uniform scalar loads) and appends the candidates {slot, path, ray} to a per-wave
 // LDS ring; lanes without a walk take ring entries, all lanes walk together, and the triangles of
 // the leaves they reach are queued and tested 64 at a time.  Results go
-// to mesh_hit[slot] = {t, geom, triangle} and one bit per path in mesh_mask[tile]; k_bounce
-// <MESH_PRE> folds them with the geom-index tie-break of pathtrace.cu:192.
+// to mesh_hit[slot] = {t, geom, triangle} with one flag per pool slot (BounceArgs::mesh_flags_*); k_bounce
+// <MESH_PRE> folds them with the geom-index tie-break of pathtrace.cu:192 and flags, among the survivors it
+// writes, the ones whose new ray can reach a mesh: the next bounce's k_mesh touches only those.
 // ---------------------------------------------------------------------------
 #ifndef PT_SKIP_PAIRS
 #define PT_SKIP_PAIRS 2                      // missed-sibling pairs remembered per walk (registers)
@@ -1458,7 +1480,10 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &
 #ifdef PT_MESH_STATS
             {
                 const uint64_t bb = ballot64(w.have && (w.node >= 0 || leaf_l >= 0 || leaf_r >= 0));
+                const uint64_t wt = ballot64(w.have && w.node < 0 && leaf_l < 0 && leaf_r < 0);     // walk over, waiting for its queued triangles
+                const uint64_t id = ballot64(!w.have);
                 if (lane == 0 && bb) { atomicAdd(&a.ctl->keep[1], (uint32_t)__popcll((unsigned long long)bb)); atomicAdd(&a.ctl->keep[2], 1u); }
+                if (lane == 0) { atomicAdd(&a.ctl->keep[8], (uint32_t)__popcll((unsigned long long)wt)); atomicAdd(&a.ctl->keep[9], (uint32_t)__popcll((unsigned long long)id)); atomicAdd(&a.ctl->keep[10], 1u); }
                 atomicMax(&a.ctl->keep[14], (uint32_t)w.steps);
             }
 #endif
@@ -1505,10 +1530,11 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, MeshRings &
                     for (int u = 0; u < PT_SKIP_PAIRS; ++u) w.skip[u] = -1;
                     keys[lane] = TRI_KEY_NONE;
                 } else {
-                    if (w.best_geom >= 0) {
+                    // flagged slots (marked by the previous bounce) always get a record, a hit or "nothing"; in scan
+                    // mode only hits are recorded and flagged here
+                    if (w.best_geom >= 0 || !a.mesh_scan)
                         a.mesh_hit[w.src] = make_float4(w.best_t, __int_as_float(w.best_geom), __int_as_float(w.best_tri), 0.0f);
-                        atomicOr(&a.mesh_mask[w.path >> 6], 1ull << (w.path & 63u));
-                    }
+                    if (w.best_geom >= 0 && a.mesh_scan) atomicOr(&a.mesh_flags_in[w.src >> 6], 1ull << (w.src & 63u));
                     w.have = false;
                 }
             }
@@ -1522,12 +1548,17 @@ __global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
     float *mq = lds_raw + (threadIdx.x >> 6) * MQ_WORDS;
     uint32_t *mi = reinterpret_cast<uint32_t *>(mq);
     const int lane = threadIdx.x & 63;
-    const uint32_t W = gridDim.x * WAVES;
     const uint32_t wid = run_id();
     const int iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;
     // bounce 0 of a batch: nlive[0] is written by that bounce's own kernel, so the count comes from the host
     const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
+    // (Measured with an instrumented build on C4: 42 of 64 lanes step on average at 64 spp per step, 27 at 16 -- a wave
+    // only has ~100-400 walks per launch to refill its lanes with, and ends with a tail as long as its longest walk.
+    // Giving the work to fewer, fuller waves was tried and is strictly slower -- 13.5 -> 13.0 / 11.3 / 7.7 Grays/s at
+    // 1/2, 1/4, 1/8 of the waves: the walk is bound by the latency of its dependent record fetches, which only waves
+    // in flight hide.)
+    const uint32_t W = gridDim.x * WAVES;
     const uint32_t R = range_tiles(n, W);
     const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
     const uint32_t Wd = a.dir_in.W;                               // waves of the grid that packed the pool
@@ -1539,54 +1570,58 @@ __global__ __launch_bounds__(BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
     w.geom = 0; w.root = 0;
 #pragma unroll
     for (int u = 0; u < PT_SKIP_PAIRS; ++u) { w.skip[u] = -1; w.to[u] = -1; }
-    for (uint32_t r = 0; r < R; ++r) {
-        // Tiles are dealt round-robin, not in runs: the pool keeps pixel order through every (stable) compaction,
-        // so the rays that reach a mesh -- and the ones that leave its surface -- sit in neighbouring tiles; a run
-        // of them would keep one wave walking long after the others are done (measured: waves alive 15 % of the
-        // launch on average).  The price is one directory search per tile instead of a cursor.
+    // Tiles are dealt round-robin, not in runs: the pool keeps pixel order through every (stable) compaction, so the
+    // rays that reach a mesh -- and the ones that leave its surface -- sit in neighbouring tiles; a run of them would
+    // keep one wave walking long after the others are done (measured: waves alive 15 % of the launch on average).
+    // mesh_scan = 0 (every bounce but the first): the previous bounce flagged the slots whose ray reaches a mesh's
+    // root boxes; this kernel walks the PHYSICAL 64-slot tiles of the pool, skips the unflagged ones after one scalar
+    // load -- no directory search, no ray loads, no root tests for the ~89 % of the paths that cannot hit a mesh -- and
+    // loads only the flagged lanes' rays.
+    const uint32_t phys_tiles = packed_in ? Wd * (span_in / TILE) : tiles;
+    const uint32_t rounds = a.mesh_scan ? R : (phys_tiles + W - 1) / W;
+    for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t tile = r * W + wid;
-        if (tile >= tiles) break;
-        uint32_t cur = 0;
-        if (packed_in) cur = find_range(a.dir_in.base(), Wd, tile * TILE);
-        const uint32_t i = tile * TILE + lane;
-        bool active = i < n;
-        uint32_t src = i;
-        if (packed_in) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
+        uint32_t src = tile * TILE + lane;
+        bool cand = false;
         f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
-        if (active) {
-            if (a.gen_rays) {
-                const uint32_t smp = sample_of(a.map, i);
-                const int pixel = local_to_pixel(a.map, (int)(i - smp * (uint32_t)a.map.tile_pixels));
-                camera_ray(a.cam, a.lens, a.trace_depth, iter0 + (int)smp, pixel, a.map.W, ro, rd);
-            } else {
+        if (!a.mesh_scan) {
+            if (tile >= phys_tiles) break;
+            const unsigned long long fl = a.mesh_flags_in[tile];          // wave-uniform
+            if (!fl) continue;
+            cand = (fl >> lane) & 1ull;
+            if (cand) {
                 char *q = a.in.slot(src);
-                if (ppid(q) == DEAD_PID) active = false;
                 ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
                 rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
             }
+        } else {
+            if (tile >= tiles) break;
+            uint32_t cur = 0;
+            if (packed_in) cur = find_range(a.dir_in.base(), Wd, tile * TILE);
+            const uint32_t i = tile * TILE + lane;
+            bool active = i < n;
+            src = i;
+            if (packed_in) src = resolve_src(a.dir_in, span_in, cur, i, active, a.ctl);
+            if (active) {
+                if (a.gen_rays) {
+                    const uint32_t smp = sample_of(a.map, i);
+                    const int pixel = local_to_pixel(a.map, (int)(i - smp * (uint32_t)a.map.tile_pixels));
+                    camera_ray(a.cam, a.lens, a.trace_depth, iter0 + (int)smp, pixel, a.map.W, ro, rd);
+                } else {
+                    char *q = a.in.slot(src);
+                    if (ppid(q) == DEAD_PID) active = false;
+                    ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
+                    rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
+                }
+            }
+            // candidate: the ray reaches one of the two root boxes of some mesh
+            cand = active && mesh_root_candidate(a.scene, ro, rd);
         }
-        // candidate: the ray reaches one of the two root boxes of some mesh (wave-uniform scalar loads)
-        bool cand = false;
-#pragma unroll 1
-        for (int k = 0; k < a.scene.bvh_nmesh; ++k) {
-            const __attribute__((address_space(4))) int *mrec =
-                (const __attribute__((address_space(4))) int *)(unsigned long long)(a.scene.bvh_meshes + k);
-            cfloat *grid = as_const(a.scene.geoms) + (size_t)mrec[0] * ptd::GEOM_WORDS + ptd::G_INV;
-            const __attribute__((address_space(4))) uint32_t *b =
-                (const __attribute__((address_space(4))) uint32_t *)(unsigned long long)(a.scene.bvh_nodes + (size_t)mrec[1] * BVH_NODE_WORDS);
-            const BvhRay br = bvh_ray(ro, rd, ptd::mk(grid[0], grid[1], grid[2]), ptd::mk(grid[3], grid[4], grid[5]));
-            float tn, tf;
-            bvh_slab(br, b[0], b[1], b[2], tn, tf);
-            cand |= tn <= tf;
-            bvh_slab(br, b[3], b[4], b[5], tn, tf);
-            cand |= tn <= tf;
-        }
-        cand = cand && active;
         const uint64_t m = ballot64(cand);
         if (m) {
             if (cand) {
                 const uint32_t s = (rg.q_total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))) & (MQ_SLOTS - 1);
-                mi[0 * MQ_SLOTS + s] = src; mi[1 * MQ_SLOTS + s] = i;
+                mi[0 * MQ_SLOTS + s] = src; mi[1 * MQ_SLOTS + s] = src;
                 mq[2 * MQ_SLOTS + s] = ro.x; mq[3 * MQ_SLOTS + s] = ro.y; mq[4 * MQ_SLOTS + s] = ro.z;
                 mq[5 * MQ_SLOTS + s] = rd.x; mq[6 * MQ_SLOTS + s] = rd.y; mq[7 * MQ_SLOTS + s] = rd.z;
             }

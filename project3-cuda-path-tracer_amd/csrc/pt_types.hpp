@@ -183,7 +183,11 @@ struct BounceArgs {
     // mesh pre-pass (k_mesh -> k_bounce<MESH_PRE>): nearest mesh hit per source slot {t, geom, triangle, -}
     // and, per logical 64-path tile, the lanes that have one
     float4 *mesh_hit;
-    unsigned long long *mesh_mask;
+    // one flag per POOL SLOT (64 per word): "mesh_hit[slot] holds this path's mesh result (possibly: no hit)".
+    // flags_in describes the pool this bounce reads, flags_out the one it writes: k_bounce marks the survivors whose
+    // new ray reaches a mesh's root boxes, so that the next bounce's k_mesh only touches those (mesh_scan = 0)
+    unsigned long long *mesh_flags_in, *mesh_flags_out;
+    int mesh_scan;         // k_mesh must find the candidates itself (bounce 0, or the previous bounce did not mark)
     // material sort: table[key][workgroup] of k_sort_hist / k_shade_sorted; keys = materials + 1 (misses)
     uint32_t *sort_table;
     int nbins;

@@ -129,7 +129,8 @@ struct Renderer {
     float *d_bvh_nodes = nullptr, *d_bvh_tris = nullptr;
     int4 *d_bvh_meshes = nullptr;
     float4 *mesh_hit = nullptr;              // mesh pre-pass results (k_mesh), one per pool slot
-    unsigned long long *mesh_mask = nullptr; // ... and which lanes of each logical tile have one
+    unsigned long long *mesh_flags[2] = {nullptr, nullptr};   // one flag per pool slot: "mesh_hit[slot] is valid" (bounce parity)
+    bool mesh_marked = false;                // the last bounce flagged the next bounce's mesh candidates
     int grid_mesh = 0;
     pt_bvh_info bvh_info{};
     // host buffers the caller hands to pt_trace (scene->state.image): page-locked once so that the per-call copy of
@@ -247,7 +248,9 @@ BounceArgs bounce_args(int depth) {
     a.depth = depth; a.trace_depth = R.trace_depth; a.iter0 = R.capturing ? -1 : R.step_iter0;
     a.pool_n = (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count;
     a.gen_rays = (depth == 0 && R.gen_fused) ? 1 : 0;
-    a.mesh_hit = R.mesh_hit; a.mesh_mask = R.mesh_mask;
+    a.mesh_hit = R.mesh_hit;
+    a.mesh_flags_in = R.mesh_flags[depth & 1]; a.mesh_flags_out = R.mesh_flags[(depth + 1) & 1];
+    a.mesh_scan = R.mesh_marked ? 0 : 1;
     return a;
 }
 
@@ -260,7 +263,11 @@ int enqueue_begin(int iter0, int count, bool stepping) {
         return fail(PT_ERR_INVALID, "iteration %d (+%d) outside [0, 2^31)", iter0, count);
     R.step_iter0 = iter0; R.step_count = count; R.step_depth = 0; R.cur = 0; R.cur_dir = -1;
     R.sorted_isects = false;
+    R.mesh_marked = false;
     HIPCHK(hipMemsetAsync(&R.ctl->stamp, 0, R.ctl_bytes, R.stream));      // everything but Control::iter0
+    if (R.mesh_mode == MESH_BVH)
+        for (int k = 0; k < 2; ++k)
+            HIPCHK(hipMemsetAsync(R.mesh_flags[k], 0, ((size_t)R.max_tiles + 1) * sizeof(unsigned long long), R.stream));
     // batch path: bounce 0 generates the camera rays itself (no 40 B/path round trip through HBM)
     R.gen_fused = !stepping && !(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER));
     if (R.gen_fused) return PT_OK;
@@ -375,6 +382,12 @@ int enqueue_bounce(int depth) {
         if (compact) launch_bounce<MODE_FUSED, true>(a); else launch_bounce<MODE_FUSED, false>(a);
     }
     HIPCHK(hipGetLastError());
+    if (R.mesh_mode == MESH_BVH) {
+        // this bounce's flags are spent; the array is the NEXT bounce's output flags.  Only a fused bounce marks
+        // the candidates of the next one (the cached / unfused pipelines leave the finding to k_mesh's scan)
+        HIPCHK(hipMemsetAsync(R.mesh_flags[depth & 1], 0, ((size_t)R.max_tiles + 1) * sizeof(unsigned long long), R.stream));
+        R.mesh_marked = !cached0 && !unfused;
+    }
     if (compact) { R.cur ^= 1; R.cur_dir = depth; }
     R.step_depth = depth + 1;
     return PT_OK;
@@ -601,6 +614,8 @@ int collect_stats(void) {
             c.keep[0], c.keep[1], c.keep[2], c.keep[2] ? (double)c.keep[1] / c.keep[2] : 0.0);
     {
         float f[7]; memcpy(f, &c.keep[4], sizeof f);
+        fprintf(stderr, "[ptmi355] per walk-loop step (%u in all, incl. steps where nobody walks): %.1f lanes waiting for queued triangles, %.1f lanes without a walk\n",
+                c.keep[10], c.keep[10] ? (double)c.keep[8] / c.keep[10] : 0.0, c.keep[10] ? (double)c.keep[9] / c.keep[10] : 0.0);
         fprintf(stderr, "[ptmi355] longest walk %u records; records where nothing was hit: %u, with a leaf hit: %u\n", c.keep[14], c.keep[12], c.keep[13]);
         fprintf(stderr, "[ptmi355] walks past 5000 steps: %u; last: o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) tz=%g depth %u\n", c.keep[3],
                 f[0], f[1], f[2], f[3], f[4], f[5], f[6], c.keep[11]);
@@ -653,7 +668,7 @@ void pt_free(void) {
     if (R.d_ginfo) (void)hipFree(R.d_ginfo);
     drop_graphs();
     if (R.mesh_hit) (void)hipFree(R.mesh_hit);
-    if (R.mesh_mask) (void)hipFree(R.mesh_mask);
+    for (int k = 0; k < 2; ++k) if (R.mesh_flags[k]) (void)hipFree(R.mesh_flags[k]);
     if (R.d_bvh_nodes) (void)hipFree(R.d_bvh_nodes);
     if (R.d_bvh_meshes) (void)hipFree(R.d_bvh_meshes);
     if (R.d_bvh_tris) (void)hipFree(R.d_bvh_tris);
@@ -962,8 +977,10 @@ static int init_impl(const pt_scene_desc *d) {
     if (R.grid < 1) R.grid = 1;
     if (R.mesh_mode == MESH_BVH) {
         HIPCHK(hipMalloc((void **)&R.mesh_hit, (size_t)(((capz + 63) / 64) * 64) * sizeof(float4)));
-        HIPCHK(hipMalloc((void **)&R.mesh_mask, ((size_t)R.max_tiles + 1) * sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(R.mesh_mask, 0, ((size_t)R.max_tiles + 1) * sizeof(unsigned long long), R.stream));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(hipMalloc((void **)&R.mesh_flags[k], ((size_t)R.max_tiles + 1) * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(R.mesh_flags[k], 0, ((size_t)R.max_tiles + 1) * sizeof(unsigned long long), R.stream));
+        }
         int per_cu_mesh = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_mesh, (const void *)k_mesh<true>, BLOCK,
                                                             (size_t)WAVES * MQ_WORDS * 4));
