@@ -46,14 +46,19 @@ BYTES_PER_SURVIVOR = 88
 
 
 def csrc_digest():
-    """sha256 (first 16 hex digits) over the kernel sources: counter profiles are only valid for the build they were taken on."""
+    """sha256 (first 16 hex digits) over the kernel sources -- comments and white space removed, so that only code
+    changes count: counter profiles are only valid for the build they were taken on."""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "project3-cuda-path-tracer_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hpp", ".hip")):
+            text = open(os.path.join(d, name), "r", errors="replace").read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", " ", text)
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -26,10 +26,15 @@
 // child boxes lie inside the parent's, so a missed sibling simply fails both child tests.
 //
 // Culling must never change which triangle wins (the loop over all triangles is the
-// specification).  Boxes are therefore padded by `pad` = 2^-13 * max(1, largest |coordinate|),
-// orders of magnitude above the rounding error of glm::intersectRayTriangle for rays that are
-// not within ~1e-3 rad of a triangle's plane, and the kernel prunes against the best distance
-// with the additive margin `prune` = 16 * pad.  The grid rounding adds at most two grid steps on top.
+// specification).  Boxes are therefore padded by `pad` = 2^-13 * max(1, largest |coordinate|), and the
+// kernel prunes against the best distance with the additive margin `prune` = 16 * pad; the grid rounding
+// adds at most two grid steps on top.  What that buys, exactly: glm::intersectRayTriangle accepts a hit
+// when its float barycentrics pass their range tests; they carry absolute errors <= 4u |dir| (|s| + |e1|)
+// |e2| / a and 8u |dir| |s| |e1| / a (u = 2^-24, s = orig - v0, a = dot(e1, cross(dir, e2))), so the exact hit
+// point of an accepted ray lies within D = 12u |dir| (|s| + |e1|) |e1| |e2| / a of the triangle in its plane.
+// The walk is provably the loop for every (ray, triangle) with D <= pad, i.e. a >= 12u (|s| + |e1|) |e1| |e2|
+// / pad (C4's mesh: rays more than ~1.6e-2 rad off the triangle's plane); closer to grazing, down to glm's
+// own cut-off a >= 1.19e-7, it rests on the tests.
 #pragma once
 #include <algorithm>
 #include <cmath>

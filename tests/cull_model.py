@@ -71,7 +71,18 @@ def stress_rays(geoms, rng, per_geom=4000, reach=12.0):
         origin[mode == 0] = on_surface[mode == 0]
         origin[mode == 1] = inside[mode == 1]
         origin[mode == 2] *= 30.0                                           # beyond the origin bound: `wild`
+        # bounce rays: the origin sits where getPointOnRay leaves it, up to 3e-4 OBJECT units off the face it hit
+        # (1e-6 world units off a 0.01-thick wall), on either side -- the exact one-axis early miss must decide these
+        # as the reference's own rounding does
+        lift = q.copy()
+        ax = np.argmax(np.abs(q) == 0.5, axis=1)
+        lift[np.arange(n), ax] *= 1.0 + rng.choice([-6e-4, -2e-4, -1e-5, 1e-5, 2e-4, 6e-4], n)
+        bounce = (np.concatenate([lift, np.ones((n, 1))], axis=1) @ T.T)[:, :3]
+        sel = (mode == 3) | (mode == 4)
+        origin[sel] = bounce[sel]
         d = target - origin
+        away = _unit(rng.normal(size=(n, 3)))                                # leaving in a random direction
+        d[mode == 4] = away[mode == 4]
         scale = rng.choice([1.0, 1.0, 1.0, 1e-3, 37.0], n)[:, None]        # un-normalised directions too
         d = _unit(d) * scale
         # behind: flip a share so the primitive lies behind the ray

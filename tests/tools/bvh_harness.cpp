@@ -2,6 +2,7 @@
 #include <cstdlib>
 #include <random>
 #include "../../project3-cuda-path-tracer_amd/csrc/pt_bvh.hpp"
+#include "../../project3-cuda-path-tracer_amd/csrc/pt_cull.hpp"
 int main() {
     std::mt19937 rng(7);
     std::uniform_real_distribution<float> U(-5, 5), S(0.001f, 2.0f);
@@ -35,6 +36,30 @@ int main() {
         }
         if (covered != n) { printf("trial %d: leaves cover %ld of %d\n", trial, covered, n); return 1; }
     }
-    printf("bvh harness ok\n");
+    // cull boxes: random affine maps incl. singular, non-finite, huge and tiny ones
+    for (int trial = 0; trial < 200; ++trial) {
+        const int n = 1 + (int)(rng() % 40);
+        std::vector<float> m((size_t)n * 16);
+        std::vector<const float *> ptr((size_t)n);
+        std::vector<char> sph((size_t)n), skip((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            for (int k = 0; k < 16; ++k) m[(size_t)i * 16 + k] = (k % 5 == 0 ? 1.0f : 0.0f) * S(rng) * 50.0f + ((rng() % 3 == 0) ? U(rng) : 0.0f);
+            if (rng() % 9 == 0) m[(size_t)i * 16 + (rng() % 16)] = (rng() % 2) ? NAN : INFINITY;
+            if (rng() % 9 == 1) for (int k = 0; k < 4; ++k) m[(size_t)i * 16 + 4 + k] = 0.0f;      // singular
+            if (rng() % 9 == 2) for (int k = 0; k < 16; ++k) m[(size_t)i * 16 + k] *= 1e30f;
+            ptr[(size_t)i] = &m[(size_t)i * 16]; sph[(size_t)i] = rng() % 2; skip[(size_t)i] = rng() % 7 == 0;
+        }
+        const double eye[3] = {U(rng), U(rng), trial % 5 == 0 ? (double)INFINITY : U(rng)};
+        std::vector<ptcull::Box> bx;
+        const float R = ptcull::make_boxes(ptr.data(), reinterpret_cast<const bool *>(sph.data()), reinterpret_cast<const bool *>(skip.data()), n, eye, 1, bx);
+        if (!(R >= 1.0f) || (int)bx.size() != n) { printf("cull: bad bound %g\n", R); return 1; }
+        for (int i = 0; i < n; ++i) {
+            float mkk, mk3;
+            const int ax = ptcull::reject_axis(ptr[(size_t)i], mkk, mk3);
+            if (ax < 0 || ax > 3) { printf("cull: bad axis\n"); return 1; }
+            for (int k = 0; k < 3; ++k) if (!(bx[(size_t)i].lo[k] <= bx[(size_t)i].hi[k])) { printf("cull: inverted / NaN box\n"); return 1; }
+        }
+    }
+    printf("bvh + cull harness ok\n");
     return 0;
 }

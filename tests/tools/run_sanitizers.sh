@@ -1,6 +1,6 @@
 #!/bin/bash
 # CPU-side sanitizer pass (GPU AddressSanitizer is not available on this pool): the host code -- oracle, scene
-# loader / image writer, hierarchy builder -- under ASan + UBSan.  Usage: bash tests/tools/run_sanitizers.sh
+# loader / image writer, hierarchy builder, cull boxes -- under ASan + UBSan.  Usage: bash tests/tools/run_sanitizers.sh
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 T=$(mktemp -d)
