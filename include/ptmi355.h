@@ -223,7 +223,8 @@ int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node
  * may be NULL): boxes = count x {lo.xyz, hi.xyz}; *origin_bound = the |origin|_1 up to which they hold.  A ray
  * outside a primitive's box is never handed to the exact test (csrc/pt_cull.hpp has the error bound that makes
  * this identical to the reference's loop over every primitive, pathtrace.cu:176-199).  reject (optional) = count x
- * {axis (0..2, 3 = none), m_kk, m_k3}: the exact one-axis early miss the kernel applies to cubes (same file). */
+ * {mode (0..2 diagonal row k, 4 general row, 3 none), m_k0, m_k1, m_k2, m_k3}: the row of the inverseTransform the
+ * kernel's exact one-axis early miss evaluates for cubes (same file). */
 int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound, float *reject);
 const char *pt_last_error(void);
 const char *pt_version(void);

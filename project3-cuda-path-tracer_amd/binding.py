@@ -313,12 +313,12 @@ def bvh_build(triangles):
 
 
 def cull_boxes(geoms, eye=(0.0, 0.0, 0.0)):
-    """Host-only: (boxes[n, 2, 3] float32 = lo / hi, origin bound, reject[n, 3] = axis / m_kk / m_k3) pt_init derives
-    for the cull stage."""
+    """Host-only: (boxes[n, 2, 3] float32 = lo / hi, origin bound, reject[n, 5] = mode / row of the inverseTransform)
+    pt_init derives for the cull stage."""
     g = np.ascontiguousarray(geoms, dtype=GEOM_DT)
     e = np.asarray(eye, dtype=np.float32)
     out = np.zeros((len(g), 2, 3), dtype=np.float32)
-    rej = np.zeros((len(g), 3), dtype=np.float32)
+    rej = np.zeros((len(g), 5), dtype=np.float32)
     r = C.c_float(0.0)
     _chk(library().pt_cull_boxes(_p(g), len(g), _p(e), _p(out), C.byref(r), _p(rej)))
     return out, r.value, rej

@@ -165,26 +165,35 @@ inline float make_boxes(const float *const *inv16, const bool *is_sphere, const 
     return round_down(R);
 }
 
-// Axis along which the kernel's exact early miss may be evaluated for a CUBE (pt_kernels.hpp, cull_scene): a row k
-// of the inverseTransform's upper 3x3 whose off-diagonal entries are exactly zero, with every entry of the matrix
-// finite and bounded (so that v = A d is finite and dot(v, v) neither NaN nor a source of NaN for non-wild rays);
-// among several, the one with the largest |A_kk|, i.e. the thinnest world extent (the faces with the largest area).
-// Returns 3 when there is none; m_kk / m_k3 = the two floats the kernel needs.
-inline int reject_axis(const float *inv16, float &mkk, float &mk3) {
-    mkk = 0.0f; mk3 = 0.0f;
+// The kernel's EXACT one-axis early miss for a CUBE (pt_kernels.hpp, cull_scene): with q_k = row k of the
+// inverseTransform applied to the origin and v_k = the same row applied to the direction, both evaluated in the
+// reference's own operation order ((m0 x + m1 y) + (m2 z + m3), glm mat4 * vec4), "|q_k| > 0.5 and q_k v_k > 0" means the
+// origin lies beyond slab k and the ray heads away from it: both slab parameters of the axis are negative (their
+// signs are those of the numerators -0.5 - q_k, 0.5 - q_k times that of q.direction[k] = v_k * (1 / sqrt(dot(v, v))),
+// a positive factor), so tmax < 0 and boxIntersectionTest returns -1 whatever the other axes say
+// (intersections.h:56-77).  Needs every entry of the matrix finite and bounded (then v is finite, dot(v, v) is neither
+// NaN nor overflowing for the non-wild rays the kernel applies this to).  The row chosen is the one with the largest
+// norm -- the thinnest world extent, i.e. the faces with the largest area: this is what takes a path's OWN wall out
+// of its candidates.  Returns the mode: 0..2 = row k has no off-diagonal entries (q_k = fl(fl(m_kk o_k) + m_k3), two
+// operations: the other products are exact zeros), 4 = general row (row[0..2], row[3] = translation), 3 = none.
+inline int reject_row(const float *inv16, float row[4]) {
+    row[0] = row[1] = row[2] = row[3] = 0.0f;
     for (int c = 0; c < 4; ++c)
         for (int r = 0; r < 3; ++r)
             if (!std::isfinite(inv16[c * 4 + r]) || std::fabs(inv16[c * 4 + r]) > 0x1p40f) return 3;
-    int best = 3;
+    int best = -1;
+    double best_norm = 0.0;
     for (int k = 0; k < 3; ++k) {
-        bool diag = true;
-        for (int j = 0; j < 3; ++j)
-            if (j != k && inv16[j * 4 + k] != 0.0f) diag = false;
-        const float d = inv16[k * 4 + k];
-        if (!diag || d == 0.0f) continue;
-        if (best == 3 || std::fabs(d) > std::fabs(mkk)) { best = k; mkk = d; mk3 = inv16[3 * 4 + k]; }
+        double nn = 0.0;
+        for (int j = 0; j < 3; ++j) nn += (double)inv16[j * 4 + k] * (double)inv16[j * 4 + k];
+        if (nn > best_norm) { best_norm = nn; best = k; }
     }
-    return best;
+    if (best < 0) return 3;
+    for (int j = 0; j < 4; ++j) row[j] = inv16[j * 4 + best];
+    bool diag = row[best] != 0.0f;
+    for (int j = 0; j < 3; ++j)
+        if (j != best && row[j] != 0.0f) diag = false;
+    return diag ? best : 4;
 }
 
 }  // namespace ptcull

@@ -56,8 +56,8 @@ constexpr int PW_BEST = PW_RING + Q_SLOTS;               // u64[2][64]: (bits(t)
 constexpr int PW_WIN = PW_BEST + 2 * 64 * 2;             // float4[2][64]: winner's normal xyz, outside flag
 constexpr int PW_RAYS = PW_WIN + 2 * 64 * 4;             // float[2][6][64]: ro.xyz rd.xyz of the tile's paths
 constexpr int PW_WORDS = PW_RAYS + 2 * 6 * 64;           // 1664 dwords = 6.5 KiB per wave
-constexpr int CULL_WORDS = 12;       // per geom, scalar-loaded: lo.x hi.x lo.y hi.y lo.z hi.z | type + (reject axis << 8), m_kk, m_k3, spare
-                                     //   | 2 spare (48 B: one s_load_dwordx8 + one s_load_dwordx4)
+constexpr int CULL_WORDS = 12;       // per geom, scalar-loaded: lo.x hi.x lo.y hi.y lo.z hi.z | type + (reject mode << 8) | the reject row:
+                                     //   m_k0 m_k1 m_k2 m_k3 | spare (48 B: one s_load_dwordx8 + one s_load_dwordx4)
 
 __host__ __device__ constexpr int scene_lds_words(int nmats, int ngeoms) {
     return ((nmats * ptd::MAT_WORDS + 3) & ~3) + ((ngeoms + 3) & ~3) + ngeoms * GREC_WORDS;
@@ -180,7 +180,14 @@ __device__ unsigned long long g_cull_stats[8];     // tiles, candidates, passes,
 #endif
 
 // stage 3: candidates [head, head + count), count <= 64
+__device__ __forceinline__ void cand_pass1(const WaveQ &q, const SceneAcc &acc, uint32_t head, uint32_t count);
 __device__ __forceinline__ void cand_pass(const WaveQ &q, const SceneAcc &acc, uint32_t head, uint32_t count) {
+    cand_pass1(q, acc, head, count);
+#ifdef PT_DBG_PASS2          // cost measurement: every pass twice (idempotent: same keys, same records)
+    cand_pass1(q, acc, head, count);
+#endif
+}
+__device__ __forceinline__ void cand_pass1(const WaveQ &q, const SceneAcc &acc, uint32_t head, uint32_t count) {
     const int lane = threadIdx.x & 63;
     CULL_STAT(2, 1); CULL_STAT(3, count);
     if ((uint32_t)lane < count) {
@@ -385,20 +392,20 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
     const float *__restrict__ tris = sc.tris;
     // the records come through wave-uniform scalar loads (s_load_dwordx8 + x4); the next primitive's is requested
     // before this one's is used, so its latency overlaps the test instead of stalling every iteration
-    float nxt[9];
+    float nxt[11];
     {
         cfloat *c0 = as_const(sc.cull);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) nxt[k] = ngeoms > 0 ? c0[k] : 0.0f;
+        for (int k = 0; k < 11; ++k) nxt[k] = ngeoms > 0 ? c0[k] : 0.0f;
     }
     for (int g = 0; g < ngeoms; ++g) {
-        float cb[9];
+        float cb[11];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) cb[k] = nxt[k];
+        for (int k = 0; k < 11; ++k) cb[k] = nxt[k];
         if (g + 1 < ngeoms) {
             cfloat *cn = as_const(sc.cull) + (g + 1) * CULL_WORDS;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) nxt[k] = cn[k];
+            for (int k = 0; k < 11; ++k) nxt[k] = cn[k];
         }
         const int tw = __float_as_int(cb[6]);
         const int type = tw & 0xff;
@@ -459,20 +466,25 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
             continue;
         }
         bool keep = cull_box(cr, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5]);
-        // EXACT early miss along one axis (cubes whose inverseTransform row k has no off-diagonal entries, chosen at
-        // pt_init: the thinnest extent).  The reference's q.origin[k] is then fl(fl(m_kk o_k) + m_k3) -- the other
-        // products are exact zeros -- and q.direction[k] has the sign of fl(m_kk d_k), so "origin beyond the slab and
-        // heading away" ( |q_k| > 0.5 and q_k d_k > 0 ) makes both slab parameters of the axis negative: tmax < 0, a
+        // EXACT early miss along one axis of a cube (pt_cull.hpp: reject_row): q_k and v_k = one row of the
+        // inverseTransform applied to origin and direction in the reference's own operation order; "origin beyond the
+        // slab and heading away" ( |q_k| > 0.5 and q_k v_k > 0 ) makes both slab parameters of the axis negative: tmax < 0, a
         // miss (intersections.h:56-77), whatever the other axes say.  This is what removes a path's OWN surface from
         // its candidates: its origin sits 1e-6 above the wall it just left, well inside any box the float error
-        // allows, and would otherwise cost every bounce ray one object-space test.
-        const int rax = (tw >> 8) & 3;                                   // wave-uniform; 3 = none
-        if (rax != 3) {
-            const float mkk = cb[7], mk3 = cb[8];
-            const float ok = rax == 0 ? ro.x : (rax == 1 ? ro.y : ro.z);
-            const float dk = rax == 0 ? rd.x : (rax == 1 ? rd.y : rd.z);
-            const float qk = mkk * ok + mk3;
-            const float vk = mkk * dk;
+        // allows, and would otherwise cost every bounce ray one object-space test (C2: 0.24 candidates per ray).
+        const int rmode = (tw >> 8) & 7;                                 // wave-uniform; 0..2 diagonal row, 4 general row, 3 none
+        if (rmode != 3) {
+            float qk, vk;
+            if (rmode == 4) {
+                qk = (cb[7] * ro.x + cb[8] * ro.y) + (cb[9] * ro.z + cb[10]);
+                vk = (cb[7] * rd.x + cb[8] * rd.y) + cb[9] * rd.z;       // the reference adds m_k3 * 0.0f = +-0: same value when it matters
+            } else {
+                const float ok = rmode == 0 ? ro.x : (rmode == 1 ? ro.y : ro.z);
+                const float dk = rmode == 0 ? rd.x : (rmode == 1 ? rd.y : rd.z);
+                const float mkk = rmode == 0 ? cb[7] : (rmode == 1 ? cb[8] : cb[9]);
+                qk = mkk * ok + cb[10];                                   // the other products are exact zeros
+                vk = mkk * dk;
+            }
             if (__builtin_fabsf(qk) > 0.5f && qk * vk > 0.0f) keep = false;
         }
         const bool cand = active && (cr.wild || keep);

@@ -520,7 +520,8 @@ int upload_cull(const pt_scene_desc *d, const pt_camera &cam) {
         for (int k = 0; k < 3; ++k) { r[2 * k] = boxes[(size_t)i].lo[k]; r[2 * k + 1] = boxes[(size_t)i].hi[k]; }
         int ax = 3;
         if (d->geoms[i].type == PT_CUBE && !getenv("PTMI355_NO_AXIS_REJECT"))
-            ax = ptcull::reject_axis(&d->geoms[i].inverseTransform.m[0][0], r[7], r[8]);
+            ax = ptcull::reject_row(&d->geoms[i].inverseTransform.m[0][0], &r[7]);       // words 7..10: the row
+        if (ax == 4 && getenv("PTMI355_NO_ROW_REJECT")) ax = 3;
         const int tw = d->geoms[i].type | (ax << 8);
         memcpy(&r[6], &tw, 4);
     }
@@ -1282,9 +1283,10 @@ int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxe
     if (origin_bound) *origin_bound = r;
     if (reject)
         for (int i = 0; i < count; ++i) {
-            float mkk = 0.0f, mk3 = 0.0f;
-            const int ax = geoms[i].type == PT_CUBE ? ptcull::reject_axis(&geoms[i].inverseTransform.m[0][0], mkk, mk3) : 3;
-            reject[3 * i] = (float)ax; reject[3 * i + 1] = mkk; reject[3 * i + 2] = mk3;
+            float row[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const int ax = geoms[i].type == PT_CUBE ? ptcull::reject_row(&geoms[i].inverseTransform.m[0][0], row) : 3;
+            reject[5 * i] = (float)ax;
+            for (int k = 0; k < 4; ++k) reject[5 * i + 1 + k] = row[k];
         }
     return PT_OK;
 }

@@ -8,7 +8,7 @@ BIG = F(2.0 ** 100)
 
 
 def candidates(rays, box, rmax, reject=None):
-    """rays[n, 6] float32 (origin, direction); box[2, 3] (lo, hi); reject = (axis, m_kk, m_k3) of the exact
+    """rays[n, 6] float32 (origin, direction); box[2, 3] (lo, hi); reject = (mode, row[4]) of the exact
     one-axis early miss or None; returns (candidate mask, wild mask)."""
     o = rays[:, :3].astype(F)
     d = rays[:, 3:].astype(F)
@@ -25,9 +25,15 @@ def candidates(rays, box, rmax, reject=None):
         tf = np.fmin(np.fmin(tb[:, 0], tb[:, 1]), tb[:, 2])
         cand = ~(tn > tf)
         if reject is not None and int(reject[0]) != 3:
-            k = int(reject[0])
-            qk = ((F(reject[1]) * o[:, k]).astype(F) + F(reject[2])).astype(F)
-            vk = (F(reject[1]) * d[:, k]).astype(F)
+            mode, row = int(reject[0]), reject[1:5].astype(F)
+            if mode == 4:                          # general row, glm's order: (m0 x + m1 y) + (m2 z + m3)
+                qk = ((row[0] * o[:, 0]).astype(F) + (row[1] * o[:, 1]).astype(F)).astype(F) + \
+                     ((row[2] * o[:, 2]).astype(F) + row[3]).astype(F)
+                vk = ((row[0] * d[:, 0]).astype(F) + (row[1] * d[:, 1]).astype(F)).astype(F) + (row[2] * d[:, 2]).astype(F)
+                qk, vk = qk.astype(F), vk.astype(F)
+            else:
+                qk = ((row[mode] * o[:, mode]).astype(F) + row[3]).astype(F)
+                vk = (row[mode] * d[:, mode]).astype(F)
             cand &= ~((np.abs(qk) > F(0.5)) & ((qk * vk).astype(F) > F(0)))
     return cand | wild, wild
 

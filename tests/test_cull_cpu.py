@@ -67,7 +67,8 @@ def test_random_transforms(pt, po, scenes, seed):
         g["scale"] = sc
         H.pth_build_geom_matrices(geoms.ctypes.data + k * pt.GEOM_DT.itemsize)
     boxes, _, rej = pt.cull_boxes(geoms, (0.0, 5.0, 10.5))
-    assert rej[5, 0] != 3 and rej[4, 0] == 3 and (rej[geoms["type"] == 0, 0] == 3).all()   # axis-aligned cubes only
+    assert rej[5, 0] in (0, 1, 2) and rej[4, 0] == 3 and (rej[geoms["type"] == 0, 0] == 3).all()   # cubes only; diagonal row for the axis-aligned one
+    assert (rej[(geoms["type"] == 1) & (np.arange(len(geoms)) != 4), 0] != 3).all()              # every finite cube has a row
     assert np.isinf(boxes[4]).all()                        # no culling for the singular one
     assert np.isfinite(boxes[0]).all()
     _check(pt, po, geoms, (0.0, 5.0, 10.5), rng, 2500)

@@ -54,9 +54,9 @@ int main() {
         const float R = ptcull::make_boxes(ptr.data(), reinterpret_cast<const bool *>(sph.data()), reinterpret_cast<const bool *>(skip.data()), n, eye, 1, bx);
         if (!(R >= 1.0f) || (int)bx.size() != n) { printf("cull: bad bound %g\n", R); return 1; }
         for (int i = 0; i < n; ++i) {
-            float mkk, mk3;
-            const int ax = ptcull::reject_axis(ptr[(size_t)i], mkk, mk3);
-            if (ax < 0 || ax > 3) { printf("cull: bad axis\n"); return 1; }
+            float row[4];
+            const int ax = ptcull::reject_row(ptr[(size_t)i], row);
+            if (ax < 0 || ax > 4) { printf("cull: bad reject mode\n"); return 1; }
             for (int k = 0; k < 3; ++k) if (!(bx[(size_t)i].lo[k] <= bx[(size_t)i].hi[k])) { printf("cull: inverted / NaN box\n"); return 1; }
         }
     }
