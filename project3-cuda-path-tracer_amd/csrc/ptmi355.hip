@@ -789,11 +789,17 @@ static int init_impl(const pt_scene_desc *d) {
         if (g.type < PT_SPHERE || g.type > PT_TRIANGLE_MESH) return fail(PT_ERR_INVALID, "pt_init: geom %d has type %d", i, g.type);
         if (g.materialid < 0 || g.materialid >= d->num_materials) return fail(PT_ERR_INVALID, "pt_init: geom %d materialid %d out of range", i, g.materialid);
     }
+    if (d->num_meshes < 0 || d->num_triangles < 0 || (d->num_meshes > 0 && !d->meshes) || (d->num_triangles > 0 && !d->triangles))
+        return fail(PT_ERR_INVALID, "pt_init: meshes / triangles missing");
     for (int k = 0; k < d->num_meshes; ++k) {
         const pt_mesh &m = d->meshes[k];
         if (m.geom_index < 0 || m.geom_index >= d->num_geoms || d->geoms[m.geom_index].type != PT_TRIANGLE_MESH ||
-            m.first_triangle < 0 || m.triangle_count < 0 || m.first_triangle + m.triangle_count > d->num_triangles)
+            m.first_triangle < 0 || m.triangle_count < 0 ||
+            (int64_t)m.first_triangle + (int64_t)m.triangle_count > (int64_t)d->num_triangles)
             return fail(PT_ERR_INVALID, "pt_init: mesh %d is inconsistent", k);
+        for (int j = 0; j < k; ++j)          // one mesh per geom, whatever the mesh mode (the loop would silently use the first)
+            if (d->meshes[j].geom_index == m.geom_index)
+                return fail(PT_ERR_INVALID, "pt_init: geom %d owns more than one mesh", m.geom_index);
     }
     if ((d->flags & PT_CACHE_FIRST) && ((d->flags & PT_AA_JITTER) || d->lens_radius > 0.0f))
         return fail(PT_ERR_INVALID, "pt_init: PT_CACHE_FIRST needs identical camera rays every iteration; it cannot be "
@@ -974,6 +980,7 @@ static int init_impl(const pt_scene_desc *d) {
             &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH, SLDS>, BLOCK, R.lds_bytes)));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
+    if (const char *e = getenv("PTMI355_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // occupancy experiments
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
     if (R.grid < 1) R.grid = 1;
     if (R.mesh_mode == MESH_BVH) {

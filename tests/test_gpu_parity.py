@@ -411,6 +411,19 @@ def test_lifecycle_and_errors(pt, scenes):
     with pytest.raises(pt.PtError):
         pt.export_intersections(10)          # not materialised in fused mode
     pt.pathtraceFree()
+    # inconsistent mesh tables are refused, not traced: a range past the triangle array (also when first + count
+    # overflows 32 bits), two meshes on one geom (in both mesh modes)
+    tris = pt.meshes.uv_sphere(n_lat=4, n_lon=6)
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
+    for bad in ("range", "overflow", "duplicate"):
+        m = np.concatenate([meshes, meshes]) if bad == "duplicate" else meshes.copy()
+        if bad == "range":
+            m["triangle_count"][0] = len(tris) + 1
+        if bad == "overflow":
+            m["first_triangle"][0], m["triangle_count"][0] = 2 ** 31 - 4, 8
+        for flags in (pt.PT_COMPACT, pt.PT_COMPACT | pt.PT_MESH_BVH):
+            with pytest.raises(pt.PtError, match="mesh"):
+                pt.pathtraceInit(pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=m), flags=flags)
 
 
 def _resized(cam, w, h):
