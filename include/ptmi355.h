@@ -209,8 +209,8 @@ int pt_get_profile(pt_profile *out);   /* synchronises the stream, drains pendin
 /* PT_MESH_BVH: what pt_init built (all meshes together) */
 typedef struct pt_bvh_info {
     int32_t nodes, triangles, depth;
-    float   pad;                       /* box padding, world units */
-    float   prune;                     /* additive slack of the distance prune */
+    float   pad;                       /* box padding, world units (= 2 x the pad of the spec's hit-point test) */
+    float   prune;                     /* additive slack of the distance prune: 0 (none is needed, csrc/pt_bvh.hpp) */
 } pt_bvh_info;
 int pt_get_bvh_info(pt_bvh_info *out);
 /* host-only (no GPU): build the hierarchy of `count` triangles; returns the node count, or the

@@ -307,14 +307,52 @@ int pto_ray_triangle(pto_vec3 orig, pto_vec3 dir, pto_vec3 v0, pto_vec3 v1, pto_
  * wins ties); the mesh reports, like the cube/sphere tests, the world point
  * P = o + d*tz, the geometric normal normalize(cross(e1,e2)) and
  * t = length(o - P).  Back-face culled (a < eps -> miss), so `outside` is
- * always true. */
-int pto_mesh_winner(const pto_tri *tris, int first, int count, pto_ray r, float *tz) {
+ * always true.
+ *
+ * Hit-point test (spec 8.0 "Triangles", second paragraph).  In single precision
+ * glm::intersectRayTriangle accepts rays that run almost inside a large
+ * triangle's plane with barycentrics that are rounding noise: the point
+ * o + d*tz it reports can lie metres away from the triangle.  The spec
+ * therefore counts a triangle hit only when that point -- evaluated as
+ * fl(o_k + fl(d_k * tz)) -- lies inside the triangle's bounding box
+ * [min, max](v0_k, fl(v0_k + e1_k), fl(v0_k + e2_k)), e = the float edge
+ * vectors of the test, widened by the mesh's pad = 2^-14 * max(1, largest
+ * finite |vertex coordinate| of the mesh).  Every geometrically meaningful
+ * hit passes; what it removes is garbage, and it is what makes a spatial
+ * hierarchy over the triangles provably equal to this loop (pt_bvh.hpp). */
+float pto_mesh_pad(const pto_tri *tris, int first, int count) {
+    float amax = 0.0f;
+    for (int i = first; i < first + count; ++i) {
+        const float *c = (const float *)&tris[i];
+        for (int k = 0; k < 9; ++k) {
+            float m = fabsf(c[k]);
+            if (m <= FLT_MAX && m > amax) amax = m;
+        }
+    }
+    return ldexpf(amax > 1.0f ? amax : 1.0f, -14);
+}
+
+int pto_tri_point_ok(pto_vec3 o, pto_vec3 d, float tz, const pto_tri *t, float pad) {
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    const float a[3] = {t->v0.x, t->v0.y, t->v0.z};
+    const float b[3] = {t->v1.x, t->v1.y, t->v1.z}, c[3] = {t->v2.x, t->v2.y, t->v2.z};
+    for (int k = 0; k < 3; ++k) {
+        float p = oo[k] + dd[k] * tz;
+        float e1 = b[k] - a[k], e2 = c[k] - a[k];
+        float x1 = a[k] + e1, x2 = a[k] + e2;
+        float lo = fminf(a[k], fminf(x1, x2)), hi = fmaxf(a[k], fmaxf(x1, x2));
+        if (!(p >= lo - pad && p <= hi + pad)) return 0;
+    }
+    return 1;
+}
+
+int pto_mesh_winner(const pto_tri *tris, int first, int count, pto_ray r, float pad, float *tz) {
     float best = FLT_MAX;
     int hit = -1;
     for (int i = first; i < first + count; ++i) {
         pto_vec3 b;
         if (pto_ray_triangle(r.origin, r.direction, tris[i].v0, tris[i].v1, tris[i].v2, &b)) {
-            if (b.z > 0.0f && best > b.z) {
+            if (b.z > 0.0f && best > b.z && pto_tri_point_ok(r.origin, r.direction, b.z, &tris[i], pad)) {
                 best = b.z;
                 hit = i;
             }
@@ -326,13 +364,14 @@ int pto_mesh_winner(const pto_tri *tris, int first, int count, pto_ray r, float 
 
 void pto_mesh_winners(const pto_tri *tris, int first, int count, const pto_path *paths, int n,
                       int32_t *index, float *tz) {
-    for (int k = 0; k < n; ++k) index[k] = pto_mesh_winner(tris, first, count, paths[k].ray, &tz[k]);
+    const float pad = pto_mesh_pad(tris, first, count);
+    for (int k = 0; k < n; ++k) index[k] = pto_mesh_winner(tris, first, count, paths[k].ray, pad, &tz[k]);
 }
 
-float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r, pto_vec3 *point,
+float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r, float pad, pto_vec3 *point,
                     pto_vec3 *normal, int *outside) {
     float best;
-    int hit = pto_mesh_winner(tris, first, count, r, &best);
+    int hit = pto_mesh_winner(tris, first, count, r, pad, &best);
     if (hit < 0) return -1;
     *outside = 1;
     *point = add3(r.origin, muls(r.direction, best));
@@ -445,6 +484,8 @@ static void compute_intersections_range(int begin, int end, const pto_path *path
                                         const pto_geom *geoms, int ngeoms, const pto_tri *tris,
                                         const pto_mesh *meshes, int nmeshes, pto_isect *isects,
                                         uint8_t *outside_out) {
+    float *pads = (float *)malloc(sizeof(float) * (size_t)(nmeshes > 0 ? nmeshes : 1));
+    for (int k = 0; k < nmeshes; ++k) pads[k] = pto_mesh_pad(tris, meshes[k].first_tri, meshes[k].tri_count);
     for (int path_index = begin; path_index < end; ++path_index) {
         pto_path pathSegment = paths[path_index];
         float t = 0.0f;
@@ -467,7 +508,7 @@ static void compute_intersections_range(int begin, int end, const pto_path *path
                 for (int k = 0; k < nmeshes; ++k) {
                     if (meshes[k].geom_index == i) {
                         t = pto_mesh_test(tris, meshes[k].first_tri, meshes[k].tri_count,
-                                          pathSegment.ray, &tmp_intersect, &tmp_normal, &outside);
+                                          pathSegment.ray, pads[k], &tmp_intersect, &tmp_normal, &outside);
                         break;
                     }
                 }
@@ -489,6 +530,7 @@ static void compute_intersections_range(int begin, int end, const pto_path *path
         }
         if (outside_out) outside_out[path_index] = (uint8_t)hit_outside;
     }
+    free(pads);
 }
 
 void pto_compute_intersections(int n, const pto_path *paths, const pto_geom *geoms, int ngeoms,

@@ -109,11 +109,14 @@ float pto_sphere_test(const pto_geom *sphere, pto_ray r, pto_vec3 *point,
                       pto_vec3 *normal, int *outside);                   /* intersections.h:102-144 */
 int   pto_ray_triangle(pto_vec3 orig, pto_vec3 dir, pto_vec3 v0, pto_vec3 v1,
                        pto_vec3 v2, pto_vec3 *bary);                     /* glm/gtx/intersect.inl:37-74 */
-int   pto_mesh_winner(const pto_tri *tris, int first, int count, pto_ray r, float *tz); /* spec 8.0: smallest
-                       bary.z > 0 over the triangles in index order, first wins ties; -1: none */
+float pto_mesh_pad(const pto_tri *tris, int first, int count);          /* spec 8.0: 2^-14 * max(1, largest finite |coordinate|) */
+int   pto_tri_point_ok(pto_vec3 orig, pto_vec3 dir, float tz, const pto_tri *t, float pad); /* spec 8.0 hit-point test */
+int   pto_mesh_winner(const pto_tri *tris, int first, int count, pto_ray r, float pad, float *tz); /* spec 8.0: smallest
+                       bary.z > 0 whose hit point passes the hit-point test, triangles in index order, first wins
+                       ties; -1: none */
 void  pto_mesh_winners(const pto_tri *tris, int first, int count, const pto_path *paths, int n,
                        int32_t *index, float *tz);
-float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r,
+float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r, float pad,
                     pto_vec3 *point, pto_vec3 *normal, int *outside);    /* spec 8.0 */
 pto_vec3 pto_hemisphere(pto_vec3 normal, uint32_t *rng, int trig);       /* interactions.h:10-42 */
 pto_vec3 pto_reflect(pto_vec3 I, pto_vec3 N);                            /* glm func_geometric.inl:175-179 */

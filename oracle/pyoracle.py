@@ -107,6 +107,10 @@ def lib():
             f.argtypes = [C.c_void_p, Ray, C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(C.c_int)]
         L.pto_ray_triangle.restype = C.c_int
         L.pto_ray_triangle.argtypes = [Vec3, Vec3, Vec3, Vec3, Vec3, C.POINTER(Vec3)]
+        L.pto_mesh_pad.restype = C.c_float
+        L.pto_mesh_pad.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.pto_tri_point_ok.restype = C.c_int
+        L.pto_tri_point_ok.argtypes = [Vec3, Vec3, C.c_float, C.c_void_p, C.c_float]
         L.pto_mesh_winners.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pto_hemisphere.restype = Vec3
         L.pto_hemisphere.argtypes = [Vec3, C.POINTER(C.c_uint32), C.c_int]
@@ -223,6 +227,12 @@ def compute_intersections(paths, geoms, tris=None, meshes=None, n=None):
     lib().pto_compute_intersections(n, _p(paths), _p(geoms), len(geoms), _p(tris), _p(meshes),
                                     0 if meshes is None else len(meshes), _p(isects), _p(outside))
     return isects, outside
+
+
+def mesh_pad(tris, first=0, count=None):
+    """Pad of the spec's hit-point test for the mesh tris[first : first + count]."""
+    count = len(tris) - first if count is None else count
+    return np.float32(lib().pto_mesh_pad(_p(tris), first, count))
 
 
 def mesh_winners(tris, paths, first=0, count=None):

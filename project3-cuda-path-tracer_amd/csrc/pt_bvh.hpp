@@ -25,16 +25,26 @@
 // A sibling reached through a miss link is entered without knowing whether its own box was hit;
 // child boxes lie inside the parent's, so a missed sibling simply fails both child tests.
 //
-// Culling must never change which triangle wins (the loop over all triangles is the
-// specification).  Boxes are therefore padded by `pad` = 2^-13 * max(1, largest |coordinate|), and the
-// kernel prunes against the best distance with the additive margin `prune` = 16 * pad; the grid rounding
-// adds at most two grid steps on top.  What that buys, exactly: glm::intersectRayTriangle accepts a hit
-// when its float barycentrics pass their range tests; they carry absolute errors <= 4u |dir| (|s| + |e1|)
-// |e2| / a and 8u |dir| |s| |e1| / a (u = 2^-24, s = orig - v0, a = dot(e1, cross(dir, e2))), so the exact hit
-// point of an accepted ray lies within D = 12u |dir| (|s| + |e1|) |e1| |e2| / a of the triangle in its plane.
-// The walk is provably the loop for every (ray, triangle) with D <= pad, i.e. a >= 12u (|s| + |e1|) |e1| |e2|
-// / pad (C4's mesh: rays more than ~1.6e-2 rad off the triangle's plane); closer to grazing, down to glm's
-// own cut-off a >= 1.19e-7, it rests on the tests.
+// Culling must never change which triangle wins (the loop over all triangles is the specification), and
+// glm::intersectRayTriangle in single precision is no help: for a ray that runs almost inside the plane of
+// a large triangle it accepts barycentrics that are rounding noise, with a "hit point" o + d*tz metres away
+// from the triangle -- no box around the triangle can promise to contain that.  The completion spec (DESIGN.md
+// section 3 "Triangles", oracle/ptoracle.c: pto_tri_point_ok) therefore counts a triangle hit only when the
+// point fl(o + fl(d*tz)) lies inside the triangle's bounding box widened by spec_pad = 2^-14 * max(1, largest
+// finite |coordinate| of the mesh), and that is exactly the handle a hierarchy needs.  Proof that the walk
+// returns the loop's winner (T, tz):
+//   * every box on the path from the root to T's leaf contains box(T) widened by `pad` = 2 * spec_pad (the
+//     grid rounding only adds to it), so the accepted point lies inside each of them with spec_pad to spare
+//     on every side;
+//   * the kernel's slab test (v_rcp + fused multiply-adds on grid coordinates, pt_kernels.hpp: bvh_slab)
+//     places a box plane within 4 * 2^-23 * (|plane - o|) of where it is, i.e. below spec_pad for every ray
+//     origin within ~128 * max(1, amax) of the mesh -- so along each axis the computed entry parameter is
+//     <= tz <= the computed exit parameter: the box is hit, and it is entered no later than tz;
+//   * tz is the smallest accepted parameter of the whole mesh, so the running best never drops below it and
+//     "entry <= best" cannot prune the path (`prune` = 0: no distance margin is needed any more);
+//   * triangles with a non-finite coordinate never pass glm's test (a or tz is NaN), so clamping their boxes
+//     to the grid loses nothing.
+// Ties (equal tz) are visited for the same reason and resolved by the original index, as the loop does.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -69,6 +79,7 @@ struct Tree {
     std::vector<float> nodes;        // NODE_WORDS per record, record 0 is the root
     std::vector<int32_t> order;      // leaf-ordered triangle slots -> index into the caller's triangle range
     float pad = 0.0f, prune = 0.0f;
+    float spec_pad = 0.0f;           // pad of the spec's hit-point test (every triangle record carries it in word 10)
     float origin[3] = {0, 0, 0}, step[3] = {1, 1, 1};   // world plane = origin + grid * step
     int depth = 0;
     int num_nodes() const { return (int)(nodes.size() / NODE_WORDS); }
@@ -224,24 +235,32 @@ inline void emit(const Work &w, const std::vector<int32_t> &rec, int s, const in
 
 }  // namespace detail
 
+// pad of the spec's hit-point test for a mesh of `count` triangles, 9 floats each (oracle/ptoracle.c: pto_mesh_pad)
+inline float spec_pad(const float *v, int count) {
+    float amax = 0.0f;
+    for (size_t k = 0; k < 9 * (size_t)count; ++k) {
+        const float m = std::fabs(v[k]);
+        if (m <= 3.402823466e+38f && m > amax) amax = m;
+    }
+    return std::ldexp(std::max(1.0f, amax), -14);
+}
+
 // v: `count` triangles, 9 floats each (v0 v1 v2, world space)
 inline void build(const float *v, int count, Tree &out) {
     out.nodes.clear(); out.order.clear(); out.depth = 0;
     detail::Work w;
     w.tbox.resize((size_t)count); w.cen.resize(3 * (size_t)count); w.idx.resize((size_t)count);
-    float amax = 0.0f;
     for (int i = 0; i < count; ++i) {
         Box &b = w.tbox[i]; b.reset();
         for (int k = 0; k < 3; ++k) b.grow(v + 9 * (size_t)i + 3 * k);
         for (int k = 0; k < 3; ++k) {
             w.cen[3 * (size_t)i + k] = 0.5f * (b.lo[k] + b.hi[k]);
-            if (std::isfinite(b.lo[k])) amax = std::max(amax, std::fabs(b.lo[k]));
-            if (std::isfinite(b.hi[k])) amax = std::max(amax, std::fabs(b.hi[k]));
         }
         w.idx[i] = i;
     }
-    out.pad = std::ldexp(std::max(1.0f, amax), -13);
-    out.prune = 16.0f * out.pad;
+    out.spec_pad = spec_pad(v, count);
+    out.pad = 2.0f * out.spec_pad;
+    out.prune = 0.0f;
     w.split.resize(1);
     if (count > 0) out.depth = detail::build(w, 0, 0, count, 0);
     // the grid spans the padded bounds of the whole mesh with a few steps of margin on either side

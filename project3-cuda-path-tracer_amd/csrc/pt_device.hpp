@@ -412,6 +412,20 @@ PTD bool ray_triangle(f3 orig, f3 dir, f3 v0, f3 e1, f3 e2, float &tz) {
     return tz >= 0.0f;
 }
 
+// Completion spec 8.0 "Triangles", hit-point test (oracle/ptoracle.c: pto_tri_point_ok): an accepted triangle
+// counts only when the point it reports, fl(o_k + fl(d_k * tz)), lies inside the triangle's bounding box
+// [min, max](v0_k, fl(v0_k + e1_k), fl(v0_k + e2_k)) widened by the mesh's pad (word 10 of the triangle
+// record).  Runs on accepted hits only -- a handful per ray.
+PTD bool tri_point_ok(f3 o, f3 d, float tz, f3 v0, f3 e1, f3 e2, float pad) {
+    auto axis = [&](float ok, float dk, float a, float b, float c) {
+        const float p = ok + dk * tz;
+        const float x1 = a + b, x2 = a + c;
+        const float lo = __builtin_fminf(a, __builtin_fminf(x1, x2)), hi = __builtin_fmaxf(a, __builtin_fmaxf(x1, x2));
+        return p >= lo - pad && p <= hi + pad;
+    };
+    return axis(o.x, d.x, v0.x, e1.x, e2.x) && axis(o.y, d.y, v0.y, e1.y, e2.y) && axis(o.z, d.z, v0.z, e1.z, e2.z);
+}
+
 // ---------------------------------------------------------------------------
 // shading / scattering (completion of interactions.h:69-79)
 // ---------------------------------------------------------------------------

@@ -340,9 +340,12 @@ __device__ __forceinline__ void bvh_leaf(const float *__restrict__ btris, const 
     for (int k = 0; k < cnt; ++k) {
         const float4 P = t4[3 * k], Q = t4[3 * k + 1], S = t4[3 * k + 2];
         float tz;
-        if (ptd::ray_triangle(r.ro, r.rd, ptd::mk(P.x, P.y, P.z), ptd::mk(P.w, Q.x, Q.y), ptd::mk(Q.z, Q.w, S.x), tz)) {
+        const f3 v0 = ptd::mk(P.x, P.y, P.z), e1 = ptd::mk(P.w, Q.x, Q.y), e2 = ptd::mk(Q.z, Q.w, S.x);
+        if (ptd::ray_triangle(r.ro, r.rd, v0, e1, e2, tz)) {
             const int orig = __float_as_int(S.y);                        // index in the caller's triangle array
-            if (tz > 0.0f && (best > tz || (best == tz && orig < best_i))) { best = tz; best_i = orig; }
+            if (tz > 0.0f && (best > tz || (best == tz && orig < best_i)) && ptd::tri_point_ok(r.ro, r.rd, tz, v0, e1, e2, S.z)) {
+                best = tz; best_i = orig;
+            }
         }
     }
 }
@@ -449,9 +452,11 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
                             for (int j = 0; j < 4; ++j) {
                                 const float4 A = w[3 * j], B = w[3 * j + 1], C = w[3 * j + 2];
                                 float tz;
-                                if (ptd::ray_triangle(ro, rd, ptd::mk(A.x, A.y, A.z), ptd::mk(A.w, B.x, B.y),
-                                                      ptd::mk(B.z, B.w, C.x), tz)) {
-                                    if (tz > 0.0f && best > tz) { best = tz; best_i = first + base + k + j; }
+                                const f3 v0 = ptd::mk(A.x, A.y, A.z), e1 = ptd::mk(A.w, B.x, B.y), e2 = ptd::mk(B.z, B.w, C.x);
+                                if (ptd::ray_triangle(ro, rd, v0, e1, e2, tz)) {
+                                    if (tz > 0.0f && best > tz && ptd::tri_point_ok(ro, rd, tz, v0, e1, e2, C.z)) {
+                                        best = tz; best_i = first + base + k + j;
+                                    }
                                 }
                             }
                         }
@@ -1412,7 +1417,8 @@ __device__ __forceinline__ void tri_pass(float *mq, uint32_t head, uint32_t coun
         const float4 *t4 = reinterpret_cast<const float4 *>(a.scene.bvh_tris + (size_t)(e >> 6) * TRI_WORDS);
         const float4 P = t4[0], Q = t4[1], S = t4[2];
         float tz;
-        if (ptd::ray_triangle(ro, rd, ptd::mk(P.x, P.y, P.z), ptd::mk(P.w, Q.x, Q.y), ptd::mk(Q.z, Q.w, S.x), tz) && tz > 0.0f)
+        const f3 v0 = ptd::mk(P.x, P.y, P.z), e1 = ptd::mk(P.w, Q.x, Q.y), e2 = ptd::mk(Q.z, Q.w, S.x);
+        if (ptd::ray_triangle(ro, rd, v0, e1, e2, tz) && tz > 0.0f && ptd::tri_point_ok(ro, rd, tz, v0, e1, e2, S.z))
             __hip_atomic_fetch_min(&keys[owner], ((unsigned long long)__float_as_uint(tz) << 32) | __float_as_uint(S.y),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }

@@ -731,6 +731,7 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
                                   t.v1.x - t.v0.x, t.v1.y - t.v0.y, t.v1.z - t.v0.z,
                                   t.v2.x - t.v0.x, t.v2.y - t.v0.y, t.v2.z - t.v0.z, 0.0f, 0.0f, 0.0f};
             memcpy(&r[9], &orig, 4);
+            r[10] = tree.spec_pad;
             btris.insert(btris.end(), r, r + TRI_WORDS);
         }
         float *g = grec.data() + (size_t)m.geom_index * ptd::GEOM_WORDS;
@@ -880,6 +881,11 @@ static int init_impl(const pt_scene_desc *d) {
         // e1 = v1 - v0, e2 = v2 - v0: the first two statements of glm::intersectRayTriangle, hoisted
         r[3] = t.v1.x - t.v0.x; r[4] = t.v1.y - t.v0.y; r[5] = t.v1.z - t.v0.z;
         r[6] = t.v2.x - t.v0.x; r[7] = t.v2.y - t.v0.y; r[8] = t.v2.z - t.v0.z;
+    }
+    for (int k = 0; k < d->num_meshes; ++k) {              // word 10: the pad of the spec's hit-point test (per mesh)
+        const pt_mesh &m = d->meshes[k];
+        const float pad = ptbvh::spec_pad(reinterpret_cast<const float *>(d->triangles + m.first_triangle), m.triangle_count);
+        for (int i = 0; i < m.triangle_count; ++i) trec[(size_t)(m.first_triangle + i) * TRI_WORDS + 10] = pad;
     }
     HIPCHK(hipMalloc(&R.d_geoms, grec.size() * 4));
     HIPCHK(hipMalloc(&R.d_mats, mrec.size() * 4));

@@ -879,6 +879,39 @@ def test_mesh_bvh_triangle_soup(pt, po, scenes, seed):
     pt.pathtraceFree()
 
 
+@pytest.mark.parametrize("seed", [17, 37, 101, 102])
+def test_mesh_grazing_rays_and_the_hit_point_test(pt, po, scenes, seed):
+    """Rays that run (almost) inside the plane of their target triangle (tests/mesh_cases.py; seeds 17 and 37 are the
+    ones on which the unfiltered glm test reports noise hits metres away from the triangle -- see
+    tests/test_bvh_cpu.py::test_walk_on_grazing_soups).  The hierarchy, the every-triangle kernel and the mesh
+    pre-pass of whole iterations all agree with the oracle's loop, spec hit-point test included."""
+    import mesh_cases
+    s = scenes["cornell_64"]
+    rng = np.random.default_rng(seed)
+    tris = mesh_cases.soup(pt.TRI_DT, rng) if seed % 2 else pt.meshes.uv_sphere(center=(0.5, 4.0, 0.0), radius=2.0, n_lat=37, n_lon=90)
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"][:6], tris, material_id=int(rng.integers(1, 5)))
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
+    k = min(len(tris), 1500)
+    origin, d, graze = mesh_cases.aimed_rays(tris, rng, k)
+    paths = np.zeros(k, dtype=pt.PATH_DT)
+    paths["origin"], paths["direction"] = origin.astype(np.float32), d.astype(np.float32)
+    og, ot, om = geoms.view(po.GEOM_DT), tris.view(po.TRI_DT), meshes.view(po.MESH_DT)
+    want, _ = po.compute_intersections(paths.view(po.PATH_DT), og, ot, om)
+    assert (want["t"] > 0).sum() > k // 4
+    for extra in (pt.PT_MESH_BVH, 0):
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | extra)
+        got, _ = pt.intersect_once(paths)
+        pt.pathtraceFree()
+        assert got.tobytes() == want.tobytes(), "hierarchy" if extra else "loop"
+    ref = po.Tracer(og, s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED, tris=ot, meshes=om)
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_MESH_BVH, max_batch=2)
+    img = np.zeros((64 * 64, 3), dtype=np.float32)
+    pt.trace_batch(1, 2, img)
+    pt.pathtraceFree()
+    ref.iterate(1); ref.iterate(2)
+    assert img.tobytes() == ref.image.tobytes()
+
+
 def test_mesh_bvh_adversarial_rays(pt, po, scenes):
     """Rays aimed exactly at vertices and edges (where several triangles tie or just miss), from outside and
     from inside the mesh, plus two meshes in one scene: winner index and distance come out as the oracle's loop

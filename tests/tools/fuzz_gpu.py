@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as ge  # noqa: E402
 import cull_model  # noqa: E402
+import mesh_cases  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
 
@@ -29,14 +30,7 @@ def mesh_fuzz(pt, first, count):
     for seed in range(first, first + count):
         rng = np.random.default_rng(seed)
         if seed % 2:
-            n = int(rng.integers(50, 3000))
-            c = rng.uniform(-3, 3, (n, 3)) + (0, 5, 0)
-            size = 10 ** rng.uniform(-2.5, 0.6, (n, 1))
-            v = [c + rng.normal(size=(n, 3)) * size for _ in range(3)]
-            sl = rng.random(n) < 0.1
-            v[2][sl] = v[1][sl] + (v[1][sl] - v[0][sl]) * 1e-4 + rng.normal(size=(sl.sum(), 3)) * 1e-6
-            tris = np.zeros(n, dtype=pt.TRI_DT)
-            tris["v0"], tris["v1"], tris["v2"] = v
+            tris = mesh_cases.soup(pt.TRI_DT, rng)
         else:
             tris = pt.meshes.uv_sphere(center=tuple(rng.uniform(-2, 2, 3) + (0, 5, 0)), radius=float(rng.uniform(0.3, 2.5)),
                                        n_lat=int(rng.integers(4, 60)), n_lon=int(rng.integers(6, 120)))
@@ -54,31 +48,20 @@ def mesh_fuzz(pt, first, count):
             print("mesh seed %d: IMAGE DIFFERS (%d pixels)" % (seed, int((img != ref.image).any(axis=1).sum())), flush=True)
         # aimed rays: vertices, edge midpoints, points just off the surface (tangential), from random origins
         k = min(len(tris), 1500)
-        pick = rng.integers(len(tris), size=k)
-        tv = np.stack([tris["v0"][pick], tris["v1"][pick], tris["v2"][pick]], axis=1).astype(np.float64)
-        w = rng.dirichlet((0.3, 0.3, 0.3), size=k)
-        w[: k // 4] = np.eye(3)[rng.integers(3, size=k // 4)]                         # exact vertices
-        target = (tv * w[:, :, None]).sum(axis=1)
-        nrm = np.cross(tv[:, 1] - tv[:, 0], tv[:, 2] - tv[:, 0])
-        nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
-        origin = rng.uniform(-6, 6, (k, 3)) + (0, 5, 0)
-        graze = rng.random(k) < 0.5                                                   # origins (almost) in the triangle's plane
-        inplane = rng.normal(size=(k, 3)); inplane -= nrm * (inplane * nrm).sum(axis=1, keepdims=True)
-        inplane /= np.maximum(np.linalg.norm(inplane, axis=1, keepdims=True), 1e-30)
-        origin[graze] = (target + inplane * rng.uniform(1, 8, (k, 1)) + nrm * (10 ** rng.uniform(-7, -2, (k, 1))) * rng.choice([-1, 1], (k, 1)))[graze]
-        d = target - origin
-        d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+        origin, d, _ = mesh_cases.aimed_rays(tris, rng, k)
         paths = np.zeros(k, dtype=pt.PATH_DT)
         paths["origin"], paths["direction"] = origin.astype(np.float32), d.astype(np.float32)
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | pt.PT_MESH_BVH)
-        got, _ = pt.intersect_once(paths)
-        pt.pathtraceFree()
         want, _ = po.compute_intersections(paths.view(po.PATH_DT), og, ot, om)
-        if got.tobytes() != want.tobytes():
-            bad += 1
-            diff = np.nonzero((got["t"].view(np.uint32) != want["t"].view(np.uint32)) | (got["materialId"] != want["materialId"]))[0]
-            print("mesh seed %d: %d of %d aimed rays differ (first: %s -> got t=%r, want t=%r)" %
-                  (seed, len(diff), k, paths[diff[0]] if len(diff) else "normal only", got["t"][diff[0]] if len(diff) else 0, want["t"][diff[0]] if len(diff) else 0), flush=True)
+        for name, extra in (("hierarchy", pt.PT_MESH_BVH), ("loop", 0)):
+            pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | extra)
+            got, _ = pt.intersect_once(paths)
+            pt.pathtraceFree()
+            if got.tobytes() != want.tobytes():
+                bad += 1
+                diff = np.nonzero((got["t"].view(np.uint32) != want["t"].view(np.uint32)) | (got["materialId"] != want["materialId"]))[0]
+                print("mesh seed %d (%s): %d of %d aimed rays differ (first: %s -> got t=%r, want t=%r)" %
+                      (seed, name, len(diff), k, paths[diff[0]] if len(diff) else "normal only", got["t"][diff[0]] if len(diff) else 0,
+                       want["t"][diff[0]] if len(diff) else 0), flush=True)
     print("mesh fuzz: seeds %d..%d, %d mismatching cases, %.0f s" % (first, first + count - 1, bad, time.time() - t0))
     return bad
 
