@@ -50,6 +50,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace ptbvh {
@@ -179,12 +180,32 @@ inline int build(Work &w, int self, int lo, int hi, int level) {
     return 1 + std::max(dl, dr);
 }
 
-// records in depth-first order: rec[s] = record index of internal split node s
-inline void number(const Work &w, int s, std::vector<int32_t> &rec, int &next) {
+// Record numbering: rec[s] = record index of internal split node s.  The first TOP_RECORDS records are the
+// internal nodes most rays visit -- grown greedily from the root, always taking the open node with the largest
+// box surface (the surface-area heuristic's visit probability) -- so that ANY prefix of the record array is a
+// connected top of the tree the walk kernel can keep in LDS (pt_kernels.hpp: k_mesh); the rest follows
+// depth-first.  Parents are numbered before their children either way.
+constexpr int TOP_RECORDS = 512;
+inline void number_rest(const Work &w, int s, std::vector<int32_t> &rec, int &next) {
     if (w.split[s].left < 0) return;
-    rec[(size_t)s] = next++;
-    number(w, w.split[s].left, rec, next);
-    number(w, w.split[s].left + 1, rec, next);
+    if (rec[(size_t)s] < 0) rec[(size_t)s] = next++;
+    number_rest(w, w.split[s].left, rec, next);
+    number_rest(w, w.split[s].left + 1, rec, next);
+}
+inline void number(const Work &w, int root, std::vector<int32_t> &rec, int &next) {
+    if (w.split[root].left < 0) return;
+    auto weight = [&](int s) { const float a = w.split[s].box.half_area(); return std::isfinite(a) ? a : 3.0e38f; };
+    std::vector<std::pair<float, int>> open;                 // max-heap on (surface, -node)
+    open.push_back({weight(root), -root});
+    while (!open.empty() && next < TOP_RECORDS) {
+        std::pop_heap(open.begin(), open.end());
+        const int s = -open.back().second;
+        open.pop_back();
+        rec[(size_t)s] = next++;
+        for (int c = w.split[s].left; c <= w.split[s].left + 1; ++c)
+            if (w.split[c].left >= 0) { open.push_back({weight(c), -c}); std::push_heap(open.begin(), open.end()); }
+    }
+    number_rest(w, root, rec, next);
 }
 
 inline void set_u(float *w, uint32_t v) { memcpy(w, &v, 4); }

@@ -163,7 +163,8 @@ struct SceneDev {
     const float *bvh_nodes;                // PT_MESH_BVH: all meshes' trees, BVH_NODE_WORDS per node
     const float *bvh_tris;                 //   leaf-ordered triangle records, word 9 = original index
     float bvh_prune;  int bvh_guard;       //   prune margin; upper bound on nodes visited per walk
-    const int4 *bvh_meshes; int bvh_nmesh; //   per mesh, in geom order: {geom, root record, triangles, -}
+    const int4 *bvh_meshes; int bvh_nmesh; //   per mesh, in geom order: {geom, root record, triangles, top offset | top count << 16}
+    const float *bvh_top;  int bvh_top_n;  //   the meshes' first records (the tops of their trees) back to back: k_mesh keeps them in LDS
 };
 
 struct BounceArgs {

@@ -112,6 +112,7 @@ struct Renderer {
     size_t dir_stride = 0;        // words per bounce
     int cur_dir = -1;             // bounce whose directory describes pool[cur] (-1: dense)
     uint32_t max_tiles = 0;
+    size_t flag_words = 0;                   // mesh pre-pass: 64-bit flag words per parity (one bit per physical pool slot)
     size_t ctl_bytes = 0;         // Control, zeroed per batch
     int grid = 0;                 // persistent grid size
     int grid_sort = 0;            // workgroups of the material-sort kernels (k_sort_hist / k_shade_sorted)
@@ -126,7 +127,7 @@ struct Renderer {
     bool use_graphs = false;      // PTMI355_GRAPH=1 turns replay on (measured slower than direct launches on ROCm 7.2: DESIGN.md 6.10)
     bool capturing = false;
     int mesh_mode = MESH_NONE;    // MESH_TILES: every triangle per ray; MESH_BVH: PT_MESH_BVH culling
-    float *d_bvh_nodes = nullptr, *d_bvh_tris = nullptr;
+    float *d_bvh_nodes = nullptr, *d_bvh_tris = nullptr, *d_bvh_top = nullptr;
     int4 *d_bvh_meshes = nullptr;
     float4 *mesh_hit = nullptr;              // mesh pre-pass results (k_mesh), one per pool slot
     unsigned long long *mesh_flags[2] = {nullptr, nullptr};   // one flag per pool slot: "mesh_hit[slot] is valid" (bounce parity)
@@ -267,7 +268,7 @@ int enqueue_begin(int iter0, int count, bool stepping) {
     HIPCHK(hipMemsetAsync(&R.ctl->stamp, 0, R.ctl_bytes, R.stream));      // everything but Control::iter0
     if (R.mesh_mode == MESH_BVH)
         for (int k = 0; k < 2; ++k)
-            HIPCHK(hipMemsetAsync(R.mesh_flags[k], 0, ((size_t)R.max_tiles + 1) * sizeof(unsigned long long), R.stream));
+            HIPCHK(hipMemsetAsync(R.mesh_flags[k], 0, R.flag_words * sizeof(unsigned long long), R.stream));
     // batch path: bounce 0 generates the camera rays itself (no 40 B/path round trip through HBM)
     R.gen_fused = !stepping && !(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER));
     if (R.gen_fused) return PT_OK;
@@ -367,9 +368,8 @@ int enqueue_bounce(int depth) {
     }
     if (!cached0 && !unfused && R.mesh_mode == MESH_BVH) {
         StageTimer tm(PT_STAGE_MESH);
-        const size_t lds = (size_t)WAVES * MQ_WORDS * 4;
-        if (compact) hipLaunchKernelGGL((k_mesh<true>), dim3(R.grid_mesh), dim3(BLOCK), lds, R.stream, a);
-        else hipLaunchKernelGGL((k_mesh<false>), dim3(R.grid_mesh), dim3(BLOCK), lds, R.stream, a);
+        if (compact) hipLaunchKernelGGL((k_mesh<true>), dim3(R.grid_mesh), dim3(MESH_BLOCK), MESH_LDS_BYTES, R.stream, a);
+        else hipLaunchKernelGGL((k_mesh<false>), dim3(R.grid_mesh), dim3(MESH_BLOCK), MESH_LDS_BYTES, R.stream, a);
         HIPCHK(hipGetLastError());
     }
     StageTimer tm(PT_STAGE_BOUNCE);
@@ -385,7 +385,7 @@ int enqueue_bounce(int depth) {
     if (R.mesh_mode == MESH_BVH) {
         // this bounce's flags are spent; the array is the NEXT bounce's output flags.  Only a fused bounce marks
         // the candidates of the next one (the cached / unfused pipelines leave the finding to k_mesh's scan)
-        HIPCHK(hipMemsetAsync(R.mesh_flags[depth & 1], 0, ((size_t)R.max_tiles + 1) * sizeof(unsigned long long), R.stream));
+        HIPCHK(hipMemsetAsync(R.mesh_flags[depth & 1], 0, R.flag_words * sizeof(unsigned long long), R.stream));
         R.mesh_marked = !cached0 && !unfused;
     }
     if (compact) { R.cur ^= 1; R.cur_dir = depth; }
@@ -673,6 +673,7 @@ void pt_free(void) {
     if (R.d_bvh_nodes) (void)hipFree(R.d_bvh_nodes);
     if (R.d_bvh_meshes) (void)hipFree(R.d_bvh_meshes);
     if (R.d_bvh_tris) (void)hipFree(R.d_bvh_tris);
+    if (R.d_bvh_top) (void)hipFree(R.d_bvh_top);
     if (R.ctl) (void)hipFree(R.ctl);
     if (R.dir_mem) (void)hipFree(R.dir_mem);
     if (R.persist) (void)hipFree(R.persist);
@@ -696,7 +697,7 @@ static int init_impl(const pt_scene_desc *d);
 // of the triangle records carry the original index in word 9.  Geom record words 2/3 of a mesh
 // become (root node, triangle count).
 static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
-    std::vector<float> nodes, btris;
+    std::vector<float> nodes, btris, tops;
     std::vector<int32_t> mesh_list;                          // {geom, root record, triangles, 0} in geom order
     float prune = 0.0f;
     int guard = 1;
@@ -737,7 +738,11 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
         float *g = grec.data() + (size_t)m.geom_index * ptd::GEOM_WORDS;
         memcpy(&g[2], &root, 4); memcpy(&g[3], &m.triangle_count, 4);
         for (int a = 0; a < 3; ++a) { g[ptd::G_INV + a] = tree.origin[a]; g[ptd::G_INV + 3 + a] = tree.step[a]; }   // the mesh's grid
-        const int32_t entry[4] = {m.geom_index, root, m.triangle_count, 0};
+        // the first records of this tree (its most visited ones, pt_bvh.hpp: number) go into the LDS copy k_mesh keeps
+        const int share = d->num_meshes <= BVH_TOP ? BVH_TOP / d->num_meshes : 0;
+        const int top_cnt = std::min(share, tree.num_nodes()), top_off = (int)(tops.size() / BVH_NODE_WORDS);
+        tops.insert(tops.end(), tree.nodes.begin(), tree.nodes.begin() + (size_t)top_cnt * BVH_NODE_WORDS);
+        const int32_t entry[4] = {m.geom_index, root, m.triangle_count, top_off | (top_cnt << 16)};
         mesh_list.insert(mesh_list.end(), entry, entry + 4);
         prune = std::max(prune, tree.prune);
         guard = std::max(guard, tree.num_nodes() + 1);
@@ -758,6 +763,11 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
     HIPCHK(hipMemcpy(R.d_bvh_meshes, mesh_list.data(), mesh_list.size() * 4, hipMemcpyHostToDevice));
     R.scene.bvh_meshes = R.d_bvh_meshes; R.scene.bvh_nmesh = d->num_meshes;
     R.scene.bvh_nodes = R.d_bvh_nodes; R.scene.bvh_tris = R.d_bvh_tris;
+    R.scene.bvh_top_n = (int)(tops.size() / BVH_NODE_WORDS);
+    if (tops.empty()) tops.assign(BVH_NODE_WORDS, 0.0f);
+    HIPCHK(hipMalloc(&R.d_bvh_top, tops.size() * 4));
+    HIPCHK(hipMemcpy(R.d_bvh_top, tops.data(), tops.size() * 4, hipMemcpyHostToDevice));
+    R.scene.bvh_top = R.d_bvh_top;
     R.scene.bvh_prune = prune; R.scene.bvh_guard = guard;
     return PT_OK;
 }
@@ -991,15 +1001,17 @@ static int init_impl(const pt_scene_desc *d) {
     if (R.grid < 1) R.grid = 1;
     if (R.mesh_mode == MESH_BVH) {
         HIPCHK(hipMalloc((void **)&R.mesh_hit, (size_t)(((capz + 63) / 64) * 64) * sizeof(float4)));
+        // k_mesh reads the flags of whole ranges (waves x tiles per range can overshoot the pool by up to one tile per
+        // wave) and in chunks of 8 tiles: the words past the pool exist and stay zero
+        R.flag_words = (size_t)R.max_tiles + (size_t)R.grid * WAVES + 8;
         for (int k = 0; k < 2; ++k) {
-            HIPCHK(hipMalloc((void **)&R.mesh_flags[k], ((size_t)R.max_tiles + 1) * sizeof(unsigned long long)));
-            HIPCHK(hipMemsetAsync(R.mesh_flags[k], 0, ((size_t)R.max_tiles + 1) * sizeof(unsigned long long), R.stream));
+            HIPCHK(hipMalloc((void **)&R.mesh_flags[k], R.flag_words * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(R.mesh_flags[k], 0, R.flag_words * sizeof(unsigned long long), R.stream));
         }
-        int per_cu_mesh = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_mesh, (const void *)k_mesh<true>, BLOCK,
-                                                            (size_t)WAVES * MQ_WORDS * 4));
-        per_cu_mesh = std::max(1, std::min(per_cu_mesh, 8));
-        R.grid_mesh = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu_mesh);
+        // one 16-wave workgroup per CU: 4 waves per SIMD (the kernel's register budget), one LDS copy of the tree tops
+        HIPCHK(hipFuncSetAttribute((const void *)k_mesh<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MESH_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void *)k_mesh<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MESH_LDS_BYTES));
+        R.grid_mesh = (int)std::min<uint32_t>((R.max_tiles + MESH_WG_WAVES - 1) / MESH_WG_WAVES, (uint32_t)cus);
         if (R.grid_mesh < 1) R.grid_mesh = 1;
     }
     if (R.flags & PT_CACHE_FIRST) HIPCHK(hipMalloc(&R.cache_mem, (size_t)R.map.tile_pixels * 5 * 4));
