@@ -1748,6 +1748,12 @@ __global__ __launch_bounds__(MESH_BLOCK) void k_mesh(BounceArgs a) {
         return;
     }
     const uint32_t rounds = R;
+    // camera rays: whole 64-pixel tiles whose pixels cannot see a mesh are skipped after one mask bit (the tile's
+    // position inside its sample is tracked incrementally: tile = r * W + wid, modulo the tiles of one sample)
+    const bool masked = a.gen_rays && a.cam_mask != nullptr;
+    const uint32_t tps = masked ? (uint32_t)a.map.tile_pixels / TILE : 1u;      // tiles per sample (tile_pixels % 64 == 0 when masked)
+    uint32_t lt = masked ? wid % tps : 0u;
+    const uint32_t lt_step = masked ? W % tps : 0u;
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t tile = r * W + wid;
         uint32_t src = tile * TILE + lane;
@@ -1755,6 +1761,11 @@ __global__ __launch_bounds__(MESH_BLOCK) void k_mesh(BounceArgs a) {
         f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
         {
             if (tile >= tiles) break;
+            if (masked) {
+                const uint32_t t = lt;
+                lt += lt_step; if (lt >= tps) lt -= tps;
+                if (!((a.cam_mask[t >> 6] >> (t & 63u)) & 1ull)) continue;
+            }
             uint32_t cur = 0;
             if (packed_in) cur = find_range(a.dir_in.base(), Wd, tile * TILE);
             const uint32_t i = tile * TILE + lane;

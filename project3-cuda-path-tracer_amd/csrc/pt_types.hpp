@@ -189,6 +189,9 @@ struct BounceArgs {
     // new ray reaches a mesh's root boxes, so that the next bounce's k_mesh only touches those (mesh_scan = 0)
     unsigned long long *mesh_flags_in, *mesh_flags_out;
     int mesh_scan;         // k_mesh must find the candidates itself (bounce 0, or the previous bounce did not mark)
+    // bounce 0 of a pinhole camera: one bit per 64 local pixels, set when a camera ray of those pixels can reach the
+    // grid of some mesh (pt_init projects the grids onto the image); nullptr: no such knowledge, test every ray
+    const unsigned long long *cam_mask;
     // material sort: table[key][workgroup] of k_sort_hist / k_shade_sorted; keys = materials + 1 (misses)
     uint32_t *sort_table;
     int nbins;

@@ -128,6 +128,9 @@ struct Renderer {
     bool capturing = false;
     int mesh_mode = MESH_NONE;    // MESH_TILES: every triangle per ray; MESH_BVH: PT_MESH_BVH culling
     float *d_bvh_nodes = nullptr, *d_bvh_tris = nullptr, *d_bvh_top = nullptr;
+    std::vector<float> mesh_grids;           // per mesh: lo xyz, hi xyz of its box grid (contains every box of its tree)
+    unsigned long long *d_cam_mask = nullptr;   // bounce-0 tile mask (BounceArgs::cam_mask)
+    bool cam_mask_valid = false;
     int4 *d_bvh_meshes = nullptr;
     float4 *mesh_hit = nullptr;              // mesh pre-pass results (k_mesh), one per pool slot
     unsigned long long *mesh_flags[2] = {nullptr, nullptr};   // one flag per pool slot: "mesh_hit[slot] is valid" (bounce parity)
@@ -252,6 +255,7 @@ BounceArgs bounce_args(int depth) {
     a.mesh_hit = R.mesh_hit;
     a.mesh_flags_in = R.mesh_flags[depth & 1]; a.mesh_flags_out = R.mesh_flags[(depth + 1) & 1];
     a.mesh_scan = R.mesh_marked ? 0 : 1;
+    a.cam_mask = (R.cam_mask_valid && !(R.lens.radius > 0.0f)) ? R.d_cam_mask : nullptr;
     return a;
 }
 
@@ -674,6 +678,8 @@ void pt_free(void) {
     if (R.d_bvh_meshes) (void)hipFree(R.d_bvh_meshes);
     if (R.d_bvh_tris) (void)hipFree(R.d_bvh_tris);
     if (R.d_bvh_top) (void)hipFree(R.d_bvh_top);
+    if (R.d_cam_mask) (void)hipFree(R.d_cam_mask);
+    R.d_cam_mask = nullptr; R.cam_mask_valid = false;
     if (R.ctl) (void)hipFree(R.ctl);
     if (R.dir_mem) (void)hipFree(R.dir_mem);
     if (R.persist) (void)hipFree(R.persist);
@@ -702,6 +708,7 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
     float prune = 0.0f;
     int guard = 1;
     R.bvh_info = pt_bvh_info{};
+    R.mesh_grids.clear();
     std::vector<int> by_geom((size_t)d->num_meshes);
     for (int k = 0; k < d->num_meshes; ++k) by_geom[(size_t)k] = k;
     std::sort(by_geom.begin(), by_geom.end(), [&](int x, int y) { return d->meshes[x].geom_index < d->meshes[y].geom_index; });
@@ -738,6 +745,8 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
         float *g = grec.data() + (size_t)m.geom_index * ptd::GEOM_WORDS;
         memcpy(&g[2], &root, 4); memcpy(&g[3], &m.triangle_count, 4);
         for (int a = 0; a < 3; ++a) { g[ptd::G_INV + a] = tree.origin[a]; g[ptd::G_INV + 3 + a] = tree.step[a]; }   // the mesh's grid
+        for (int a = 0; a < 3; ++a) R.mesh_grids.push_back(tree.origin[a] - tree.step[a]);
+        for (int a = 0; a < 3; ++a) R.mesh_grids.push_back(tree.origin[a] + (float)(ptbvh::GRID_MAX + 1) * tree.step[a]);
         // the first records of this tree (its most visited ones, pt_bvh.hpp: number) go into the LDS copy k_mesh keeps
         const int share = d->num_meshes <= BVH_TOP ? BVH_TOP / d->num_meshes : 0;
         const int top_cnt = std::min(share, tree.num_nodes()), top_off = (int)(tops.size() / BVH_NODE_WORDS);
@@ -769,6 +778,69 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
     HIPCHK(hipMemcpy(R.d_bvh_top, tops.data(), tops.size() * 4, hipMemcpyHostToDevice));
     R.scene.bvh_top = R.d_bvh_top;
     R.scene.bvh_prune = prune; R.scene.bvh_guard = guard;
+    return PT_OK;
+}
+
+// Bounce 0, pinhole camera: which 64-pixel tiles of the local frame can see a mesh at all.  A camera ray is
+// d = view - right * alpha - up * beta with alpha = pixelLength.x * (fx - W/2), beta likewise (pathtrace.cu:136-139),
+// fx within half a pixel of the pixel's x.  A ray whose triangle hit the spec accepts reports a point inside that
+// mesh's box grid (the hit-point test, pt_bvh.hpp), so the pixel lies inside the perspective image of the grid's
+// eight corners -- computed here in double, widened by two pixels -- and every other tile can skip ray generation,
+// root tests and walks in k_mesh.  No mask (nullptr) when a corner is not in front of the camera, the frame does
+// not tile by 64 pixels, or a thin lens is on (then rays do not start at the eye).
+static int update_cam_mask() {
+    R.cam_mask_valid = false;
+    if (R.mesh_mode != MESH_BVH || R.map.tile_pixels % TILE != 0 || R.mesh_grids.empty()) return PT_OK;
+    const pt_camera &c = R.cam;
+    const double M[3][3] = {{c.view.x, -c.right.x, -c.up.x}, {c.view.y, -c.right.y, -c.up.y}, {c.view.z, -c.right.z, -c.up.z}};
+    const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                       M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+    if (!(std::fabs(det) > 1e-9) || !(c.pixelLength[0] != 0.0f) || !(c.pixelLength[1] != 0.0f)) return PT_OK;
+    double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    for (size_t m = 0; m + 6 <= R.mesh_grids.size(); m += 6) {
+        for (int corner = 0; corner < 8; ++corner) {
+            const double v[3] = {(double)R.mesh_grids[m + ((corner & 1) ? 3 : 0)] - c.position.x,
+                                 (double)R.mesh_grids[m + 1 + ((corner & 2) ? 3 : 0)] - c.position.y,
+                                 (double)R.mesh_grids[m + 2 + ((corner & 4) ? 3 : 0)] - c.position.z};
+            // Cramer: (s, s*alpha, s*beta) = M^-1 v
+            auto det3 = [](const double A[3][3]) {
+                return A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                       A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+            };
+            double sol[3];
+            for (int k = 0; k < 3; ++k) {
+                double A[3][3];
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = (j == k) ? v[i] : M[i][j];
+                sol[k] = det3(A) / det;
+            }
+            const double reach = std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(v[2]);
+            if (!(sol[0] > 1e-6 * (reach + 1.0))) return PT_OK;                  // at or behind the eye: no mask
+            const double fx = 0.5 * c.resolution[0] + sol[1] / sol[0] / (double)c.pixelLength[0];
+            const double fy = 0.5 * c.resolution[1] + sol[2] / sol[0] / (double)c.pixelLength[1];
+            if (!std::isfinite(fx) || !std::isfinite(fy)) return PT_OK;
+            x0 = std::min(x0, fx); x1 = std::max(x1, fx); y0 = std::min(y0, fy); y1 = std::max(y1, fy);
+        }
+    }
+    x0 -= 2.0; x1 += 2.0; y0 -= 2.0; y1 += 2.0;
+    const uint32_t tps = (uint32_t)R.map.tile_pixels / TILE;
+    std::vector<unsigned long long> mask((tps + 63) / 64, 0ull);
+    for (uint32_t t = 0; t < tps; ++t) {
+        bool any = false;
+        for (int k = 0; k < TILE && !any; ++k) {
+            const int j = (int)t * TILE + k;
+            int pix = j;
+            if (R.map.tile_count != 1) {                                          // pt_types.hpp: local_to_pixel
+                const int ly = j / R.map.W, x = j - ly * R.map.W, ls = ly / R.map.strip_rows;
+                pix = x + ((ls * R.map.tile_count + R.map.tile_index) * R.map.strip_rows + (ly - ls * R.map.strip_rows)) * R.map.W;
+            }
+            const int y = pix / R.map.W, x = pix - y * R.map.W;
+            any = x >= x0 && x <= x1 && y >= y0 && y <= y1;
+        }
+        if (any) mask[t >> 6] |= 1ull << (t & 63u);
+    }
+    if (!R.d_cam_mask) HIPCHK(hipMalloc((void **)&R.d_cam_mask, mask.size() * sizeof(unsigned long long)));
+    HIPCHK(hipMemcpy(R.d_cam_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    R.cam_mask_valid = true;
     return PT_OK;
 }
 
@@ -1032,6 +1104,10 @@ static int init_impl(const pt_scene_desc *d) {
         // one directory per bounce up to MAX_DEPTH: traceDepth is re-read on every call and may GROW (pathtrace.cu:286)
         HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)MAX_DEPTH * R.dir_stride * sizeof(uint32_t)));
     }
+    {
+        const int rc = update_cam_mask();
+        if (rc != PT_OK) return rc;
+    }
     HIPCHK(hipStreamSynchronize(R.stream));
     g_err[0] = 0;
     return PT_OK;
@@ -1061,8 +1137,16 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
         R.ctl_bytes = offsetof(Control, bucket) - offsetof(Control, stamp) +
                       (size_t)trace_depth * sizeof(((Control *)nullptr)->bucket[0]);
     }
+    const bool moved = memcmp(&R.cam, camera, sizeof R.cam) != 0;
     R.cam = *camera;
     R.trace_depth = trace_depth;
+    if (moved && R.mesh_mode == MESH_BVH) {
+        const bool had = R.cam_mask_valid;
+        HIPCHK(hipStreamSynchronize(R.stream));                  // launches in flight still read the old mask
+        const int rc = update_cam_mask();
+        if (rc != PT_OK) return rc;
+        if (had != R.cam_mask_valid) drop_graphs();              // the mask pointer is a (frozen) kernel argument
+    }
     return PT_OK;
 }
 

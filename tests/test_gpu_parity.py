@@ -812,6 +812,51 @@ def test_mesh_bvh_vs_oracle(pt, po, scenes, size):
         pt.pathtraceFree()
 
 
+@pytest.mark.parametrize("aa", [False, True])
+def test_camera_tile_mask(pt, po, scenes, aa):
+    """Bounce 0 of the mesh pre-pass skips the 64-pixel tiles that cannot see a mesh (ptmi355.hip: update_cam_mask).
+    Same frames as the oracle with the mesh in full view, half off-screen, seen from very close, from INSIDE its box
+    (a corner behind the eye: no mask), and as the camera moves between batches (pt_set_camera rebuilds the mask)."""
+    s = scenes["cornell_64"]
+    tris = pt.meshes.uv_sphere(center=(1.2, 4.0, 0.5), radius=1.4, n_lat=16, n_lon=32)
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"][:6], tris, material_id=2)
+    og, ot, om = geoms.view(po.GEOM_DT), tris.view(po.TRI_DT), meshes.view(po.MESH_DT)
+    gflags = pt.PT_COMPACT | pt.PT_MESH_BVH | (pt.PT_AA_JITTER if aa else 0)
+    oflags = po.F_COMPACT | (po.F_AA if aa else 0)
+    moves = [(0.0, 0.0, 0.0), (3.2, 0.0, 0.0), (1.0, -1.0, -6.5), (1.2, -1.0, -9.8), (0.0, 0.0, 0.0), (-4.0, 2.0, -3.0)]
+    cams = []
+    for dx, dy, dz in moves:
+        cam = np.array(s["camera"], copy=True).reshape(1)
+        cam["position"][0] += np.float32([dx, dy, dz])
+        cams.append(cam)
+    n = int(cams[0]["resolution"][0][0]) * int(cams[0]["resolution"][0][1])
+    # (a) a renderer initialised at each position (mask built by pt_init)
+    for k, cam in enumerate(cams):
+        scene = pt.Scene(geoms, s["materials"], cam, s["depth"], triangles=tris, meshes=meshes)
+        ref = po.Tracer(og, s["materials"], cam, s["depth"], flags=oflags, trig=po.TRIG_SHARED, tris=ot, meshes=om)
+        pt.pathtraceInit(scene, flags=gflags, max_batch=2)
+        img = np.zeros((n, 3), dtype=np.float32)
+        pt.trace_batch(1 + 2 * k, 2, img)
+        pt.pathtraceFree()
+        ref.iterate(1 + 2 * k); ref.iterate(2 + 2 * k)
+        assert img.tobytes() == ref.image.tobytes(), k
+        assert (ref.image.sum(axis=1) > 0).any()
+    # (b) ONE renderer whose camera moves between batches (mask rebuilt by pt_set_camera); the running sum carries over
+    scene = pt.Scene(geoms, s["materials"], cams[0], s["depth"], triangles=tris, meshes=meshes)
+    pt.pathtraceInit(scene, flags=gflags, max_batch=2)
+    img = np.zeros((n, 3), dtype=np.float32)
+    total = np.zeros((n, 3), dtype=np.float32)
+    for k, cam in enumerate(cams):
+        pt.set_camera(cam, s["depth"])
+        pt.trace_batch(1 + 2 * k, 2, img)
+        ref = po.Tracer(og, s["materials"], cam, s["depth"], flags=oflags, trig=po.TRIG_SHARED, tris=ot, meshes=om)
+        ref.image[:] = total
+        ref.iterate(1 + 2 * k); ref.iterate(2 + 2 * k)
+        total = ref.image.copy()
+        assert img.tobytes() == total.tobytes(), k
+    pt.pathtraceFree()
+
+
 def test_mesh_bvh_two_meshes_fused(pt, po, scenes):
     """Two meshes (one nested inside the glass ball's silhouette, one overlapping the first) through the mesh
     pre-pass: every walk visits both trees and keeps the nearer hit, geom order on ties."""
