@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device exercises the N>1 code path on a single GPU (debug)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on a 1-GPU box: run the N > 1 code path (process group, tile exchange, max / sum over "
+                         "ranks) with a world of ONE rank, so that the RCCL calls themselves execute on hardware")
     ap.add_argument("--digest", action="store_true", help="add the md5 of the (reduced) accumulation image")
     ap.add_argument("--pcie", action="store_true",
                     help="also time the reference's own calling pattern: one pathtrace() per iteration with the "
@@ -119,7 +122,10 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.backend == "nccl":      # "nccl" is RCCL on ROCm
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -143,19 +149,19 @@ def main():
         flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED,
                   "cache": pt.PT_CACHE_FIRST, "bvh": pt.PT_MESH_BVH, "aa": pt.PT_AA_JITTER, "": 0}[f]
     per_step_iters = pt.sharding.step_iterations(0, args.batch, world, args.scaling)[1]
-    every = per_step_iters if (args.reduce_every <= 0 or world == 1) else min(args.reduce_every, per_step_iters)
+    every = per_step_iters if (args.reduce_every <= 0 or not dist_on) else min(args.reduce_every, per_step_iters)
 
     # an explicit (non-null) torch stream: the library launches on it, torch copies / RCCL order against it
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     image = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")     # accumulation buffer (torch-owned)
-    frame = torch.zeros_like(image) if world > 1 else None                # rank 0: the assembled frame / reduce staging
+    frame = torch.zeros_like(image) if dist_on else None                # rank 0: the assembled frame / reduce staging
     torch.cuda.synchronize()
     pt.pathtraceInit(scene, flags=flags, device=local_rank, stream=stream.cuda_stream,
                      tile=(rank, world, args.strip_rows), max_batch=every,
                      device_image=image.data_ptr())
     gather = None
-    if world > 1 and args.collective == "gather":
+    if dist_on and args.collective == "gather":
         gather = pt.sharding.TileGather(torch, dist, rank, world, args.strip_rows, W, H, torch.device("cuda"),
                                         via_host=(args.backend == "gloo"))
     pending = [None]
@@ -178,11 +184,11 @@ def main():
         iter0, count = pt.sharding.step_iterations(i, args.batch, world, args.scaling)
         for j in range(0, count, every):
             pt.trace_batch_async(iter0 + j, min(every, count - j))          # enqueue only
-            if world > 1:
+            if dist_on:
                 exchange()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             if gather is not None:
                 gather.drain(frame)
             if pending[0] is not None:
@@ -207,7 +213,7 @@ def main():
     rays1, first1, _ = pt.counters()
     rays, first = rays1 - rays0, first1 - first0
     rank_rays = rays
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rsum = torch.tensor([float(rays)], dtype=torch.float64, device="cuda"); dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
         dt, rays = float(tmax.item()), float(rsum.item())
@@ -309,7 +315,7 @@ def main():
         import hashlib
         barrier()
         final = image
-        if world > 1:
+        if dist_on:
             # the frame rank 0 holds after the last exchange IS the result (gather: copies; reduce: sum with zeros)
             final = frame
         torch.cuda.synchronize()
@@ -327,13 +333,13 @@ def main():
             "config": {"workload": "scenes/cornell.txt (%s) %dx%d depth %d, compaction on, %d spp per step per GPU-tile"
                                    % (scene_name, W, H, scene.traceDepth, per_step_iters),
                        "batch_spp": args.batch, "flags": args.flags,
-                       "sharding": "whole frame" if world == 1 else
+                       "sharding": "whole frame" if not dist_on else
                        "interleaved %d-row strips over %d GPUs; %s scaling; tiles' running sums to rank 0 every %d "
                        "iterations by %s, overlapped with the next batch"
                        % (args.strip_rows, world, args.scaling, every,
                           "a gather of the packed tile rows (%.2f MB per rank)" % (gather.bytes_per_rank / 1e6) if gather
                           else "reduce(SUM) of the zero-padded frames (%.2f MB per rank)" % (npix * 12 / 1e6)),
-                       "exchanges_per_step": 0 if world == 1 else -(-per_step_iters // every),
+                       "exchanges_per_step": 0 if not dist_on else -(-per_step_iters // every),
                        "rays_per_step": int(rays / args.steps)},
         }
         if digest:
@@ -346,7 +352,7 @@ def main():
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -103,7 +103,8 @@ def library():
     """Load libptmi355.so; raise loudly if the HIP extension has not been built."""
     global _lib
     if _lib is None:
-        path = os.path.join(HERE, "libptmi355.so")
+        # PTMI355_LIB: another build of the same library (A/B measurements of kernel variants within one GPU box)
+        path = os.environ.get("PTMI355_LIB") or os.path.join(HERE, "libptmi355.so")
         if not os.path.exists(path):
             raise PtError("libptmi355.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")

@@ -10,6 +10,13 @@ namespace {
 // wave64 ballot straight from the compare (HIP's __ballot() goes through select 0/1 + compare-not-equal)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// Final colour of the path that ends here: one 16-B store into final[pid] (float4, w unused).  As three planes
+// (round 1) every ending path dirtied three 32-B sectors to deliver 12 B -- measured on C2: 86 B of HBM traffic per
+// ray against 62 B of payload, the difference being these stores; one sector now.
+__device__ __forceinline__ void put_final(float *fin, uint32_t pid, f3 c) {
+    reinterpret_cast<float4 *>(fin)[pid] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
 // ---------------------------------------------------------------------------
 // generateRayFromCamera -> SoA pool, `count` samples (stepping interface; the
 // batch path generates rays inside bounce 0)
@@ -1004,8 +1011,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
                 alive = ptd::shade_scatter(ps, t, nrm, m & 0x7fffffff, (m < 0) ? 0 : 1, mat_src, iter0 + (int)smp, pixel,
                                            a.depth, last_bounce);
                 if (!alive) {
-                    at(a.fin, pid) = ps.c.x; at(a.fin + (size_t)a.in.cap, pid) = ps.c.y;
-                    at(a.fin + 2 * (size_t)a.in.cap, pid) = ps.c.z;
+                    put_final(a.fin, pid, ps.c);
                 }
             }
             traced += (uint32_t)__popcll((unsigned long long)ballot64(active));
@@ -1024,6 +1030,145 @@ __global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
         for (int b = threadIdx.x; b < a.nbins; b += BLOCK)
             if (!COMPACT || key_survives(mat_src, (uint32_t)b, a.nbins, last_bounce)) gbase[b] += ktot[b];
         __syncthreads();
+    }
+    if (COMPACT) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->alive[a.depth] = n;
+    } else {
+        if (lane == 0) sctl[8 + wave] = traced;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tb = sctl[8] + sctl[9] + sctl[10] + sctl[11];
+            if (tb) atomicAdd(&a.ctl->alive[a.depth], tb);
+        }
+    }
+}
+
+// k_shade_sorted_w: the same result with WAVE-PRIVATE sorting, for up to 64 keys (lane k of a wave holds key k's
+// counters in registers).  k_shade_sorted above spends its time between six workgroup barriers per 512-path chunk
+// (per-wave counts -> per-key prefix -> key starts -> positions -> shade -> advance), each phase waiting for the
+// slowest wave's memory latency: 34 us per chunk and workgroup on C3, of which ~2 us are instructions.  Here a wave
+// sorts and shades ITS OWN 128 paths of the chunk (two tiles: stable counting sort through a 128-word LDS strip that
+// only this wave touches, so LDS program order replaces the barriers), and the four waves of the workgroup meet once
+// per chunk, to exchange their per-key counts: the output position of wave w's first key-k path is
+//     gbase[k] + sum over w' < w of count_w'[k],
+// the order of the workgroup-wide sort (chunks in order, elements in order), so the global result -- pool order after
+// the bounce = stable partition of the stable sort by key -- is unchanged and k_sort_hist's per-workgroup table too.
+// The exchange slots alternate by chunk parity: a wave that has passed barrier c cannot still be reading the slots of
+// chunk c - 1, so one barrier per chunk is enough.  The gathers of a wave touch only its own two tiles' rows (at most
+// four 128-B lines per instruction), so nothing is staged.
+constexpr int SORTW_MAX_BINS = 64;
+__host__ __device__ constexpr size_t shade_sorted_w_lds_words(int nmats) {
+    return (size_t)LDS_CTL_WORDS + 2 * WAVES * 64 + (size_t)((nmats * ptd::MAT_WORDS + 3) & ~3);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(v, off);
+        if (lane >= off) v += u;
+    }
+    return v;
+}
+
+template <bool COMPACT>
+__global__ __launch_bounds__(BLOCK, 8) void k_shade_sorted_w(BounceArgs a) {
+    static_assert(SORT_TPW == 2, "a wave handles two tiles per chunk");
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
+    uint32_t *xch = sctl + LDS_CTL_WORDS;                    // [2][WAVES][64]: per-key counts of each wave, by chunk parity
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *mats = reinterpret_cast<float *>(xch + 2 * WAVES * 64);
+    const int iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;
+    const uint32_t n = (COMPACT && a.depth > 0) ? a.ctl->nlive[a.depth] : a.pool_n;
+    const bool last_bounce = a.depth == a.trace_depth - 1;
+    uint32_t first, count;
+    sort_run(n, first, count);
+    // lane k: where this workgroup's next path with key k goes, and whether paths with key k go on at all
+    uint32_t gbase = lane < a.nbins ? a.sort_table[(size_t)lane * gridDim.x + blockIdx.x] : 0u;
+    const bool key_lives = lane < a.nbins && (!COMPACT || key_survives(a.scene.mats, (uint32_t)lane, a.nbins, last_bounce));
+    for (int k = threadIdx.x; k < a.scene.nmats * ptd::MAT_WORDS; k += BLOCK) mats[k] = a.scene.mats[k];
+    __syncthreads();
+    const uint64_t lt = (1ull << lane) - 1;
+    uint32_t traced = 0;
+    for (uint32_t c = 0; c < count; ++c) {
+        const uint32_t sub_base = (first + c) * SORT_CHUNK + (uint32_t)wave * (SORT_TPW * TILE);
+        // ---- the wave's two tiles, whole rows: state + intersection (every load coalesced, all in flight together) ----
+        uint32_t idx[SORT_TPW], pid[SORT_TPW], key[SORT_TPW];
+        bool valid[SORT_TPW];
+        f3 ro[SORT_TPW], rd[SORT_TPW], col[SORT_TPW], nrm[SORT_TPW];
+        float th[SORT_TPW];
+        int mh[SORT_TPW];
+#pragma unroll
+        for (int s = 0; s < SORT_TPW; ++s) {
+            idx[s] = sub_base + (uint32_t)s * TILE + lane;
+            valid[s] = idx[s] < n;
+            pid[s] = DEAD_PID; th[s] = -1.0f; mh[s] = 0;
+            ro[s] = ptd::mk(0, 0, 0); rd[s] = ptd::mk(0, 0, 1); col[s] = ptd::mk(1, 1, 1); nrm[s] = ptd::mk(0, 0, 0);
+            if (valid[s]) {
+                th[s] = at(a.isect.plane(0), idx[s]);
+                mh[s] = at(a.isect.mat(), idx[s]);
+                nrm[s] = ptd::mk(at(a.isect.plane(1), idx[s]), at(a.isect.plane(2), idx[s]), at(a.isect.plane(3), idx[s]));
+                char *q = a.in.slot(idx[s]);
+                pid[s] = ppid(q);
+                ro[s] = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
+                rd[s] = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
+                col[s] = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8));
+            }
+            key[s] = valid[s] ? (th[s] > 0.0f ? (uint32_t)(mh[s] & 0x7fffffff) : (uint32_t)(a.nbins - 1)) : 0u;
+        }
+        // ---- lane k counts key k over the wave's two tiles ----
+        uint32_t cnt0 = 0, cnt1 = 0;
+        for_each_key(valid[0], key[0], [&](uint32_t k, uint64_t m) { if ((uint32_t)lane == k) cnt0 = (uint32_t)__popcll((unsigned long long)m); });
+        for_each_key(valid[1], key[1], [&](uint32_t k, uint64_t m) { if ((uint32_t)lane == k) cnt1 = (uint32_t)__popcll((unsigned long long)m); });
+        uint32_t *slot = xch + (c & 1u) * (WAVES * 64);
+        slot[wave * 64 + lane] = cnt0 + cnt1;
+        __syncthreads();                                                   // the only barrier of the chunk: the waves' counts
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t v = slot[w * 64 + lane];
+            if (w < wave) before += v;
+            all += v;
+        }
+        const uint32_t g0 = gbase + before;                                // lane k: output slot of the wave's first key-k path
+        const uint32_t g1 = g0 + cnt0;                                     //         ... of tile 1's first key-k path
+        if (key_lives) gbase += all;
+        // ---- output slots: stable within a key (tile 0's paths, then tile 1's, lanes in order) ----
+        uint32_t dst[SORT_TPW] = {0u, 0u};
+        for_each_key(valid[0], key[0], [&](uint32_t k, uint64_t m) {
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)g0, (int)k);
+            if (valid[0] && key[0] == k) dst[0] = base + (uint32_t)__popcll((unsigned long long)(m & lt));
+        });
+        for_each_key(valid[1], key[1], [&](uint32_t k, uint64_t m) {
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)g1, (int)k);
+            if (valid[1] && key[1] == k) dst[1] = base + (uint32_t)__popcll((unsigned long long)(m & lt));
+        });
+        // ---- shade in place (the order of shading is not observable; the output order is) ----
+#pragma unroll
+        for (int s = 0; s < SORT_TPW; ++s) {
+            const bool have = valid[s];
+            const bool active = have && pid[s] != DEAD_PID;
+            bool alive = false;
+            ptd::PathState ps;
+            ps.o = ro[s]; ps.d = rd[s]; ps.c = col[s];
+            if (active) {
+                const uint32_t smp = sample_of(a.map, pid[s]);
+                const int pixel = local_to_pixel(a.map, (int)(pid[s] - smp * (uint32_t)a.map.tile_pixels));
+                alive = ptd::shade_scatter(ps, th[s], nrm[s], mh[s] & 0x7fffffff, (mh[s] < 0) ? 0 : 1, mats, iter0 + (int)smp, pixel,
+                                           a.depth, last_bounce);
+                if (!alive) {
+                    put_final(a.fin, pid[s], ps.c);
+                }
+            }
+            traced += (uint32_t)__popcll((unsigned long long)ballot64(active));
+            if (alive) {
+                char *q = a.out.slot(dst[s]);
+                pf(q, 0) = ps.o.x; pf(q, 1) = ps.o.y; pf(q, 2) = ps.o.z;
+                pf(q, 3) = ps.d.x; pf(q, 4) = ps.d.y; pf(q, 5) = ps.d.z;
+                pf(q, 6) = ps.c.x; pf(q, 7) = ps.c.y; pf(q, 8) = ps.c.z;
+                ppid(q) = pid[s];
+            } else if (!COMPACT && have) {
+                a.out.pid(dst[s]) = DEAD_PID;
+            }
+        }
     }
     if (COMPACT) {
         if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->alive[a.depth] = n;
@@ -1127,8 +1272,7 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
         alive = ptd::shade_scatter(ps, t, nrm, mat, outside, c.acc.mats, c.iter0 + (int)tr.smp, tr.pixel, depth,
                                    depth == a.trace_depth - 1);
         if (!alive) {
-            at(a.fin, tr.pid) = ps.c.x; at(a.fin + (size_t)in.cap, tr.pid) = ps.c.y;
-            at(a.fin + 2 * (size_t)in.cap, tr.pid) = ps.c.z;
+            put_final(a.fin, tr.pid, ps.c);
         }
     }
     // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
@@ -1868,7 +2012,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const fl
         c = ptd::mk(0.0f, 0.0f, 0.0f);
     }
     p.f(i, 6) = c.x; p.f(i, 7) = c.y; p.f(i, 8) = c.z;
-    fin[pid] = c.x; fin[(size_t)p.cap + pid] = c.y; fin[2 * (size_t)p.cap + pid] = c.z;
+    put_final(fin, pid, c);
 }
 
 // finalGather (pathtrace.cu:269-278): image[pixelIndex] += colour, one add per
@@ -1895,7 +2039,8 @@ __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin
     float r = image[3 * pix + 0], g = image[3 * pix + 1], b = image[3 * pix + 2];
     for (int s = 0; s < count; ++s) {
         const size_t k = (size_t)s * map.tile_pixels + j;
-        r += fin[k]; g += fin[(size_t)cap + k]; b += fin[2 * (size_t)cap + k];
+        const float4 c = reinterpret_cast<const float4 *>(fin)[k];
+        r += c.x; g += c.y; b += c.z;
     }
     image[3 * pix + 0] = r; image[3 * pix + 1] = g; image[3 * pix + 2] = b;
 }

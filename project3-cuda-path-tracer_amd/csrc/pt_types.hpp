@@ -176,7 +176,7 @@ struct BounceArgs {
     Control *ctl;
     RangeDir dir_in;       // directory of the pool being read (mem == nullptr: dense)
     RangeDir dir_out;      // directory this launch produces
-    float *fin;            // final colour planes r g b (stride in.cap), index = pid
+    float *fin;            // final colours, float4[cap] (w unused), index = pid
     pt_camera cam;         // used when gen_rays != 0
     int depth, trace_depth, iter0;   // iter0 < 0: read Control::iter0 (graph replay)
     uint32_t pool_n;       // paths in the pool when compaction is off / at bounce 0

@@ -94,7 +94,7 @@ struct Renderer {
     float *cache_mem = nullptr;   // first-bounce cache: 5 planes of tile_pixels (PT_CACHE_FIRST)
     bool cache_valid = false;
     Isect isect{};
-    float *final_mem = nullptr;   // 3 planes of cap floats
+    float *final_mem = nullptr;   // float4[cap]: final colour of every path of the batch, index = pid
     float *image = nullptr;
     bool own_image = false;
     float *d_geoms = nullptr, *d_mats = nullptr, *d_tris = nullptr;
@@ -116,6 +116,7 @@ struct Renderer {
     size_t ctl_bytes = 0;         // Control, zeroed per batch
     int grid = 0;                 // persistent grid size
     int grid_sort = 0;            // workgroups of the material-sort kernels (k_sort_hist / k_shade_sorted)
+    bool sort_wave = true;        // <= 64 keys: k_shade_sorted_w (PTMI355_SORT_WAVE=0 forces the workgroup-wide kernel)
     bool sorted_isects = false;   // the last bounce was shaded in material order (the intersection planes keep the order the bounce received)
     bool gen_fused = false;       // bounce 0 of the current batch generates its own rays
     Lens lens{0, 0.0f, 0.0f};     // PT_AA_JITTER / thin lens (pt_scene_desc, pt_set_lens)
@@ -349,11 +350,18 @@ int enqueue_bounce(int depth) {
             HIPCHK(hipGetLastError());
         }
         StageTimer tm(PT_STAGE_BOUNCE);
-        const size_t nb = (size_t)((a.nbins + 3) & ~3);
-        const size_t lds = ((size_t)LDS_CTL_WORDS + (3 + WAVES) * nb + 2 * SORT_CHUNK +
-                            (a.nbins <= 64 ? (size_t)R.scene.nmats * ptd::MAT_WORDS : 0)) * 4;
-        if (compact) hipLaunchKernelGGL(k_shade_sorted<true>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
-        else hipLaunchKernelGGL(k_shade_sorted<false>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+        if (a.nbins <= SORTW_MAX_BINS && R.sort_wave) {
+            // up to 64 keys: wave-private sorting, one barrier per 512-path chunk (pt_kernels.hpp: k_shade_sorted_w)
+            const size_t lds = shade_sorted_w_lds_words(R.scene.nmats) * 4;
+            if (compact) hipLaunchKernelGGL(k_shade_sorted_w<true>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+            else hipLaunchKernelGGL(k_shade_sorted_w<false>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+        } else {
+            const size_t nb = (size_t)((a.nbins + 3) & ~3);
+            const size_t lds = ((size_t)LDS_CTL_WORDS + (3 + WAVES) * nb + 2 * SORT_CHUNK +
+                                (a.nbins <= 64 ? (size_t)R.scene.nmats * ptd::MAT_WORDS : 0)) * 4;
+            if (compact) hipLaunchKernelGGL(k_shade_sorted<true>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+            else hipLaunchKernelGGL(k_shade_sorted<false>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+        }
         HIPCHK(hipGetLastError());
         R.cur ^= 1; R.cur_dir = -1;                      // the sorted pool is dense
         R.sorted_isects = true;
@@ -1039,7 +1047,7 @@ static int init_impl(const pt_scene_desc *d) {
         const int rc = ensure_isect();
         if (rc != PT_OK) return rc;
     }
-    HIPCHK(hipMalloc(&R.final_mem, capz * 3 * 4));
+    HIPCHK(hipMalloc(&R.final_mem, capz * 4 * 4));
     if (d->device_image) { R.image = d->device_image; R.own_image = false; }
     else {
         HIPCHK(hipMalloc(&R.image, (size_t)R.npix * 3 * 4));
@@ -1093,6 +1101,8 @@ static int init_impl(const pt_scene_desc *d) {
         {
             int per_cu_sort = 8;                              // nothing in these kernels needs co-residency; 8 per CU measured best (5: -4 %)
             if (const char *e = getenv("PTMI355_SORT_WGS")) per_cu_sort = std::max(1, atoi(e));
+            R.sort_wave = true;
+            if (const char *e = getenv("PTMI355_SORT_WAVE")) R.sort_wave = atoi(e) != 0;
             const uint32_t chunks = (R.cap + SORT_CHUNK - 1) / SORT_CHUNK;
             R.grid_sort = (int)std::max<uint32_t>(1u, std::min<uint32_t>(chunks, (uint32_t)cus * (uint32_t)per_cu_sort));
         }

@@ -65,6 +65,26 @@ def test_two_ranks_same_frame():
         assert two["image_md5"] == one["image_md5"], extra
 
 
+def test_one_rank_rccl():
+    """The N > 1 code path over RCCL ITSELF on this one GPU: a world of one rank (bench.py --force-dist) initialises
+    the RCCL process group on the device, packs and gathers its tile (the whole frame) per step / per iteration,
+    reduces the full frame, and takes the max / sum over ranks -- every RCCL call the driver's multi-GPU launch makes
+    executes on hardware, and the assembled frame equals the plain 1-process frame bit for bit."""
+    one = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
+               "--no-roofline", "--digest"])
+    for k, extra in enumerate(([], ["--reduce-every", "1"], ["--collective", "reduce"], ["--scaling", "strong", "--reduce-every", "3"])):
+        env_port = str(29733 + k)
+        os.environ["MASTER_PORT"] = env_port
+        try:
+            d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
+                     "--no-roofline", "--digest", "--force-dist", "--backend", "nccl"] + extra)
+        finally:
+            os.environ.pop("MASTER_PORT", None)
+        assert d["n_gpus"] == 1 and d["config"]["exchanges_per_step"] >= 1, extra
+        assert d["config"]["rays_per_step"] == one["config"]["rays_per_step"], extra
+        assert d["image_md5"] == one["image_md5"], extra
+
+
 def test_two_gpus_rccl():
     """The same over RCCL, one rank per GPU -- needs two GPUs (skipped on the 1-GPU boxes of this pool)."""
     import torch
