@@ -168,6 +168,35 @@ __device__ __forceinline__ bool cull_box(const CullRay &c, float lox, float hix,
     return !(tn > tf);
 }
 
+// Is the ray a candidate of the primitive whose cull record is cb[0..10] (wave-uniform)?  The padded world box,
+// then an EXACT early miss along one axis of a cube (pt_cull.hpp: reject_row): q_k and v_k = one row of the
+// inverseTransform applied to origin and direction in the reference's own operation order; "origin beyond the
+// slab and heading away" ( |q_k| > 0.5 and q_k v_k > 0 ) makes both slab parameters of the axis negative: tmax < 0, a
+// miss (intersections.h:56-77), whatever the other axes say.  This is what removes a path's OWN surface from
+// its candidates: its origin sits 1e-6 above the wall it just left, well inside any box the float error
+// allows, and would otherwise cost every bounce ray one object-space test (C2: 0.24 candidates per ray).
+// One function for k_bounce / k_intersect and for k_cull0_mask, which memoises its wave-wide OR per camera tile.
+__device__ __forceinline__ bool cull_candidate(const CullRay &cr, f3 ro, f3 rd, float lox, float hix, float loy, float hiy,
+                                               float loz, float hiz, int tw, float m0, float m1, float m2, float m3) {
+    bool keep = cull_box(cr, lox, hix, loy, hiy, loz, hiz);
+    const int rmode = (tw >> 8) & 7;                                     // wave-uniform; 0..2 diagonal row, 4 general row, 3 none
+    if (rmode != 3) {
+        float qk, vk;
+        if (rmode == 4) {
+            qk = (m0 * ro.x + m1 * ro.y) + (m2 * ro.z + m3);
+            vk = (m0 * rd.x + m1 * rd.y) + m2 * rd.z;                    // the reference adds m_k3 * 0.0f = +-0: same value when it matters
+        } else {
+            const float ok = rmode == 0 ? ro.x : (rmode == 1 ? ro.y : ro.z);
+            const float dk = rmode == 0 ? rd.x : (rmode == 1 ? rd.y : rd.z);
+            const float mkk = rmode == 0 ? m0 : (rmode == 1 ? m1 : m2);
+            qk = mkk * ok + m3;                                           // the other products are exact zeros
+            vk = mkk * dk;
+        }
+        if (__builtin_fabsf(qk) > 0.5f && qk * vk > 0.0f) keep = false;
+    }
+    return cr.wild || keep;
+}
+
 struct WaveQ {                        // wave-uniform ring cursors + the wave's LDS block
     float *pw;
     uint32_t head, total;
@@ -401,7 +430,8 @@ struct MeshBest { float t; int geom, tri; };
 // paths (every triangle through LDS tiles / the hierarchy inline / the k_mesh pre-pass) and fold into `mb`.
 template <int MESH>
 __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &acc, WaveQ &q, int par, float *tri_lds,
-                                           bool active, f3 ro, f3 rd, MeshBest &mb, const float4 *pre_hit) {
+                                           bool active, f3 ro, f3 rd, MeshBest &mb, const float4 *pre_hit,
+                                           bool masked = false, unsigned long long gmask = 0) {
     const int lane = threadIdx.x & 63;
     {
         float *ry = q.rays(par) + lane;
@@ -435,6 +465,8 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
 #pragma unroll
             for (int k = 0; k < 11; ++k) nxt[k] = cn[k];
         }
+        // bounce 0: primitives no camera ray of this tile is a candidate of (k_cull0_mask, bit g of the tile's word)
+        if (masked && !((gmask >> (g & 63)) & 1ull)) continue;
         const int tw = __float_as_int(cb[6]);
         const int type = tw & 0xff;
         if (MESH != MESH_NONE && type == PT_TRIANGLE_MESH) {
@@ -495,29 +527,7 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
             }
             continue;
         }
-        bool keep = cull_box(cr, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5]);
-        // EXACT early miss along one axis of a cube (pt_cull.hpp: reject_row): q_k and v_k = one row of the
-        // inverseTransform applied to origin and direction in the reference's own operation order; "origin beyond the
-        // slab and heading away" ( |q_k| > 0.5 and q_k v_k > 0 ) makes both slab parameters of the axis negative: tmax < 0, a
-        // miss (intersections.h:56-77), whatever the other axes say.  This is what removes a path's OWN surface from
-        // its candidates: its origin sits 1e-6 above the wall it just left, well inside any box the float error
-        // allows, and would otherwise cost every bounce ray one object-space test (C2: 0.24 candidates per ray).
-        const int rmode = (tw >> 8) & 7;                                 // wave-uniform; 0..2 diagonal row, 4 general row, 3 none
-        if (rmode != 3) {
-            float qk, vk;
-            if (rmode == 4) {
-                qk = (cb[7] * ro.x + cb[8] * ro.y) + (cb[9] * ro.z + cb[10]);
-                vk = (cb[7] * rd.x + cb[8] * rd.y) + cb[9] * rd.z;       // the reference adds m_k3 * 0.0f = +-0: same value when it matters
-            } else {
-                const float ok = rmode == 0 ? ro.x : (rmode == 1 ? ro.y : ro.z);
-                const float dk = rmode == 0 ? rd.x : (rmode == 1 ? rd.y : rd.z);
-                const float mkk = rmode == 0 ? cb[7] : (rmode == 1 ? cb[8] : cb[9]);
-                qk = mkk * ok + cb[10];                                   // the other products are exact zeros
-                vk = mkk * dk;
-            }
-            if (__builtin_fabsf(qk) > 0.5f && qk * vk > 0.0f) keep = false;
-        }
-        const bool cand = active && (cr.wild || keep);
+        const bool cand = active && cull_candidate(cr, ro, rd, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], tw, cb[7], cb[8], cb[9], cb[10]);
         const uint64_t m = ballot64(cand);
         if (m) {
             if (cand) {
@@ -696,6 +706,35 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
         prev_i = have ? i : 0xffffffffu; prev_mb = mb; prev_ticket = ticket; pending = true; par ^= 1;
     }
     if (pending) { drain_to(q, acc, prev_ticket); finish(prev_i, par ^ 1, prev_mb); }
+}
+
+// Bounce 0 of a pinhole camera without jitter traces the same rays every iteration, tile by tile: the primitives
+// that at least one ray of a 64-pixel camera tile is a candidate of are found once per camera (one wave per tile,
+// the very arithmetic of cull_scene) and written down as one bit per primitive; bounce 0 then skips the cull test of
+// the others for the whole wave (C2: five or six of the seven).  Only the conservative candidate decision is
+// memoised -- every exact test, every hit and every random number is computed per ray and per iteration as before.
+// Scenes of up to 64 primitives; meshes are always "candidates" (they have their own paths).
+__global__ __launch_bounds__(BLOCK) void k_cull0_mask(SceneDev sc, pt_camera cam, TileMap map, int trace_depth,
+                                                     unsigned long long *mask, uint32_t ntiles) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t tile = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const Lens pinhole{0, 0.0f, 0.0f};
+    f3 ro, rd;
+    camera_ray(cam, pinhole, trace_depth, 0, local_to_pixel(map, (int)(tile * TILE + lane)), map.W, ro, rd);
+    const CullRay cr = cull_ray(ro, rd, sc.rmax);
+    unsigned long long bits = 0;
+    for (int g = 0; g < sc.ngeoms; ++g) {
+        float cb[11];
+        cfloat *cn = as_const(sc.cull) + g * CULL_WORDS;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) cb[k] = cn[k];
+        const bool mesh = (__float_as_int(cb[6]) & 0xff) == PT_TRIANGLE_MESH;
+        if (mesh || ballot64(cull_candidate(cr, ro, rd, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], __float_as_int(cb[6]), cb[7],
+                                            cb[8], cb[9], cb[10])) != 0)
+            bits |= 1ull << (g & 63);
+    }
+    if (lane == 0) mask[tile] = bits;
 }
 
 // ---------------------------------------------------------------------------
@@ -1327,9 +1366,18 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
     TileRegs prev{};
     uint32_t prev_ticket = 0;
     int par = 0;
+    // bounce 0 of a pinhole camera: pool tile t holds the pixels of camera tile t mod (tiles per sample), whose
+    // candidate primitives k_cull0_mask has written down
+    const bool masked = MODE == MODE_FUSED && gen_rays && a.cull0 != nullptr;
+    uint32_t mtile = masked ? first_tile % a.cull0_tiles : 0u;
     for (uint32_t r = 0; r < count; ++r) {
         const uint32_t tile = first_tile + r;
         if (MESH != MESH_TILES && !own_span && tile >= tiles) break;
+        unsigned long long gmask = 0;
+        if (masked) {
+            gmask = ((const __attribute__((address_space(4))) unsigned long long *)(unsigned long long)a.cull0)[mtile];
+            if (++mtile == a.cull0_tiles) mtile = 0;
+        }
         bool have, active;
         uint32_t i, src;
         if (own_span) {                                   // k_iteration: the wave's own packed span
@@ -1351,7 +1399,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
                 // slots whose flag is set carry a mesh result from k_mesh (a hit, or "walked, nothing hit")
                 if ((a.mesh_flags_in[src >> 6] >> (src & 63u)) & 1ull) pre_hit = a.mesh_hit + src;
             }
-            cull_scene<MESH>(a.scene, c.acc, q, par, c.tri_lds, tr.active, ro, rd, tr.mb, pre_hit);
+            cull_scene<MESH>(a.scene, c.acc, q, par, c.tri_lds, tr.active, ro, rd, tr.mb, pre_hit, masked, gmask);
             const uint32_t ticket = q.total;
             if (pending) {
                 drain_to(q, c.acc, prev_ticket);
@@ -2037,9 +2085,19 @@ __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin
     if (j >= (uint32_t)map.tile_pixels) return;
     const int pix = local_to_pixel(map, (int)j);
     float r = image[3 * pix + 0], g = image[3 * pix + 1], b = image[3 * pix + 2];
-    for (int s = 0; s < count; ++s) {
-        const size_t k = (size_t)s * map.tile_pixels + j;
-        const float4 c = reinterpret_cast<const float4 *>(fin)[k];
+    // samples are added in iteration order (one add per pixel per iteration, as the reference does); the loads of
+    // eight samples are issued together, the adds stay in order
+    const float4 *f4 = reinterpret_cast<const float4 *>(fin) + j;
+    int s = 0;
+    for (; s + 8 <= count; s += 8) {
+        float4 c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = f4[(size_t)(s + u) * map.tile_pixels];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { r += c[u].x; g += c[u].y; b += c[u].z; }
+    }
+    for (; s < count; ++s) {
+        const float4 c = f4[(size_t)s * map.tile_pixels];
         r += c.x; g += c.y; b += c.z;
     }
     image[3 * pix + 0] = r; image[3 * pix + 1] = g; image[3 * pix + 2] = b;

@@ -192,6 +192,10 @@ struct BounceArgs {
     // bounce 0 of a pinhole camera: one bit per 64 local pixels, set when a camera ray of those pixels can reach the
     // grid of some mesh (pt_init projects the grids onto the image); nullptr: no such knowledge, test every ray
     const unsigned long long *cam_mask;
+    // bounce 0 of a pinhole camera without jitter: per 64 local pixels, the primitives (bit g) some camera ray of
+    // those pixels is a cull candidate of (k_cull0_mask); nullptr: test every primitive
+    const unsigned long long *cull0;
+    uint32_t cull0_tiles;  // words in cull0 = tile_pixels / 64
     // material sort: table[key][workgroup] of k_sort_hist / k_shade_sorted; keys = materials + 1 (misses)
     uint32_t *sort_table;
     int nbins;

@@ -132,6 +132,8 @@ struct Renderer {
     std::vector<float> mesh_grids;           // per mesh: lo xyz, hi xyz of its box grid (contains every box of its tree)
     unsigned long long *d_cam_mask = nullptr;   // bounce-0 tile mask (BounceArgs::cam_mask)
     bool cam_mask_valid = false;
+    unsigned long long *d_cull0 = nullptr;      // bounce-0 candidate primitives per camera tile (BounceArgs::cull0)
+    uint32_t cull0_tiles = 0;                   // 0: not applicable (> 64 primitives, tile_pixels not a multiple of 64, switched off)
     int4 *d_bvh_meshes = nullptr;
     float4 *mesh_hit = nullptr;              // mesh pre-pass results (k_mesh), one per pool slot
     unsigned long long *mesh_flags[2] = {nullptr, nullptr};   // one flag per pool slot: "mesh_hit[slot] is valid" (bounce parity)
@@ -257,6 +259,10 @@ BounceArgs bounce_args(int depth) {
     a.mesh_flags_in = R.mesh_flags[depth & 1]; a.mesh_flags_out = R.mesh_flags[(depth + 1) & 1];
     a.mesh_scan = R.mesh_marked ? 0 : 1;
     a.cam_mask = (R.cam_mask_valid && !(R.lens.radius > 0.0f)) ? R.d_cam_mask : nullptr;
+    // the candidate masks describe the rays of a pinhole camera through pixel centres
+    const bool same_rays = !R.lens.aa && !(R.lens.radius > 0.0f);
+    a.cull0 = (R.cull0_tiles && same_rays) ? R.d_cull0 : nullptr;
+    a.cull0_tiles = R.cull0_tiles;
     return a;
 }
 
@@ -688,6 +694,8 @@ void pt_free(void) {
     if (R.d_bvh_top) (void)hipFree(R.d_bvh_top);
     if (R.d_cam_mask) (void)hipFree(R.d_cam_mask);
     R.d_cam_mask = nullptr; R.cam_mask_valid = false;
+    if (R.d_cull0) (void)hipFree(R.d_cull0);
+    R.d_cull0 = nullptr; R.cull0_tiles = 0;
     if (R.ctl) (void)hipFree(R.ctl);
     if (R.dir_mem) (void)hipFree(R.dir_mem);
     if (R.persist) (void)hipFree(R.persist);
@@ -796,6 +804,17 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
 // eight corners -- computed here in double, widened by two pixels -- and every other tile can skip ray generation,
 // root tests and walks in k_mesh.  No mask (nullptr) when a corner is not in front of the camera, the frame does
 // not tile by 64 pixels, or a thin lens is on (then rays do not start at the eye).
+// (re)build the bounce-0 candidate masks for the current camera and cull boxes: one launch on the stream, ordered
+// behind whatever still reads the old masks and ahead of everything enqueued later (the buffer never moves, so
+// captured graphs stay valid)
+static int update_cull0() {
+    if (!R.cull0_tiles) return PT_OK;
+    hipLaunchKernelGGL(k_cull0_mask, dim3((R.cull0_tiles + WAVES - 1) / WAVES), dim3(BLOCK), 0, R.stream, R.scene, R.cam,
+                       R.map, R.trace_depth, R.d_cull0, R.cull0_tiles);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
 static int update_cam_mask() {
     R.cam_mask_valid = false;
     if (R.mesh_mode != MESH_BVH || R.map.tile_pixels % TILE != 0 || R.mesh_grids.empty()) return PT_OK;
@@ -1118,6 +1137,16 @@ static int init_impl(const pt_scene_desc *d) {
         const int rc = update_cam_mask();
         if (rc != PT_OK) return rc;
     }
+    {
+        bool on = true;
+        if (const char *e = getenv("PTMI355_CULL0")) on = atoi(e) != 0;
+        if (on && R.scene.ngeoms >= 1 && R.scene.ngeoms <= 64 && R.map.tile_pixels % TILE == 0) {
+            R.cull0_tiles = (uint32_t)(R.map.tile_pixels / TILE);
+            HIPCHK(hipMalloc((void **)&R.d_cull0, (size_t)R.cull0_tiles * sizeof(unsigned long long)));
+            const int rc = update_cull0();
+            if (rc != PT_OK) return rc;
+        }
+    }
     HIPCHK(hipStreamSynchronize(R.stream));
     g_err[0] = 0;
     return PT_OK;
@@ -1132,6 +1161,7 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
     if (trace_depth < 1 || trace_depth > MAX_DEPTH)
         return fail(PT_ERR_INVALID, "pt_set_camera: trace_depth %d outside [1, %d]", trace_depth, MAX_DEPTH);
     if (memcmp(&R.cam, camera, sizeof R.cam) != 0) { R.cache_valid = false; drop_graphs(); }   // refill the bounce-0 cache
+    bool recull = false;
     {   // the cull boxes hold for ray origins within R.scene.rmax (1-norm); a camera outside that range would only
         // make its rays candidates of every primitive (correct, slow): remake the boxes around the new position
         const double reach = (double)std::fabs(camera->position.x) + std::fabs(camera->position.y) + std::fabs(camera->position.z);
@@ -1139,6 +1169,7 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
             const int rc = upload_cull(&R.desc, *camera);
             if (rc != PT_OK) return rc;
             drop_graphs();
+            recull = true;
         }
     }
     if (trace_depth != R.trace_depth) {
@@ -1150,6 +1181,10 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
     const bool moved = memcmp(&R.cam, camera, sizeof R.cam) != 0;
     R.cam = *camera;
     R.trace_depth = trace_depth;
+    if (moved || recull) {
+        const int rc = update_cull0();
+        if (rc != PT_OK) return rc;
+    }
     if (moved && R.mesh_mode == MESH_BVH) {
         const bool had = R.cam_mask_valid;
         HIPCHK(hipStreamSynchronize(R.stream));                  // launches in flight still read the old mask

@@ -857,6 +857,47 @@ def test_camera_tile_mask(pt, po, scenes, aa):
     pt.pathtraceFree()
 
 
+def test_bounce0_candidate_masks(pt, po, scenes, monkeypatch):
+    """Bounce 0 of a pinhole camera skips, per 64-pixel camera tile, the cull test of the primitives no ray of the
+    tile is a candidate of (k_cull0_mask, rebuilt by pt_set_camera).  Frames equal the oracle's as the camera moves
+    between batches -- sideways, far outside the scene (the cull boxes are remade for the new reach), looking
+    away from it -- and equal the frames of a renderer with the masks switched off; a tile of a sharded frame and the
+    stepping interface (which loads rays written by k_raygen: no masks) are covered by the other tests."""
+    s = scenes["cornell_64"]
+    moves = [(0.0, 0.0, 0.0), (2.5, 0.5, 0.0), (0.0, 0.0, -40.0), (30.0, 10.0, 5.0), (0.0, 0.0, 0.0), (-3.0, 2.0, -2.0)]
+    cams = []
+    for k, (dx, dy, dz) in enumerate(moves):
+        cam = np.array(s["camera"], copy=True).reshape(1)
+        cam["position"][0] += np.float32([dx, dy, dz])
+        if k == 5:                                           # look away from the box: most tiles see nothing at all
+            cam["view"][0] = np.float32([0.6, 0.0, 0.8])
+            cam["right"][0] = np.float32([-0.8, 0.0, 0.6])
+        cams.append(cam)
+    n = int(cams[0]["resolution"][0][0]) * int(cams[0]["resolution"][0][1])
+    frames = {}
+    for masks in ("1", "0"):
+        monkeypatch.setenv("PTMI355_CULL0", masks)
+        scene = pt.Scene(s["geoms"], s["materials"], cams[0], s["depth"])
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=3)
+        img = np.zeros((n, 3), dtype=np.float32)
+        total = np.zeros((n, 3), dtype=np.float32)
+        for k, cam in enumerate(cams):
+            pt.set_camera(cam, s["depth"])
+            pt.trace_batch(1 + 3 * k, 3, img)
+            if masks == "1":
+                ref = po.Tracer(s["geoms"], s["materials"], cam, s["depth"], flags=po.F_COMPACT, trig=po.TRIG_SHARED)
+                ref.image[:] = total
+                for it in range(3):
+                    ref.iterate(1 + 3 * k + it)
+                total = ref.image.copy()
+                assert img.tobytes() == total.tobytes(), k
+            frames[(masks, k)] = img.copy()
+        pt.pathtraceFree()
+    for k in range(len(cams)):
+        assert frames[("1", k)].tobytes() == frames[("0", k)].tobytes(), k
+    monkeypatch.delenv("PTMI355_CULL0")
+
+
 def test_mesh_bvh_two_meshes_fused(pt, po, scenes):
     """Two meshes (one nested inside the glass ball's silhouette, one overlapping the first) through the mesh
     pre-pass: every walk visits both trees and keeps the nearer hit, geom order on ties."""
