@@ -1556,6 +1556,44 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    // pathtrace() per call with a host image (the reference's pattern, pathtrace.cu:380-392): at 1 spp a wave owns the
+    // pixels of its run of tiles through every bounce, so when it is done their final colours are all its own stores
+    // and it can do finalGather for them itself -- image[pixel] += colour -- and write the new sums straight into the
+    // caller's page-locked image (mapped into the device's address space), while other waves still trace: the 7.68 MB
+    // that used to cross PCIe AFTER the iteration now cross during it.  The 192 dwords of a tile's 64 float3 pixels
+    // are transposed through the wave's LDS block so that every store instruction writes 256 contiguous bytes
+    // (whole lines for the PCIe write combiner), not 64 dwords 12 bytes apart.
+    if (a.epi_host) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's final colours have left the CU
+        float *tr = lc.pw;                                          // the wave's LDS block is free now
+        for (uint32_t r = 0; r < R; ++r) {
+            const uint32_t tile = wid * R + r;
+            if (tile >= tiles) break;
+            const uint32_t j = tile * TILE + lane;                  // one sample: pid == local pixel
+            float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+            if (j < n) {                                            // agent-scope loads: from the L2 the stores went to
+                const float *f = a.fin + (size_t)j * 4;
+                cx = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cy = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cz = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            tr[3 * lane] = cx; tr[3 * lane + 1] = cy; tr[3 * lane + 2] = cz;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t w = (uint32_t)k * TILE + lane;       // dword of the tile's 192
+                const uint32_t jl = w / 3u;
+                const uint32_t jj = tile * TILE + jl;
+                if (jj < n) {
+                    const size_t idx = (size_t)local_to_pixel(a.map, (int)jj) * 3 + (w - jl * 3u);
+                    const float v = a.epi_image[idx] + tr[w];
+                    a.epi_image[idx] = v;
+                    a.epi_host[idx] = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2067,7 +2105,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const fl
 // pixel per iteration, samples added in iteration order
 __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin, uint32_t cap, TileMap map,
                                                   int count, Control *ctl, Persist *per, int depths,
-                                                  uint32_t fake_rays, int partial_counts) {
+                                                  uint32_t fake_rays, int partial_counts, int counters_only) {
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
     if (j == 0) {                    // fold this batch's ray count into the persistent counter
         if (partial_counts)          // k_iteration left 32 partial sums per bounce
@@ -2082,7 +2120,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin
         per->iterations += (unsigned long long)count;
         per->first_rays += depths > 0 ? ctl->alive[0] : fake_rays;
     }
-    if (j >= (uint32_t)map.tile_pixels) return;
+    if (counters_only || j >= (uint32_t)map.tile_pixels) return;       // k_iteration gathered its own pixels (epi_host)
     const int pix = local_to_pixel(map, (int)j);
     float r = image[3 * pix + 0], g = image[3 * pix + 1], b = image[3 * pix + 2];
     // samples are added in iteration order (one add per pixel per iteration, as the reference does); the loads of

@@ -196,6 +196,9 @@ struct BounceArgs {
     // those pixels is a cull candidate of (k_cull0_mask); nullptr: test every primitive
     const unsigned long long *cull0;
     uint32_t cull0_tiles;  // words in cull0 = tile_pixels / 64
+    // k_iteration at 1 spp with a host image: every wave gathers its own pixels into epi_image (the device's running
+    // sum) and writes the new sums to epi_host (the caller's page-locked image, device-mapped); nullptr: k_gather does it
+    float *epi_image, *epi_host;
     // material sort: table[key][workgroup] of k_sort_hist / k_shade_sorted; keys = materials + 1 (misses)
     uint32_t *sort_table;
     int nbins;

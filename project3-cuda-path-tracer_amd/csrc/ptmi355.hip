@@ -125,6 +125,9 @@ struct Renderer {
     std::map<int, BatchGraph> graphs;
     uint64_t whole_max_paths = 6000000;  // batches up to this many paths run as ONE launch (k_iteration); PTMI355_WHOLE_MAX
     bool whole = false;           // the current batch did
+    float *epi_host = nullptr;    // pt_trace: the caller's image, device-mapped, for k_iteration's own gather (this call only)
+    bool epi_done = false;        // ... and k_iteration took it
+    bool epi_enabled = true;      // PTMI355_HOST_EPILOGUE=0: always copy after the iteration
     bool use_graphs = false;      // PTMI355_GRAPH=1 turns replay on (measured slower than direct launches on ROCm 7.2: DESIGN.md 6.10)
     bool capturing = false;
     int mesh_mode = MESH_NONE;    // MESH_TILES: every triangle per ray; MESH_BVH: PT_MESH_BVH culling
@@ -429,7 +432,7 @@ int enqueue_end(void) {
                        R.final_mem, R.cap, R.map,
                        R.step_count, R.ctl, R.persist, (R.flags & PT_FAKE_SHADER) ? 0 : R.trace_depth,
                        (R.flags & PT_FAKE_SHADER) ? (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count : 0u,
-                       R.whole ? 1 : 0);
+                       R.whole ? 1 : 0, R.epi_done ? 1 : 0);
     R.whole = false;
     HIPCHK(hipGetLastError());
     return PT_OK;
@@ -446,6 +449,7 @@ int enqueue_batch_direct(int iter0, int count) {
         // small batch: every bounce in one launch (k_iteration)
         StageTimer tm(PT_STAGE_BOUNCE);
         BounceArgs a = bounce_args(0);
+        if (R.epi_host && count == 1 && !R.capturing) { a.epi_image = R.image; a.epi_host = R.epi_host; R.epi_done = true; }
         if (R.scene_lds) hipLaunchKernelGGL(k_iteration<true>, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
         else hipLaunchKernelGGL(k_iteration<false>, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
         HIPCHK(hipGetLastError());
@@ -565,8 +569,16 @@ void pin_host(void *ptr, size_t bytes) {
         (void)hipHostUnregister(R.host_regs.front().ptr);
         R.host_regs.erase(R.host_regs.begin());
     }
-    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) R.host_regs.push_back({ptr, bytes});
+    if (hipHostRegister(ptr, bytes, hipHostRegisterMapped) == hipSuccess) R.host_regs.push_back({ptr, bytes});
     else (void)hipGetLastError();
+}
+
+// the device's address of a page-locked host buffer (nullptr: not mappable -- the caller falls back to a copy)
+float *map_host(float *host, size_t bytes) {
+    pin_host(host, bytes);
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (float *)dev;
 }
 
 // PT_ASYNC_IMAGE: the running sum after this call is snapshotted on the launch stream (device to device, microseconds)
@@ -928,6 +940,8 @@ static int init_impl(const pt_scene_desc *d) {
     if (const char *ug = getenv("PTMI355_GRAPH")) R.use_graphs = atoi(ug) != 0;
     R.whole_max_paths = 6000000;     // measured at 800x800 (r02): 1 spp +38 %, 4 spp +20 %, 8 spp +8 %, 16 spp -4 %
     if (const char *wm = getenv("PTMI355_WHOLE_MAX")) R.whole_max_paths = strtoull(wm, nullptr, 10);
+    R.epi_enabled = true;
+    if (const char *e = getenv("PTMI355_HOST_EPILOGUE")) R.epi_enabled = atoi(e) != 0;
     R.npix = W * H;
     R.map.W = W; R.map.H = H; R.map.tile_index = d->tile_index; R.map.tile_count = tile_count;
     R.map.strip_rows = tile_count > 1 ? d->strip_rows : H;
@@ -1235,7 +1249,14 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
     (void)frame;                                          // unused in the reference too (main.cpp:136)
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace: not initialised");
     R.in_step = false;
+    // synchronous host image: when this iteration runs as one launch, its waves write the new sums into the caller's
+    // (page-locked, device-mapped) buffer as they finish, under the tracing of the others (k_iteration's epilogue)
+    R.epi_host = nullptr; R.epi_done = false;
+    if (host_image_sum && !(R.flags & PT_ASYNC_IMAGE) && R.epi_enabled && !R.use_graphs && R.map.tile_count == 1)
+        R.epi_host = map_host(host_image_sum, (size_t)R.npix * 12);
     int rc = enqueue_batch(iter, 1);
+    const bool gathered = R.epi_done;
+    R.epi_host = nullptr; R.epi_done = false;
     if (rc) return rc;
     if (pbo_rgba) {
         hipLaunchKernelGGL(k_tonemap, dim3((R.npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, pbo_rgba,
@@ -1243,7 +1264,7 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
         HIPCHK(hipGetLastError());
     }
     if (host_image_sum && (R.flags & PT_ASYNC_IMAGE)) return enqueue_async_image(host_image_sum);
-    if (host_image_sum) {
+    if (host_image_sum && !gathered) {
         rc = enqueue_image_copy(host_image_sum);
         if (rc) return rc;
     }
