@@ -656,7 +656,10 @@ template <int MESH, bool SLDS>
 __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc,
                                                                     const uint32_t *n_ptr, uint32_t n_fixed,
                                                                     RangeDir dir_in, const uint32_t *nprev_ptr,
-                                                                    Control *ctl) {
+                                                                    Control *ctl, const unsigned long long *cull0,
+                                                                    uint32_t cull0_tiles) {
+    // cull0 != nullptr: the pool is k_raygen's output for a pinhole camera (bounce 0 of the unfused / sorted
+    // pipelines): tile t holds the pixels of camera tile t mod cull0_tiles (k_cull0_mask)
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const LdsCarve lc = carve_lds(lds_raw, sc, SLDS);
     const SceneAcc acc = stage_scene<SLDS>(lc.scene, sc);
@@ -684,6 +687,8 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
     uint32_t prev_i = 0, prev_ticket = 0;
     MeshBest prev_mb{FLT_MAX, -1, -1};
     int par = 0;
+    const bool masked = cull0 != nullptr;
+    uint32_t mtile = masked ? (wid * R) % cull0_tiles : 0u;
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t tile = wid * R + r;
         if (MESH != MESH_TILES && tile >= tiles) break;
@@ -692,6 +697,11 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
         bool active = have && i < n;
         uint32_t src = i;
         if (packed && have) src = resolve_src(dir_in, span, cur, i, active, ctl);
+        unsigned long long gmask = 0;
+        if (masked) {
+            gmask = ((const __attribute__((address_space(4))) unsigned long long *)(unsigned long long)cull0)[mtile];
+            if (++mtile == cull0_tiles) mtile = 0;
+        }
         f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
         if (active) {
             char *p = in.slot(src);
@@ -700,7 +710,7 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
             rd = ptd::mk(pf(p, 3), pf(p, 4), pf(p, 5));
         }
         MeshBest mb;
-        cull_scene<MESH>(sc, acc, q, par, lc.tri, active, ro, rd, mb, nullptr);
+        cull_scene<MESH>(sc, acc, q, par, lc.tri, active, ro, rd, mb, nullptr, masked, gmask);
         const uint32_t ticket = q.total;
         if (pending) { drain_to(q, acc, prev_ticket); finish(prev_i, par ^ 1, prev_mb); }
         prev_i = have ? i : 0xffffffffu; prev_mb = mb; prev_ticket = ticket; pending = true; par ^= 1;

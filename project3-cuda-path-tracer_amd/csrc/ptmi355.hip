@@ -311,10 +311,13 @@ int enqueue_begin(int iter0, int count, bool stepping) {
         }                                                               \
     } while (0)
 
+// `raygen_pool`: `in` is what k_raygen wrote for the current camera (bounce 0 of a batch or of the stepping interface)
 void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, const RangeDir &dir,
-                      const uint32_t *nprev) {
+                      const uint32_t *nprev, bool raygen_pool = false) {
+    const bool same_rays = !R.lens.aa && !(R.lens.radius > 0.0f);
+    const unsigned long long *cull0 = (raygen_pool && R.cull0_tiles && same_rays) ? R.d_cull0 : nullptr;
     PT_MESH_DISPATCH(hipLaunchKernelGGL((k_intersect<MESH, SLDS>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, in,
-                                        R.isect, R.scene, n_ptr, n_fixed, dir, nprev, R.ctl));
+                                        R.isect, R.scene, n_ptr, n_fixed, dir, nprev, R.ctl, cull0, R.cull0_tiles));
 }
 
 template <int MODE, bool COMPACT>
@@ -343,7 +346,7 @@ int enqueue_bounce(int depth) {
         StageTimer tm(PT_STAGE_INTERSECT);
         const uint32_t *n_ptr = compact ? &R.ctl->nlive[depth] : (const uint32_t *)nullptr;
         const uint32_t *nprev = (compact && depth > 0) ? &R.ctl->nlive[depth - 1] : (const uint32_t *)nullptr;
-        launch_intersect(a.in, n_ptr, a.pool_n, a.dir_in, nprev);
+        launch_intersect(a.in, n_ptr, a.pool_n, a.dir_in, nprev, depth == 0);
         HIPCHK(hipGetLastError());
     }
     if (R.flags & PT_SORT_MATERIAL) {
