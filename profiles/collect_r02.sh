@@ -30,6 +30,11 @@ b c4_bvh --config c4 --flags compact,bvh --steps 10 --warmup 2 --no-cpu-baseline
 b c4_loop --config c4 --flags compact --steps 2 --warmup 1 --batch 1 --no-cpu-baseline
 b c2_aa --config c2 --flags compact,aa --no-cpu-baseline
 b c5 --config c5 --batch 4 --steps 5 --warmup 1 --no-cpu-baseline
+PTMI355_CULL0=0 b c2_nomask --config c2 --no-cpu-baseline
+# the N > 1 code path over RCCL itself, world of one rank (every RCCL call of the multi-GPU launch executes here)
+for m in "" "--reduce-every 1" "--collective reduce"; do
+  MASTER_PORT=29741 python bench.py --force-dist --backend nccl --steps 10 --warmup 2 --no-roofline --no-cpu-baseline $m 2>/dev/null | tail -1 | cut -c1-900
+done > "$OUT/bench_r02_one_rank_rccl.txt"
 # two processes of the library on this one GPU (gloo; RCCL refuses two ranks per device): the N > 1 code path
 for m in "--scaling weak" "--scaling strong" "--scaling strong --reduce-every 1"; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29711 bench.py --gpus 2 --backend gloo --same-device --steps 10 --warmup 2 --batch 8 --no-roofline $m 2>/dev/null | tail -1 | cut -c1-900
