@@ -95,20 +95,14 @@ PTD void sincos_shared(float x, float &s, float &c) {
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    // The DEFINITION (oracle/ptoracle.c: pto_sincos) is this sequence with every product and sum
-    // rounded separately.  Here each multiply-add is one v_fma_f64 (21 binary64 instructions instead of 37): the
-    // binary64 results then differ from the definition's in the last place for 0.08 % of the arguments, but the two
-    // binary32 results -- all that leaves this function -- are IDENTICAL for every float in [0, 6.3], the whole domain
-    // (the callers pass u01 * 2 pi): checked exhaustively, 1 086 953 883 arguments, by tests/tools/sincos_fused_check.c
-    // (run by tests/test_oracle_golden.py).
     double xd = (double)x;
-    double kd = __builtin_fma(xd, TWO_OVER_PI, MAGIC) - MAGIC;
-    double r = __builtin_fma(-kd, PIO2_1T, __builtin_fma(-kd, PIO2_1, xd));
+    double kd = (xd * TWO_OVER_PI + MAGIC) - MAGIC;
+    double r = (xd - kd * PIO2_1) - kd * PIO2_1T;
     double z = r * r;
-    double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2), S1);
-    double sn = __builtin_fma(r * z, ps, r);
-    double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
-    double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
+    double sn = r + (r * z) * ps;
+    double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
+    double cs = (1.0 - 0.5 * z) + (z * z) * pc;
     int q = (int)kd & 3;
     double so = (q & 1) ? cs : sn;
     double co = (q & 1) ? sn : cs;

@@ -652,14 +652,16 @@ __device__ __forceinline__ LdsCarve carve_lds(float *lds_raw, const SceneDev &sc
 
 // standalone computeIntersections: materialises the ShadeableIntersection planes
 // (indexed by LOGICAL path index).  Two tiles in flight per wave, as in k_bounce.
-template <int MESH, bool SLDS>
+template <int MESH, bool SLDS, bool GEN = false>
 __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Isect out, SceneDev sc,
                                                                     const uint32_t *n_ptr, uint32_t n_fixed,
                                                                     RangeDir dir_in, const uint32_t *nprev_ptr,
                                                                     Control *ctl, const unsigned long long *cull0,
-                                                                    uint32_t cull0_tiles) {
+                                                                    uint32_t cull0_tiles, RayGen gen) {
     // cull0 != nullptr: the pool is k_raygen's output for a pinhole camera (bounce 0 of the unfused / sorted
-    // pipelines): tile t holds the pixels of camera tile t mod cull0_tiles (k_cull0_mask)
+    // pipelines): tile t holds the pixels of camera tile t mod cull0_tiles (k_cull0_mask).
+    // GEN (bounce 0 of a sorted batch): path i's camera ray is generated here, in registers -- k_raygen does
+    // not run and `in` is not read; k_shade_sorted_w generates the same ray again when it shades the path.
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const LdsCarve lc = carve_lds(lds_raw, sc, SLDS);
     const SceneAcc acc = stage_scene<SLDS>(lc.scene, sc);
@@ -703,7 +705,12 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
             if (++mtile == cull0_tiles) mtile = 0;
         }
         f3 ro = ptd::mk(0, 0, 0), rd = ptd::mk(0, 0, 1);
-        if (active) {
+        if (GEN && active) {
+            const uint32_t smp = sample_of(gen.map, i);
+            const int pixel = local_to_pixel(gen.map, (int)(i - smp * (uint32_t)gen.map.tile_pixels));
+            const int it0 = gen.iter0 >= 0 ? gen.iter0 : (int)ctl->iter0;
+            camera_ray(gen.cam, gen.lens, gen.trace_depth, it0 + (int)smp, pixel, gen.map.W, ro, rd);
+        } else if (!GEN && active) {
             char *p = in.slot(src);
             if (ppid(p) == DEAD_PID) active = false;
             ro = ptd::mk(pf(p, 0), pf(p, 1), pf(p, 2));
@@ -1117,8 +1124,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     return v;
 }
 
-template <bool COMPACT>
-__global__ __launch_bounds__(BLOCK, 8) void k_shade_sorted_w(BounceArgs a) {
+template <bool COMPACT, bool GEN = false>
+__global__ __launch_bounds__(BLOCK, GEN ? 6 : 8) void k_shade_sorted_w(BounceArgs a) {
     static_assert(SORT_TPW == 2, "a wave handles two tiles per chunk");
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
@@ -1155,11 +1162,18 @@ __global__ __launch_bounds__(BLOCK, 8) void k_shade_sorted_w(BounceArgs a) {
                 th[s] = at(a.isect.plane(0), idx[s]);
                 mh[s] = at(a.isect.mat(), idx[s]);
                 nrm[s] = ptd::mk(at(a.isect.plane(1), idx[s]), at(a.isect.plane(2), idx[s]), at(a.isect.plane(3), idx[s]));
-                char *q = a.in.slot(idx[s]);
-                pid[s] = ppid(q);
-                ro[s] = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
-                rd[s] = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
-                col[s] = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8));
+                if (GEN) {                                         // bounce 0 of a batch: the ray k_intersect<GEN> generated
+                    pid[s] = idx[s];
+                    const uint32_t smp = sample_of(a.map, pid[s]);
+                    const int pixel = local_to_pixel(a.map, (int)(pid[s] - smp * (uint32_t)a.map.tile_pixels));
+                    camera_ray(a.cam, a.lens, a.trace_depth, iter0 + (int)smp, pixel, a.map.W, ro[s], rd[s]);
+                } else {
+                    char *q = a.in.slot(idx[s]);
+                    pid[s] = ppid(q);
+                    ro[s] = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
+                    rd[s] = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
+                    col[s] = ptd::mk(pf(q, 6), pf(q, 7), pf(q, 8));
+                }
             }
             key[s] = valid[s] ? (th[s] > 0.0f ? (uint32_t)(mh[s] & 0x7fffffff) : (uint32_t)(a.nbins - 1)) : 0u;
         }

@@ -204,6 +204,14 @@ struct BounceArgs {
     int nbins;
 };
 
+// what k_intersect needs to generate bounce 0's camera rays itself (sorted batches: no k_raygen, no pool to read)
+struct RayGen {
+    pt_camera cam;
+    Lens lens;
+    TileMap map;
+    int trace_depth, iter0;    // iter0 < 0: read Control::iter0 (graph replay)
+};
+
 __device__ __forceinline__ int local_to_pixel(const TileMap &m, int j) {
     if (m.tile_count == 1) return j;
     int ly = j / m.W;

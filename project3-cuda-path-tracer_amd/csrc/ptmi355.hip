@@ -119,6 +119,7 @@ struct Renderer {
     bool sort_wave = true;        // <= 64 keys: k_shade_sorted_w (PTMI355_SORT_WAVE=0 forces the workgroup-wide kernel)
     bool sorted_isects = false;   // the last bounce was shaded in material order (the intersection planes keep the order the bounce received)
     bool gen_fused = false;       // bounce 0 of the current batch generates its own rays
+    bool gen_sort = false;        // ... in the sorted pipeline (k_intersect + k_shade_sorted_w), no k_raygen either
     Lens lens{0, 0.0f, 0.0f};     // PT_AA_JITTER / thin lens (pt_scene_desc, pt_set_lens)
     // one captured graph per batch size: memset + every launch of a batch replayed with one hipGraphLaunch
     struct BatchGraph { hipGraphExec_t exec; int cur, cur_dir, step_depth; bool sorted_isects, gen_fused; };
@@ -285,7 +286,10 @@ int enqueue_begin(int iter0, int count, bool stepping) {
             HIPCHK(hipMemsetAsync(R.mesh_flags[k], 0, R.flag_words * sizeof(unsigned long long), R.stream));
     // batch path: bounce 0 generates the camera rays itself (no 40 B/path round trip through HBM)
     R.gen_fused = !stepping && !(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER));
-    if (R.gen_fused) return PT_OK;
+    // sorted batches of up to 64 keys: k_intersect and k_shade_sorted_w generate bounce 0's rays themselves
+    R.gen_sort = !stepping && (R.flags & PT_SORT_MATERIAL) && !(R.flags & PT_FAKE_SHADER) && R.sort_wave &&
+                 R.scene.nmats + 1 <= SORTW_MAX_BINS;
+    if (R.gen_fused || R.gen_sort) return PT_OK;
     const uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)count;
     StageTimer tm(PT_STAGE_RAYGEN);
     hipLaunchKernelGGL(k_raygen, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.pool[0], R.cam,
@@ -312,12 +316,21 @@ int enqueue_begin(int iter0, int count, bool stepping) {
     } while (0)
 
 // `raygen_pool`: `in` is what k_raygen wrote for the current camera (bounce 0 of a batch or of the stepping interface)
+// `generate`: bounce 0 of a sorted batch -- the kernel generates the camera rays itself (R.gen_sort), `in` is not read
 void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, const RangeDir &dir,
-                      const uint32_t *nprev, bool raygen_pool = false) {
+                      const uint32_t *nprev, bool raygen_pool = false, bool generate = false) {
     const bool same_rays = !R.lens.aa && !(R.lens.radius > 0.0f);
     const unsigned long long *cull0 = (raygen_pool && R.cull0_tiles && same_rays) ? R.d_cull0 : nullptr;
+    RayGen gen{};
+    if (generate) {
+        gen.cam = R.cam; gen.lens = R.lens; gen.map = R.map; gen.trace_depth = R.trace_depth;
+        gen.iter0 = R.capturing ? -1 : R.step_iter0;
+        PT_MESH_DISPATCH(hipLaunchKernelGGL((k_intersect<MESH, SLDS, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, in,
+                                            R.isect, R.scene, n_ptr, n_fixed, dir, nprev, R.ctl, cull0, R.cull0_tiles, gen));
+        return;
+    }
     PT_MESH_DISPATCH(hipLaunchKernelGGL((k_intersect<MESH, SLDS>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, in,
-                                        R.isect, R.scene, n_ptr, n_fixed, dir, nprev, R.ctl, cull0, R.cull0_tiles));
+                                        R.isect, R.scene, n_ptr, n_fixed, dir, nprev, R.ctl, cull0, R.cull0_tiles, gen));
 }
 
 template <int MODE, bool COMPACT>
@@ -344,9 +357,10 @@ int enqueue_bounce(int depth) {
     const bool unfused = (R.flags & (PT_UNFUSED | PT_SORT_MATERIAL)) != 0;
     if (unfused) {
         StageTimer tm(PT_STAGE_INTERSECT);
-        const uint32_t *n_ptr = compact ? &R.ctl->nlive[depth] : (const uint32_t *)nullptr;
+        const bool generate = depth == 0 && R.gen_sort;          // nobody has written nlive[0] yet: the pool size is a.pool_n
+        const uint32_t *n_ptr = (compact && !generate) ? &R.ctl->nlive[depth] : (const uint32_t *)nullptr;
         const uint32_t *nprev = (compact && depth > 0) ? &R.ctl->nlive[depth - 1] : (const uint32_t *)nullptr;
-        launch_intersect(a.in, n_ptr, a.pool_n, a.dir_in, nprev, depth == 0);
+        launch_intersect(a.in, n_ptr, a.pool_n, a.dir_in, nprev, depth == 0, generate);
         HIPCHK(hipGetLastError());
     }
     if (R.flags & PT_SORT_MATERIAL) {
@@ -354,6 +368,7 @@ int enqueue_bounce(int depth) {
         // with shading: survivors land in the other pool in globally sorted, compacted order (pt_kernels.hpp)
         a.in = R.pool[R.cur]; a.out = R.pool[R.cur ^ 1];
         a.sort_table = R.sort_table; a.nbins = R.scene.nmats + 1;
+        a.gen_rays = (depth == 0 && R.gen_sort) ? 1 : 0;         // k_shade_sorted_w generates bounce 0's rays as k_intersect did
         {
             StageTimer tm(PT_STAGE_SORT);
             const size_t lds = ((size_t)LDS_CTL_WORDS + (size_t)((a.nbins + 3) & ~3)) * 4;
@@ -365,8 +380,13 @@ int enqueue_bounce(int depth) {
         if (a.nbins <= SORTW_MAX_BINS && R.sort_wave) {
             // up to 64 keys: wave-private sorting, one barrier per 512-path chunk (pt_kernels.hpp: k_shade_sorted_w)
             const size_t lds = shade_sorted_w_lds_words(R.scene.nmats) * 4;
-            if (compact) hipLaunchKernelGGL(k_shade_sorted_w<true>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
-            else hipLaunchKernelGGL(k_shade_sorted_w<false>, dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+            if (a.gen_rays) {
+                if (compact) hipLaunchKernelGGL((k_shade_sorted_w<true, true>), dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+                else hipLaunchKernelGGL((k_shade_sorted_w<false, true>), dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+            } else {
+                if (compact) hipLaunchKernelGGL((k_shade_sorted_w<true, false>), dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+                else hipLaunchKernelGGL((k_shade_sorted_w<false, false>), dim3(R.grid_sort), dim3(BLOCK), lds, R.stream, a);
+            }
         } else {
             const size_t nb = (size_t)((a.nbins + 3) & ~3);
             const size_t lds = ((size_t)LDS_CTL_WORDS + (3 + WAVES) * nb + 2 * SORT_CHUNK +
