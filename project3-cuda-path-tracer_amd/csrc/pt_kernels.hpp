@@ -1380,11 +1380,19 @@ __device__ __forceinline__ void tile_finish(const BounceArgs &a, const TileCtx &
 // above): tile T+1 is loaded and culled before tile T is shaded, so T's last candidates share a pass with T+1's
 // first.  `logical0` = logical index of the run's first path; with `own_span` (k_iteration) the paths sit densely
 // in the wave's own span and `live` of them exist.
+// k_iteration, bounces >= 1: the survivors of a WORKGROUP's four waves, each packed at the front of its wave's span,
+// read as one sequence -- wave s holds the workgroup-logical paths [p[s], p[s+1]) (p[0] = 0, p[4] = total) in the
+// slots b[s] + (L - p[s]).  Wave-uniform.
+struct WgSpans {
+    uint32_t p1, p2, p3, total;
+    uint32_t b0, b1, b2, b3;
+};
+
 template <int MODE, bool COMPACT, int MESH>
 __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c, WaveQ &q, const Pool &in, const Pool &out,
                                           int depth, bool gen_rays, uint32_t first_tile, uint32_t count, uint32_t tiles,
                                           uint32_t n, bool packed_in, uint32_t span_in, uint32_t &cur, uint32_t dst_base,
-                                          bool own_span, uint32_t live, uint32_t &packed, uint32_t &traced) {
+                                          bool own_span, const WgSpans &ws, uint32_t &packed, uint32_t &traced) {
     const int lane = c.lane;
     bool pending = false;
     TileRegs prev{};
@@ -1404,9 +1412,14 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
         }
         bool have, active;
         uint32_t i, src;
-        if (own_span) {                                   // k_iteration: the wave's own packed span
-            const uint32_t k = r * TILE + lane;
-            have = true; active = k < live; i = dst_base + k; src = i;
+        if (own_span) {                                   // k_iteration: tile `tile` of the workgroup's survivors
+            const uint32_t L = tile * TILE + lane;
+            have = true; active = L < ws.total;
+            uint32_t off = L, b = ws.b0;                      // the span that holds L: three compares, wave s's span
+            if (L >= ws.p1) { off = L - ws.p1; b = ws.b1; }
+            if (L >= ws.p2) { off = L - ws.p2; b = ws.b2; }
+            if (L >= ws.p3) { off = L - ws.p3; b = ws.b3; }
+            src = b + off; i = src;
         } else {
             have = tile < tiles;
             i = tile * TILE + lane;                        // logical path index
@@ -1485,7 +1498,7 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
     // every wave walks its own run of R consecutive 64-path tiles; no workgroup barrier inside
     // the loop unless a mesh needs block-wide triangle staging (then all waves run R iterations)
     run_tiles<MODE, COMPACT, MESH>(a, c, q, a.in, a.out, a.depth, a.gen_rays != 0, wid * R, R, tiles, n, packed_in, span_in,
-                                   cur, wid * R * TILE, false, 0, packed, traced);
+                                   cur, wid * R * TILE, false, WgSpans{}, packed, traced);
     STAMP(6);
     // paths traced this bounce: with compaction it is simply the live count; otherwise count the alive
     // slots, one atomic per workgroup (summed through LDS) rather than one per wave on a single address
@@ -1530,15 +1543,16 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
 // A whole batch in ONE launch, for small batches (the reference's calling pattern is one iteration per
 // call): at 1 spp every bounce kernel is ~20 us of fixed cost (launch, scene staging, directory search,
 // last-workgroup scan) around a few microseconds of work.  Here every wave generates the camera rays of its
-// run of tiles and then keeps ITS OWN survivors through all the bounces: bounce d+1 reads the span the wave
-// packed at bounce d (the two pools ping-pong inside the launch), so there is no exchange between waves, no
-// directory and no barrier.  The concatenation of the spans is still the stable partition's order; the paths
-// just are not dealt out again after every bounce, which costs load balance (a wave whose pixels live long
-// works longer) -- the price that makes this the small-batch path only.  Traced counts go to 32 partial sums
-// per bounce (Control::bucket[d][1]; a same-address atomic per wave would serialise), folded by k_gather.
+// run of tiles; from then on the survivors stay inside the WORKGROUP: every wave packs its survivors at the front
+// of its own span (the two pools ping-pong inside the launch), and bounce d+1 deals the four spans of the workgroup
+// out again to its four waves (one barrier per bounce; WgSpans).  No exchange between workgroups, no directory.
+// The paths are not dealt out again across the whole grid after every bounce, which costs load balance (a
+// workgroup whose pixels live long works longer) -- the price that makes this the small-batch path only.  Traced
+// counts go to 32 partial sums per bounce (Control::bucket[d][1]; a same-address atomic per wave would
+// serialise), folded by k_gather.
 //
-// The wave's stores of bounce d are read back by its own (other) lanes at bounce d+1 through the CU's vector
-// L1, which its own write-through stores update: workgroup scope is enough for that, on the condition that the
+// A wave's stores of bounce d are read back by the waves of its workgroup at bounce d+1 through the CU's vector
+// L1, which the write-through stores update: workgroup scope is enough for that, on the condition that the
 // workgroup runs in CU mode (not tgsplit: a workgroup's waves then share one CU and one L1) -- the mode hipcc
 // compiles for by default and the only one this library is built in (build.py passes no -mtgsplit).
 template <bool SLDS>
@@ -1560,25 +1574,45 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a)
     const uint32_t base = wid * R * TILE;                         // this wave's span in both pools
     if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = n;
     Pool in = a.in, out = a.out;
-    uint32_t count = 0;                                           // paths of this wave entering the bounce (d > 0)
     uint32_t cur = 0;
+    // Bounces >= 1 deal the WORKGROUP's survivors out again: every wave packs its survivors at the front of its own span
+    // (no exchange inside a bounce), the four counts cross through LDS at one barrier per bounce, and wave w then takes
+    // the w-th quarter of the tiles of the four spans read as one sequence (WgSpans).  Left with its own survivors only,
+    // a wave ran half-empty tiles from bounce 2 on (36 paths in a tile of 64 at bounce 5): 11 tile passes per wave and
+    // iteration at 1 spp instead of 8.5.  Slots alternate by bounce parity, so one barrier per bounce is enough.
+    uint32_t *xcnt = reinterpret_cast<uint32_t *>(lds_raw);      // [2][WAVES] (the LDS control words; unused by this kernel)
+    const int wave = threadIdx.x >> 6;
+    WgSpans ws{};
+    ws.b0 = (0u * gridDim.x + blockIdx.x) * R * TILE; ws.b1 = (1u * gridDim.x + blockIdx.x) * R * TILE;
+    ws.b2 = (2u * gridDim.x + blockIdx.x) * R * TILE; ws.b3 = (3u * gridDim.x + blockIdx.x) * R * TILE;
+    static_assert(WAVES == 4, "four spans per workgroup");
     for (int d = 0; d < a.trace_depth; ++d) {
         uint32_t traced = 0, packed = 0;
-        if (d == 0)
-            run_tiles<MODE_FUSED, true, MESH_NONE>(a, c, q, in, out, 0, true, wid * R, R, tiles, n, false, 0, cur, base, false, 0,
+        if (d == 0) {
+            run_tiles<MODE_FUSED, true, MESH_NONE>(a, c, q, in, out, 0, true, wid * R, R, tiles, n, false, 0, cur, base, false, ws,
                                                    packed, traced);
-        else
-            run_tiles<MODE_FUSED, true, MESH_NONE>(a, c, q, in, out, d, false, 0, (count + TILE - 1) / TILE, tiles, n, false, 0, cur,
-                                                   base, true, count, packed, traced);
+        } else {
+            const uint32_t wg_tiles = (ws.total + TILE - 1) / TILE;
+            const uint32_t per = (wg_tiles + WAVES - 1) / WAVES;              // <= R: a wave's output still fits its span
+            const uint32_t first = (uint32_t)wave * per;
+            const uint32_t mine = first < wg_tiles ? min(per, wg_tiles - first) : 0u;
+            run_tiles<MODE_FUSED, true, MESH_NONE>(a, c, q, in, out, d, false, first, mine, tiles, n, false, 0, cur, base, true, ws,
+                                                   packed, traced);
+        }
         if (lane == 0 && traced)
             atomicAdd(&a.ctl->bucket[d][1][(wid % ELECT_BUCKETS) * 16], traced);
-        count = packed;
-        if (count == 0) break;
-        const Pool tmp = in; in = out; out = tmp;
-        // the span this wave just wrote is read back by its own (other) lanes; an agent-scope fence writes back /
-        // invalidates the L2 and made the launch 4x slower
+        // this wave's survivors are read by the workgroup's other waves at the next bounce, through the CU's vector L1
+        // that the write-through stores went through: workgroup scope (CU mode, see above); an agent-scope fence writes
+        // back / invalidates the L2 and made the launch 4x slower
+        uint32_t *slot = xcnt + (d & 1) * WAVES;
+        if (lane == 0) slot[wave] = packed;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                                     // every wave, every bounce: exits are uniform
+        const uint32_t c0 = slot[0], c1 = slot[1], c2 = slot[2], c3 = slot[3];
+        ws.p1 = c0; ws.p2 = c0 + c1; ws.p3 = c0 + c1 + c2; ws.total = c0 + c1 + c2 + c3;
+        if (ws.total == 0) break;
+        const Pool tmp = in; in = out; out = tmp;
     }
     // pathtrace() per call with a host image (the reference's pattern, pathtrace.cu:380-392): at 1 spp a wave owns the
     // pixels of its run of tiles through every bounce, so when it is done their final colours are all its own stores

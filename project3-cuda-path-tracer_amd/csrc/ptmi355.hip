@@ -1094,7 +1094,11 @@ static int init_impl(const pt_scene_desc *d) {
     // pools, intersections, final colours, image, control
     const size_t capz = R.cap;
     for (int k = 0; k < 2; ++k) {
-        HIPCHK(hipMalloc(&R.pool_mem[k], (((capz + 63) / 64) * 64) * 10 * 4));     // whole 64-path tiles
+        // whole 64-path tiles, plus one tile per wave of the largest grid (W <= 8192): wave w's span starts at slot
+        // w * R * 64 with R = ceil(tiles / W), so the spans of the last waves reach up to W tiles past the pool's paths --
+        // never written while a wave only packs its own survivors, but k_iteration deals a workgroup's survivors to
+        // all four of its waves, whichever of them had paths at bounce 0
+        HIPCHK(hipMalloc(&R.pool_mem[k], (((capz + 63) / 64) + 8192) * 64 * 10 * 4));
         R.pool[k] = carve_pool(R.pool_mem[k], R.cap);
     }
     // the ShadeableIntersection planes exist only where a pipeline materialises them (the fused path keeps them
@@ -1135,6 +1139,7 @@ static int init_impl(const pt_scene_desc *d) {
     if (const char *e = getenv("PTMI355_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // occupancy experiments
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
     if (R.grid < 1) R.grid = 1;
+    if (R.grid * WAVES > 8192) R.grid = 8192 / WAVES;           // the pools' slack and the directory scan are sized for W <= 8192
     if (R.mesh_mode == MESH_BVH) {
         HIPCHK(hipMalloc((void **)&R.mesh_hit, (size_t)(((capz + 63) / 64) * 64) * sizeof(float4)));
         // k_mesh reads the flags of whole ranges (waves x tiles per range can overshoot the pool by up to one tile per
