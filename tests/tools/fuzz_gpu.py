@@ -112,19 +112,38 @@ def main():
             g["scale"] = sc
             H.pth_build_geom_matrices(geoms.ctypes.data + k * pt.GEOM_DT.itemsize)
         depth = int(rng.integers(1, 12))
+        # the camera moves too (the bounce-0 candidate masks and the cull boxes' reach follow it): near the scene, far
+        # outside it, sometimes looking elsewhere; and either launch plan (a kernel per bounce / one launch per batch)
+        cam = np.array(z["cornell_64__camera"], copy=True).reshape(1)
+        r = rng.random()
+        if r < 0.5:
+            cam["position"][0] += rng.uniform(-3, 3, 3).astype(np.float32)
+        elif r < 0.6:
+            cam["position"][0] += (rng.uniform(-1, 1, 3) * rng.choice([30.0, 300.0])).astype(np.float32)
+        if rng.random() < 0.2:
+            a = rng.uniform(-0.8, 0.8)
+            cam["view"][0] = np.float32([np.sin(a), 0.0, np.cos(a)]) * np.float32(np.sign(cam["view"][0][2]) or 1.0)
+        if rng.random() < 0.5:
+            os.environ["PTMI355_WHOLE_MAX"] = "0"
+        else:
+            os.environ.pop("PTMI355_WHOLE_MAX", None)
         scene = pt.Scene(geoms, mats, cam, depth)
         ogeoms, omats = geoms.view(po.GEOM_DT), mats.view(po.MATERIAL_DT)
-        # (a) whole iterations under three pipelines
+        # (a) whole iterations under three pipelines: a batch of two, then pathtrace() per call with the host image
         for flags, oflags in ((pt.PT_COMPACT, po.F_COMPACT), (0, 0), (pt.PT_COMPACT | pt.PT_SORT_MATERIAL, po.F_COMPACT | po.F_SORT)):
             ref = po.Tracer(ogeoms, omats, cam, depth, flags=oflags, trig=po.TRIG_SHARED)
             pt.pathtraceInit(scene, flags=flags, max_batch=2)
             img = np.zeros((64 * 64, 3), dtype=np.float32)
             pt.trace_batch(1, 2, img)
-            pt.pathtraceFree()
             ref.iterate(1); ref.iterate(2)
-            if img.tobytes() != ref.image.tobytes():
+            same = img.tobytes() == ref.image.tobytes()
+            got = pt.pathtrace(None, 0, 3)
+            ref.iterate(3)
+            same = same and got.tobytes() == ref.image.tobytes()
+            pt.pathtraceFree()
+            if not same:
                 bad += 1
-                print("seed %d flags %d: IMAGE DIFFERS (%d pixels)" % (seed, flags, int((img != ref.image).any(axis=1).sum())), flush=True)
+                print("seed %d flags %d: IMAGE DIFFERS (%d pixels)" % (seed, flags, int((got != ref.image).any(axis=1).sum())), flush=True)
         # (b) cull-stress rays through computeIntersections
         finite = np.isfinite(geoms["transform"]).all(axis=(1, 2))
         rays = cull_model.stress_rays(geoms[finite], rng, per_geom=max(200, 6000 // max(1, int(finite.sum()))))
