@@ -9,6 +9,13 @@ namespace {
 
 // wave64 ballot straight from the compare (HIP's __ballot() goes through select 0/1 + compare-not-equal)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// number of set bits of the wave mask m below this lane: v_mbcnt_lo + v_mbcnt_hi on the scalar mask (the generic
+// popcount(m & ((1 << lane) - 1)) compiles to two ands and two bit counts on per-lane copies of the mask)
+__device__ __forceinline__ uint32_t rank_below(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// the lanes of a wave mask as a per-lane predicate, for free (the mask becomes the exec mask of the branch)
+__device__ __forceinline__ bool lane_of(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 // Final colour of the path that ends here: one 16-B store into final[pid] (float4, w unused).  As three planes
 // (round 1) every ending path dirtied three 32-B sectors to deliver 12 B -- measured on C2: 86 B of HBM traffic per
@@ -175,26 +182,29 @@ __device__ __forceinline__ bool cull_box(const CullRay &c, float lox, float hix,
 // miss (intersections.h:56-77), whatever the other axes say.  This is what removes a path's OWN surface from
 // its candidates: its origin sits 1e-6 above the wall it just left, well inside any box the float error
 // allows, and would otherwise cost every bounce ray one object-space test (C2: 0.24 candidates per ray).
-// One function for k_bounce / k_intersect and for k_cull0_mask, which memoises its wave-wide OR per camera tile.
-__device__ __forceinline__ bool cull_candidate(const CullRay &cr, f3 ro, f3 rd, float lox, float hix, float loy, float hiy,
-                                               float loz, float hiz, int tw, float m0, float m1, float m2, float m3) {
-    bool keep = cull_box(cr, lox, hix, loy, hiy, loz, hiz);
+// One function for k_bounce / k_intersect and for k_cull0_mask, which memoises "some lane" per camera tile.
+// Returns the WAVE MASK of the candidate lanes: every compare goes straight to a scalar register pair and the
+// combination -- box and not(early miss) or wild -- is scalar mask arithmetic, not per-lane selects.
+__device__ __forceinline__ uint64_t cull_candidates(const CullRay &cr, uint64_t m_wild, f3 ro, f3 rd, float lox, float hix,
+                                                    float loy, float hiy, float loz, float hiz, int tw, float m0, float m1,
+                                                    float m2, float m3) {
+    uint64_t keep = ballot64(cull_box(cr, lox, hix, loy, hiy, loz, hiz));
     const int rmode = (tw >> 8) & 7;                                     // wave-uniform; 0..2 diagonal row, 4 general row, 3 none
     if (rmode != 3) {
         float qk, vk;
         if (rmode == 4) {
             qk = (m0 * ro.x + m1 * ro.y) + (m2 * ro.z + m3);
             vk = (m0 * rd.x + m1 * rd.y) + m2 * rd.z;                    // the reference adds m_k3 * 0.0f = +-0: same value when it matters
+        } else if (rmode == 0) {                                          // (scalar branches: selecting the component with
+            qk = m0 * ro.x + m3; vk = m0 * rd.x;                          //  wave-uniform v_cndmasks costs nine instructions)
+        } else if (rmode == 1) {
+            qk = m1 * ro.y + m3; vk = m1 * rd.y;                          // the other products are exact zeros
         } else {
-            const float ok = rmode == 0 ? ro.x : (rmode == 1 ? ro.y : ro.z);
-            const float dk = rmode == 0 ? rd.x : (rmode == 1 ? rd.y : rd.z);
-            const float mkk = rmode == 0 ? m0 : (rmode == 1 ? m1 : m2);
-            qk = mkk * ok + m3;                                           // the other products are exact zeros
-            vk = mkk * dk;
+            qk = m2 * ro.z + m3; vk = m2 * rd.z;
         }
-        if (__builtin_fabsf(qk) > 0.5f && qk * vk > 0.0f) keep = false;
+        keep &= ~(ballot64(__builtin_fabsf(qk) > 0.5f) & ballot64(qk * vk > 0.0f));
     }
-    return cr.wild || keep;
+    return keep | m_wild;
 }
 
 struct WaveQ {                        // wave-uniform ring cursors + the wave's LDS block
@@ -444,6 +454,7 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
         mb.t = m.x; mb.geom = __float_as_int(m.y); mb.tri = __float_as_int(m.z);
     }
     const CullRay cr = cull_ray(ro, rd, sc.rmax);
+    const uint64_t m_act = ballot64(active), m_wild = ballot64(cr.wild);
     CULL_STAT(0, 1); CULL_STAT(5, __popcll((unsigned long long)ballot64(active && cr.wild))); CULL_STAT(6, __popcll((unsigned long long)ballot64(active)));
     const uint32_t tag = (uint32_t)lane | ((uint32_t)par << 6);
     const int ngeoms = sc.ngeoms;
@@ -527,11 +538,10 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
             }
             continue;
         }
-        const bool cand = active && cull_candidate(cr, ro, rd, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], tw, cb[7], cb[8], cb[9], cb[10]);
-        const uint64_t m = ballot64(cand);
+        const uint64_t m = m_act & cull_candidates(cr, m_wild, ro, rd, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], tw, cb[7], cb[8], cb[9], cb[10]);
         if (m) {
-            if (cand) {
-                const uint32_t s = (q.total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))) & (Q_SLOTS - 1);
+            if (lane_of(m)) {
+                const uint32_t s = (q.total + rank_below(m)) & (Q_SLOTS - 1);
                 q.ring()[s] = tag | ((uint32_t)type << 7) | ((uint32_t)g << 9);
             }
             q.total += (uint32_t)__popcll((unsigned long long)m);
@@ -740,6 +750,7 @@ __global__ __launch_bounds__(BLOCK) void k_cull0_mask(SceneDev sc, pt_camera cam
     f3 ro, rd;
     camera_ray(cam, pinhole, trace_depth, 0, local_to_pixel(map, (int)(tile * TILE + lane)), map.W, ro, rd);
     const CullRay cr = cull_ray(ro, rd, sc.rmax);
+    const uint64_t m_wild = ballot64(cr.wild);
     unsigned long long bits = 0;
     for (int g = 0; g < sc.ngeoms; ++g) {
         float cb[11];
@@ -747,8 +758,8 @@ __global__ __launch_bounds__(BLOCK) void k_cull0_mask(SceneDev sc, pt_camera cam
 #pragma unroll
         for (int k = 0; k < 11; ++k) cb[k] = cn[k];
         const bool mesh = (__float_as_int(cb[6]) & 0xff) == PT_TRIANGLE_MESH;
-        if (mesh || ballot64(cull_candidate(cr, ro, rd, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], __float_as_int(cb[6]), cb[7],
-                                            cb[8], cb[9], cb[10])) != 0)
+        if (mesh || cull_candidates(cr, m_wild, ro, rd, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], __float_as_int(cb[6]), cb[7],
+                                    cb[8], cb[9], cb[10]) != 0)
             bits |= 1ull << (g & 63);
     }
     if (lane == 0) mask[tile] = bits;
@@ -1344,7 +1355,7 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
     traced += (uint32_t)__popcll((unsigned long long)act);
     uint32_t dst = tr.i;
     if (COMPACT) {
-        dst = dst_base + packed + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1)));
+        dst = dst_base + packed + rank_below(bal);
         packed += (uint32_t)__popcll((unsigned long long)bal);
     }
     if (alive) {
