@@ -1095,7 +1095,7 @@ def test_camera_jitter_and_lens(pt, po, scenes, mode):
     pt.trace_batch(5, 2, img)
     assert img.tobytes() == ref.image.tobytes()
     pt.pathtraceFree()
-    # unfused / sorted pipelines read rays written by k_raygen
+    # sorted batches generate bounce 0 in k_intersect<GEN> / k_shade_sorted_w<GEN> (jitter and lens included)
     ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], flags=oflags | po.F_SORT, trig=po.TRIG_SHARED,
                     lens=lens)
     pt.pathtraceInit(scene, flags=gflags | pt.PT_SORT_MATERIAL, lens=lens)
@@ -1127,16 +1127,18 @@ def test_camera_extensions_exclude_the_first_bounce_cache(pt, scenes):
     pt.pathtraceFree()
 
 
-def test_graph_replay_equals_direct_launches(pt, scenes, monkeypatch):
+@pytest.mark.parametrize("sort", [False, True])
+def test_graph_replay_equals_direct_launches(pt, scenes, monkeypatch, sort):
     """PTMI355_GRAPH=1: a batch captured once and replayed with hipGraphLaunch (iteration number through
-    Control::iter0) gives the same image as direct launches, across batch sizes and a camera change."""
+    Control::iter0) gives the same image as direct launches, across batch sizes and a camera change -- fused, and with
+    the material sort (whose bounce-0 kernels generate the camera rays themselves)."""
     s = scenes["cornell_glass_64"]
     scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
     n = scene.resolution[0] * scene.resolution[1]
 
     def run():
         img = np.zeros((n, 3), dtype=np.float32)
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=4)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | (pt.PT_SORT_MATERIAL if sort else 0), max_batch=4)
         for it in (1, 2, 3):
             pt.pathtrace(None, 0, it)                 # batch size 1, three replays
         pt.trace_batch(4, 4, img)                     # batch size 4
