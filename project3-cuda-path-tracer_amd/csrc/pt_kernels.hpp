@@ -1,8 +1,9 @@
 // pt_kernels.hpp -- the HIP kernels of libptmi355.so (included by ptmi355.hip only), counterparts of
 // the reference's src/pathtrace.cu kernels: k_raygen (generateRayFromCamera :122-143), k_intersect
 // (computeIntersections :149-213), k_bounce (intersect + shade/scatter + stable compaction, fused),
-// k_sort_* (material sort), k_shade_fake (shadeFakeMaterial :224-266), k_gather (finalGather
-// :269-278), k_tonemap (sendImageToPBO :48-68) and the AoS import/export helpers.
+// k_iteration (all bounces of a small batch in one launch), k_sort_hist / k_shade_sorted_w / k_shade_sorted (material
+// sort), k_mesh (triangle-mesh pre-pass), k_cull0_mask (bounce-0 candidate masks), k_shade_fake (shadeFakeMaterial
+// :224-266), k_gather (finalGather :269-278), k_tonemap (sendImageToPBO :48-68) and the AoS import/export helpers.
 #pragma once
 
 namespace {

@@ -11,8 +11,10 @@
 //     to the front of the wave's own span; each wave publishes its count, the last workgroup out of the launch
 //     scans the <= 8192 counts into bases (range directory) and the next bounce maps logical index -> slot;
 //   * the live count stays on the device: the next bounce reads it from HBM, no host round trip inside a batch;
-//   * terminated paths drop their final colour into final[sample][pixel]; one gather kernel adds the samples into
-//     the float3 accumulation buffer in iteration order (bit-identical to sequential iterations).
+//   * terminated paths drop their final colour into final[sample][pixel] (one 16-B store); one gather kernel adds the
+//     samples into the float3 accumulation buffer in iteration order (bit-identical to sequential iterations);
+//   * small batches (the reference's one iteration per call) run all their bounces in ONE launch (k_iteration); with a
+//     host image the kernel's waves write the new sums into the caller's device-mapped buffer themselves.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction:
 // parity with the reference arithmetic is bit-exact, tests/test_gpu_parity.py).
