@@ -1169,7 +1169,7 @@ static int init_impl(const pt_scene_desc *d) {
             const uint32_t chunks = (R.cap + SORT_CHUNK - 1) / SORT_CHUNK;
             R.grid_sort = (int)std::max<uint32_t>(1u, std::min<uint32_t>(chunks, (uint32_t)cus * (uint32_t)per_cu_sort));
         }
-        HIPCHK(hipMalloc((void **)&R.sort_table, (size_t)(d->num_materials + 1) * R.grid_sort * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void **)&R.sort_table, ((size_t)(d->num_materials + 1) * R.grid_sort + 4) * sizeof(uint32_t)));   // + the scan's last 16-B load
     }
     {   // range directory: one count + one base per wave of the persistent grid, per bounce
         const size_t Wp = ((size_t)R.grid * WAVES + 3) & ~(size_t)3;
