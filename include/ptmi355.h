@@ -158,11 +158,11 @@ int pt_set_lens(float lens_radius, float focal_distance);   /* see pt_scene_desc
  * GL PBO in the reference), may be NULL.  host_image_sum: optional HOST buffer
  * of W*H*3 floats that receives the running sum (scene->state.image,
  * pathtrace.cu:389-390), may be NULL.  Synchronous: the buffer is complete
- * when the call returns.  The library page-locks the buffer on first use
- * (hipHostRegister, released by pt_free or when a fifth buffer is handed over)
- * and, when the iteration runs as one launch, lets the kernel write the new
- * sums into it directly over PCIe while it is still tracing; keep the buffer
- * allocated until pt_free. */
+ * when the call returns.  Buffers of 1 MiB and more are page-locked on first
+ * use (hipHostRegister, released by pt_free or when a fifth buffer is handed
+ * over) and, when the iteration runs as one launch, the kernel writes the new
+ * sums into them directly over PCIe while it is still tracing; keep such a
+ * buffer allocated until pt_free. */
 int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum);
 
 /* `count` consecutive iterations iter0..iter0+count-1 traced as one path pool

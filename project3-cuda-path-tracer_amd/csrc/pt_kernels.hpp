@@ -18,12 +18,17 @@ __device__ __forceinline__ uint32_t rank_below(uint64_t m) {
 // the lanes of a wave mask as a per-lane predicate, for free (the mask becomes the exec mask of the branch)
 __device__ __forceinline__ bool lane_of(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
-// Final colour of the path that ends here: one 16-B store into final[pid] (float4, w unused).  As three planes
-// (round 1) every ending path dirtied three 32-B sectors to deliver 12 B -- measured on C2: 86 B of HBM traffic per
-// ray against 62 B of payload, the difference being these stores; one sector now.
-__device__ __forceinline__ void put_final(float *fin, uint32_t pid, f3 c) {
-    reinterpret_cast<float4 *>(fin)[pid] = make_float4(c.x, c.y, c.z, 0.0f);
+// Final colour of the path that ends here: one 16-B store into final[pid] = {r, g, b, stamp of this batch} -- and only
+// when the colour is not zero.  As three planes (round 1) every ending path dirtied three 32-B sectors to deliver
+// 12 B; and four paths in five end with colour 0 (they leave the open box or run out of bounces), which adds nothing to
+// the sum (x + 0 = x exactly; the sums are never -0): k_gather takes an entry whose stamp is not this batch's as 0.
+// Measured on the sorted C3 pipeline: 58 B of HBM writes per ending path before, the 16-B store and its sector.
+__device__ __forceinline__ void put_final(float *fin, uint32_t pid, f3 c, uint32_t stamp) {
+    if (!(c.x == 0.0f && c.y == 0.0f && c.z == 0.0f))                       // NaN compares false: written
+        reinterpret_cast<float4 *>(fin)[pid] = make_float4(c.x, c.y, c.z, __uint_as_float(stamp));
 }
+// the stamp of the current batch: a launch argument, or (graph replay: arguments are frozen) Control::keep[0]
+__device__ __forceinline__ uint32_t batch_stamp(uint32_t arg, const Control *ctl) { return arg ? arg : ctl->keep[0]; }
 
 // ---------------------------------------------------------------------------
 // generateRayFromCamera -> SoA pool, `count` samples (stepping interface; the
@@ -1030,6 +1035,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
     const bool mats_lds = a.nbins <= 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;
+    const uint32_t stamp = batch_stamp(a.fin_stamp, a.ctl);
     const uint32_t n = (COMPACT && a.depth > 0) ? a.ctl->nlive[a.depth] : a.pool_n;
     const bool last_bounce = a.depth == a.trace_depth - 1;
     uint32_t first, count;
@@ -1123,7 +1129,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
                 alive = ptd::shade_scatter(ps, t, nrm, m & 0x7fffffff, (m < 0) ? 0 : 1, mat_src, iter0 + (int)smp, pixel,
                                            a.depth, last_bounce);
                 if (!alive) {
-                    put_final(a.fin, pid, ps.c);
+                    put_final(a.fin, pid, ps.c, stamp);
                 }
             }
             traced += (uint32_t)__popcll((unsigned long long)ballot64(active));
@@ -1189,6 +1195,7 @@ __global__ __launch_bounds__(BLOCK, GEN ? 6 : 8) void k_shade_sorted_w(BounceArg
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *mats = reinterpret_cast<float *>(xch + 2 * WAVES * 64);
     const int iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;
+    const uint32_t stamp = batch_stamp(a.fin_stamp, a.ctl);
     const uint32_t n = (COMPACT && a.depth > 0) ? a.ctl->nlive[a.depth] : a.pool_n;
     const bool last_bounce = a.depth == a.trace_depth - 1;
     uint32_t first, count;
@@ -1274,7 +1281,7 @@ __global__ __launch_bounds__(BLOCK, GEN ? 6 : 8) void k_shade_sorted_w(BounceArg
                 alive = ptd::shade_scatter(ps, th[s], nrm[s], mh[s] & 0x7fffffff, (mh[s] < 0) ? 0 : 1, mats, iter0 + (int)smp, pixel,
                                            a.depth, last_bounce);
                 if (!alive) {
-                    put_final(a.fin, pid[s], ps.c);
+                    put_final(a.fin, pid[s], ps.c, stamp);
                 }
             }
             traced += (uint32_t)__popcll((unsigned long long)ballot64(active));
@@ -1314,6 +1321,7 @@ struct TileCtx {
     SceneAcc acc;               // per-lane gathers: materials, geom info, matrices (LDS or global)
     float *tri_lds;             // triangle tile (MESH_TILES)
     int lane, iter0;
+    uint32_t stamp;             // of this batch's final colours (put_final)
 };
 
 // a tile in flight: what its shading needs besides the wave's LDS block (rays, best keys, winner records)
@@ -1391,7 +1399,7 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
         alive = ptd::shade_scatter(ps, t, nrm, mat, outside, c.acc.mats, c.iter0 + (int)tr.smp, tr.pixel, depth,
                                    depth == a.trace_depth - 1);
         if (!alive) {
-            put_final(a.fin, tr.pid, ps.c);
+            put_final(a.fin, tr.pid, ps.c, c.stamp);
         }
     }
     // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
@@ -1539,6 +1547,7 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
     const uint32_t W = gridDim.x * WAVES;
     const uint32_t wid = run_id();
     c.iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;       // graph replay: arguments are frozen
+    c.stamp = batch_stamp(a.fin_stamp, a.ctl);
     const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);                        // logical tiles per wave (one contiguous run)
@@ -1624,6 +1633,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a)
     const uint32_t W = gridDim.x * WAVES;
     const uint32_t wid = run_id();
     c.iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;
+    c.stamp = batch_stamp(a.fin_stamp, a.ctl);
     const uint32_t n = a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);
@@ -1687,9 +1697,11 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a)
             float cx = 0.0f, cy = 0.0f, cz = 0.0f;
             if (j < n) {                                            // agent-scope loads: from the L2 the stores went to
                 const float *f = a.fin + (size_t)j * 4;
-                cx = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cy = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cz = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__float_as_uint(__hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == c.stamp) {
+                    cx = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cy = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cz = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             tr[3 * lane] = cx; tr[3 * lane + 1] = cy; tr[3 * lane + 2] = cz;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2186,7 +2198,7 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_cache_first(Isect cache
 
 // shadeFakeMaterial (pathtrace.cu:224-266): one bounce, never spawns a ray
 __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const float *mats_g, TileMap map,
-                                                      int iter0, uint32_t n, float *fin) {
+                                                      int iter0, uint32_t n, float *fin, uint32_t stamp_arg, const Control *ctl) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint32_t pid = p.pid(i);
@@ -2212,14 +2224,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const fl
         c = ptd::mk(0.0f, 0.0f, 0.0f);
     }
     p.f(i, 6) = c.x; p.f(i, 7) = c.y; p.f(i, 8) = c.z;
-    put_final(fin, pid, c);
+    put_final(fin, pid, c, batch_stamp(stamp_arg, ctl));
 }
 
 // finalGather (pathtrace.cu:269-278): image[pixelIndex] += colour, one add per
 // pixel per iteration, samples added in iteration order
 __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin, uint32_t cap, TileMap map,
                                                   int count, Control *ctl, Persist *per, int depths,
-                                                  uint32_t fake_rays, int partial_counts, int counters_only) {
+                                                  uint32_t fake_rays, int partial_counts, int counters_only, uint32_t stamp_arg) {
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
     if (j == 0) {                    // fold this batch's ray count into the persistent counter
         if (partial_counts)          // k_iteration left 32 partial sums per bounce
@@ -2239,6 +2251,8 @@ __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin
     float r = image[3 * pix + 0], g = image[3 * pix + 1], b = image[3 * pix + 2];
     // samples are added in iteration order (one add per pixel per iteration, as the reference does); the loads of
     // eight samples are issued together, the adds stay in order
+    // an entry counts when it carries this batch's stamp; the others are paths that ended with colour 0 (put_final)
+    const uint32_t stamp = batch_stamp(stamp_arg, ctl);
     const float4 *f4 = reinterpret_cast<const float4 *>(fin) + j;
     int s = 0;
     for (; s + 8 <= count; s += 8) {
@@ -2246,11 +2260,12 @@ __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin
 #pragma unroll
         for (int u = 0; u < 8; ++u) c[u] = f4[(size_t)(s + u) * map.tile_pixels];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { r += c[u].x; g += c[u].y; b += c[u].z; }
+        for (int u = 0; u < 8; ++u)
+            if (__float_as_uint(c[u].w) == stamp) { r += c[u].x; g += c[u].y; b += c[u].z; }
     }
     for (; s < count; ++s) {
         const float4 c = f4[(size_t)s * map.tile_pixels];
-        r += c.x; g += c.y; b += c.z;
+        if (__float_as_uint(c.w) == stamp) { r += c.x; g += c.y; b += c.z; }
     }
     image[3 * pix + 0] = r; image[3 * pix + 1] = g; image[3 * pix + 2] = b;
 }

@@ -80,7 +80,9 @@ __device__ __forceinline__ uint32_t sample_of(const TileMap &m, uint32_t pid) {
 
 struct Control {         // zeroed from `stamp` on by one hipMemsetAsync per batch (2 KiB)
     uint32_t iter0;                 // first iteration of the batch when the launches come from a replayed graph
-    uint32_t keep[15];              //   (kernel arguments are frozen at capture time); survives the per-batch clear
+    uint32_t keep[15];              //   (kernel arguments are frozen at capture time); survives the per-batch clear.
+                                    //   keep[0]: the batch's final-colour stamp under graph replay (-DPT_MESH_STATS builds count
+                                    //   walks there: do not combine them with PTMI355_GRAPH=1)
     unsigned long long stamp[16];   // -DPT_STAMPS: s_memrealtime at the phases of wave 0 / the last workgroup
     uint32_t nlive[MAX_DEPTH + 1];  // nlive[d] = paths entering bounce d (compaction on)
     uint32_t alive[MAX_DEPTH + 1];  // paths actually traced at bounce d
@@ -176,7 +178,8 @@ struct BounceArgs {
     Control *ctl;
     RangeDir dir_in;       // directory of the pool being read (mem == nullptr: dense)
     RangeDir dir_out;      // directory this launch produces
-    float *fin;            // final colours, float4[cap] (w unused), index = pid
+    float *fin;            // final colours, float4[cap] = {r, g, b, batch stamp}, index = pid; written for non-zero colours only
+    uint32_t fin_stamp;    // this batch's stamp; 0: read Control::keep[0] (graph replay)
     pt_camera cam;         // used when gen_rays != 0
     int depth, trace_depth, iter0;   // iter0 < 0: read Control::iter0 (graph replay)
     uint32_t pool_n;       // paths in the pool when compaction is off / at bounce 0

@@ -96,7 +96,8 @@ struct Renderer {
     float *cache_mem = nullptr;   // first-bounce cache: 5 planes of tile_pixels (PT_CACHE_FIRST)
     bool cache_valid = false;
     Isect isect{};
-    float *final_mem = nullptr;   // float4[cap]: final colour of every path of the batch, index = pid
+    float *final_mem = nullptr;   // float4[cap]: {r, g, b, stamp} of the paths that ended with a non-zero colour, index = pid
+    uint32_t fin_serial = 0;      // stamp of the current batch's entries (never 0; a wrap clears the buffer)
     float *image = nullptr;
     bool own_image = false;
     float *d_geoms = nullptr, *d_mats = nullptr, *d_tris = nullptr;
@@ -131,6 +132,7 @@ struct Renderer {
     float *epi_host = nullptr;    // pt_trace: the caller's image, device-mapped, for k_iteration's own gather (this call only)
     bool epi_done = false;        // ... and k_iteration took it
     bool epi_enabled = true;      // PTMI355_HOST_EPILOGUE=0: always copy after the iteration
+    bool pin_enabled = true;      // PTMI355_PIN=0: never page-lock caller buffers (copies take the runtime's pageable path)
     bool use_graphs = false;      // PTMI355_GRAPH=1 turns replay on (measured slower than direct launches on ROCm 7.2: DESIGN.md 6.10)
     bool capturing = false;
     int mesh_mode = MESH_NONE;    // MESH_TILES: every triangle per ray; MESH_BVH: PT_MESH_BVH culling
@@ -256,6 +258,7 @@ BounceArgs bounce_args(int depth) {
     a.dir_in = tile_dir((R.flags & PT_COMPACT) ? R.cur_dir : -1);
     a.dir_out = tile_dir(depth);
     a.fin = R.final_mem;
+    a.fin_stamp = R.capturing ? 0u : R.fin_serial;
     a.cam = R.cam;
     a.lens = R.lens;
     a.depth = depth; a.trace_depth = R.trace_depth; a.iter0 = R.capturing ? -1 : R.step_iter0;
@@ -272,6 +275,16 @@ BounceArgs bounce_args(int depth) {
     return a;
 }
 
+// every batch stamps the final colours it writes with a fresh serial number (put_final / k_gather); under graph replay
+// the kernels read it from Control::keep[0]
+int next_fin_stamp(void) {
+    if (++R.fin_serial == 0) {                                    // 2^32 batches later: forget every old stamp
+        HIPCHK(hipMemsetAsync(R.final_mem, 0, (size_t)R.cap * 16, R.stream));
+        R.fin_serial = 1;
+    }
+    return PT_OK;
+}
+
 int enqueue_begin(int iter0, int count, bool stepping) {
     if (count < 1 || count > R.max_batch)
         return fail(PT_ERR_INVALID, "batch count %d outside [1, max_batch=%d]", count, R.max_batch);
@@ -280,6 +293,7 @@ int enqueue_begin(int iter0, int count, bool stepping) {
     if (iter0 < 0 || (int64_t)iter0 + count - 1 > 0x7fffffff)
         return fail(PT_ERR_INVALID, "iteration %d (+%d) outside [0, 2^31)", iter0, count);
     R.step_iter0 = iter0; R.step_count = count; R.step_depth = 0; R.cur = 0; R.cur_dir = -1;
+    if (!R.capturing) { const int rc = next_fin_stamp(); if (rc) return rc; }
     R.sorted_isects = false;
     R.mesh_marked = false;
     HIPCHK(hipMemsetAsync(&R.ctl->stamp, 0, R.ctl_bytes, R.stream));      // everything but Control::iter0
@@ -445,7 +459,7 @@ int enqueue_fake(void) {
     launch_intersect(R.pool[R.cur], nullptr, total, tile_dir(-1), nullptr);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_shade_fake, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.pool[R.cur],
-                       R.isect, R.scene.mats, R.map, R.step_iter0, total, R.final_mem);
+                       R.isect, R.scene.mats, R.map, R.step_iter0, total, R.final_mem, R.fin_serial, R.ctl);
     HIPCHK(hipGetLastError());
     R.step_depth = 1;
     return PT_OK;
@@ -457,7 +471,7 @@ int enqueue_end(void) {
                        R.final_mem, R.cap, R.map,
                        R.step_count, R.ctl, R.persist, (R.flags & PT_FAKE_SHADER) ? 0 : R.trace_depth,
                        (R.flags & PT_FAKE_SHADER) ? (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count : 0u,
-                       R.whole ? 1 : 0, R.epi_done ? 1 : 0);
+                       R.whole ? 1 : 0, R.epi_done ? 1 : 0, R.capturing ? 0u : R.fin_serial);
     R.whole = false;
     HIPCHK(hipGetLastError());
     return PT_OK;
@@ -530,7 +544,12 @@ int enqueue_batch(int iter0, int count) {
         it = R.graphs.emplace(count, g).first;
     }
     const Renderer::BatchGraph &g = it->second;
+    {
+        const int rc = next_fin_stamp();
+        if (rc) return rc;
+    }
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&R.ctl->iter0, iter0, 1, R.stream));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&R.ctl->keep[0], (int)R.fin_serial, 1, R.stream));
     HIPCHK(hipGraphLaunch(g.exec, R.stream));
     R.step_iter0 = iter0; R.step_count = count;
     R.cur = g.cur; R.cur_dir = g.cur_dir; R.step_depth = g.step_depth;
@@ -581,26 +600,43 @@ int upload_cull(const pt_scene_desc *d, const pt_camera &cam) {
 }
 
 // page-lock a caller-owned host buffer (idempotent per pointer; failures are not errors: the copy then takes the
-// runtime's pageable path)
-void pin_host(void *ptr, size_t bytes) {
-    for (auto &h : R.host_regs)
-        if (h.ptr == ptr) {
-            if (h.bytes >= bytes) return;
+// runtime's pageable path).  Returns true when [ptr, ptr + bytes) is registered BY THIS LIBRARY right now.  A recorded
+// registration that overlaps the new range without being it belongs to a buffer the caller has since freed (the
+// allocator handed part of its pages to this one): it is dropped first -- a stale registration would make
+// hipHostRegister fail for the new buffer while hipHostGetDevicePointer / the runtime's copy path still resolve the
+// new address through the old mapping, which ends where the OLD buffer ended (a GPU page fault past it).
+// Only buffers of 1 MiB and more are page-locked: the allocator gives those their own mapping (whole pages that belong
+// to nothing else).  Smaller ones share their pages with the caller's other heap objects; registering and later
+// unregistering such pages left the runtime's copy path with stale ideas about them -- device-to-host copies into
+// OTHER small buffers on the same pages ended in GPU page faults ("Memory access fault", found by the full GPU test
+// suite) -- and at that size the pageable path costs nothing that matters.
+bool pin_host(void *ptr, size_t bytes) {
+    if (!R.pin_enabled || bytes < ((size_t)1 << 20)) return false;
+    const char *lo = (const char *)ptr, *hi = lo + bytes;
+    for (size_t k = 0; k < R.host_regs.size();) {
+        auto &h = R.host_regs[k];
+        const char *hlo = (const char *)h.ptr, *hhi = hlo + h.bytes;
+        if (h.ptr == ptr && h.bytes >= bytes) return true;
+        if (hlo < hi && lo < hhi) {                       // overlaps (or the same start, too short): stale
             (void)hipHostUnregister(h.ptr);
-            h = R.host_regs.back(); R.host_regs.pop_back();
-            break;
+            R.host_regs.erase(R.host_regs.begin() + (long)k);
+            continue;
         }
+        ++k;
+    }
     if (R.host_regs.size() >= 4) {                    // a host that keeps handing over new buffers: forget the oldest
         (void)hipHostUnregister(R.host_regs.front().ptr);
         R.host_regs.erase(R.host_regs.begin());
     }
-    if (hipHostRegister(ptr, bytes, hipHostRegisterMapped) == hipSuccess) R.host_regs.push_back({ptr, bytes});
-    else (void)hipGetLastError();
+    if (hipHostRegister(ptr, bytes, hipHostRegisterMapped) == hipSuccess) { R.host_regs.push_back({ptr, bytes}); return true; }
+    (void)hipGetLastError();
+    return false;
 }
 
-// the device's address of a page-locked host buffer (nullptr: not mappable -- the caller falls back to a copy)
+// the device's address of a page-locked host buffer (nullptr: not registered by us or not mappable -- the caller falls
+// back to a copy)
 float *map_host(float *host, size_t bytes) {
-    pin_host(host, bytes);
+    if (!pin_host(host, bytes)) return nullptr;
     void *dev = nullptr;
     if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return (float *)dev;
@@ -967,6 +1003,8 @@ static int init_impl(const pt_scene_desc *d) {
     if (const char *wm = getenv("PTMI355_WHOLE_MAX")) R.whole_max_paths = strtoull(wm, nullptr, 10);
     R.epi_enabled = true;
     if (const char *e = getenv("PTMI355_HOST_EPILOGUE")) R.epi_enabled = atoi(e) != 0;
+    R.pin_enabled = true;
+    if (const char *e = getenv("PTMI355_PIN")) R.pin_enabled = atoi(e) != 0;
     R.npix = W * H;
     R.map.W = W; R.map.H = H; R.map.tile_index = d->tile_index; R.map.tile_count = tile_count;
     R.map.strip_rows = tile_count > 1 ? d->strip_rows : H;
@@ -1110,6 +1148,8 @@ static int init_impl(const pt_scene_desc *d) {
         if (rc != PT_OK) return rc;
     }
     HIPCHK(hipMalloc(&R.final_mem, capz * 4 * 4));
+    HIPCHK(hipMemsetAsync(R.final_mem, 0, capz * 4 * 4, R.stream));          // no entry carries a stamp yet (stamps start at 1)
+    R.fin_serial = 0;
     if (d->device_image) { R.image = d->device_image; R.own_image = false; }
     else {
         HIPCHK(hipMalloc(&R.image, (size_t)R.npix * 3 * 4));
