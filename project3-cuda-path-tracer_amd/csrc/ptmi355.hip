@@ -1150,6 +1150,7 @@ static int init_impl(const pt_scene_desc *d) {
     HIPCHK(hipMalloc(&R.final_mem, capz * 4 * 4));
     HIPCHK(hipMemsetAsync(R.final_mem, 0, capz * 4 * 4, R.stream));          // no entry carries a stamp yet (stamps start at 1)
     R.fin_serial = 0;
+    if (const char *e = getenv("PTMI355_FIN_SERIAL")) R.fin_serial = (uint32_t)strtoul(e, nullptr, 0);   // tests: start near the wrap
     if (d->device_image) { R.image = d->device_image; R.own_image = false; }
     else {
         HIPCHK(hipMalloc(&R.image, (size_t)R.npix * 3 * 4));

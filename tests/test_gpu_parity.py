@@ -898,6 +898,35 @@ def test_bounce0_candidate_masks(pt, po, scenes, monkeypatch):
     monkeypatch.delenv("PTMI355_CULL0")
 
 
+def test_final_colour_stamps(pt, po, scenes, monkeypatch):
+    """Paths that end with colour 0 write nothing; k_gather tells this batch's entries from stale ones by the batch's
+    stamp (a per-session serial number in the entry's fourth component).  The same iteration traced again after
+    clear_image, batches of different sizes over the same entries, and the serial's wrap-around at 2^32 (the buffer
+    is cleared and the serial restarts) all give the oracle's sums."""
+    s = scenes["cornell_64"]
+    n = 64 * 64
+    for start in (None, "0xfffffffd"):                    # the second run wraps after three batches
+        if start:
+            monkeypatch.setenv("PTMI355_FIN_SERIAL", start)
+        scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=4)
+        ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], flags=po.F_COMPACT, trig=po.TRIG_SHARED)
+        img = np.zeros((n, 3), dtype=np.float32)
+        for iter0, count in ((1, 4), (5, 1), (6, 3), (9, 4), (13, 2), (15, 1)):
+            pt.trace_batch(iter0, count, img)
+            for it in range(iter0, iter0 + count):
+                ref.iterate(it)
+            assert img.tobytes() == ref.image.tobytes(), (start, iter0)
+        pt.clear_image()
+        ref.image[:] = 0
+        pt.trace_batch(1, 4, img)                          # the same iterations again: new stamps, same colours
+        for it in range(1, 5):
+            ref.iterate(it)
+        assert img.tobytes() == ref.image.tobytes()
+        pt.pathtraceFree()
+    monkeypatch.delenv("PTMI355_FIN_SERIAL")
+
+
 def test_mesh_bvh_two_meshes_fused(pt, po, scenes):
     """Two meshes (one nested inside the glass ball's silhouette, one overlapping the first) through the mesh
     pre-pass: every walk visits both trees and keeps the nearer hit, geom order on ties."""
