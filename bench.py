@@ -286,7 +286,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(scene)
 
-    pcie = pcie_async = None
+    pcie = pcie_async = pcie_md5 = None
     if args.pcie and world == 1:
         # the reference's calling pattern: one pathtrace() per iteration, the running sum in host memory after every
         # call (pathtrace.cu:389-390).  Synchronous (the default: exact reference semantics, host buffer page-locked by
@@ -308,6 +308,9 @@ def main():
             rate = round((pt.total_rays() - r0) / el / 1e6, 2)
             if mode_flags == flags:
                 pcie = rate
+                if args.digest:
+                    import hashlib
+                    pcie_md5 = hashlib.md5(host.tobytes()).hexdigest()   # the host image after the synchronous calls
             else:
                 pcie_async = rate
     digest = None
@@ -347,6 +350,8 @@ def main():
         if pcie:
             out["config"]["pcie_inclusive_mrays_per_s"] = pcie
             out["config"]["pcie_inclusive_async_mrays_per_s"] = pcie_async
+            if pcie_md5:
+                out["config"]["pcie_host_image_md5"] = pcie_md5
         if roofline:
             out["roofline"] = roofline
         if cpu:

@@ -13,10 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(cmd, timeout=600):
+def run(cmd, timeout=600, per_bounce=True):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env["PTMI355_WHOLE_MAX"] = "0"           # a kernel per bounce whatever the batch size (the launch count is asserted)
+    if per_bounce:
+        env["PTMI355_WHOLE_MAX"] = "0"       # a kernel per bounce whatever the batch size (the launch count is asserted)
+    else:
+        env.pop("PTMI355_WHOLE_MAX", None)
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
@@ -25,10 +28,12 @@ def run(cmd, timeout=600):
 
 def test_single_gpu_line():
     d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
-             "--digest"])
+             "--digest", "--pcie"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
+    # the reference's calling pattern (one pathtrace() per iteration with the host image): synchronous and PT_ASYNC_IMAGE
+    assert d["config"]["pcie_inclusive_mrays_per_s"] > 100 and d["config"]["pcie_inclusive_async_mrays_per_s"] > 100
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["value"] > 100
     r = d["roofline"]
     assert r["bound"] in ("valu-issue", "hbm") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
@@ -39,6 +44,19 @@ def test_single_gpu_line():
         assert r["traffic"] is None             # never a stale number
     assert r["launches"] == 3 * 8
     test_single_gpu_line.md5 = d["image_md5"]
+
+
+def test_one_iteration_per_call_with_the_host_image():
+    """bench.py --pcie at 1 spp per step under the default launch plan: the iteration runs as ONE launch whose waves
+    write the running sum into the (page-locked, device-mapped) host image themselves; the frame after the timed
+    steps equals the frame of the launch-per-bounce plan with a copy after every iteration."""
+    args = [sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--batch", "1", "--no-cpu-baseline",
+            "--no-roofline", "--digest", "--pcie"]
+    one = run(args, per_bounce=False)
+    per = run(args, per_bounce=True)
+    assert one["config"]["pcie_inclusive_mrays_per_s"] > 100 and per["config"]["pcie_inclusive_mrays_per_s"] > 100
+    assert one["image_md5"] == per["image_md5"]
+    assert one["config"]["pcie_host_image_md5"] == per["config"]["pcie_host_image_md5"]     # 136 calls' running sum, on the host
 
 
 def _two(port, *extra, backend="gloo", same_device=True):
