@@ -18,6 +18,31 @@ __device__ __forceinline__ uint32_t rank_below(uint64_t m) {
 // the lanes of a wave mask as a per-lane predicate, for free (the mask becomes the exec mask of the branch)
 __device__ __forceinline__ bool lane_of(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+// The instruction arbiter serves the OLDEST wave of a SIMD first.  In a persistent grid whose waves all have the same
+// amount of work that is the worst order: measured on k_bounce (per-wave start / end times, 5 waves per SIMD), the wave
+// in slot 0 -- the first-dispatched fifth of the workgroups -- ended at 0.55-0.7 of the launch, the one in slot 4 at
+// 0.92, and every SIMD spent the last third of every launch with fewer and fewer waves to pick instructions from (mean
+// residency 0.71-0.81 of the launch).  Rotating the user priority (s_setprio, which the arbiter ranks above age) with
+// the wave's tile counter gives every wave the same share of every level: mean residency 0.84-0.94, C2 +10 %.  (No
+// effect in k_mesh -- one 16-wave workgroup per CU, whose waves wait on dependent fetches -- and -2 % in the sorted
+// shade kernel, eight short-lived workgroups per CU that wait on memory: not used there.)
+// `step`: the wave's loop counter (tiles); `slots`: workgroups per CU of the launch (slot = dispatch order).
+#ifndef PT_NO_ROTATE_PRIO
+__device__ __forceinline__ void set_priority(uint32_t level) {
+    switch (level & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+#else
+__device__ __forceinline__ void set_priority(uint32_t) {}
+#endif
+__device__ __forceinline__ void rotate_priority(uint32_t step, uint32_t slots) {
+    set_priority((blockIdx.x * slots) / gridDim.x + step);
+}
+
 // Final colour of the path that ends here: one 16-B store into final[pid] = {r, g, b, stamp of this batch} -- and only
 // when the colour is not zero.  As three planes (round 1) every ending path dirtied three 32-B sectors to deliver
 // 12 B; and four paths in five end with colour 0 (they leave the open box or run out of bounces), which adds nothing to
@@ -710,6 +735,7 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t tile = wid * R + r;
         if (MESH != MESH_TILES && tile >= tiles) break;
+        rotate_priority(r, PT_ISECT_WAVES + 1);
         const bool have = tile < tiles;
         const uint32_t i = tile * TILE + lane;
         bool active = have && i < n;
@@ -1469,6 +1495,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
     for (uint32_t r = 0; r < count; ++r) {
         const uint32_t tile = first_tile + r;
         if (MESH != MESH_TILES && !own_span && tile >= tiles) break;
+        rotate_priority(r + (uint32_t)depth, PT_MIN_WAVES + 1);
         unsigned long long gmask = 0;
         if (masked) {
             gmask = ((const __attribute__((address_space(4))) unsigned long long *)(unsigned long long)a.cull0)[mtile];
