@@ -40,6 +40,8 @@ for m in "--scaling weak" "--scaling strong" "--scaling strong --reduce-every 1"
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29711 bench.py --gpus 2 --backend gloo --same-device --steps 10 --warmup 2 --batch 8 --no-roofline $m 2>/dev/null | tail -1 | cut -c1-900
 done > "$OUT/bench_r02_two_ranks_one_gpu.txt"
 (cd profiles/microbench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_peak valu_peak.hip && timeout 400 /tmp/valu_peak > "$OUT/valu_peak_r02.json")
+# per-wave start / end times of k_bounce with and without the priority rotation (two diagnostic builds)
+timeout 600 python profiles/wave_times.py > "$OUT/wave_times_r02.txt" 2>&1
 # soak: random cube/sphere scenes under every pipeline + the cull-stress rays, then random meshes (hierarchy and
 # every-triangle kernel) incl. grazing rays -- all against the CPU oracle, bit for bit
 (timeout 900 python tests/tools/fuzz_gpu.py 1000 300; timeout 900 python tests/tools/fuzz_gpu.py mesh 1 120) 2>&1 | grep -v amdgpu.ids | tail -12 > "$OUT/fuzz.log"

@@ -1553,8 +1553,18 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
     }
 }
 
+#ifdef PT_WAVE_TIMES
+// diagnostic build (profiles/wave_times.py): start / end time (100 MHz ticks) and hardware slot of every wave of
+// k_bounce, per bounce -- what showed the arbiter's oldest-first order (rotate_priority)
+__device__ unsigned long long g_wave_times[8][8192][2];
+__device__ uint32_t g_wave_hw[8][8192];
+#endif
+
 template <int MODE, bool COMPACT, int MESH, bool SLDS>
 __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
+#ifdef PT_WAVE_TIMES
+    const unsigned long long wt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
     const LdsCarve lc = carve_lds(lds_raw, a.scene, SLDS);
@@ -1592,6 +1602,15 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
     run_tiles<MODE, COMPACT, MESH>(a, c, q, a.in, a.out, a.depth, a.gen_rays != 0, wid * R, R, tiles, n, packed_in, span_in,
                                    cur, wid * R * TILE, false, WgSpans{}, packed, traced);
     STAMP(6);
+#ifdef PT_WAVE_TIMES
+    if (lane == 0 && a.depth < 8 && wid < 8192) {
+        g_wave_times[a.depth][wid][0] = wt0; g_wave_times[a.depth][wid][1] = __builtin_amdgcn_s_memrealtime();
+        uint32_t xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_wave_hw[a.depth][wid] = (xcc & 0xf) | (hwid << 4);
+    }
+#endif
     // paths traced this bounce: with compaction it is simply the live count; otherwise count the alive
     // slots, one atomic per workgroup (summed through LDS) rather than one per wave on a single address
     if (COMPACT) {

@@ -1579,3 +1579,12 @@ int pt_get_stats(pt_stats *stats) {
 }
 
 }  // extern "C"
+
+#ifdef PT_WAVE_TIMES
+// diagnostic build only (not in include/ptmi355.h): per-wave start / end ticks and hardware ids of k_bounce's last launches
+extern "C" int ptdbg_wave_times(unsigned long long *times /* [8][8192][2] */, uint32_t *hw /* [8][8192] */) {
+    if (hipMemcpyFromSymbol(times, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 8 * 8192 * 2) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_wave_hw), sizeof(uint32_t) * 8 * 8192) != hipSuccess) return -1;
+    return 0;
+}
+#endif
