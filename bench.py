@@ -2,7 +2,7 @@
 """bench.py -- Mrays/s of the wavefront path tracer on the BASELINE.json workload.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config c2|c3|c4|c5]
-                    [--scaling weak|strong] [--reduce-every I] [--collective gather|reduce]
+                    [--scaling weak|strong] [--reduce-every I] [--collective gather|reduce] [--inproc]
 
 A *step* is one pass of the hot path over one batch of synthetic input: B iterations (samples per pixel) of the
 800x800 depth-8 Cornell box with the mirror ball (BASELINE.json configs[1], "c2"), traced as one path pool through
@@ -15,6 +15,8 @@ of its tile per step.  --scaling strong: the frame gets B iterations per step wh
 tiles' running sums travel to rank 0 once per --reduce-every iterations (default: once per step; 1 = the per-iteration
 exchange of BASELINE.json's north_star) as a gather of the packed tile rows (N/k*12 B per rank) or, with
 --collective reduce, as a sum of the zero-padded full frames; either overlaps the next batch's tracing.
+--inproc: the same tiling inside the library, one process driving all N devices (include/ptmi355.h:
+pt_scene_desc::devices; RCCL send/recv from C++) -- what a host that links libptmi355.so gets; same JSON line.
 
 Extra JSON objects (see the task statement): `roofline` for the dominant kernel and `cpu_baseline` (the plain-C
 oracle on this host's cores, rank 0, N = 1 only).  The kernel is bound by vector-instruction issue, not by HBM:
@@ -94,6 +96,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device exercises the N>1 code path on a single GPU (debug)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--inproc", action="store_true",
+                    help="N > 1 in ONE process: the library tiles the frame over --gpus devices itself (one host thread, one "
+                         "stream per device; tiles gathered onto device 0 over RCCL -- csrc/pt_multi.hpp); no torch.distributed")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on a 1-GPU box: run the N > 1 code path (process group, tile exchange, max / sum over "
                          "ranks) with a world of ONE rank, so that the RCCL calls themselves execute on hardware")
@@ -113,7 +118,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    inproc = args.inproc
+    if inproc and world != 1:
+        raise SystemExit("--inproc is one process: do not launch it through torch.distributed.run")
+    if world != args.gpus and not inproc:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
@@ -122,7 +130,8 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist_on = world > 1 or args.force_dist
+    dist_on = (world > 1 or args.force_dist) and not inproc
+    n_tiles = args.gpus if inproc else world          # GPUs the frame is tiled over
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -148,8 +157,8 @@ def main():
     for f in args.flags.split(","):
         flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED,
                   "cache": pt.PT_CACHE_FIRST, "bvh": pt.PT_MESH_BVH, "aa": pt.PT_AA_JITTER, "": 0}[f]
-    per_step_iters = pt.sharding.step_iterations(0, args.batch, world, args.scaling)[1]
-    every = per_step_iters if (args.reduce_every <= 0 or not dist_on) else min(args.reduce_every, per_step_iters)
+    per_step_iters = pt.sharding.step_iterations(0, args.batch, n_tiles, args.scaling)[1]
+    every = per_step_iters if (args.reduce_every <= 0 or not (dist_on or inproc)) else min(args.reduce_every, per_step_iters)
 
     # an explicit (non-null) torch stream: the library launches on it, torch copies / RCCL order against it
     stream = torch.cuda.Stream()
@@ -157,9 +166,14 @@ def main():
     image = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")     # accumulation buffer (torch-owned)
     frame = torch.zeros_like(image) if dist_on else None                # rank 0: the assembled frame / reduce staging
     torch.cuda.synchronize()
-    pt.pathtraceInit(scene, flags=flags, device=local_rank, stream=stream.cuda_stream,
-                     tile=(rank, world, args.strip_rows), max_batch=every,
-                     device_image=image.data_ptr())
+    if inproc:
+        # the library owns every device's stream and buffers; device 0 assembles the frame after every batch
+        devices = [0] * args.gpus if args.same_device else list(range(args.gpus))
+        pt.pathtraceInit(scene, flags=flags, tile=(0, 1, args.strip_rows), max_batch=every, devices=devices)
+    else:
+        pt.pathtraceInit(scene, flags=flags, device=local_rank, stream=stream.cuda_stream,
+                         tile=(rank, world, args.strip_rows), max_batch=every,
+                         device_image=image.data_ptr())
     gather = None
     if dist_on and args.collective == "gather":
         gather = pt.sharding.TileGather(torch, dist, rank, world, args.strip_rows, W, H, torch.device("cuda"),
@@ -181,7 +195,7 @@ def main():
             pending[0] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)
 
     def step(i):
-        iter0, count = pt.sharding.step_iterations(i, args.batch, world, args.scaling)
+        iter0, count = pt.sharding.step_iterations(i, args.batch, n_tiles, args.scaling)
         for j in range(0, count, every):
             pt.trace_batch_async(iter0 + j, min(every, count - j))          # enqueue only
             if dist_on:
@@ -196,13 +210,15 @@ def main():
                 pending[0] = None
             torch.cuda.synchronize()
             dist.barrier()
+        if inproc:
+            pt.synchronize()                       # every device's launch and exchange stream
         torch.cuda.synchronize()
 
     it = 0
     for _ in range(args.warmup):
         step(it); it += 1
     barrier()
-    profile_on = not args.no_roofline and args.steps * (scene.traceDepth + 2) <= 2000
+    profile_on = not args.no_roofline and args.steps * (scene.traceDepth + 2) * -(-per_step_iters // every) <= 2000
     rays0, first0, _ = pt.counters()
     barrier()
     t0 = time.perf_counter()
@@ -283,11 +299,11 @@ def main():
 
     # ---- CPU baseline: the oracle (plain-C port) on this host, rank 0, N = 1 only ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not inproc and not args.no_cpu_baseline:
         cpu = cpu_baseline(scene)
 
     pcie = pcie_async = pcie_md5 = None
-    if args.pcie and world == 1:
+    if args.pcie and world == 1 and not inproc:
         # the reference's calling pattern: one pathtrace() per iteration, the running sum in host memory after every
         # call (pathtrace.cu:389-390).  Synchronous (the default: exact reference semantics, host buffer page-locked by
         # the library) and with PT_ASYNC_IMAGE (the copy of call i overlaps the tracing of call i+1).
@@ -318,6 +334,8 @@ def main():
         import hashlib
         barrier()
         final = image
+        if inproc:
+            final = torch.from_numpy(pt.get_image(npix))        # the frame device 0 assembled
         if dist_on:
             # the frame rank 0 holds after the last exchange IS the result (gather: copies; reduce: sum with zeros)
             final = frame
@@ -329,20 +347,24 @@ def main():
         out = {
             "metric": "Mrays/sec (live paths x bounces) at 800x800 Cornell depth 8" if args.config == "c2" else
                       "Mrays/sec (live paths x bounces), config %s" % args.config,
-            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_tiles, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 4),
-            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling if n_tiles > 1 else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "scenes/cornell.txt (%s) %dx%d depth %d, compaction on, %d spp per step per GPU-tile"
                                    % (scene_name, W, H, scene.traceDepth, per_step_iters),
                        "batch_spp": args.batch, "flags": args.flags,
-                       "sharding": "whole frame" if not dist_on else
+                       "sharding": ("in the library (one process): interleaved %d-row strips over %d devices, one host thread and "
+                                    "stream per device; %s scaling; after every batch of %d iterations the tiles' running sums "
+                                    "travel to device 0 (%s) and are unpacked into the frame, overlapped with the next batch"
+                                    % (args.strip_rows, n_tiles, args.scaling, every, pt.exchange_transport())) if inproc else
+                       "whole frame" if not dist_on else
                        "interleaved %d-row strips over %d GPUs; %s scaling; tiles' running sums to rank 0 every %d "
                        "iterations by %s, overlapped with the next batch"
                        % (args.strip_rows, world, args.scaling, every,
                           "a gather of the packed tile rows (%.2f MB per rank)" % (gather.bytes_per_rank / 1e6) if gather
                           else "reduce(SUM) of the zero-padded frames (%.2f MB per rank)" % (npix * 12 / 1e6)),
-                       "exchanges_per_step": 0 if not dist_on else -(-per_step_iters // every),
+                       "exchanges_per_step": 0 if not (dist_on or inproc) else -(-per_step_iters // every),
                        "rays_per_step": int(rays / args.steps)},
         }
         if digest:
@@ -365,7 +387,7 @@ def counter_profile(args, world):
     """profiles/traffic.json (written by profiles/summarize.py from the rocprofv3 PMC passes) when it belongs to THIS
     build (hash of the kernel sources) and THIS command line; None otherwise -- stale counters are never reported."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if world != 1 or not os.path.exists(path):
+    if world != 1 or (args.inproc and args.gpus != 1) or not os.path.exists(path):
         return None
     try:
         t = json.load(open(path))

@@ -17,6 +17,8 @@
  *
  * Contract (same as the reference, src/pathtrace.cu:70-75): one renderer
  * instance per process, not re-entrant, calls are synchronous unless stated.
+ * One instance may drive several GPUs of the node (pt_scene_desc::devices):
+ * that stays invisible to the caller, who still sees one frame.
  * Every int-returning entry point returns PT_OK (0) or a negative pt_status;
  * pt_last_error() then describes the failure.  The library never falls back
  * to a CPU path: without a HIP device every call fails with PT_ERR_DEVICE.
@@ -129,6 +131,18 @@ typedef struct pt_scene_desc {
      * around camera.position and meet the pinhole ray on the plane focal_distance along
      * camera.view.  0 (a zeroed descriptor) = the reference's pinhole camera. */
     float lens_radius, focal_distance;
+    /* Several GPUs of one node behind this one session (SURVEY 8b "Threading", 8e): the frame is tiled over
+     * devices[0..num_devices) in interleaved strips of strip_rows rows (0 = 8), every device traces its tile on its
+     * own host thread and stream, and after every pt_trace / batch the tiles' running sums travel to devices[0] over
+     * RCCL (one grouped ncclSend / ncclRecv exchange on a communicator from ncclCommInitAll; peer copies where RCCL
+     * cannot be used), which assembles the frame pt_trace hands back -- bit-identical to the single-device image
+     * (global pixelIndex as RNG key).  num_devices == 0 (a zeroed descriptor): the single device `device`, unless
+     * the environment names several (PTMI355_DEVICES="0,1,2,3" | "all": the reference's host, which knows one
+     * device -- preview.cpp:107 -- then needs no change).  With several devices: `device`, tile_index / tile_count
+     * are ignored (tile_count must be 0 or 1), `stream` and `device_image` belong to devices[0], PT_ASYNC_IMAGE is
+     * ignored (calls that hand over a host image are synchronous) and the stepping interface is unavailable. */
+    const int32_t *devices;
+    int32_t num_devices;
 } pt_scene_desc;
 
 typedef struct pt_stats {
@@ -231,6 +245,10 @@ int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node
  * {mode (0..2 diagonal row k, 4 general row, 3 none), m_k0, m_k1, m_k2, m_k3}: the row of the inverseTransform the
  * kernel's exact one-axis early miss evaluates for cubes (same file). */
 int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound, float *reject);
+/* devices of the current session (0: not initialised) and how their tiles reach devices[0]: "rccl", "peer"
+ * (hipMemcpyPeerAsync) or "none" (one device) */
+int pt_num_devices(void);
+const char *pt_exchange_transport(void);
 const char *pt_last_error(void);
 const char *pt_version(void);
 

@@ -53,7 +53,8 @@ class _SceneDesc(C.Structure):
                 ("device", C.c_int32), ("stream", C.c_void_p),
                 ("tile_index", C.c_int32), ("tile_count", C.c_int32), ("strip_rows", C.c_int32),
                 ("max_batch", C.c_int32), ("device_image", C.c_void_p),
-                ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+                ("devices", C.c_void_p), ("num_devices", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -141,6 +142,7 @@ def library():
         L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pt_cull_boxes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
         L.pt_free.restype = None
+        L.pt_exchange_transport.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -160,8 +162,9 @@ def version():
 
 
 def pathtraceInit(scene, flags=PT_COMPACT, device=0, stream=None, tile=(0, 1, 8), max_batch=1,
-                  device_image=None, lens=(0.0, 0.0)):
-    """pathtraceInit(Scene*) (pathtrace.cu:79-98) + the run-time toggles of include/ptmi355.h."""
+                  device_image=None, lens=(0.0, 0.0), devices=None):
+    """pathtraceInit(Scene*) (pathtrace.cu:79-98) + the run-time toggles of include/ptmi355.h.
+    devices=[d0, d1, ...]: the frame tiled over several GPUs inside the library (tile[2] = rows per strip)."""
     global _scene
     d = _SceneDesc()
     d.geoms, d.num_geoms = _p(scene.geoms), len(scene.geoms)
@@ -175,6 +178,10 @@ def pathtraceInit(scene, flags=PT_COMPACT, device=0, stream=None, tile=(0, 1, 8)
     d.max_batch = max_batch
     d.device_image = device_image
     d.lens_radius, d.focal_distance = lens
+    devs = None
+    if devices is not None:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        d.devices, d.num_devices = _p(devs), len(devs)
     _chk(library().pt_init(C.byref(d)))
     _scene = scene
 
@@ -273,6 +280,14 @@ def clear_image():
 
 def device_image_ptr():
     return library().pt_device_image()
+
+
+def num_devices():
+    return library().pt_num_devices()
+
+
+def exchange_transport():
+    return library().pt_exchange_transport().decode()
 
 
 def get_stats():

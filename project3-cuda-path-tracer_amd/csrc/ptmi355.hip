@@ -57,12 +57,16 @@ namespace {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-char g_err[512] = "";
+constexpr size_t ERR_BYTES = 512;
+char g_err[ERR_BYTES] = "";
+// where fail() writes: the calling thread's buffer.  The host's thread uses g_err (pt_last_error); every worker thread
+// of the multi-device layer (pt_multi.hpp) has its own, copied into g_err when its job fails.
+thread_local char *t_err = g_err;
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    vsnprintf(t_err, ERR_BYTES, fmt, ap);
     va_end(ap);
     return code;
 }
@@ -170,7 +174,14 @@ struct Renderer {
     std::vector<int> ev_stage;        // stage of each recorded pair
     size_t ev_used = 0;               // pairs recorded since the last drain
     pt_profile prof{};
-} R;
+};
+
+// One context = one device's renderer (the reference has one file-static set of buffers, pathtrace.cu:70-75).  A
+// single-device session uses g_single on the caller's thread; a multi-device session (pt_multi.hpp) owns one context
+// per device, each driven by its own host thread.  `R` is the context of the calling thread.
+Renderer g_single;
+thread_local Renderer *t_ctx = &g_single;
+#define R (*t_ctx)
 
 constexpr size_t EV_PAIRS = 2048;
 
@@ -736,9 +747,11 @@ int collect_stats(void) {
 }  // namespace
 
 // ===========================================================================
-// C-ABI
+// the entry points of ONE context (the C-ABI of include/ptmi355.h, applied to the calling thread's context `R`);
+// the exported symbols are defined in pt_multi.hpp, which forwards to these directly (one device) or through the
+// per-device worker threads (several)
 // ===========================================================================
-extern "C" {
+namespace one {
 
 const char *pt_last_error(void) { return g_err; }
 const char *pt_version(void) { return "ptmi355 0.1 (gfx950, fp32 no-contract, wave64)"; }
@@ -949,11 +962,11 @@ int pt_init(const pt_scene_desc *d) {
     if (R.live) pt_free();
     const int rc = init_impl(d);
     if (rc != PT_OK) {                 // release whatever was allocated; keep the message
-        char keep[sizeof g_err];
-        memcpy(keep, g_err, sizeof keep);
+        char keep[ERR_BYTES];
+        memcpy(keep, t_err, sizeof keep);
         R.live = true;
         pt_free();
-        memcpy(g_err, keep, sizeof keep);
+        memcpy(t_err, keep, sizeof keep);
     }
     return rc;
 }
@@ -1233,7 +1246,7 @@ static int init_impl(const pt_scene_desc *d) {
         }
     }
     HIPCHK(hipStreamSynchronize(R.stream));
-    g_err[0] = 0;
+    t_err[0] = 0;
     return PT_OK;
 }
 
@@ -1578,7 +1591,9 @@ int pt_get_stats(pt_stats *stats) {
     return PT_OK;
 }
 
-}  // extern "C"
+}  // namespace one
+
+#include "pt_multi.hpp"
 
 #ifdef PT_WAVE_TIMES
 // diagnostic build only (not in include/ptmi355.h): per-wave start / end ticks and hardware ids of k_bounce's last launches

@@ -4,6 +4,11 @@
 //
 //   ptbench SCENEFILE.txt [--iters N] [--batch B] [--out BASENAME] [--sort] [--no-compact]
 //           [--cache-first] [--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D] [--tile R/K] [--strip-rows S]
+//           [--gpus K | --devices D0,D1,...]
+//
+// --gpus K / --devices LIST: ONE process renders the frame on several GPUs: the library tiles it over the devices
+// (interleaved strips of S rows), traces every tile on its own host thread and gathers the tiles' sums onto the first
+// device over RCCL after every call (include/ptmi355.h: pt_scene_desc::devices); the image is the single-GPU image.
 //
 // --tile R/K: this process renders only tile R of K (the rows y with (y / S) % K == R, global pixelIndex and RNG
 // keys unchanged), so K processes -- one per GPU, --device each -- render one frame between them; the other rows
@@ -22,7 +27,8 @@
 int main(int argc, char **argv) {
     if (argc < 2) {
         printf("Usage: %s SCENEFILE.txt [--iters N] [--batch B] [--out BASE] [--sort] [--no-compact] [--cache-first] "
-               "[--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D] [--tile R/K] [--strip-rows S]\n", argv[0]);
+               "[--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D] [--tile R/K] [--strip-rows S] "
+               "[--gpus K | --devices D0,D1,...]\n", argv[0]);
         return 1;
     }
     int iters = -1, batch = 1, device = 0, tile_index = 0, tile_count = 1, strip_rows = 8;
@@ -30,6 +36,7 @@ int main(int argc, char **argv) {
     bool pfm = false;
     float lens_radius = 0.0f, focal_distance = 0.0f;
     std::string out;
+    std::vector<int32_t> devices;
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
@@ -50,6 +57,11 @@ int main(int argc, char **argv) {
             }
         }
         else if (a == "--strip-rows" && i + 1 < argc) strip_rows = atoi(argv[++i]);
+        else if (a == "--gpus" && i + 1 < argc) { devices.clear(); for (int k = 0, n = atoi(argv[++i]); k < n; ++k) devices.push_back(k); }
+        else if (a == "--devices" && i + 1 < argc) {
+            devices.clear();
+            for (const char *p = argv[++i]; *p;) { devices.push_back((int32_t)strtol(p, (char **)&p, 10)); if (*p == ',') ++p; else if (*p) { fprintf(stderr, "--devices wants D0,D1,...\n"); return 1; } }
+        }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
     }
     pth_scene *sc = pth_load_scene(argv[1]);
@@ -69,6 +81,7 @@ int main(int argc, char **argv) {
     d.camera = sc->camera; d.trace_depth = sc->trace_depth; d.flags = flags; d.device = device;
     d.tile_index = tile_index; d.tile_count = tile_count; d.strip_rows = strip_rows; d.max_batch = batch;
     d.lens_radius = lens_radius; d.focal_distance = focal_distance;
+    if (!devices.empty()) { d.devices = devices.data(); d.num_devices = (int32_t)devices.size(); }
     pt_free();                                            // main.cpp:126
     if (pt_init(&d) != PT_OK) { fprintf(stderr, "pathtraceInit: %s\n", pt_last_error()); return 1; }
 
@@ -85,7 +98,8 @@ int main(int argc, char **argv) {
     }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const long long rays = pt_total_rays();
-    printf("%d iterations, %lld rays, %.3f s, %.1f Mrays/s\n", iteration, rays, sec, rays / sec / 1e6);
+    printf("%d iterations, %lld rays, %.3f s, %.1f Mrays/s on %d device(s), tile exchange: %s\n", iteration, rays, sec, rays / sec / 1e6,
+           pt_num_devices(), pt_exchange_transport());
 
     if (out.empty()) out = std::string(sc->image_name[0] ? sc->image_name : "render");
     char name[512];

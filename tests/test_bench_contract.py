@@ -83,6 +83,28 @@ def test_two_ranks_same_frame():
         assert two["image_md5"] == one["image_md5"], extra
 
 
+def _ranks(n, port, *extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(n), "--steps", "2",
+           "--warmup", "1", "--no-roofline", "--backend", "gloo", "--same-device", "--digest"] + list(extra)
+    return run(cmd, timeout=900)
+
+
+@pytest.mark.parametrize("config", ["c2", "c5"])
+def test_six_ranks_same_frame(config):
+    """Rehearsal of the driver's scaling run with as many PROCESSES of the HIP library as this pool lets one GPU hold
+    (six; eight in tests/test_sharding_gloo.py on the CPU): 800 rows = 100 strips (C2) and 2160 rows = 270 strips
+    (C5, `--config c5`) do not divide by six, so the ranks own different numbers of rows; weak scaling (6 x 1
+    iterations per step per tile), gather per step and per iteration -- rank 0's frame is the 1-process frame."""
+    one = run([sys.executable, "bench.py", "--config", config, "--steps", "2", "--warmup", "1", "--batch", "6",
+               "--no-cpu-baseline", "--no-roofline", "--digest"])
+    for k, extra in enumerate((["--batch", "1"], ["--batch", "1", "--reduce-every", "2"])):
+        six = _ranks(6, 29833 + k + (10 if config == "c5" else 0), "--config", config, *extra)
+        assert six["n_gpus"] == 6 and six["scaling"] == "weak"
+        assert six["config"]["rays_per_step"] == one["config"]["rays_per_step"], extra
+        assert six["image_md5"] == one["image_md5"], (config, extra)
+
+
 def test_one_rank_rccl():
     """The N > 1 code path over RCCL ITSELF on this one GPU: a world of one rank (bench.py --force-dist) initialises
     the RCCL process group on the device, packs and gathers its tile (the whole frame) per step / per iteration,

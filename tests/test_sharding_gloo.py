@@ -73,6 +73,18 @@ def test_two_rank_reduce_equals_single(tmp_path, strip_rows, mode):
     assert got.tobytes() == want.tobytes()
 
 
+def test_eight_ranks_uneven_strips(tmp_path):
+    """What the driver launches at N = 8: eight ranks, a strip count that does not divide (64 rows in strips of 5 =
+    13 strips: ranks 0-4 own two, 5-7 one; the last strip is short), the gather of packed tile rows with two slots in
+    flight -- rank 0's frame equals the 1-process image."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "frame.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, 5, out, "gather"), nprocs=8, join=True)
+    got, want = np.load(out), np.load(out + ".ref.npy")
+    assert got.tobytes() == want.tobytes()
+
+
 def test_tiles_partition_the_frame():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
