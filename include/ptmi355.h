@@ -245,6 +245,12 @@ int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node
  * {mode (0..2 diagonal row k, 4 general row, 3 none), m_k0, m_k1, m_k2, m_k3}: the row of the inverseTransform the
  * kernel's exact one-axis early miss evaluates for cubes (same file). */
 int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound, float *reject);
+/* host-only (no GPU): the per-triangle spheres of the every-triangle loop's first stage for ONE mesh of `count` triangles and
+ * ray origins with |origin|_1 <= origin_bound: bounds = ((count + 3) & ~3) x {centre xyz, Rs^2} (padding entries: Rs^2 = -1).
+ * A ray whose line passes a centre at more than Rs is never accepted for that triangle by the completion spec
+ * (glm::intersectRayTriangle + the hit-point test; csrc/ptmi355.hip: make_tri_bounds has the derivation), so the kernel
+ * does not run the exact test for the pair.  Returns the number of entries written. */
+int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, float *bounds);
 /* devices of the current session (0: not initialised) and how their tiles reach devices[0]: "rccl", "peer"
  * (hipMemcpyPeerAsync) or "none" (one device) */
 int pt_num_devices(void);

@@ -368,6 +368,19 @@ void pto_mesh_winners(const pto_tri *tris, int first, int count, const pto_path 
     for (int k = 0; k < n; ++k) index[k] = pto_mesh_winner(tris, first, count, paths[k].ray, pad, &tz[k]);
 }
 
+/* every (ray, triangle) pair the spec counts, not only the winner: accepted[k * count + i] (tests of the kernels' cull stages) */
+void pto_mesh_accepted(const pto_tri *tris, int first, int count, const pto_path *paths, int n, uint8_t *accepted) {
+    const float pad = pto_mesh_pad(tris, first, count);
+    for (int k = 0; k < n; ++k)
+        for (int i = 0; i < count; ++i) {
+            pto_vec3 b;
+            const pto_tri *t = &tris[first + i];
+            accepted[(size_t)k * count + i] =
+                pto_ray_triangle(paths[k].ray.origin, paths[k].ray.direction, t->v0, t->v1, t->v2, &b) && b.z > 0.0f &&
+                pto_tri_point_ok(paths[k].ray.origin, paths[k].ray.direction, b.z, t, pad);
+        }
+}
+
 float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r, float pad, pto_vec3 *point,
                     pto_vec3 *normal, int *outside) {
     float best;
@@ -938,5 +951,54 @@ void pto_trace_iteration_mt(const pto_scene *sc, int iter, pto_vec3 *image, pto_
     pto_final_gather(N, image, paths);
     free(outside);
     free(scratch);
+    if (stats) *stats = st;
+}
+
+/* The rows [y0, y1) of one iteration: exactly the paths pto_trace_iteration traces for those pixels (a path's
+ * whole history is keyed by (iter, global pixelIndex, depth): SURVEY 8.0), nothing else.  Lets the parity tests
+ * hold a frame tile of a scene that is too heavy for a whole-frame oracle run (C4: 100 032 triangles per ray)
+ * against the oracle.  image (N vec3, whole frame) accumulates the rows' pixels only. */
+void pto_trace_rows_mt(const pto_scene *sc, int iter, pto_vec3 *image, int y0, int y1, pto_stats *stats, int nthreads) {
+    const int W = sc->camera.resolution[0], H = sc->camera.resolution[1];
+    const int N = W * H;
+    if (y0 < 0) y0 = 0;
+    if (y1 > H) y1 = H;
+    pto_stats st;
+    memset(&st, 0, sizeof st);
+    if (stats) *stats = st;
+    if (y1 <= y0) return;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pto_path *all = (pto_path *)malloc((size_t)N * sizeof(pto_path));
+    pto_generate_rays_ex(sc, iter, all);                     /* generateRayFromCamera for every pixel; keep the rows */
+    int n = (y1 - y0) * W;
+    pto_path *paths = (pto_path *)malloc((size_t)n * sizeof(pto_path));
+    memcpy(paths, all + (size_t)y0 * W, (size_t)n * sizeof(pto_path));
+    free(all);
+    pto_isect *isects = (pto_isect *)malloc((size_t)n * sizeof(pto_isect));
+    uint8_t *outside = (uint8_t *)malloc((size_t)n);
+    pto_path *scratch = (pto_path *)malloc((size_t)n * sizeof(pto_path));
+    const int n0 = n;
+    pthread_t th[256];
+    mt_job jobs[256];
+    for (int depth = 0; depth < sc->traceDepth && n > 0; ++depth) {
+        for (int t = 0; t < nthreads; ++t) {
+            mt_job *j = &jobs[t];
+            j->sc = sc; j->iter = iter; j->depth = depth;
+            j->begin = (int)((int64_t)n * t / nthreads);
+            j->end = (int)((int64_t)n * (t + 1) / nthreads);
+            j->paths = paths; j->isects = isects; j->outside = outside;
+            pthread_create(&th[t], NULL, mt_bounce, j);
+        }
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+        if (depth < 64) st.live[depth] = n;
+        st.rays += n;
+        st.bounces = depth + 1;
+        n = pto_compact(n, paths, scratch);
+        if (depth < 64)
+            st.seq_hash[depth] = pto_fnv1a_i32(&paths[0].pixelIndex, (int)sizeof(pto_path), n);
+    }
+    pto_final_gather(n0, image, paths);
+    free(scratch); free(outside); free(isects); free(paths);
     if (stats) *stats = st;
 }

@@ -116,6 +116,7 @@ int   pto_mesh_winner(const pto_tri *tris, int first, int count, pto_ray r, floa
                        ties; -1: none */
 void  pto_mesh_winners(const pto_tri *tris, int first, int count, const pto_path *paths, int n,
                        int32_t *index, float *tz);
+void pto_mesh_accepted(const pto_tri *tris, int first, int count, const pto_path *paths, int n, uint8_t *accepted);
 float pto_mesh_test(const pto_tri *tris, int first, int count, pto_ray r, float pad,
                     pto_vec3 *point, pto_vec3 *normal, int *outside);    /* spec 8.0 */
 pto_vec3 pto_hemisphere(pto_vec3 normal, uint32_t *rng, int trig);       /* interactions.h:10-42 */
@@ -180,6 +181,9 @@ void pto_trace_iteration(const pto_scene *sc, int iter, pto_vec3 *image,
 void pto_trace_iteration_mt(const pto_scene *sc, int iter, pto_vec3 *image,
                             pto_path *paths, pto_isect *isects, pto_stats *stats,
                             int nthreads);
+
+/* rows [y0, y1) of one iteration (the same paths pto_trace_iteration traces for those pixels), `nthreads` threads */
+void pto_trace_rows_mt(const pto_scene *sc, int iter, pto_vec3 *image, int y0, int y1, pto_stats *stats, int nthreads);
 
 /* `count` iterations iter0 .. iter0+count-1, one whole iteration per thread, images added in iteration order
  * (== sequential pto_trace_iteration calls, bit for bit); returns rays traced, -1 when out of memory.  This is

@@ -134,6 +134,8 @@ def lib():
                                              C.c_void_p, C.POINTER(Stats), C.c_int]
         L.pto_trace_iterations_parallel.restype = C.c_int64
         L.pto_trace_iterations_parallel.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.pto_trace_rows_mt.argtypes = [C.POINTER(Scene), C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(Stats), C.c_int]
+        L.pto_mesh_accepted.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.pto_fnv1a_i32.restype = C.c_uint64
         L.pto_fnv1a_i32.argtypes = [C.c_void_p, C.c_int, C.c_int]
         _lib = L
@@ -244,6 +246,15 @@ def mesh_winners(tris, paths, first=0, count=None):
     return idx, tz
 
 
+def mesh_accepted(tris, paths, first=0, count=None):
+    """accepted[ray, triangle] = the spec counts this triangle for this ray (glm::intersectRayTriangle, bary.z > 0, the
+    hit-point test) -- every accepted pair, not only the winner."""
+    count = len(tris) - first if count is None else count
+    out = np.zeros((len(paths), count), dtype=np.uint8)
+    lib().pto_mesh_accepted(_p(tris), first, count, _p(paths), len(paths), _p(out))
+    return out
+
+
 def make_scene(geoms, materials, cam_np, trace_depth, flags=F_COMPACT, trig=TRIG_SHARED,
                tris=None, meshes=None, lens=(0.0, 0.0)):
     sc = Scene()
@@ -275,6 +286,12 @@ class Tracer:
         if rays < 0:
             raise MemoryError("pto_trace_iterations_parallel")
         return rays
+
+    def iterate_rows(self, it, y0, y1, threads=1):
+        """Iteration `it` for the pixels of rows [y0, y1) only (what a frame tile owns)."""
+        st = Stats()
+        lib().pto_trace_rows_mt(C.byref(self.scene), it, _p(self.image), y0, y1, C.byref(st), threads)
+        return st
 
     def iterate(self, it, snapshots=None, threads=0):
         """Run iteration `it` (1-based). If `snapshots` is a list, append per-bounce

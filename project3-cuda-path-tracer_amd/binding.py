@@ -141,6 +141,7 @@ def library():
         L.pt_get_bvh_info.argtypes = [C.POINTER(BvhInfo)]
         L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pt_cull_boxes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
+        L.pt_tri_bounds.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         L.pt_free.restype = None
         L.pt_exchange_transport.restype = C.c_char_p
         _lib = L
@@ -338,6 +339,14 @@ def cull_boxes(geoms, eye=(0.0, 0.0, 0.0)):
     r = C.c_float(0.0)
     _chk(library().pt_cull_boxes(_p(g), len(g), _p(e), _p(out), C.byref(r), _p(rej)))
     return out, r.value, rej
+
+
+def tri_bounds(triangles, origin_bound):
+    """Host-only: {centre xyz, Rs^2} per triangle of one mesh (the every-triangle loop's first stage)."""
+    t = np.ascontiguousarray(triangles, dtype=TRI_DT)
+    out = np.zeros(((len(t) + 3) & ~3, 4), dtype=np.float32)
+    _chk(library().pt_tri_bounds(_p(t), len(t), float(origin_bound), _p(out)))
+    return out[:len(t)]
 
 
 def total_rays():

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, Lens le
 // Dynamic LDS carve (no static __shared__: the dynamic base stays 16-B aligned, guide G17):
 //   [ctl: 16 dwords]
 //   [scene block, SLDS only: materials nmats*12 | ginfo ngeoms (padded to 4) | gather records ngeoms*36]
-//   [per wave: PW_WORDS]  [triangle tile: TRI_TILE*12 dwords (MESH_TILES only)]
+//   [per wave: PW_WORDS]  [per wave: TRQ_WORDS, the triangle candidate ring + best keys (MESH_TILES only)]
 // What every lane of a wave reads alike (the cull boxes, mesh records) comes through wave-uniform scalar
 // loads from global memory; what lanes gather individually (the matrices of the primitive a candidate names,
 // the material of a winner) is staged in LDS when the scene fits (SLDS) and read from global memory through
@@ -466,6 +466,110 @@ __device__ __forceinline__ void bvh_walk(const float *__restrict__ nodes, const 
 // nearest mesh hit of a path so far (meshes fold in geom order: strict `>` keeps the first on ties)
 struct MeshBest { float t; int geom, tri; };
 
+// ---------------------------------------------------------------------------
+// MESH_TILES: the loop over EVERY triangle of a mesh for every ray (completion spec 8.0 "Triangles"; BASELINE's
+// "naive triangle loop (no BVH)"; INSTRUCTION.md:123-128).  No hierarchy, no grouping: each (ray, triangle) pair is
+// visited.  Like the cubes and spheres (stages 1-3 above) a pair is visited in two stages:
+//
+//  1. BOUND.  pt_init computes per triangle a sphere (centre c, radius Rs) that contains every point a hit the spec
+//     accepts can report: the spec's hit-point test (tri_point_ok) only counts a triangle whose reported point
+//     P = fl(o + fl(d * tz)) lies inside the triangle's box widened by the mesh's pad, P lies within
+//     sqrt3 * 2^-23 (|o| + |P|) of the ray's line, and the test below misplaces that line by less than
+//     2^-20 (R + |c|) (R = the |origin|_1 bound of the non-wild rays: ptmi355.hip, tri_bounds, with the error budget)
+//     -- so a ray whose line passes the centre at more than Rs cannot be accepted for this triangle, whatever
+//     glm::intersectRayTriangle's float arithmetic returns for it.  All lanes test their ray against it:
+//     q = c x d' - o x d' (d' = d scaled to unit length, o x d' hoisted per ray), |q|^2 > Rs^2 -> skip: six fused
+//     multiply-adds, a three-term dot and one compare per (ray, triangle), the triangle's four floats coming through
+//     wave-uniform scalar loads (s_load_dwordx16 per four triangles).  Round 2 ran the exact test on every pair with
+//     the triangle read from LDS by three wave-uniform ds_read_b128: bound by the LDS pipe at 41 cycles per
+//     (wave, triangle).  Rays the bound was not derived for (non-finite, huge, odd direction magnitudes: `wild`) are
+//     candidates of every triangle; NaNs fail the compare towards "candidate".
+//  2. EXACT.  Candidates (lane, triangle) queue in a per-wave LDS ring; whenever 64 wait, lane k runs
+//     glm::intersectRayTriangle (operation for operation, ptd::ray_triangle) + the hit-point test for candidate k
+//     -- the ray from the wave's LDS copy, the triangle record gathered from global memory -- and folds
+//     (bits(bary.z) << 32) | triangle index into the owner's key with an LDS 64-bit min: the smallest bary.z, the
+//     lowest index on ties, i.e. the loop's strict `best > tz` scan in index order.
+// ---------------------------------------------------------------------------
+constexpr unsigned long long TRI_KEY_NONE = (0x7f7fffffull << 32) | 0xffffffffull;   // bary.z = FLT_MAX, no triangle
+constexpr int TRQ_SLOTS = 128;                 // triangle candidates waiting per wave (a triangle adds <= 64 while < 64 wait)
+constexpr int TRQ_WORDS = TRQ_SLOTS + 2 * 64;  // ring + the 64 per-lane best keys (u64): 1 KiB per wave
+
+__device__ __forceinline__ void tri_cand_pass(const float *ry0, const uint32_t *ring, unsigned long long *keys,
+                                              const float *__restrict__ tris, uint32_t head, uint32_t count) {
+    const int lane = threadIdx.x & 63;
+    if ((uint32_t)lane < count) {
+        const uint32_t e = ring[(head + (uint32_t)lane) & (TRQ_SLOTS - 1)];
+        const int owner = (int)(e & 63u);
+        const uint32_t idx = e >> 6;
+        const float *ry = ry0 + owner;
+        const f3 ro = ptd::mk(ry[0], ry[64], ry[128]);
+        const f3 rd = ptd::mk(ry[192], ry[256], ry[320]);
+        const float4 *t4 = reinterpret_cast<const float4 *>(tris + (size_t)idx * TRI_WORDS);
+        const float4 A = t4[0], B = t4[1], C = t4[2];
+        const f3 v0 = ptd::mk(A.x, A.y, A.z), e1 = ptd::mk(A.w, B.x, B.y), e2 = ptd::mk(B.z, B.w, C.x);
+        float tz;
+        if (ptd::ray_triangle(ro, rd, v0, e1, e2, tz) && tz > 0.0f && ptd::tri_point_ok(ro, rd, tz, v0, e1, e2, C.z))
+            __hip_atomic_fetch_min(&keys[owner], ((unsigned long long)__float_as_uint(tz) << 32) | idx, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// nearest accepted triangle of the mesh [first, first + count) for this lane's ray: best = bary.z, best_i = index
+__device__ __forceinline__ void mesh_sweep(const SceneDev &sc, const WaveQ &q, int par, float *trq, int first, int count, int boff,
+                                           f3 ro, f3 rd, uint64_t m_act, uint64_t m_wild, float &best, int &best_i) {
+    const int lane = threadIdx.x & 63;
+    uint32_t *ring = reinterpret_cast<uint32_t *>(trq);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(trq + TRQ_SLOTS);
+    const float *ry0 = q.rays(par);
+    keys[lane] = TRI_KEY_NONE;
+    uint32_t head = 0, total = 0;
+    // the ray's line in Pluecker form, direction scaled to unit length (v_rsq: the scale only has to be about right)
+    const float sc1 = __builtin_amdgcn_rsqf((rd.x * rd.x + rd.y * rd.y) + rd.z * rd.z);
+    const float dx = rd.x * sc1, dy = rd.y * sc1, dz = rd.z * sc1;
+    const float mx = __builtin_fmaf(ro.y, dz, -(ro.z * dy)), my = __builtin_fmaf(ro.z, dx, -(ro.x * dz)),
+                mz = __builtin_fmaf(ro.x, dy, -(ro.y * dx));
+    cfloat *tb = as_const(sc.tri_bound) + (size_t)boff * 4;
+    const uint64_t m_all = m_act & m_wild;                        // candidates of everything
+    auto one = [&](float cx, float cy, float cz, float r2, int k) {
+        const float qx = __builtin_fmaf(cy, dz, __builtin_fmaf(-cz, dy, -mx));
+        const float qy = __builtin_fmaf(cz, dx, __builtin_fmaf(-cx, dz, -my));
+        const float qz = __builtin_fmaf(cx, dy, __builtin_fmaf(-cy, dx, -mz));
+        const float qq = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+        const uint64_t m = (m_act & ~ballot64(qq > r2)) | m_all;  // NaN: not greater, a candidate
+        if (m && k < count) {                                      // rare: ~1e-5 of the pairs
+            if (lane_of(m)) ring[(total + rank_below(m)) & (TRQ_SLOTS - 1)] = (uint32_t)lane | ((uint32_t)(first + k) << 6);
+            total += (uint32_t)__popcll((unsigned long long)m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (total - head >= 64) { tri_cand_pass(ry0, ring, keys, sc.tris, head, 64); head += 64; }
+        }
+    };
+    // four triangles per step: one s_load_dwordx16, the next step's already requested (the array is padded to a
+    // multiple of four with spheres nothing reaches)
+    float nxt[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) nxt[j] = count > 0 ? tb[j] : 0.0f;
+    for (int k = 0; k < count; k += 4) {
+        float b[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b[j] = nxt[j];
+        if (k + 4 < count) {
+            cfloat *tn = tb + (size_t)(k + 4) * 4;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) nxt[j] = tn[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) one(b[4 * j], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3], k + j);
+    }
+    while (total != head) {
+        const uint32_t cnt = min(64u, total - head);
+        tri_cand_pass(ry0, ring, keys, sc.tris, head, cnt);
+        head += cnt;
+    }
+    const unsigned long long key = keys[lane];
+    if ((uint32_t)key != 0xffffffffu) { best = __uint_as_float((uint32_t)(key >> 32)); best_i = (int)(uint32_t)key; }
+}
+
 // Stages 1 + 2 for one tile (parity `par` of the wave's LDS block): store the rays, reset the best keys, test every
 // primitive's cull box and queue the candidates; passes run as the ring fills.  Triangle meshes keep their own
 // paths (every triangle through LDS tiles / the hierarchy inline / the k_mesh pre-pass) and fold into `mb`.
@@ -489,7 +593,6 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
     CULL_STAT(0, 1); CULL_STAT(5, __popcll((unsigned long long)ballot64(active && cr.wild))); CULL_STAT(6, __popcll((unsigned long long)ballot64(active)));
     const uint32_t tag = (uint32_t)lane | ((uint32_t)par << 6);
     const int ngeoms = sc.ngeoms;
-    const float *__restrict__ tris = sc.tris;
     // the records come through wave-uniform scalar loads (s_load_dwordx8 + x4); the next primitive's is requested
     // before this one's is used, so its latency overlaps the test instead of stalling every iteration
     float nxt[11];
@@ -525,42 +628,11 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
                     bvh_walk(sc.bvh_nodes + (size_t)root * BVH_NODE_WORDS, sc.bvh_tris, rec + ptd::G_INV, sc.bvh_prune,
                              sc.bvh_guard, ro, rd, best, best_i);
             } else {
-                // completion spec 8.0: nearest triangle by strictly smaller bary.z, first wins ties
+                // every triangle of the mesh, for every ray (the completion spec's loop, 8.0): mesh_sweep
                 const int first = __float_as_int(rec[2]);
                 const int count = __float_as_int(rec[3]);
-                for (int base = 0; base < count; base += TRI_TILE) {
-                    const int nt = min(TRI_TILE, count - base);
-                    const int nt4 = (nt + 3) & ~3;                   // the tile is zero-padded to a multiple of 4
-                    __syncthreads();
-                    {   // global -> LDS, 16 B per thread per step; zero triangles (a = 0 < eps: never hit) as padding
-                        const float4 *src = reinterpret_cast<const float4 *>(tris + (size_t)(first + base) * TRI_WORDS);
-                        float4 *dst = reinterpret_cast<float4 *>(tri_lds);
-                        for (int k = threadIdx.x; k < nt4 * 3; k += BLOCK)
-                            dst[k] = k < nt * 3 ? src[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    }
-                    __syncthreads();
-                    if (active) {
-                        // four triangles per step: their twelve ds_read_b128 (wave-uniform addresses, LDS
-                        // broadcasts) are issued together so the LDS latency is paid once per four tests
-                        const float4 *tl = reinterpret_cast<const float4 *>(tri_lds);
-                        for (int k = 0; k < nt4; k += 4) {
-                            float4 w[12];
-#pragma unroll
-                            for (int j = 0; j < 12; ++j) w[j] = tl[k * 3 + j];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float4 A = w[3 * j], B = w[3 * j + 1], C = w[3 * j + 2];
-                                float tz;
-                                const f3 v0 = ptd::mk(A.x, A.y, A.z), e1 = ptd::mk(A.w, B.x, B.y), e2 = ptd::mk(B.z, B.w, C.x);
-                                if (ptd::ray_triangle(ro, rd, v0, e1, e2, tz)) {
-                                    if (tz > 0.0f && best > tz && ptd::tri_point_ok(ro, rd, tz, v0, e1, e2, C.z)) {
-                                        best = tz; best_i = first + base + k + j;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
+                const int boff = __float_as_int(rec[ptd::G_INV + 6]);
+                mesh_sweep(sc, q, par, tri_lds, first, count, boff, ro, rd, m_act, m_wild, best, best_i);
             }
             if (active && best_i >= 0) {
                 f3 p = ptd::add(ro, ptd::scale(rd, best));
@@ -687,7 +759,7 @@ __device__ __forceinline__ LdsCarve carve_lds(float *lds_raw, const SceneDev &sc
     c.scene = lds_raw + LDS_CTL_WORDS;
     float *after = c.scene + (slds ? scene_lds_words(sc.nmats, sc.ngeoms) : 0);
     c.pw = after + (threadIdx.x >> 6) * PW_WORDS;
-    c.tri = after + WAVES * PW_WORDS;
+    c.tri = after + WAVES * PW_WORDS + (threadIdx.x >> 6) * TRQ_WORDS;        // this wave's triangle queue (MESH_TILES)
     return c;
 }
 
@@ -734,7 +806,7 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
     uint32_t mtile = masked ? (wid * R) % cull0_tiles : 0u;
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t tile = wid * R + r;
-        if (MESH != MESH_TILES && tile >= tiles) break;
+        if (tile >= tiles) break;
         rotate_priority(r, PT_ISECT_WAVES + 1);
         const bool have = tile < tiles;
         const uint32_t i = tile * TILE + lane;
@@ -1494,7 +1566,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
     uint32_t mtile = masked ? first_tile % a.cull0_tiles : 0u;
     for (uint32_t r = 0; r < count; ++r) {
         const uint32_t tile = first_tile + r;
-        if (MESH != MESH_TILES && !own_span && tile >= tiles) break;
+        if (!own_span && tile >= tiles) break;
         rotate_priority(r + (uint32_t)depth, PT_MIN_WAVES + 1);
         unsigned long long gmask = 0;
         if (masked) {
@@ -1597,8 +1669,7 @@ __global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_W
     if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), W, wid * R * TILE);
     STAMP(2);
 
-    // every wave walks its own run of R consecutive 64-path tiles; no workgroup barrier inside
-    // the loop unless a mesh needs block-wide triangle staging (then all waves run R iterations)
+    // every wave walks its own run of R consecutive 64-path tiles; no workgroup barrier inside the loop
     run_tiles<MODE, COMPACT, MESH>(a, c, q, a.in, a.out, a.depth, a.gen_rays != 0, wid * R, R, tiles, n, packed_in, span_in,
                                    cur, wid * R * TILE, false, WgSpans{}, packed, traced);
     STAMP(6);
@@ -1804,7 +1875,6 @@ static_assert(MESH_LDS_BYTES <= 160 * 1024, "k_mesh: per-wave rings + tree tops 
 #endif
 constexpr int MQ_STEPS = PT_MQ_STEPS;         // walk steps between two looks at the ray ring
 constexpr int MQ_LEAVE = PT_MQ_LEAVE;         // lanes still busy when the wave goes back to scanning
-constexpr unsigned long long TRI_KEY_NONE = (0x7f7fffffull << 32) | 0xffffffffull;   // bary.z = FLT_MAX, no triangle
 static_assert(2 * PT_LEAF_MAX * 64 + 63 <= TQ_SLOTS, "a step's triangles must fit beside the waiting ones");
 
 // per-lane state of a walk in flight; it survives across the scanning of further tiles

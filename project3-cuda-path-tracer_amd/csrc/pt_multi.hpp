@@ -656,6 +656,9 @@ int pt_get_bvh_info(pt_bvh_info *out) {
 int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node_capacity, int32_t *order, float *grid) {
     return one::pt_bvh_build(triangles, count, nodes, node_capacity, order, grid);
 }
+int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, float *bounds) {
+    return one::pt_tri_bounds(triangles, count, origin_bound, bounds);
+}
 int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound, float *reject) {
     return one::pt_cull_boxes(geoms, count, eye, boxes, origin_bound, reject);
 }

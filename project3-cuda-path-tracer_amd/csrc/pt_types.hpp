@@ -18,7 +18,6 @@ namespace {
 constexpr int BLOCK = 256;                 // 4 waves of 64
 constexpr int WAVES = BLOCK / 64;
 constexpr int TILE = 64;                   // paths per tile = one wave64
-constexpr int TRI_TILE = 512;              // triangles staged in LDS per pass (24 KiB)
 constexpr int TRI_WORDS = 12;              // v0 e1 e2 + 3 pad: three 16-B words per triangle
 constexpr int BVH_NODE_WORDS = 16;         // one 64-B record per internal node, pt_bvh.hpp
 enum { MESH_NONE = 0, MESH_TILES = 1, MESH_BVH = 2, MESH_PRE = 3 };   // how triangle meshes are intersected (template
@@ -162,6 +161,8 @@ struct SceneDev {
     float rmax;                            // |origin|_1 bound the cull boxes were derived for
     const float *mats;   int nmats;        // MAT_WORDS dwords each
     const float *tris;   int ntris;        // v0, e1, e2 + pad (12 dwords each)
+    const float *tri_bound;                // per triangle {centre xyz, Rs^2} of the every-triangle loop's first stage (scalar loads;
+                                           //   per mesh padded to a multiple of 4, offset in word G_INV + 6 of its geom record)
     const float *bvh_nodes;                // PT_MESH_BVH: all meshes' trees, BVH_NODE_WORDS per node
     const float *bvh_tris;                 //   leaf-ordered triangle records, word 9 = original index
     float bvh_prune;  int bvh_guard;       //   prune margin; upper bound on nodes visited per walk

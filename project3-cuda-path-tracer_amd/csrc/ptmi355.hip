@@ -106,10 +106,13 @@ struct Renderer {
     bool own_image = false;
     float *d_geoms = nullptr, *d_mats = nullptr, *d_tris = nullptr;
     float *d_cull = nullptr, *d_grec = nullptr;
+    float *d_tri_bound = nullptr;  // every-triangle loop, stage 1: {centre, Rs^2} per triangle (upload_tri_bounds)
+    size_t tri_bound_words = 0;
     uint32_t *d_ginfo = nullptr;
     double cull_eye_reach = 0.0;  // |camera position|_1 the cull boxes were made for
     std::vector<pt_geom> geoms_keep;   // host copies (pt_set_camera may have to remake the cull boxes)
     std::vector<pt_triangle> tris_keep;
+    std::vector<pt_mesh> meshes_keep;
     bool scene_lds = true;        // gather records + materials staged in LDS (else read through the vector cache)
     SceneDev scene{};
     size_t lds_bytes = 0;
@@ -568,6 +571,8 @@ int enqueue_batch(int iter0, int count) {
     return PT_OK;
 }
 
+int upload_tri_bounds(const pt_scene_desc *d, double Rorigin);
+
 // per-primitive cull boxes (pt_cull.hpp) for the scene of R.desc as seen from camera `cam`: the |origin|_1 bound
 // they are derived for covers the scene and the camera; a camera that later moves beyond it gets new boxes
 int upload_cull(const pt_scene_desc *d, const pt_camera &cam) {
@@ -607,6 +612,75 @@ int upload_cull(const pt_scene_desc *d, const pt_camera &cam) {
     HIPCHK(hipStreamSynchronize(R.stream));            // `rec` is pageable host memory about to go out of scope
     R.scene.cull = R.d_cull;
     R.cull_eye_reach = std::fabs(eye[0]) + std::fabs(eye[1]) + std::fabs(eye[2]);
+    return upload_tri_bounds(d, (double)R.scene.rmax);       // the bounding spheres hold for origins within the same bound
+}
+
+// Every-triangle loop (MESH_TILES), stage 1 (pt_kernels.hpp: mesh_sweep): per triangle a sphere {c, Rs} such that a
+// ray whose line passes c at more than Rs cannot be ACCEPTED for the triangle.  Derivation (u = 2^-24):
+//   * the spec accepts a hit only if the point it reports, P_k = fl(o_k + fl(d_k tz)), lies in the triangle's box
+//     [fl(lo_k - pad), fl(hi_k + pad)] (tri_point_ok, evaluated on these very floats): |P - c| <= R0 = half diagonal
+//     of that box, c its centre;
+//   * P_k differs from the line's point o_k + d_k tz by at most u |d_k tz| + u |P_k| <= 2u (|o_k| + |P_k|): the line
+//     passes P within delta = 2 sqrt3 u (R + |c|_inf + R0)  (non-wild rays: |o|_1 <= R);
+//   * the kernel's q = c x d' - fl(o x d') (fused multiply-adds, d' = d / |d| up to 2^-20) is off by at most
+//     2^-21 (|o|_inf + |c|_inf) |d'|_inf per component, and its |q|^2 and the compare lose another 2^-20 relative;
+//     rounding c to float moves it by u |c|_inf.
+//   Rs = (R0 + 4 (delta + 2^-19 (R + |c|_inf + R0))) (1 + 2^-10), squared and rounded up.  Non-finite triangles get
+//   Rs^2 = +inf (always a candidate: the exact test decides, and it never accepts them).  Each mesh's entries are
+//   padded to a multiple of four with Rs^2 = -1 (no ray is a candidate: |q|^2 > -1).
+// one mesh: `count` triangles -> ((count + 3) & ~3) x {cx, cy, cz, Rs^2}
+void make_tri_bounds(const pt_triangle *tris, int count, double Rorigin, float *out) {
+    const double u = 0x1p-24;
+    const float pad = ptbvh::spec_pad(reinterpret_cast<const float *>(tris), count);
+    const int n4 = (count + 3) & ~3;
+    for (int i = 0; i < n4; ++i) {
+        float *o = out + (size_t)i * 4;
+        if (i >= count) { o[0] = o[1] = o[2] = 0.0f; o[3] = -1.0f; continue; }
+        const pt_triangle &t = tris[i];
+        const float v0[3] = {t.v0.x, t.v0.y, t.v0.z};
+        const float e1[3] = {t.v1.x - t.v0.x, t.v1.y - t.v0.y, t.v1.z - t.v0.z};      // the device record's e1, e2
+        const float e2[3] = {t.v2.x - t.v0.x, t.v2.y - t.v0.y, t.v2.z - t.v0.z};
+        double c[3], h2 = 0.0, cinf = 0.0;
+        bool fin = true;
+        for (int a = 0; a < 3; ++a) {
+            const float x1 = v0[a] + e1[a], x2 = v0[a] + e2[a];                       // tri_point_ok's own floats
+            const float lo = std::fmin(v0[a], std::fmin(x1, x2)) - pad, hi = std::fmax(v0[a], std::fmax(x1, x2)) + pad;
+            if (!std::isfinite(lo) || !std::isfinite(hi)) fin = false;
+            c[a] = 0.5 * ((double)lo + (double)hi);
+            const double h = 0.5 * ((double)hi - (double)lo);
+            h2 += h * h;
+            cinf = std::fmax(cinf, std::fabs(c[a]));
+        }
+        if (!fin || !std::isfinite(Rorigin)) { o[0] = o[1] = o[2] = 0.0f; o[3] = INFINITY; continue; }
+        const double R0 = std::sqrt(h2);
+        const double reach = Rorigin + cinf + R0;
+        const double delta = 2.0 * 1.7320508075688772 * u * reach;
+        const double Rs = (R0 + 4.0 * (delta + 0x1p-19 * reach)) * (1.0 + 0x1p-10);
+        for (int a = 0; a < 3; ++a) o[a] = (float)c[a];
+        o[3] = ptcull::round_up(Rs * Rs);
+        if (!std::isfinite(o[3])) o[3] = INFINITY;
+    }
+}
+
+int upload_tri_bounds(const pt_scene_desc *d, double Rorigin) {
+    if (R.mesh_mode != MESH_TILES || d->num_meshes <= 0) return PT_OK;
+    size_t words = 0;
+    for (int k = 0; k < d->num_meshes; ++k) words += (size_t)((d->meshes[k].triangle_count + 3) & ~3) * 4;
+    std::vector<float> tb(std::max<size_t>(words, 16), 0.0f);
+    size_t off = 0;
+    for (int k = 0; k < d->num_meshes; ++k) {
+        const pt_mesh &m = d->meshes[k];
+        make_tri_bounds(d->triangles + m.first_triangle, m.triangle_count, Rorigin, tb.data() + off);
+        off += (size_t)((m.triangle_count + 3) & ~3) * 4;
+    }
+    if (!R.d_tri_bound || R.tri_bound_words < tb.size()) {
+        if (R.d_tri_bound) { HIPCHK(hipStreamSynchronize(R.stream)); (void)hipFree(R.d_tri_bound); R.d_tri_bound = nullptr; }
+        HIPCHK(hipMalloc(&R.d_tri_bound, tb.size() * 4));
+        R.tri_bound_words = tb.size();
+    }
+    HIPCHK(hipMemcpyAsync(R.d_tri_bound, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, R.stream));
+    HIPCHK(hipStreamSynchronize(R.stream));            // `tb` is pageable host memory about to go out of scope
+    R.scene.tri_bound = R.d_tri_bound;
     return PT_OK;
 }
 
@@ -770,6 +844,7 @@ void pt_free(void) {
     if (R.d_tris) (void)hipFree(R.d_tris);
     if (R.d_cull) (void)hipFree(R.d_cull);
     if (R.d_grec) (void)hipFree(R.d_grec);
+    if (R.d_tri_bound) (void)hipFree(R.d_tri_bound);
     if (R.d_ginfo) (void)hipFree(R.d_ginfo);
     drop_graphs();
     if (R.mesh_hit) (void)hipFree(R.mesh_hit);
@@ -1054,15 +1129,18 @@ static int init_impl(const pt_scene_desc *d) {
     for (int i = 0; i < d->num_geoms; ++i) {
         const pt_geom &g = d->geoms[i];
         float *r = grec.data() + (size_t)i * ptd::GEOM_WORDS;
-        int first = 0, count = 0;
-        for (int k = 0; k < d->num_meshes; ++k)
-            if (d->meshes[k].geom_index == i) { first = d->meshes[k].first_triangle; count = d->meshes[k].triangle_count; break; }
+        int first = 0, count = 0, boff = 0;
+        for (int k = 0, off = 0; k < d->num_meshes; ++k) {       // boff: where upload_tri_bounds puts the mesh's spheres
+            if (d->meshes[k].geom_index == i) { first = d->meshes[k].first_triangle; count = d->meshes[k].triangle_count; boff = off; break; }
+            off += (d->meshes[k].triangle_count + 3) & ~3;
+        }
         memcpy(&r[0], &g.type, 4); memcpy(&r[1], &g.materialid, 4); memcpy(&r[2], &first, 4); memcpy(&r[3], &count, 4);
         const pt_mat4 *ms[3] = {&g.inverseTransform, &g.transform, &g.invTranspose};
         const int offs[3] = {ptd::G_INV, ptd::G_FWD, ptd::G_INVT};
         for (int m = 0; m < 3; ++m)
             for (int c = 0; c < 4; ++c)
                 for (int rr = 0; rr < 3; ++rr) r[offs[m] + c * 3 + rr] = ms[m]->m[c][rr];
+        if (g.type == PT_TRIANGLE_MESH) memcpy(&r[ptd::G_INV + 6], &boff, 4);     // a mesh's matrices are never read
     }
     std::vector<float> mrec((size_t)d->num_materials * ptd::MAT_WORDS, 0.0f);
     for (int i = 0; i < d->num_materials; ++i) {
@@ -1114,17 +1192,19 @@ static int init_impl(const pt_scene_desc *d) {
         HIPCHK(hipMemcpy(R.d_ginfo, ginfo.data(), ginfo.size() * 4, hipMemcpyHostToDevice));
         R.scene.grec = R.d_grec; R.scene.ginfo = R.d_ginfo;
     }
+    R.mesh_mode = MESH_NONE;
+    for (int i = 0; i < d->num_geoms; ++i)
+        if (d->geoms[i].type == PT_TRIANGLE_MESH) R.mesh_mode = (d->flags & PT_MESH_BVH) ? MESH_BVH : MESH_TILES;
     R.geoms_keep.assign(d->geoms, d->geoms + d->num_geoms);
     if (d->num_triangles > 0) R.tris_keep.assign(d->triangles, d->triangles + d->num_triangles);
     R.desc.geoms = R.geoms_keep.data();
     R.desc.triangles = R.tris_keep.empty() ? nullptr : R.tris_keep.data();
+    if (d->num_meshes > 0) R.meshes_keep.assign(d->meshes, d->meshes + d->num_meshes);
+    R.desc.meshes = R.meshes_keep.empty() ? nullptr : R.meshes_keep.data();
     {
         const int rc = upload_cull(&R.desc, R.cam);
         if (rc != PT_OK) return rc;
     }
-    R.mesh_mode = MESH_NONE;
-    for (int i = 0; i < d->num_geoms; ++i)
-        if (d->geoms[i].type == PT_TRIANGLE_MESH) R.mesh_mode = (d->flags & PT_MESH_BVH) ? MESH_BVH : MESH_TILES;
     if (R.mesh_mode == MESH_BVH) {
         const int rc = upload_bvh(d, grec);
         if (rc != PT_OK) return rc;
@@ -1135,9 +1215,9 @@ static int init_impl(const pt_scene_desc *d) {
     // memory through the vector cache instead: any number of primitives / materials runs.
     {
         const size_t base = ((size_t)LDS_CTL_WORDS + (size_t)WAVES * PW_WORDS) * 4 +
-                            (R.mesh_mode == MESH_TILES ? (size_t)TRI_TILE * TRI_WORDS * 4 : 0);
+                            (R.mesh_mode == MESH_TILES ? (size_t)WAVES * TRQ_WORDS * 4 : 0);
         const size_t scene = (size_t)scene_lds_words(d->num_materials, d->num_geoms) * 4;
-        R.scene_lds = base + scene <= 32 * 1024 || (R.mesh_mode == MESH_TILES && base + scene <= 64 * 1024);
+        R.scene_lds = base + scene <= 32 * 1024;
         if (const char *e = getenv("PTMI355_SCENE_LDS")) R.scene_lds = atoi(e) != 0 && base + scene <= 64 * 1024;   // tests force the global path
         R.lds_bytes = base + (R.scene_lds ? scene : 0);
         R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
@@ -1522,6 +1602,12 @@ int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node
     if (order && count > 0) memcpy(order, tree.order.data(), (size_t)count * 4);
     if (grid) { for (int a = 0; a < 3; ++a) { grid[a] = tree.origin[a]; grid[3 + a] = tree.step[a]; } grid[6] = tree.pad; grid[7] = tree.prune; }
     return tree.num_nodes();
+}
+
+int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, float *bounds) {
+    if (count < 0 || (count > 0 && !triangles) || !bounds) return fail(PT_ERR_INVALID, "pt_tri_bounds: bad argument");
+    make_tri_bounds(triangles, count, (double)origin_bound, bounds);
+    return (count + 3) & ~3;
 }
 
 int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound, float *reject) {

@@ -1089,6 +1089,38 @@ def test_mesh_bvh_c4_equals_every_triangle(pt, scenes):
     assert out["loop"][1][1] > 100000
 
 
+def test_c4_strip_against_the_oracle(pt, po, scenes):
+    """BASELINE config C4 at full size (800x800, depth 8, 100 032 triangles) held against the ORACLE, not against
+    itself: a whole-frame oracle iteration is 2.5 * 10^11 triangle tests, but every path is keyed by (iteration, global
+    pixelIndex, depth), so one 16-row strip -- tile (37, 50, 16), the rows the mesh's centre projects to -- is the same
+    12 800 paths in both and costs the oracle seconds.  Loop over every triangle and hierarchy: image and live counts."""
+    import os
+    s = scenes["cornell"]
+    tris = pt.meshes.uv_sphere()
+    assert len(tris) == 100032
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
+    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
+    W, H = scene.resolution
+    r, strip = 37, 16
+    rows = slice(r * strip * W, (r + 1) * strip * W)
+    ref = po.Tracer(geoms, s["materials"], s["camera"], s["depth"], tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
+    st = ref.iterate_rows(1, r * strip, (r + 1) * strip, threads=min(32, os.cpu_count() or 8))
+    assert st.live[0] == strip * W and st.live[1] > 0
+    for flags in (pt.PT_COMPACT, pt.PT_COMPACT | pt.PT_MESH_BVH):
+        pt.pathtraceInit(scene, flags=flags, tile=(r, H // strip, strip))
+        img = pt.pathtrace(None, 0, 1).copy()
+        live = list(pt.get_stats().live[:s["depth"]])
+        pt.pathtraceFree()
+        assert live == list(st.live[:s["depth"]]), flags
+        assert img[rows].tobytes() == ref.image[rows].tobytes(), flags
+        assert not img[:rows.start].any() and not img[rows.stop:].any()
+    # the strip does see the mesh: without it the same rows come out differently
+    plain = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(plain, tile=(r, H // strip, strip))
+    assert pt.pathtrace(None, 0, 1)[rows].tobytes() != ref.image[rows].tobytes()
+    pt.pathtraceFree()
+
+
 @pytest.mark.parametrize("mode", ["aa", "lens", "aa+lens"])
 def test_camera_jitter_and_lens(pt, po, scenes, mode):
     """Stochastic antialiasing and the thin lens (completion spec; pathtrace.cu:134 TODO, INSTRUCTION.md:110-113):
