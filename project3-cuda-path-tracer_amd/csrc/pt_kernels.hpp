@@ -479,10 +479,9 @@ struct MeshBest { float t; int geom, tri; };
 //     -- so a ray whose line passes the centre at more than Rs cannot be accepted for this triangle, whatever
 //     glm::intersectRayTriangle's float arithmetic returns for it.  All lanes test their ray against it:
 //     q = c x d' - o x d' (d' = d scaled to unit length, o x d' hoisted per ray), |q|^2 > Rs^2 -> skip: six fused
-//     multiply-adds, a three-term dot and one compare per (ray, triangle), the triangle's four floats coming through
-//     wave-uniform scalar loads (s_load_dwordx16 per four triangles).  Round 2 ran the exact test on every pair with
-//     the triangle read from LDS by three wave-uniform ds_read_b128: bound by the LDS pipe at 41 cycles per
-//     (wave, triangle).  Rays the bound was not derived for (non-finite, huge, odd direction magnitudes: `wild`) are
+//     multiply-adds, a three-term dot and one compare per (ray, triangle), the triangle's four floats coming from the
+//     wave's own LDS strip by ONE wave-uniform ds_read_b128.  Round 2 ran the exact test on every pair with the
+//     triangle read from LDS by three wave-uniform ds_read_b128: bound by the LDS pipe at 41 cycles per (wave, triangle).  Rays the bound was not derived for (non-finite, huge, odd direction magnitudes: `wild`) are
 //     candidates of every triangle; NaNs fail the compare towards "candidate".
 //  2. EXACT.  Candidates (lane, triangle) queue in a per-wave LDS ring; whenever 64 wait, lane k runs
 //     glm::intersectRayTriangle (operation for operation, ptd::ray_triangle) + the hit-point test for candidate k
@@ -491,8 +490,11 @@ struct MeshBest { float t; int geom, tri; };
 //     lowest index on ties, i.e. the loop's strict `best > tz` scan in index order.
 // ---------------------------------------------------------------------------
 constexpr unsigned long long TRI_KEY_NONE = (0x7f7fffffull << 32) | 0xffffffffull;   // bary.z = FLT_MAX, no triangle
+#ifndef PT_SWEEP_AHEAD
+#define PT_SWEEP_AHEAD 4                       // spheres read from LDS ahead of the tests that use them
+#endif
 constexpr int TRQ_SLOTS = 128;                 // triangle candidates waiting per wave (a triangle adds <= 64 while < 64 wait)
-constexpr int TRQ_WORDS = TRQ_SLOTS + 2 * 64;  // ring + the 64 per-lane best keys (u64): 1 KiB per wave
+constexpr int TRQ_WORDS = TRQ_SLOTS + 2 * 64 + 2 * 64 * 4;   // ring + the 64 per-lane best keys (u64) + two groups of 64 spheres: 3 KiB per wave
 
 __device__ __forceinline__ void tri_cand_pass(const float *ry0, const uint32_t *ring, unsigned long long *keys,
                                               const float *__restrict__ tris, uint32_t head, uint32_t count) {
@@ -529,37 +531,49 @@ __device__ __forceinline__ void mesh_sweep(const SceneDev &sc, const WaveQ &q, i
     const float dx = rd.x * sc1, dy = rd.y * sc1, dz = rd.z * sc1;
     const float mx = __builtin_fmaf(ro.y, dz, -(ro.z * dy)), my = __builtin_fmaf(ro.z, dx, -(ro.x * dz)),
                 mz = __builtin_fmaf(ro.x, dy, -(ro.y * dx));
-    cfloat *tb = as_const(sc.tri_bound) + (size_t)boff * 4;
+    const float4 *__restrict__ tb = reinterpret_cast<const float4 *>(sc.tri_bound) + (size_t)boff;
+    float4 *stage = reinterpret_cast<float4 *>(trq + TRQ_SLOTS + 2 * 64);       // [2][64] spheres, this wave's own
     const uint64_t m_all = m_act & m_wild;                        // candidates of everything
-    auto one = [&](float cx, float cy, float cz, float r2, int k) {
-        const float qx = __builtin_fmaf(cy, dz, __builtin_fmaf(-cz, dy, -mx));
-        const float qy = __builtin_fmaf(cz, dx, __builtin_fmaf(-cx, dz, -my));
-        const float qz = __builtin_fmaf(cx, dy, __builtin_fmaf(-cy, dx, -mz));
+    auto one = [&](float4 t, int k) {
+        const float qx = __builtin_fmaf(t.y, dz, __builtin_fmaf(-t.z, dy, -mx));
+        const float qy = __builtin_fmaf(t.z, dx, __builtin_fmaf(-t.x, dz, -my));
+        const float qz = __builtin_fmaf(t.x, dy, __builtin_fmaf(-t.y, dx, -mz));
         const float qq = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
-        const uint64_t m = (m_act & ~ballot64(qq > r2)) | m_all;  // NaN: not greater, a candidate
-        if (m && k < count) {                                      // rare: ~1e-5 of the pairs
+        const uint64_t m = (m_act & ~ballot64(qq > t.w)) | m_all;  // NaN: not greater, a candidate
+        if (__builtin_expect(m != 0, 0)) {                         // rare: ~1e-5 of the pairs
+            if (k >= count) return;                                // (a padding sphere and a wild ray)
             if (lane_of(m)) ring[(total + rank_below(m)) & (TRQ_SLOTS - 1)] = (uint32_t)lane | ((uint32_t)(first + k) << 6);
             total += (uint32_t)__popcll((unsigned long long)m);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (total - head >= 64) { tri_cand_pass(ry0, ring, keys, sc.tris, head, 64); head += 64; }
         }
     };
-    // four triangles per step: one s_load_dwordx16, the next step's already requested (the array is padded to a
-    // multiple of four with spheres nothing reaches)
-    float nxt[16];
+    // 64 spheres per group: one coalesced 16-B load per lane (the next group's is in flight while this one is tested),
+    // parked in the wave's own LDS strip and read back as wave-uniform ds_read_b128 -- one LDS read per (wave,
+    // triangle), four in flight ahead of the tests that use them.  (Wave-uniform scalar loads straight from memory
+    // were measured first: s_load returns out of order, so only one batch can be in flight, and 81 cycles per pair
+    // went by waiting on the scalar cache; the array is padded to a multiple of 64 with spheres nothing reaches.)
+    const int ngroups = (count + 63) >> 6;
+    float4 g_next = ngroups > 0 ? tb[lane] : make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    for (int g = 0; g < ngroups; ++g) {
+        float4 *buf = stage + (g & 1) * 64;
+        buf[lane] = g_next;
+        if (g + 1 < ngroups) g_next = tb[(size_t)(g + 1) * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float4 cur[PT_SWEEP_AHEAD];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) nxt[j] = count > 0 ? tb[j] : 0.0f;
-    for (int k = 0; k < count; k += 4) {
-        float b[16];
+        for (int u = 0; u < PT_SWEEP_AHEAD; ++u) cur[u] = buf[u];
+#pragma unroll 2
+        for (int j = 0; j < 64; j += PT_SWEEP_AHEAD) {
+            const int jn = (j + PT_SWEEP_AHEAD) & 63;             // the last step re-reads the first entries: harmless
+            float4 nxt[PT_SWEEP_AHEAD];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) b[j] = nxt[j];
-        if (k + 4 < count) {
-            cfloat *tn = tb + (size_t)(k + 4) * 4;
+            for (int u = 0; u < PT_SWEEP_AHEAD; ++u) nxt[u] = buf[jn + u];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) nxt[j] = tn[j];
+            for (int u = 0; u < PT_SWEEP_AHEAD; ++u) one(cur[u], g * 64 + j + u);
+#pragma unroll
+            for (int u = 0; u < PT_SWEEP_AHEAD; ++u) cur[u] = nxt[u];
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) one(b[4 * j], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3], k + j);
     }
     while (total != head) {
         const uint32_t cnt = min(64u, total - head);
@@ -1633,7 +1647,7 @@ __device__ uint32_t g_wave_hw[8][8192];
 #endif
 
 template <int MODE, bool COMPACT, int MESH, bool SLDS>
-__global__ __launch_bounds__(BLOCK, (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
+__global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 #ifdef PT_WAVE_TIMES
     const unsigned long long wt0 = __builtin_amdgcn_s_memrealtime();
 #endif

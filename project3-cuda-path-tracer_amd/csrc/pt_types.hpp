@@ -15,6 +15,9 @@ namespace {
 #ifndef PT_PRE_WAVES
 #define PT_PRE_WAVES 5                       // k_bounce<MESH_PRE>: 97 VGPRs unconstrained; budgeted for 5 waves per SIMD (+6 %)
 #endif
+#ifndef PT_LOOP_WAVES
+#define PT_LOOP_WAVES 4                      // k_bounce<MESH_TILES>: measured 41.9 Mrays/s on C4 against 36.9 at 3 and 40.1 at 5 (profiles/r03)
+#endif
 constexpr int BLOCK = 256;                 // 4 waves of 64
 constexpr int WAVES = BLOCK / 64;
 constexpr int TILE = 64;                   // paths per tile = one wave64
@@ -162,7 +165,7 @@ struct SceneDev {
     const float *mats;   int nmats;        // MAT_WORDS dwords each
     const float *tris;   int ntris;        // v0, e1, e2 + pad (12 dwords each)
     const float *tri_bound;                // per triangle {centre xyz, Rs^2} of the every-triangle loop's first stage (scalar loads;
-                                           //   per mesh padded to a multiple of 4, offset in word G_INV + 6 of its geom record)
+                                           //   per mesh padded to a multiple of 64, offset in word G_INV + 6 of its geom record)
     const float *bvh_nodes;                // PT_MESH_BVH: all meshes' trees, BVH_NODE_WORDS per node
     const float *bvh_tris;                 //   leaf-ordered triangle records, word 9 = original index
     float bvh_prune;  int bvh_guard;       //   prune margin; upper bound on nodes visited per walk

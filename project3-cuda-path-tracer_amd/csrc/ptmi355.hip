@@ -665,13 +665,15 @@ void make_tri_bounds(const pt_triangle *tris, int count, double Rorigin, float *
 int upload_tri_bounds(const pt_scene_desc *d, double Rorigin) {
     if (R.mesh_mode != MESH_TILES || d->num_meshes <= 0) return PT_OK;
     size_t words = 0;
-    for (int k = 0; k < d->num_meshes; ++k) words += (size_t)((d->meshes[k].triangle_count + 3) & ~3) * 4;
-    std::vector<float> tb(std::max<size_t>(words, 16), 0.0f);
+    for (int k = 0; k < d->num_meshes; ++k) words += (size_t)((d->meshes[k].triangle_count + 63) & ~63) * 4;
+    std::vector<float> tb(std::max<size_t>(words, 256), 0.0f);
     size_t off = 0;
     for (int k = 0; k < d->num_meshes; ++k) {
         const pt_mesh &m = d->meshes[k];
         make_tri_bounds(d->triangles + m.first_triangle, m.triangle_count, Rorigin, tb.data() + off);
-        off += (size_t)((m.triangle_count + 3) & ~3) * 4;
+        const size_t n4 = (size_t)((m.triangle_count + 3) & ~3), n64 = (size_t)((m.triangle_count + 63) & ~63);
+        for (size_t i = n4; i < n64; ++i) { float *o = tb.data() + off + i * 4; o[0] = o[1] = o[2] = 0.0f; o[3] = -1.0f; }
+        off += n64 * 4;
     }
     if (!R.d_tri_bound || R.tri_bound_words < tb.size()) {
         if (R.d_tri_bound) { HIPCHK(hipStreamSynchronize(R.stream)); (void)hipFree(R.d_tri_bound); R.d_tri_bound = nullptr; }
@@ -1132,7 +1134,7 @@ static int init_impl(const pt_scene_desc *d) {
         int first = 0, count = 0, boff = 0;
         for (int k = 0, off = 0; k < d->num_meshes; ++k) {       // boff: where upload_tri_bounds puts the mesh's spheres
             if (d->meshes[k].geom_index == i) { first = d->meshes[k].first_triangle; count = d->meshes[k].triangle_count; boff = off; break; }
-            off += (d->meshes[k].triangle_count + 3) & ~3;
+            off += (d->meshes[k].triangle_count + 63) & ~63;
         }
         memcpy(&r[0], &g.type, 4); memcpy(&r[1], &g.materialid, 4); memcpy(&r[2], &first, 4); memcpy(&r[3], &count, 4);
         const pt_mat4 *ms[3] = {&g.inverseTransform, &g.transform, &g.invTranspose};
