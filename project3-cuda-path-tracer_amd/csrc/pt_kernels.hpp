@@ -1447,9 +1447,11 @@ struct TileRegs {
 
 // First half of one 64-path tile of one bounce: load (or generate) the paths.  `i` = logical path index (what
 // MODE_ISECT planes and the mesh mask are keyed by), `src` = pool slot.
-__device__ __forceinline__ void tile_load(const BounceArgs &a, const TileCtx &c, const Pool &in, bool gen_rays,
+template <bool GEN>
+__device__ __forceinline__ void tile_load(const BounceArgs &a, const TileCtx &c, const Pool &in,
                                           uint32_t tile, uint32_t i, uint32_t src, bool have, bool active,
                                           TileRegs &tr, f3 &ro, f3 &rd) {
+    constexpr bool gen_rays = GEN;
     tr.have = have; tr.i = i; tr.src = src; tr.tile = tile;
     tr.pid = DEAD_PID; tr.smp = 0; tr.pixel = 0;
     tr.col = ptd::mk(1.0f, 1.0f, 1.0f);
@@ -1564,9 +1566,12 @@ struct WgSpans {
     uint32_t b0, b1, b2, b3;
 };
 
-template <int MODE, bool COMPACT, int MESH>
+// GEN: bounce 0 of a batch generates the camera rays in registers (a compile-time switch: the camera, the lens and
+// the candidate masks then never occupy scalar registers in the kernels of the other bounces, and the pool's input
+// side never does in bounce 0's)
+template <int MODE, bool COMPACT, int MESH, bool GEN>
 __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c, WaveQ &q, const Pool &in, const Pool &out,
-                                          int depth, bool gen_rays, uint32_t first_tile, uint32_t count, uint32_t tiles,
+                                          int depth, uint32_t first_tile, uint32_t count, uint32_t tiles,
                                           uint32_t n, bool packed_in, uint32_t span_in, uint32_t &cur, uint32_t dst_base,
                                           bool own_span, const WgSpans &ws, uint32_t &packed, uint32_t &traced) {
     const int lane = c.lane;
@@ -1576,7 +1581,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
     int par = 0;
     // bounce 0 of a pinhole camera: pool tile t holds the pixels of camera tile t mod (tiles per sample), whose
     // candidate primitives k_cull0_mask has written down
-    const bool masked = MODE == MODE_FUSED && gen_rays && a.cull0 != nullptr;
+    const bool masked = MODE == MODE_FUSED && GEN && a.cull0 != nullptr;
     uint32_t mtile = masked ? first_tile % a.cull0_tiles : 0u;
     for (uint32_t r = 0; r < count; ++r) {
         const uint32_t tile = first_tile + r;
@@ -1606,7 +1611,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
         }
         TileRegs tr;
         f3 ro, rd;
-        tile_load(a, c, in, gen_rays, tile, i, src, have, active, tr, ro, rd);
+        tile_load<GEN>(a, c, in, tile, i, src, have, active, tr, ro, rd);
         if (MODE == MODE_FUSED) {
             const float4 *pre_hit = nullptr;
             if (MESH == MESH_PRE && tr.active) {
@@ -1646,7 +1651,7 @@ __device__ unsigned long long g_wave_times[8][8192][2];
 __device__ uint32_t g_wave_hw[8][8192];
 #endif
 
-template <int MODE, bool COMPACT, int MESH, bool SLDS>
+template <int MODE, bool COMPACT, int MESH, bool SLDS, bool GEN = false>
 __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 #ifdef PT_WAVE_TIMES
     const unsigned long long wt0 = __builtin_amdgcn_s_memrealtime();
@@ -1671,21 +1676,21 @@ __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH =
     const uint32_t wid = run_id();
     c.iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;       // graph replay: arguments are frozen
     c.stamp = batch_stamp(a.fin_stamp, a.ctl);
-    const uint32_t n = (COMPACT && !a.gen_rays) ? a.ctl->nlive[a.depth] : a.pool_n;
+    const uint32_t n = (COMPACT && !GEN) ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);                        // logical tiles per wave (one contiguous run)
-    const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
+    const bool packed_in = COMPACT && !GEN && a.dir_in.mem != nullptr;
     const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
     uint32_t traced = 0;
     uint32_t packed = 0;                                         // survivors this wave has written (wave-uniform)
     uint32_t cur = 0;                                            // source range of the run's current position
-    if (a.gen_rays && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = a.pool_n;   // k_raygen's job otherwise
+    if (GEN && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = a.pool_n;   // k_raygen's job otherwise
     if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), W, wid * R * TILE);
     STAMP(2);
 
     // every wave walks its own run of R consecutive 64-path tiles; no workgroup barrier inside the loop
-    run_tiles<MODE, COMPACT, MESH>(a, c, q, a.in, a.out, a.depth, a.gen_rays != 0, wid * R, R, tiles, n, packed_in, span_in,
-                                   cur, wid * R * TILE, false, WgSpans{}, packed, traced);
+    run_tiles<MODE, COMPACT, MESH, GEN>(a, c, q, a.in, a.out, a.depth, wid * R, R, tiles, n, packed_in, span_in,
+                                        cur, wid * R * TILE, false, WgSpans{}, packed, traced);
     STAMP(6);
 #ifdef PT_WAVE_TIMES
     if (lane == 0 && a.depth < 8 && wid < 8192) {
@@ -1786,15 +1791,15 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a)
     for (int d = 0; d < a.trace_depth; ++d) {
         uint32_t traced = 0, packed = 0;
         if (d == 0) {
-            run_tiles<MODE_FUSED, true, MESH_NONE>(a, c, q, in, out, 0, true, wid * R, R, tiles, n, false, 0, cur, base, false, ws,
-                                                   packed, traced);
+            run_tiles<MODE_FUSED, true, MESH_NONE, true>(a, c, q, in, out, 0, wid * R, R, tiles, n, false, 0, cur, base, false, ws,
+                                                         packed, traced);
         } else {
             const uint32_t wg_tiles = (ws.total + TILE - 1) / TILE;
             const uint32_t per = (wg_tiles + WAVES - 1) / WAVES;              // <= R: a wave's output still fits its span
             const uint32_t first = (uint32_t)wave * per;
             const uint32_t mine = first < wg_tiles ? min(per, wg_tiles - first) : 0u;
-            run_tiles<MODE_FUSED, true, MESH_NONE>(a, c, q, in, out, d, false, first, mine, tiles, n, false, 0, cur, base, true, ws,
-                                                   packed, traced);
+            run_tiles<MODE_FUSED, true, MESH_NONE, false>(a, c, q, in, out, d, first, mine, tiles, n, false, 0, cur, base, true, ws,
+                                                          packed, traced);
         }
         if (lane == 0 && traced)
             atomicAdd(&a.ctl->bucket[d][1][(wid % ELECT_BUCKETS) * 16], traced);

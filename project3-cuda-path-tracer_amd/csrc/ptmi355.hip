@@ -363,22 +363,24 @@ void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, c
                                         R.isect, R.scene, n_ptr, n_fixed, dir, nprev, R.ctl, cull0, R.cull0_tiles, gen));
 }
 
+// The instantiations of k_bounce that are ever launched: MODE_ISECT / MODE_CACHE0 intersect nothing (one mesh mode
+// serves them all, no ray generation); the fused kernel reads the results of the mesh pre-pass under PT_MESH_BVH
+// (the hierarchy is never walked inline by k_bounce) and generates bounce 0's rays itself in batches (GEN).
+template <int MODE, bool COMPACT, int MESH, bool GEN>
+void launch_bounce_at(const BounceArgs &a) {
+    if (R.scene_lds) hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH, true, GEN>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+    else hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH, false, GEN>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+}
 template <int MODE, bool COMPACT>
 void launch_bounce(const BounceArgs &a) {
-    if (MODE != MODE_FUSED) {
-        // nothing is intersected: one instantiation serves every mesh mode
-        if (R.scene_lds) hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH_NONE, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
-        else hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH_NONE, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
-        return;
+    if constexpr (MODE != MODE_FUSED) {
+        launch_bounce_at<MODE, COMPACT, MESH_NONE, false>(a);
+    } else {
+        const bool gen = a.gen_rays != 0;
+        if (R.mesh_mode == MESH_BVH) { if (gen) launch_bounce_at<MODE, COMPACT, MESH_PRE, true>(a); else launch_bounce_at<MODE, COMPACT, MESH_PRE, false>(a); }
+        else if (R.mesh_mode == MESH_TILES) { if (gen) launch_bounce_at<MODE, COMPACT, MESH_TILES, true>(a); else launch_bounce_at<MODE, COMPACT, MESH_TILES, false>(a); }
+        else { if (gen) launch_bounce_at<MODE, COMPACT, MESH_NONE, true>(a); else launch_bounce_at<MODE, COMPACT, MESH_NONE, false>(a); }
     }
-    if (R.mesh_mode == MESH_BVH) {
-        // meshes were walked by the pre-pass (enqueue_bounce); this launch reads its results
-        if (R.scene_lds) hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH_PRE, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
-        else hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH_PRE, false>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
-        return;
-    }
-    PT_MESH_DISPATCH(hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH, SLDS>), dim3(R.grid), dim3(BLOCK), R.lds_bytes,
-                                        R.stream, a));
 }
 
 int enqueue_bounce(int depth) {
@@ -1268,10 +1270,13 @@ static int init_impl(const pt_scene_desc *d) {
     int per_cu = 0;
     if (R.mesh_mode == MESH_BVH)
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH_PRE, true>, BLOCK, R.lds_bytes));
+            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH_PRE, true, false>, BLOCK, R.lds_bytes));
+    else if (R.mesh_mode == MESH_TILES)
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH_TILES, true, false>, BLOCK, R.lds_bytes));
     else
-        PT_MESH_DISPATCH(HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH, SLDS>, BLOCK, R.lds_bytes)));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH_NONE, true, false>, BLOCK, R.lds_bytes));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     if (const char *e = getenv("PTMI355_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // occupancy experiments
