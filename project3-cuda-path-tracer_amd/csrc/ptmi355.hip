@@ -373,8 +373,10 @@ void launch_bounce_at(const BounceArgs &a) {
 }
 template <int MODE, bool COMPACT>
 void launch_bounce(const BounceArgs &a) {
-    if constexpr (MODE != MODE_FUSED) {
+    if constexpr (MODE == MODE_ISECT) {
         launch_bounce_at<MODE, COMPACT, MESH_NONE, false>(a);
+    } else if constexpr (MODE == MODE_CACHE0) {                  // bounce 0 by definition: batches generate their rays here too
+        if (a.gen_rays) launch_bounce_at<MODE, COMPACT, MESH_NONE, true>(a); else launch_bounce_at<MODE, COMPACT, MESH_NONE, false>(a);
     } else {
         const bool gen = a.gen_rays != 0;
         if (R.mesh_mode == MESH_BVH) { if (gen) launch_bounce_at<MODE, COMPACT, MESH_PRE, true>(a); else launch_bounce_at<MODE, COMPACT, MESH_PRE, false>(a); }
