@@ -456,7 +456,26 @@ def cpu_baseline(scene):
     ref = reference_headers_baseline(scene, po)
     if ref:
         out["reference_headers"] = ref
+    c1 = c1_baseline(po)
+    if c1:
+        out["c1"] = c1
     return out
+
+
+def c1_baseline(po):
+    """BASELINE configs[0] exactly as stated: scenes/cornell_diffuse.txt (400 x 400, depth 4, diffuse only), 1 spp,
+    the oracle's plain single-thread loop."""
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+        g = lambda k: z["cornell_diffuse__" + k]
+        tr = po.Tracer(g("geoms"), g("materials"), g("camera"), int(g("depth")), flags=po.F_COMPACT, trig=po.TRIG_SHARED)
+        t0 = time.perf_counter()
+        st = tr.iterate(1)
+        el = time.perf_counter() - t0
+        return {"value": round(st.rays / el / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                "sample": "configs[0]: cornell_diffuse 400x400, 1 spp, depth 4, %d rays in %.2f s, single thread" % (st.rays, el)}
+    except Exception as e:
+        return {"error": str(e)[:200]}
 
 
 def reference_headers_baseline(scene, po):

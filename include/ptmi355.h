@@ -103,11 +103,19 @@ enum pt_flags {
     PT_AA_JITTER     = 1u << 6,  /* stochastic antialiasing: jitter each camera ray inside its
                                     pixel (the TODO at pathtrace.cu:134; INSTRUCTION.md:110).
                                     Excludes PT_CACHE_FIRST (INSTRUCTION.md:113). */
+    PT_PIN_IMAGE     = 1u << 8,  /* opt-in: the host image handed to pt_trace / pt_trace_batch is ONE buffer that stays
+                                    allocated at its address until pt_free (the reference's scene->state.image is: sized at
+                                    load, scene.cpp:145-147).  The library then page-locks it on first use and, when an
+                                    iteration runs as one launch, lets the kernel write the new sums into it over PCIe
+                                    while it is still tracing.  Without the flag every call copies into whatever buffer
+                                    it is given (pageable path), exactly like the reference's cudaMemcpy
+                                    (pathtrace.cu:389-390): buffers may be freed or reallocated between calls. */
     PT_ASYNC_IMAGE   = 1u << 7   /* opt-in: pt_trace / pt_trace_batch return without waiting; the copy of the
                                     running sum into host_image_sum overlaps the NEXT call's tracing and is
                                     complete when the next pt_trace / pt_trace_batch returns, or after
                                     pt_synchronize, pt_get_image or pt_free (pt_get_stats needs pt_synchronize).  Off = the reference's synchronous pathtrace()
-                                    (pathtrace.cu:389-392), with the host buffer page-locked on first use. */
+                                    (pathtrace.cu:389-392).  Implies the lifetime rule of PT_PIN_IMAGE for the buffers
+                                    handed over (they are read by a copy that is still running when the call returns). */
 };
 
 typedef struct pt_scene_desc {
@@ -172,11 +180,9 @@ int pt_set_lens(float lens_radius, float focal_distance);   /* see pt_scene_desc
  * GL PBO in the reference), may be NULL.  host_image_sum: optional HOST buffer
  * of W*H*3 floats that receives the running sum (scene->state.image,
  * pathtrace.cu:389-390), may be NULL.  Synchronous: the buffer is complete
- * when the call returns.  Buffers of 1 MiB and more are page-locked on first
- * use (hipHostRegister, released by pt_free or when a fifth buffer is handed
- * over) and, when the iteration runs as one launch, the kernel writes the new
- * sums into them directly over PCIe while it is still tracing; keep such a
- * buffer allocated until pt_free. */
+ * when the call returns, and belongs to the caller again (it may be freed).
+ * With PT_PIN_IMAGE (see there) buffers of 1 MiB and more are page-locked on
+ * first use and written by the kernel itself. */
 int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum);
 
 /* `count` consecutive iterations iter0..iter0+count-1 traced as one path pool

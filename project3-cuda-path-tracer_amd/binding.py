@@ -32,7 +32,7 @@ ISECT_DT = np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("materialId", "<i4")])
 TRI_DT = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3)])
 MESH_DT = np.dtype([("geom_index", "<i4"), ("first_triangle", "<i4"), ("triangle_count", "<i4")])
 
-PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH, PT_AA_JITTER, PT_ASYNC_IMAGE = 1, 2, 4, 8, 16, 32, 64, 128
+PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH, PT_AA_JITTER, PT_ASYNC_IMAGE, PT_PIN_IMAGE = 1, 2, 4, 8, 16, 32, 64, 128, 256
 BVH_NODE_WORDS = 16
 
 
@@ -163,9 +163,11 @@ def version():
 
 
 def pathtraceInit(scene, flags=PT_COMPACT, device=0, stream=None, tile=(0, 1, 8), max_batch=1,
-                  device_image=None, lens=(0.0, 0.0), devices=None):
+                  device_image=None, lens=(0.0, 0.0), devices=None, pin_image=True):
     """pathtraceInit(Scene*) (pathtrace.cu:79-98) + the run-time toggles of include/ptmi355.h.
-    devices=[d0, d1, ...]: the frame tiled over several GPUs inside the library (tile[2] = rows per strip)."""
+    devices=[d0, d1, ...]: the frame tiled over several GPUs inside the library (tile[2] = rows per strip).
+    pin_image: PT_PIN_IMAGE -- pathtrace() below always hands over scene.image, which lives as long as the scene
+    (like the reference's scene->state.image); callers that pass their own short-lived buffers to pt_trace say False."""
     global _scene
     d = _SceneDesc()
     d.geoms, d.num_geoms = _p(scene.geoms), len(scene.geoms)
@@ -173,7 +175,7 @@ def pathtraceInit(scene, flags=PT_COMPACT, device=0, stream=None, tile=(0, 1, 8)
     d.triangles, d.num_triangles = _p(scene.triangles), 0 if scene.triangles is None else len(scene.triangles)
     d.meshes, d.num_meshes = _p(scene.meshes), 0 if scene.meshes is None else len(scene.meshes)
     C.memmove(C.byref(d.camera), scene.camera.tobytes(), 84)
-    d.trace_depth, d.flags, d.device = scene.traceDepth, flags, device
+    d.trace_depth, d.flags, d.device = scene.traceDepth, flags | (PT_PIN_IMAGE if pin_image else 0), device
     d.stream = stream
     d.tile_index, d.tile_count, d.strip_rows = tile
     d.max_batch = max_batch

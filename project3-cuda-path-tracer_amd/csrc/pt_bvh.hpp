@@ -38,8 +38,11 @@
 //     on every side;
 //   * the kernel's slab test (v_rcp + fused multiply-adds on grid coordinates, pt_kernels.hpp: bvh_slab)
 //     places a box plane within 4 * 2^-23 * (|plane - o|) of where it is, i.e. below spec_pad for every ray
-//     origin within ~128 * max(1, amax) of the mesh -- so along each axis the computed entry parameter is
-//     <= tz <= the computed exit parameter: the box is hit, and it is entered no later than tz;
+//     origin within ~128 * max(1, amax) of the mesh; pt_init knows the bound R on |origin|_1 of every ray that is
+//     not `wild` (it covers the scene and the camera, and pt_set_camera re-derives it and REBUILDS the trees when the
+//     camera leaves it) and widens the pad to spec_pad + 8 * 2^-23 * (R + amax) where that is more (build(): a far
+//     camera) -- so along each axis the computed entry parameter is <= tz <= the computed exit
+//     parameter: the box is hit, and it is entered no later than tz;
 //   * tz is the smallest accepted parameter of the whole mesh, so the running best never drops below it and
 //     "entry <= best" cannot prune the path (`prune` = 0: no distance margin is needed any more);
 //   * triangles with a non-finite coordinate never pass glm's test (a or tz is NaN), so clamping their boxes
@@ -266,8 +269,20 @@ inline float spec_pad(const float *v, int count) {
     return std::ldexp(std::max(1.0f, amax), -14);
 }
 
-// v: `count` triangles, 9 floats each (v0 v1 v2, world space)
-inline void build(const float *v, int count, Tree &out) {
+// largest finite |coordinate| of the mesh
+inline float coord_max(const float *v, int count) {
+    float amax = 0.0f;
+    for (size_t k = 0; k < 9 * (size_t)count; ++k) {
+        const float m = std::fabs(v[k]);
+        if (m <= 3.402823466e+38f && m > amax) amax = m;
+    }
+    return amax;
+}
+
+// v: `count` triangles, 9 floats each (v0 v1 v2, world space).  origin_bound: the |origin|_1 bound of the rays that
+// will walk the tree (pt_init: SceneDev::rmax, which covers the scene and the camera and is re-derived when the
+// camera leaves it); < 0: the bound the pad of 2 * spec_pad covers by itself, ~128 * max(1, amax).
+inline void build(const float *v, int count, Tree &out, double origin_bound = -1.0) {
     out.nodes.clear(); out.order.clear(); out.depth = 0;
     detail::Work w;
     w.tbox.resize((size_t)count); w.cen.resize(3 * (size_t)count); w.idx.resize((size_t)count);
@@ -281,6 +296,14 @@ inline void build(const float *v, int count, Tree &out) {
     }
     out.spec_pad = spec_pad(v, count);
     out.pad = 2.0f * out.spec_pad;
+    if (origin_bound >= 0.0) {
+        // the slab test misplaces a plane by at most 4 * 2^-23 * |plane - o| <= 4 * 2^-23 * (amax + pad + |o|); the
+        // accepted point must keep its spec_pad of clearance with that on top: twice the error, for the rounding of
+        // the planes to the grid and of this sum itself
+        const double slab = 8.0 * 0x1p-23 * (origin_bound + (double)coord_max(v, count) + 4.0 * (double)out.spec_pad);
+        const float need = (float)((double)out.spec_pad + slab) * 1.0000005f;
+        if (std::isfinite(need) && need > out.pad) out.pad = need;
+    }
     out.prune = 0.0f;
     w.split.resize(1);
     if (count > 0) out.depth = detail::build(w, 0, 0, count, 0);

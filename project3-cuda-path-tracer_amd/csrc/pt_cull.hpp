@@ -131,7 +131,10 @@ inline float make_boxes(const float *const *inv16, const bool *is_sphere, const 
         if (std::isfinite(s)) reach = std::fmax(reach, s);
     }
     double R = 2.0 * reach + 1.0;
-    if (!(R < 0x1p40)) R = 0x1p40;
+    // the kernel forms n = -o * (1/d) with 1/d clamped to +-2^100: |o| must stay below 2^27 for that product to be
+    // finite (an axis-parallel ray from farther out would see -inf for both planes of a slab it runs inside and be
+    // culled).  Scenes that reach beyond 2^27 keep this bound; their far rays are `wild` -- candidates of everything.
+    if (!(R < 0x1p27)) R = 0x1p27;
     const double u = 0x1p-24;
     for (int g = 0; g < n; ++g) {
         const Affine &f = aff[(size_t)g];

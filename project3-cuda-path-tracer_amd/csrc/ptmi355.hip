@@ -113,6 +113,7 @@ struct Renderer {
     std::vector<pt_geom> geoms_keep;   // host copies (pt_set_camera may have to remake the cull boxes)
     std::vector<pt_triangle> tris_keep;
     std::vector<pt_mesh> meshes_keep;
+    std::vector<float> grec_keep;      // the geom records as uploaded (PT_MESH_BVH rewrites the meshes' words when the trees are rebuilt)
     bool scene_lds = true;        // gather records + materials staged in LDS (else read through the vector cache)
     SceneDev scene{};
     size_t lds_bytes = 0;
@@ -702,7 +703,10 @@ int upload_tri_bounds(const pt_scene_desc *d, double Rorigin) {
 // OTHER small buffers on the same pages ended in GPU page faults ("Memory access fault", found by the full GPU test
 // suite) -- and at that size the pageable path costs nothing that matters.
 bool pin_host(void *ptr, size_t bytes) {
-    if (!R.pin_enabled || bytes < ((size_t)1 << 20)) return false;
+    // only on the caller's word that the buffer outlives the session (PT_PIN_IMAGE / PT_ASYNC_IMAGE): a registration
+    // cannot be re-validated -- a buffer freed and reallocated at the same address looks exactly like the old one to
+    // the runtime while the device mapping still points at the old (pinned) pages
+    if (!R.pin_enabled || !(R.flags & (PT_PIN_IMAGE | PT_ASYNC_IMAGE)) || bytes < ((size_t)1 << 20)) return false;
     const char *lo = (const char *)ptr, *hi = lo + bytes;
     for (size_t k = 0; k < R.host_regs.size();) {
         auto &h = R.host_regs[k];
@@ -901,7 +905,7 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
         if (kk > 0 && d->meshes[by_geom[(size_t)kk - 1]].geom_index == m.geom_index)
             return fail(PT_ERR_INVALID, "pt_init: geom %d owns more than one mesh", m.geom_index);
         ptbvh::Tree tree;
-        ptbvh::build(reinterpret_cast<const float *>(d->triangles + m.first_triangle), m.triangle_count, tree);
+        ptbvh::build(reinterpret_cast<const float *>(d->triangles + m.first_triangle), m.triangle_count, tree, (double)R.scene.rmax);
         const int root = (int)(nodes.size() / BVH_NODE_WORDS);
         const int slot0 = (int)(btris.size() / TRI_WORDS);
         if ((int64_t)slot0 + m.triangle_count >= (1 << ptbvh::LINK_BITS) || tree.num_nodes() >= (1 << ptbvh::LINK_BITS))
@@ -1212,10 +1216,11 @@ static int init_impl(const pt_scene_desc *d) {
         if (rc != PT_OK) return rc;
     }
     if (R.mesh_mode == MESH_BVH) {
-        const int rc = upload_bvh(d, grec);
+        const int rc = upload_bvh(&R.desc, grec);
         if (rc != PT_OK) return rc;
         HIPCHK(hipMemcpy(R.d_geoms, grec.data(), grec.size() * 4, hipMemcpyHostToDevice));   // records now name tree roots
     }
+    R.grec_keep = grec;
     // LDS per workgroup: control words + (scene block, when it is small enough to leave room for five workgroups
     // per CU) + the four per-wave blocks (+ the triangle tile).  A scene that does not fit is gathered from global
     // memory through the vector cache instead: any number of primitives / materials runs.
@@ -1372,7 +1377,18 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
         const int rc = update_cull0();
         if (rc != PT_OK) return rc;
     }
-    if (moved && R.mesh_mode == MESH_BVH) {
+    if (recull && R.mesh_mode == MESH_BVH) {
+        // the trees' box padding covers ray origins within the bound that has just grown: rebuild them for the new one
+        HIPCHK(hipStreamSynchronize(R.stream));
+        float **old[] = {&R.d_bvh_nodes, &R.d_bvh_tris, &R.d_bvh_top};
+        for (float **p : old) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        if (R.d_bvh_meshes) { (void)hipFree(R.d_bvh_meshes); R.d_bvh_meshes = nullptr; }
+        const int rc = upload_bvh(&R.desc, R.grec_keep);
+        if (rc != PT_OK) return rc;
+        HIPCHK(hipMemcpy(R.d_geoms, R.grec_keep.data(), R.grec_keep.size() * 4, hipMemcpyHostToDevice));
+        drop_graphs();
+    }
+    if ((moved || recull) && R.mesh_mode == MESH_BVH) {
         const bool had = R.cam_mask_valid;
         HIPCHK(hipStreamSynchronize(R.stream));                  // launches in flight still read the old mask
         const int rc = update_cam_mask();

@@ -46,7 +46,9 @@ void pathtraceInit(Scene *scene) {
     d.num_materials = (int32_t)scene->materials.size();
     memcpy(&d.camera, &scene->state.camera, sizeof d.camera);
     d.trace_depth = scene->state.traceDepth;
-    d.flags = PT_COMPACT;            // the toggles the assignment asks for: PT_SORT_MATERIAL, PT_CACHE_FIRST
+    // the toggles the assignment asks for: PT_SORT_MATERIAL, PT_CACHE_FIRST.  PT_PIN_IMAGE: scene->state.image is sized
+    // once at load (scene.cpp:145-147) and lives as long as the Scene, so the library may page-lock it
+    d.flags = PT_COMPACT | PT_PIN_IMAGE;
     d.device = 0;                    // cudaGLSetGLDevice(0), preview.cpp:107
     d.tile_index = 0; d.tile_count = 1; d.strip_rows = 8;
     d.max_batch = 1;

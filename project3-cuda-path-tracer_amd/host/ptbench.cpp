@@ -32,7 +32,7 @@ int main(int argc, char **argv) {
         return 1;
     }
     int iters = -1, batch = 1, device = 0, tile_index = 0, tile_count = 1, strip_rows = 8;
-    unsigned flags = PT_COMPACT;
+    unsigned flags = PT_COMPACT | PT_PIN_IMAGE;          // `image` below lives until pt_free
     bool pfm = false;
     float lens_radius = 0.0f, focal_distance = 0.0f;
     std::string out;

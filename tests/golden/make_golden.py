@@ -291,6 +291,16 @@ def main():
     print("C2 live counts iter1:", r["live"][0], "rays", r["rays"])
     np.savez_compressed(os.path.join(OUT, "completion.npz"), **comp)
 
+    # ---- BASELINE configs[0] exactly as stated: cornell_diffuse.txt (400 x 400, depth 4, diffuse only), iteration 1,
+    # through the reference's own headers in a single-thread loop ----
+    c1s = scenes["cornell_diffuse"]
+    assert tuple(c1s["camera"][0]["resolution"]) == (400, 400) and c1s["depth"] == 4
+    r = completion(BS, c1s, 1, keep_order=False)
+    np.savez_compressed(os.path.join(OUT, "c1.npz"), live=r["live"], rays=r["rays"],
+                        img_md5=np.array(hashlib.md5(r["images"][0].tobytes()).hexdigest()),
+                        img_sub=r["images"][0][::53].copy())
+    print("C1 live counts:", r["live"][0], "rays", r["rays"])
+
     # ---- image output through the reference's saveImage / image::savePNG (+ stb_image_write) -------
     from PIL import Image as _Image
     img_in = f64.copy()                                  # 3-iteration fake-shader sum, 64x64

@@ -72,3 +72,32 @@ def test_random_transforms(pt, po, scenes, seed):
     assert np.isinf(boxes[4]).all()                        # no culling for the singular one
     assert np.isfinite(boxes[0]).all()
     _check(pt, po, geoms, (0.0, 5.0, 10.5), rng, 2500)
+
+
+def test_far_scene_axis_parallel_rays(pt, po):
+    """the kernel forms n = -o / d with 1 / d clamped to +-2^100, so |o| must stay below 2^27 for a ray
+    that is parallel to an axis (d_k = 0) -- beyond it the product is inf, both planes of the slab the ray runs INSIDE
+    come out -inf and the ray would be culled.  make_boxes caps the origin bound at 2^27: rays from farther out are
+    `wild` (candidates of every primitive).  A cube 6e8 units across, rays along the axes from inside it, 3e8 out."""
+    H = pt.host_binding.host_library()
+    geoms = np.zeros(1, dtype=pt.GEOM_DT)
+    geoms[0]["type"] = 1
+    geoms[0]["scale"] = (6e8, 6e8, 6e8)
+    H.pth_build_geom_matrices(geoms.ctypes.data)
+    boxes, rmax, rej = pt.cull_boxes(geoms, (0.0, 0.0, 0.0))
+    assert rmax <= 2.0 ** 27
+    rng = np.random.default_rng(1)
+    n = 600
+    rays = np.zeros((n, 6), dtype=np.float32)
+    rays[:, :3] = rng.uniform(-2.9e8, 2.9e8, (n, 3))
+    ax = rng.integers(0, 3, n)
+    rays[np.arange(n), 3 + ax] = rng.choice([-1.0, 1.0], n)
+    rays[: n // 2, ax[0] % 3] = rng.choice([-2.95e8, 2.95e8], n // 2)          # close to a face, far beyond 2^28
+    paths = np.zeros(n, dtype=po.PATH_DT)
+    paths["origin"], paths["direction"] = rays[:, :3], rays[:, 3:]
+    want, _ = po.compute_intersections(paths, geoms.view(po.GEOM_DT))
+    hit = (want["t"] > 0) | np.isnan(want["t"])
+    assert hit.sum() > n // 2                                                  # from inside: they do hit
+    cand, wild = cull_model.candidates(rays, boxes[0], rmax, rej[0])
+    assert not (hit & ~cand).any()
+    assert wild[np.abs(rays[:, :3]).sum(axis=1) > 2.0 ** 27].all()

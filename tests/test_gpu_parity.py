@@ -426,6 +426,93 @@ def test_lifecycle_and_errors(pt, scenes):
                 pt.pathtraceInit(pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=m), flags=flags)
 
 
+def test_host_image_freed_and_reallocated_between_calls(pt, po, scenes):
+    """pathtrace() copies the running sum into WHATEVER buffer it is handed (pathtrace.cu:389-390 is a plain
+    cudaMemcpy): without PT_PIN_IMAGE the library keeps no claim on a buffer after the call returns -- the host may
+    free it, and a new allocation (often at the same address) is just another buffer.  1200 x 900 x 12 B: above the
+    1 MiB from which PT_PIN_IMAGE would page-lock.  With the flag the one long-lived buffer gives the same sums."""
+    s = scenes["cornell"]
+    cam = _resized(s["camera"], 1200, 900)
+    scene = pt.Scene(s["geoms"], s["materials"], cam, 3)
+    n = 1200 * 900
+    L = pt.library()
+    ref = po.Tracer(s["geoms"], s["materials"], cam, 3)
+    want = []
+    for it in range(1, 7):
+        ref.iterate(it, threads=8)
+        want.append(ref.image.copy())
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, pin_image=False)
+    for it in range(1, 7):
+        buf = np.empty((n, 3), dtype=np.float32)          # a fresh buffer per call ...
+        buf[:] = -1.0
+        assert L.pt_trace(None, 0, it, buf.ctypes.data) == 0
+        assert buf.tobytes() == want[it - 1].tobytes(), it
+        del buf                                           # ... freed before the next
+    pt.pathtraceFree()
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE, pin_image=False)
+    keep = np.zeros((n, 3), dtype=np.float32)
+    for it in range(1, 7):
+        assert L.pt_trace(None, 0, it, keep.ctypes.data) == 0
+        assert keep.tobytes() == want[it - 1].tobytes(), it
+    pt.pathtraceFree()
+
+
+@pytest.mark.parametrize("flags_name", ["loop", "bvh"])
+def test_unit_mesh_seen_from_far_away(pt, po, scenes, flags_name):
+    """A unit-size mesh viewed from 300 and then from 5000 units away: the hierarchy's box padding and the
+    every-triangle loop's spheres are derived for ray origins within the scene's bound, which pt_init stretches to
+    the camera and pt_set_camera re-derives (rebuilding the trees) when the camera leaves it.  Image == oracle."""
+    s = scenes["cornell_64"]
+    tris = pt.meshes.uv_sphere(center=(0.0, 5.0, 0.0), radius=0.5, n_lat=12, n_lon=24)
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"][:0], tris, material_id=1)        # the mesh alone
+    light = s["geoms"][:1].copy()                                                      # + the scene's light so paths end lit
+    geoms = np.concatenate([geoms, light])
+    flags = pt.PT_COMPACT | (pt.PT_MESH_BVH if flags_name == "bvh" else 0)
+
+    def camera_at(dist):
+        c = _resized(s["camera"], 64, 64)
+        c["position"][0] = (0.0, 5.0, dist)
+        # a narrow field of view so that the mesh fills a good part of the frame from that distance
+        half = np.float32(0.75 / dist)
+        c["pixelLength"][0] = (np.float32(2 * half / 64), np.float32(2 * half / 64))
+        return c
+
+    near = camera_at(300.0)
+    scene = pt.Scene(geoms, s["materials"], near, 4, triangles=tris, meshes=meshes)
+    pt.pathtraceInit(scene, flags=flags)
+    for dist in (300.0, 5000.0, 300.0):
+        cam = camera_at(dist)
+        scene.camera[:] = cam
+        pt.clear_image()
+        img = pt.pathtrace(None, 0, 1).copy()             # re-reads the camera (pathtrace.cu:285-286)
+        ref = po.Tracer(geoms, s["materials"], cam, 4, tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
+        st = ref.iterate(1)
+        assert st.live[1] > 500, dist                      # the mesh is hit
+        assert list(pt.get_stats().live[:4]) == list(st.live[:4]), dist
+        assert img.tobytes() == ref.image.tobytes(), dist
+    pt.pathtraceFree()
+
+
+def test_c1_as_stated(pt, po, scenes, golden):
+    """BASELINE configs[0]: scenes/cornell_diffuse.txt as the reference loader reads it -- the Cornell box with the
+    sphere made diffuse, 400 x 400, 1 spp, depth 4 -- on the GPU against the oracle's single-thread loop and against
+    the image the REFERENCE'S OWN headers produce for it (tests/golden/c1.npz; tests/test_oracle_golden.py holds the
+    oracle against the same fixture on the CPU)."""
+    s = scenes["cornell_diffuse"]
+    assert tuple(s["camera"][0]["resolution"]) == (400, 400) and s["depth"] == 4
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene)
+    img = pt.pathtrace(None, 0, 1).copy()
+    live = list(pt.get_stats().live[:4])
+    pt.pathtraceFree()
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
+    st = ref.iterate(1)
+    z = golden["c1"]
+    assert live == list(st.live[:4]) == list(z["live"][0]) and live[0] == 160000
+    assert img.tobytes() == ref.image.tobytes()
+    assert hashlib.md5(img.tobytes()).hexdigest() == str(z["img_md5"])
+
+
 def _resized(cam, w, h):
     """The reference camera at another resolution: pixelLength follows scene.cpp:131-135 (2 * tan(fov) / resolution)."""
     c = cam.copy()
@@ -898,13 +985,18 @@ def test_bounce0_candidate_masks(pt, po, scenes, monkeypatch):
     monkeypatch.delenv("PTMI355_CULL0")
 
 
-def test_final_colour_stamps(pt, po, scenes, monkeypatch):
-    """Paths that end with colour 0 write nothing; k_gather tells this batch's entries from stale ones by the batch's
+@pytest.mark.parametrize("graph", [False, True])
+def test_final_colour_stamps(pt, po, scenes, monkeypatch, graph):
+    """(Run with direct launches and under hipGraph replay, PTMI355_GRAPH=1: the stamp then travels through
+    Control::keep[0] because kernel arguments are frozen at capture.)
+    Paths that end with colour 0 write nothing; k_gather tells this batch's entries from stale ones by the batch's
     stamp (a per-session serial number in the entry's fourth component).  The same iteration traced again after
     clear_image, batches of different sizes over the same entries, and the serial's wrap-around at 2^32 (the buffer
     is cleared and the serial restarts) all give the oracle's sums."""
     s = scenes["cornell_64"]
     n = 64 * 64
+    if graph:
+        monkeypatch.setenv("PTMI355_GRAPH", "1")
     for start in (None, "0xfffffffd"):                    # the second run wraps after three batches
         if start:
             monkeypatch.setenv("PTMI355_FIN_SERIAL", start)

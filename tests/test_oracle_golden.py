@@ -228,3 +228,20 @@ def test_iteration_parallel_driver_equals_sequential(po, scenes):
     got = b.iterate_parallel(3, 11, 4)
     assert got == want and a.image.tobytes() == b.image.tobytes()
 
+
+def test_c1_as_stated(po, scenes, golden):
+    """BASELINE configs[0] exactly as stated -- scenes/cornell_diffuse.txt: 400 x 400, 1 spp, depth 4, diffuse only,
+    the __host__ intersection / shade path in a SINGLE-THREAD loop: the oracle's iteration 1 against the image, live
+    counts and ray count the reference's own headers produce (tests/golden/c1.npz, written by make_golden.py from
+    oracle/_ref/libptref_b_shared.so)."""
+    import hashlib
+    s = scenes["cornell_diffuse"]
+    assert tuple(s["camera"][0]["resolution"]) == (400, 400) and s["depth"] == 4
+    used = s["materials"][np.unique(s["geoms"]["materialid"])]          # the mirror of cornell.txt is still listed, unused
+    assert (used["hasReflective"] == 0).all() and (used["hasRefractive"] == 0).all()
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
+    st = ref.iterate(1)                                   # threads = 0: the plain single-thread loop
+    z = golden["c1"]
+    assert list(st.live[:4]) == list(z["live"][0]) and st.rays == int(z["rays"][0])
+    assert hashlib.md5(ref.image.tobytes()).hexdigest() == str(z["img_md5"])
+    assert ref.image[::53].tobytes() == z["img_sub"].tobytes()
