@@ -91,7 +91,11 @@ enum pt_status {
  *      INSTRUCTION.md:77-89, as flags) ------------------------------------- */
 enum pt_flags {
     PT_COMPACT       = 1u << 0,  /* stable live-path compaction after every bounce */
-    PT_SORT_MATERIAL = 1u << 1,  /* stable sort of live paths by materialId before shading */
+    PT_SORT_MATERIAL = 1u << 1,  /* live paths stably sorted by the materialId they hit (INSTRUCTION.md:78-86): the pool
+                                    order after every bounce is the stable partition of that sorted order.  With
+                                    compaction and up to 64 materials the survivors are PLACED by material as the fused
+                                    kernel writes them (csrc/pt_types.hpp: RangeDir); PT_UNFUSED | PT_SORT_MATERIAL, or
+                                    no compaction, runs the separate intersect -> key histogram -> sorted-shade kernels */
     PT_FAKE_SHADER   = 1u << 2,  /* the reference as shipped: one bounce + shadeFakeMaterial
                                     (pathtrace.cu:224-266,339-377) */
     PT_CACHE_FIRST   = 1u << 3,  /* cache the bounce-0 intersections (INSTRUCTION.md:87-89) */

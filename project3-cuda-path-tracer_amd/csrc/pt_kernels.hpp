@@ -742,12 +742,12 @@ __device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t sp
     uint32_t s = cur;
     // bounded: a sane directory resolves within W/63 + 1 windows; every wave reaches the exit
     for (uint32_t guard = 0;; ++guard) {
-        if (guard > dir.W / 63 + 1) {
+        if (guard > dir.nr / 63 + 1) {
             if (lane == 0) atomicOr(&ctl->error, 2u);
             break;
         }
         const uint32_t t = s + (uint32_t)lane;
-        const uint32_t w = t <= dir.W ? base[t] : 0xffffffffu;
+        const uint32_t w = t <= dir.nr ? base[t] : 0xffffffffu;
         int lo = 0, hi = 63;                        // w(lane 0) <= p always holds for unresolved lanes
 #pragma unroll
         for (int step = 0; step < 6; ++step) {
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
     const bool packed = dir_in.mem && nprev_ptr;
     const uint32_t span = packed ? range_tiles(*nprev_ptr, W) * TILE : 0;
     uint32_t cur = 0;
-    if (packed && wid * R < tiles) cur = find_range(dir_in.base(), W, wid * R * TILE);
+    if (packed && wid * R < tiles) cur = find_range(dir_in.base(), dir_in.nr, wid * R * TILE);
     auto finish = [&](uint32_t i, int par, const MeshBest &mb) {
         if (i < n) {
             float t; f3 nrm; int mat, outside;
@@ -893,55 +893,62 @@ __global__ __launch_bounds__(BLOCK) void k_cull0_mask(SceneDev sc, pt_camera cam
 // on dispatch order.
 __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t *n_out,
                                                   uint32_t *lds_scan /* >= 8 words */) {
-    // One step: thread t owns the `per` consecutive entries [t*per, (t+1)*per) (per = ceil(W/256) rounded
-    // to a multiple of 4, at most 32 for W <= 8192), loads them with 16-B loads all issued up front,
-    // and the 256 partial sums cross through one wave scan + one LDS exchange.
+    // One step covers 8192 entries: thread t owns the `per` consecutive entries [t*per, (t+1)*per) of the step (per =
+    // a multiple of 4, at most 32), loads them with 16-B loads all issued up front, and the 256 partial sums cross
+    // through one wave scan + one LDS exchange.  W <= 8192 waves: one step; K * W ranges (survivors placed by
+    // material): K steps at most, the running total carried from step to step.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t W = dir.W;
+    const uint32_t NR = dir.nr;
     const uint4 *count4 = reinterpret_cast<const uint4 *>(dir.count());
     uint4 *base4 = reinterpret_cast<uint4 *>(dir.base());
-    const uint32_t per4 = ((W + BLOCK - 1) / BLOCK + 3) / 4;          // uint4s per thread, <= 8
-    const uint32_t first = threadIdx.x * per4 * 4;                    // first entry of this thread
-    uint4 v[8];
-    uint32_t sum = 0;
+    uint32_t carry = 0;
+    for (uint32_t s0 = 0, step = 0; s0 < NR; s0 += 8192u, ++step) {
+        const uint32_t W = min(8192u, NR - s0);                           // entries of this step
+        const uint32_t per4 = ((W + BLOCK - 1) / BLOCK + 3) / 4;          // uint4s per thread, <= 8
+        const uint32_t first = threadIdx.x * per4 * 4;                    // first entry of this thread within the step
+        uint4 v[8];
+        uint32_t sum = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) {
-        const uint32_t e = first + 4 * k;
-        v[k] = make_uint4(0, 0, 0, 0);
-        if (k < per4 && e < W) {
-            v[k] = count4[e >> 2];                                      // count[] is padded to a multiple of 4
-            if (e + 1 >= W) v[k].y = 0;
-            if (e + 2 >= W) v[k].z = 0;
-            if (e + 3 >= W) v[k].w = 0;
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t e = first + 4 * k;
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (k < per4 && e < W) {
+                v[k] = count4[(s0 + e) >> 2];                                // count[] is padded to a multiple of 4
+                if (e + 1 >= W) v[k].y = 0;
+                if (e + 2 >= W) v[k].z = 0;
+                if (e + 3 >= W) v[k].w = 0;
+            }
+            sum += v[k].x + v[k].y + v[k].z + v[k].w;
         }
-        sum += v[k].x + v[k].y + v[k].z + v[k].w;
-    }
-    uint32_t incl = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t u = __shfl_up(incl, off);
-        if (lane >= off) incl += u;
-    }
-    if (lane == 63) lds_scan[wave] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        const uint32_t c = lds_scan[w];
-        if (w < wave) wave_off += c;
-        total += c;
-    }
-    uint32_t run = wave_off + incl - sum;
-#pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) {
-        const uint32_t e = first + 4 * k;
-        if (k < per4 && e < W) {
-            uint4 b;
-            b.x = run; b.y = b.x + v[k].x; b.z = b.y + v[k].y; b.w = b.z + v[k].z;
-            base4[e >> 2] = b;                                           // base[] has 4 spare entries
-            run = b.w + v[k].w;
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off);
+            if (lane >= off) incl += u;
         }
+        uint32_t *slot = lds_scan + (step & 1u) * WAVES;
+        if (lane == 63) slot[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c = slot[w];
+            if (w < wave) wave_off += c;
+            total += c;
+        }
+        uint32_t run = carry + wave_off + incl - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t e = first + 4 * k;
+            if (k < per4 && e < W) {
+                uint4 b;
+                b.x = run; b.y = b.x + v[k].x; b.z = b.y + v[k].y; b.w = b.z + v[k].z;
+                base4[(s0 + e) >> 2] = b;                                    // base[] has 4 spare entries; steps start at multiples of 8192
+                run = b.w + v[k].w;
+            }
+        }
+        carry += total;
     }
-    if (threadIdx.x == 0) { dir.base()[W] = total; *n_out = total; }
+    if (threadIdx.x == 0) { dir.base()[NR] = carry; *n_out = carry; }
 }
 
 // ---------------------------------------------------------------------------
@@ -1501,10 +1508,13 @@ __device__ __forceinline__ bool mesh_root_candidate(const SceneDev &sc, f3 ro, f
     return cand;
 }
 
-template <bool COMPACT, int MESH = MESH_NONE>
+// SORT (PT_SORT_MATERIAL, fused form): the survivors of key (= material hit) k go to the wave's span of range
+// k * W + w -- `key_stride` slots further per key -- and `packed` is per LANE: lane k counts the wave's key-k survivors.
+template <bool COMPACT, int MESH = MESH_NONE, bool SORT = false>
 __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c, const Pool &in, const Pool &out, int depth,
                                            const TileRegs &tr, f3 ro, f3 rd, float t, f3 nrm, int mat, int outside,
-                                           uint32_t n, uint32_t dst_base, uint32_t &packed, uint32_t &traced) {
+                                           uint32_t n, uint32_t dst_base, uint32_t &packed, uint32_t &traced,
+                                           uint32_t key_stride = 0) {
     const int lane = c.lane;
     bool alive = false;
     ptd::PathState ps;
@@ -1521,7 +1531,15 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
     const uint64_t act = ballot64(tr.active);
     traced += (uint32_t)__popcll((unsigned long long)act);
     uint32_t dst = tr.i;
-    if (COMPACT) {
+    if (COMPACT && SORT) {
+        // one round per material among the tile's survivors (two to four on Cornell): stable within a key -- lanes in
+        // order, tiles in order, waves in order (the directory is key-major)
+        for_each_key(alive, (uint32_t)mat, [&](uint32_t k, uint64_t m) {
+            const uint32_t have = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)k);
+            if (alive && (uint32_t)mat == k) dst = k * key_stride + dst_base + have + rank_below(m);
+            if ((uint32_t)lane == k) packed += (uint32_t)__popcll((unsigned long long)m);
+        });
+    } else if (COMPACT) {
         dst = dst_base + packed + rank_below(bal);
         packed += (uint32_t)__popcll((unsigned long long)bal);
     }
@@ -1542,16 +1560,16 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
 
 // the tile with parity `par` has been fully tested: read its rays back from the wave's LDS block, fold the
 // winner and shade
-template <bool COMPACT, int MESH>
+template <bool COMPACT, int MESH, bool SORT = false>
 __device__ __forceinline__ void tile_finish(const BounceArgs &a, const TileCtx &c, const WaveQ &q, int par, const Pool &in,
                                             const Pool &out, int depth, const TileRegs &tr, uint32_t n, uint32_t dst_base,
-                                            uint32_t &packed, uint32_t &traced) {
+                                            uint32_t &packed, uint32_t &traced, uint32_t key_stride = 0) {
     const float *ry = q.rays(par) + c.lane;
     const f3 ro = ptd::mk(ry[0], ry[64], ry[128]);
     const f3 rd = ptd::mk(ry[192], ry[256], ry[320]);
     float t = -1.0f; f3 nrm = ptd::mk(0, 0, 0); int mat = 0, outside = 1;
     if (tr.active) tile_result(q, par, c.acc, a.scene.tris, tr.mb, t, nrm, mat, outside);
-    tile_shade<COMPACT, MESH>(a, c, in, out, depth, tr, ro, rd, t, nrm, mat, outside, n, dst_base, packed, traced);
+    tile_shade<COMPACT, MESH, SORT>(a, c, in, out, depth, tr, ro, rd, t, nrm, mat, outside, n, dst_base, packed, traced, key_stride);
 }
 
 // The tiles [first, first + count) of one wave's run at one bounce, two in flight (see the intersection stages
@@ -1569,11 +1587,12 @@ struct WgSpans {
 // GEN: bounce 0 of a batch generates the camera rays in registers (a compile-time switch: the camera, the lens and
 // the candidate masks then never occupy scalar registers in the kernels of the other bounces, and the pool's input
 // side never does in bounce 0's)
-template <int MODE, bool COMPACT, int MESH, bool GEN>
+template <int MODE, bool COMPACT, int MESH, bool GEN, bool SORT = false>
 __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c, WaveQ &q, const Pool &in, const Pool &out,
                                           int depth, uint32_t first_tile, uint32_t count, uint32_t tiles,
                                           uint32_t n, bool packed_in, uint32_t span_in, uint32_t &cur, uint32_t dst_base,
-                                          bool own_span, const WgSpans &ws, uint32_t &packed, uint32_t &traced) {
+                                          bool own_span, const WgSpans &ws, uint32_t &packed, uint32_t &traced,
+                                          uint32_t key_stride = 0) {
     const int lane = c.lane;
     bool pending = false;
     TileRegs prev{};
@@ -1622,7 +1641,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
             const uint32_t ticket = q.total;
             if (pending) {
                 drain_to(q, c.acc, prev_ticket);
-                tile_finish<COMPACT, MESH>(a, c, q, par ^ 1, in, out, depth, prev, n, dst_base, packed, traced);
+                tile_finish<COMPACT, MESH, SORT>(a, c, q, par ^ 1, in, out, depth, prev, n, dst_base, packed, traced, key_stride);
             }
             prev = tr; prev_ticket = ticket; pending = true; par ^= 1;
         } else {
@@ -1640,7 +1659,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
     }
     if (pending) {
         drain_to(q, c.acc, prev_ticket);
-        tile_finish<COMPACT, MESH>(a, c, q, par ^ 1, in, out, depth, prev, n, dst_base, packed, traced);
+        tile_finish<COMPACT, MESH, SORT>(a, c, q, par ^ 1, in, out, depth, prev, n, dst_base, packed, traced, key_stride);
     }
 }
 
@@ -1651,7 +1670,7 @@ __device__ unsigned long long g_wave_times[8][8192][2];
 __device__ uint32_t g_wave_hw[8][8192];
 #endif
 
-template <int MODE, bool COMPACT, int MESH, bool SLDS, bool GEN = false>
+template <int MODE, bool COMPACT, int MESH, bool SLDS, bool GEN = false, bool SORT = false>
 __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 #ifdef PT_WAVE_TIMES
     const unsigned long long wt0 = __builtin_amdgcn_s_memrealtime();
@@ -1682,15 +1701,15 @@ __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH =
     const bool packed_in = COMPACT && !GEN && a.dir_in.mem != nullptr;
     const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
     uint32_t traced = 0;
-    uint32_t packed = 0;                                         // survivors this wave has written (wave-uniform)
+    uint32_t packed = 0;                                         // survivors this wave has written (wave-uniform; SORT: lane k counts key k)
     uint32_t cur = 0;                                            // source range of the run's current position
     if (GEN && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = a.pool_n;   // k_raygen's job otherwise
-    if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), W, wid * R * TILE);
+    if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), a.dir_in.nr, wid * R * TILE);
     STAMP(2);
 
     // every wave walks its own run of R consecutive 64-path tiles; no workgroup barrier inside the loop
-    run_tiles<MODE, COMPACT, MESH, GEN>(a, c, q, a.in, a.out, a.depth, wid * R, R, tiles, n, packed_in, span_in,
-                                        cur, wid * R * TILE, false, WgSpans{}, packed, traced);
+    run_tiles<MODE, COMPACT, MESH, GEN, SORT>(a, c, q, a.in, a.out, a.depth, wid * R, R, tiles, n, packed_in, span_in,
+                                              cur, wid * R * TILE, false, WgSpans{}, packed, traced, W * R * TILE);
     STAMP(6);
 #ifdef PT_WAVE_TIMES
     if (lane == 0 && a.depth < 8 && wid < 8192) {
@@ -1715,8 +1734,11 @@ __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH =
     }
 
     if (COMPACT) {
-        // every wave publishes its range count; the last workgroup out scans them
-        if (lane == 0)
+        // every wave publishes its range count(s); the last workgroup out scans them
+        if (SORT) {
+            if ((uint32_t)lane * W < a.dir_out.nr)                        // lane k: the wave's key-k survivors, range k * W + w
+                __hip_atomic_store(&a.dir_out.count()[(uint32_t)lane * W + wid], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == 0)
             __hip_atomic_store(&a.dir_out.count()[wid], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's count store has left
         __syncthreads();
@@ -2258,7 +2280,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void k_mesh(BounceArgs a) {
                 if (!((a.cam_mask[t >> 6] >> (t & 63u)) & 1ull)) continue;
             }
             uint32_t cur = 0;
-            if (packed_in) cur = find_range(a.dir_in.base(), Wd, tile * TILE);
+            if (packed_in) cur = find_range(a.dir_in.base(), a.dir_in.nr, tile * TILE);
             const uint32_t i = tile * TILE + lane;
             bool active = i < n;
             src = i;
@@ -2429,7 +2451,7 @@ __global__ void k_export_paths(Pool p, TileMap map, uint32_t n_total, uint32_t n
     uint32_t src = i;
     if (dir.mem) {                        // logical -> physical: largest r with base[r] <= i
         const uint32_t *base = dir.base();
-        uint32_t lo = 0, hi = dir.W - 1;
+        uint32_t lo = 0, hi = dir.nr - 1;
         while (lo < hi) {
             const uint32_t mid = (lo + hi + 1) >> 1;
             if (base[mid] <= i) lo = mid; else hi = mid - 1;

@@ -123,11 +123,19 @@ __device__ __forceinline__ bool elect_last(uint32_t *buckets /* [32*16] */, uint
 // of the output therefore lives in slot r*R*64 + (i - base[r]) for the range r with
 // base[r] <= i < base[r+1] -- the stable partition's order, with no cross-wave communication
 // inside the launch and only W (<= 8192) words to scan at its end.
+//
+// Material sort folded into the compaction (PT_SORT_MATERIAL, fused form): the pool order the completion spec asks for
+// after a sorted bounce is "survivors, stably sorted by the material they hit".  With K materials the directory
+// simply has K * W ranges, KEY-MAJOR: range k * W + w holds wave w's survivors whose hit had material k, packed at the
+// front of a span of their own (same stride R*64: the pool is K times as large -- 288 GB of HBM are there to be
+// used), and the exclusive scan of count[] in that order is the sorted order.  Readers are unchanged: logical path i
+// lives in slot r*R*64 + (i - base[r]).  Nothing is moved to be sorted, and nothing extra is read or written.
 struct RangeDir {
-    uint32_t *mem;       // count[Wp] | base[Wp+4]  (Wp = W rounded up to 4); nullptr = dense pool
-    uint32_t W;          // waves in the persistent grid = ranges
+    uint32_t *mem;       // count[nrp] | base[nrp+4]  (nrp = nr rounded up to 4); nullptr = dense pool
+    uint32_t W;          // waves in the persistent grid
+    uint32_t nr;         // ranges = W, or K * W when survivors are placed by material
     __device__ __forceinline__ uint32_t *count() const { return mem; }
-    __device__ __forceinline__ uint32_t *base() const { return mem + ((W + 3u) & ~3u); }
+    __device__ __forceinline__ uint32_t *base() const { return mem + ((nr + 3u) & ~3u); }
 };
 
 // Which run of tiles a wave owns: wave j of workgroup b takes run j*G + b, so the first G runs go
@@ -206,7 +214,7 @@ struct BounceArgs {
     // k_iteration at 1 spp with a host image: every wave gathers its own pixels into epi_image (the device's running
     // sum) and writes the new sums to epi_host (the caller's page-locked image, device-mapped); nullptr: k_gather does it
     float *epi_image, *epi_host;
-    // material sort: table[key][workgroup] of k_sort_hist / k_shade_sorted; keys = materials + 1 (misses)
+    // material sort, two-kernel form: table[key][workgroup] of k_sort_hist / k_shade_sorted; keys = materials + 1 (misses)
     uint32_t *sort_table;
     int nbins;
 };

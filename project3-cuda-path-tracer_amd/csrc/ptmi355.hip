@@ -128,6 +128,7 @@ struct Renderer {
     int grid = 0;                 // persistent grid size
     int grid_sort = 0;            // workgroups of the material-sort kernels (k_sort_hist / k_shade_sorted)
     bool sort_wave = true;        // <= 64 keys: k_shade_sorted_w (PTMI355_SORT_WAVE=0 forces the workgroup-wide kernel)
+    int sort_keys = 0;            // > 0: PT_SORT_MATERIAL in its fused form -- survivors placed by material, K = sort_keys ranges per wave (pt_types.hpp: RangeDir)
     bool sorted_isects = false;   // the last bounce was shaded in material order (the intersection planes keep the order the bounce received)
     bool gen_fused = false;       // bounce 0 of the current batch generates its own rays
     bool gen_sort = false;        // ... in the sorted pipeline (k_intersect + k_shade_sorted_w), no k_raygen either
@@ -258,8 +259,9 @@ int ensure_scratch(size_t bytes) {
 
 RangeDir tile_dir(int depth) {
     const uint32_t W = (uint32_t)R.grid * WAVES;
-    if (depth < 0) return RangeDir{nullptr, W};
-    return RangeDir{R.dir_mem + (size_t)depth * R.dir_stride, W};
+    const uint32_t nr = W * (uint32_t)std::max(1, R.sort_keys);
+    if (depth < 0) return RangeDir{nullptr, W, nr};
+    return RangeDir{R.dir_mem + (size_t)depth * R.dir_stride, W, nr};
 }
 
 BounceArgs bounce_args(int depth) {
@@ -316,9 +318,9 @@ int enqueue_begin(int iter0, int count, bool stepping) {
         for (int k = 0; k < 2; ++k)
             HIPCHK(hipMemsetAsync(R.mesh_flags[k], 0, R.flag_words * sizeof(unsigned long long), R.stream));
     // batch path: bounce 0 generates the camera rays itself (no 40 B/path round trip through HBM)
-    R.gen_fused = !stepping && !(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER));
+    R.gen_fused = !stepping && (!(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER)) || R.sort_keys > 0);
     // sorted batches of up to 64 keys: k_intersect and k_shade_sorted_w generate bounce 0's rays themselves
-    R.gen_sort = !stepping && (R.flags & PT_SORT_MATERIAL) && !(R.flags & PT_FAKE_SHADER) && R.sort_wave &&
+    R.gen_sort = !stepping && (R.flags & PT_SORT_MATERIAL) && !R.sort_keys && !(R.flags & PT_FAKE_SHADER) && R.sort_wave &&
                  R.scene.nmats + 1 <= SORTW_MAX_BINS;
     if (R.gen_fused || R.gen_sort) return PT_OK;
     const uint32_t total = (uint32_t)R.map.tile_pixels * (uint32_t)count;
@@ -369,6 +371,13 @@ void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, c
 // (the hierarchy is never walked inline by k_bounce) and generates bounce 0's rays itself in batches (GEN).
 template <int MODE, bool COMPACT, int MESH, bool GEN>
 void launch_bounce_at(const BounceArgs &a) {
+    if constexpr (MODE == MODE_FUSED && COMPACT && MESH != MESH_PRE) {
+        if (R.sort_keys > 0) {                                // PT_SORT_MATERIAL, fused: survivors placed by material
+            if (R.scene_lds) hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH, true, GEN, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+            else hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH, false, GEN, true>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+            return;
+        }
+    }
     if (R.scene_lds) hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH, true, GEN>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
     else hipLaunchKernelGGL((k_bounce<MODE, COMPACT, MESH, false, GEN>), dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
 }
@@ -389,7 +398,8 @@ void launch_bounce(const BounceArgs &a) {
 int enqueue_bounce(int depth) {
     BounceArgs a = bounce_args(depth);
     const bool compact = (R.flags & PT_COMPACT) != 0;
-    const bool unfused = (R.flags & (PT_UNFUSED | PT_SORT_MATERIAL)) != 0;
+    const bool sort2 = (R.flags & PT_SORT_MATERIAL) && R.sort_keys == 0;      // the two-kernel form of the sort
+    const bool unfused = (R.flags & PT_UNFUSED) != 0 || sort2;
     if (unfused) {
         StageTimer tm(PT_STAGE_INTERSECT);
         const bool generate = depth == 0 && R.gen_sort;          // nobody has written nlive[0] yet: the pool size is a.pool_n
@@ -398,7 +408,7 @@ int enqueue_bounce(int depth) {
         launch_intersect(a.in, n_ptr, a.pool_n, a.dir_in, nprev, depth == 0, generate);
         HIPCHK(hipGetLastError());
     }
-    if (R.flags & PT_SORT_MATERIAL) {
+    if (sort2) {
         // intersections of the (dense) pool -> per-workgroup key histogram + scan -> chunk-local counting sort fused
         // with shading: survivors land in the other pool in globally sorted, compacted order (pt_kernels.hpp)
         a.in = R.pool[R.cur]; a.out = R.pool[R.cur ^ 1];
@@ -502,7 +512,7 @@ int enqueue_batch_direct(int iter0, int count) {
     if (R.flags & PT_FAKE_SHADER) {
         rc = enqueue_fake();
         if (rc) return rc;
-    } else if (R.gen_fused && (R.flags & PT_COMPACT) && !(R.flags & PT_CACHE_FIRST) && R.mesh_mode == MESH_NONE &&
+    } else if (R.gen_fused && (R.flags & PT_COMPACT) && !(R.flags & PT_CACHE_FIRST) && R.mesh_mode == MESH_NONE && R.sort_keys == 0 &&
                (uint64_t)R.map.tile_pixels * (uint64_t)count <= R.whole_max_paths) {
         // small batch: every bounce in one launch (k_iteration)
         StageTimer tm(PT_STAGE_BOUNCE);
@@ -1235,19 +1245,36 @@ static int init_impl(const pt_scene_desc *d) {
         if (const char *pad = getenv("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
     }
 
+    // PT_SORT_MATERIAL in its fused form (pt_types.hpp: RangeDir): survivors are placed by the material they hit, one span
+    // per (material, wave) -- the pools are K times as large, nothing else is read or written for the sort.  Taken when
+    // the scene has up to 64 materials (one counter per lane), compaction is on, no other pipeline flag asks for
+    // materialised intersections, meshes are not walked by the pre-pass (its flags are per physical slot) and the pools
+    // fit the budget (PTMI355_SORT_FUSED_GB, default 96 of the 288 GB); otherwise the two-kernel form (k_intersect ->
+    // k_sort_hist -> k_shade_sorted_w) runs.  PT_UNFUSED | PT_SORT_MATERIAL always selects the latter.
+    R.sort_keys = 0;
+    if ((R.flags & PT_SORT_MATERIAL) && (R.flags & PT_COMPACT) && !(R.flags & (PT_UNFUSED | PT_FAKE_SHADER | PT_CACHE_FIRST)) &&
+        R.mesh_mode != MESH_BVH && d->num_materials <= 64) {
+        bool on = true;
+        if (const char *e = getenv("PTMI355_SORT_FUSED")) on = atoi(e) != 0;
+        double budget_gb = 96.0;
+        if (const char *e = getenv("PTMI355_SORT_FUSED_GB")) budget_gb = atof(e);
+        const double tiles_k = (double)d->num_materials * ((double)((R.cap + 63) / 64) + 8192.0);
+        if (on && tiles_k * 2560.0 * 2.0 <= budget_gb * 1e9 && tiles_k * 64.0 < 2147483648.0) R.sort_keys = d->num_materials;
+    }
     // pools, intersections, final colours, image, control
     const size_t capz = R.cap;
+    const size_t pool_mult = (size_t)std::max(1, R.sort_keys);
     for (int k = 0; k < 2; ++k) {
         // whole 64-path tiles, plus one tile per wave of the largest grid (W <= 8192): wave w's span starts at slot
         // w * R * 64 with R = ceil(tiles / W), so the spans of the last waves reach up to W tiles past the pool's paths --
         // never written while a wave only packs its own survivors, but k_iteration deals a workgroup's survivors to
         // all four of its waves, whichever of them had paths at bounce 0
-        HIPCHK(hipMalloc(&R.pool_mem[k], (((capz + 63) / 64) + 8192) * 64 * 10 * 4));
+        HIPCHK(hipMalloc(&R.pool_mem[k], pool_mult * (((capz + 63) / 64) + 8192) * 64 * 10 * 4));
         R.pool[k] = carve_pool(R.pool_mem[k], R.cap);
     }
     // the ShadeableIntersection planes exist only where a pipeline materialises them (the fused path keeps them
     // in registers): unfused / sorted / fake-shader pipelines now, pt_intersect_once on first use
-    if (R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER)) {
+    if ((R.flags & (PT_UNFUSED | PT_FAKE_SHADER)) || ((R.flags & PT_SORT_MATERIAL) && !R.sort_keys)) {
         const int rc = ensure_isect();
         if (rc != PT_OK) return rc;
     }
@@ -1306,7 +1333,7 @@ static int init_impl(const pt_scene_desc *d) {
         if (R.grid_mesh < 1) R.grid_mesh = 1;
     }
     if (R.flags & PT_CACHE_FIRST) HIPCHK(hipMalloc(&R.cache_mem, (size_t)R.map.tile_pixels * 5 * 4));
-    if (R.flags & PT_SORT_MATERIAL) {
+    if ((R.flags & PT_SORT_MATERIAL) && !R.sort_keys) {
         if (d->num_materials + 1 > SORT_MAX_BINS)
             return fail(PT_ERR_INVALID, "pt_init: PT_SORT_MATERIAL keeps one bin per material in LDS: at most %d materials", SORT_MAX_BINS - 1);
         {
@@ -1320,7 +1347,7 @@ static int init_impl(const pt_scene_desc *d) {
         HIPCHK(hipMalloc((void **)&R.sort_table, ((size_t)(d->num_materials + 1) * R.grid_sort + 4) * sizeof(uint32_t)));   // + the scan's last 16-B load
     }
     {   // range directory: one count + one base per wave of the persistent grid, per bounce
-        const size_t Wp = ((size_t)R.grid * WAVES + 3) & ~(size_t)3;
+        const size_t Wp = ((size_t)R.grid * WAVES * pool_mult + 3) & ~(size_t)3;
         R.dir_stride = 2 * Wp + 8;
         // one directory per bounce up to MAX_DEPTH: traceDepth is re-read on every call and may GROW (pathtrace.cu:286)
         HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)MAX_DEPTH * R.dir_stride * sizeof(uint32_t)));
@@ -1522,8 +1549,9 @@ int pt_export_paths(pt_path_segment *host_paths, int capacity, int *n_live) {
 
 int pt_export_intersections(pt_shadeable_intersection *host_isects, uint8_t *host_outside, int capacity) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_export_intersections: not initialised");
-    if (!(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER)))
-        return fail(PT_ERR_INVALID, "pt_export_intersections: intersections are only materialised with PT_UNFUSED, PT_SORT_MATERIAL or PT_FAKE_SHADER");
+    if (!(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER)) || R.sort_keys)
+        return fail(PT_ERR_INVALID, "pt_export_intersections: intersections are only materialised with PT_UNFUSED (also beside "
+                                    "PT_SORT_MATERIAL: its two-kernel form) or PT_FAKE_SHADER");
     if (R.step_depth < 1) return fail(PT_ERR_INVALID, "pt_export_intersections: no bounce has run");
     uint32_t n = (uint32_t)R.map.tile_pixels * (uint32_t)std::max(1, R.step_count);
     HIPCHK(hipStreamSynchronize(R.stream));

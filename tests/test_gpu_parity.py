@@ -118,13 +118,16 @@ def test_first_bounce_intersections_c2(pt, po, scenes, golden):
     pt.pathtraceFree()
 
 
-@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort", "cache"])
+@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort", "sort2", "cache"])
 @pytest.mark.parametrize("scene_name", ["cornell_64", "cornell_glass_64", "cornell_diffuse_64"])
 def test_bounce_by_bounce(pt, po, scenes, scene_name, flags_name):
     """Every bounce: live count, compacted pixelIndex sequence and full path state bit-exact."""
     s = scenes[scene_name]
     flags = {"fused": pt.PT_COMPACT, "unfused": pt.PT_COMPACT | pt.PT_UNFUSED, "nocompact": 0,
-             "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL, "cache": pt.PT_COMPACT | pt.PT_CACHE_FIRST}[flags_name]
+             "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL, "cache": pt.PT_COMPACT | pt.PT_CACHE_FIRST,
+             # sort: survivors placed by material inside the fused kernel; sort2: the two-kernel form (intersections
+             # materialised, k_sort_hist + k_shade_sorted_w)
+             "sort2": pt.PT_COMPACT | pt.PT_SORT_MATERIAL | pt.PT_UNFUSED}[flags_name]
     scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
     n = scene.resolution[0] * scene.resolution[1]
     pt.pathtraceInit(scene, flags=flags)
@@ -167,13 +170,14 @@ def _after(snaps, d, ref):
     return snaps[d]["paths"]
 
 
-@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort", "sort_nocompact", "cache"])
+@pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort", "sort2", "sort_nocompact", "cache"])
 def test_c2_full_iteration(pt, po, scenes, golden, flags_name):
     """Config C2 (800x800, depth 8): image, live counts and compaction order vs golden + oracle."""
     z = golden["completion"]
     s = scenes["cornell"]
     flags = {"fused": pt.PT_COMPACT, "unfused": pt.PT_COMPACT | pt.PT_UNFUSED, "nocompact": 0,
              "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL, "sort_nocompact": pt.PT_SORT_MATERIAL,
+             "sort2": pt.PT_COMPACT | pt.PT_SORT_MATERIAL | pt.PT_UNFUSED,
              "cache": pt.PT_COMPACT | pt.PT_CACHE_FIRST}[flags_name]
     scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
     pt.pathtraceInit(scene, flags=flags)
@@ -226,7 +230,7 @@ def test_c2_compaction_order_hash(pt, po, scenes, golden):
     pt.pathtraceFree()
 
 
-@pytest.mark.parametrize("flags_name", ["compact", "sort"])
+@pytest.mark.parametrize("flags_name", ["compact", "sort", "sort2"])
 def test_c3_full_size(pt, po, scenes, flags_name):
     """Config C3 at its full size -- glass ball, 1280x720, depth 16, material sort on / off: live counts, the
     compacted pixelIndex sequence after every bounce (its hash) and the image of two iterations equal the oracle's
@@ -234,14 +238,14 @@ def test_c3_full_size(pt, po, scenes, flags_name):
     s = scenes["cornell_glass"]
     cam = s["camera"]
     assert tuple(cam[0]["resolution"]) == (1280, 720) and s["depth"] == 16
-    flags = pt.PT_COMPACT | (pt.PT_SORT_MATERIAL if flags_name == "sort" else 0)
-    oflags = po.F_COMPACT | (po.F_SORT if flags_name == "sort" else 0)
+    flags = pt.PT_COMPACT | {"compact": 0, "sort": pt.PT_SORT_MATERIAL, "sort2": pt.PT_SORT_MATERIAL | pt.PT_UNFUSED}[flags_name]
+    oflags = po.F_COMPACT | (po.F_SORT if flags_name != "compact" else 0)
     n = 1280 * 720
     scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
     ref = po.Tracer(s["geoms"], s["materials"], cam, s["depth"], flags=oflags, trig=po.TRIG_SHARED)
     pt.pathtraceInit(scene, flags=flags)
     for it in (1, 2):
-        st = ref.iterate(it) if flags_name == "sort" else ref.iterate(it, threads=8)
+        st = ref.iterate(it) if flags_name != "compact" else ref.iterate(it, threads=8)
         pt.trace_begin(it, 1)
         for d in range(s["depth"]):
             live = pt.trace_bounce(d)
