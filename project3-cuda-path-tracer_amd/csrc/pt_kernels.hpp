@@ -740,9 +740,9 @@ __device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t sp
     bool resolved = !active;
     uint32_t src = 0, rng = cur;
     uint32_t s = cur;
-    // bounded: a sane directory resolves within W/63 + 1 windows; every wave reaches the exit
+    // bounded: every window resolves at least the first unresolved lane; every wave reaches the exit
     for (uint32_t guard = 0;; ++guard) {
-        if (guard > dir.nr / 63 + 1) {
+        if (guard > 66) {
             if (lane == 0) atomicOr(&ctl->error, 2u);
             break;
         }
@@ -757,8 +757,15 @@ __device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t sp
         }
         const uint32_t wl = (uint32_t)__shfl((int)w, lo);
         if (!resolved && lo < 63) { resolved = true; rng = s + (uint32_t)lo; src = rng * span + (p - wl); }
-        if (!__any(!resolved)) break;
-        s += 63;
+        const uint64_t un = ballot64(!resolved);
+        if (!un) break;
+        // The next window starts at the range that holds the first unresolved path (paths ascend with the lane), found
+        // by the 64-ary search -- not 63 ranges further on: between two keys of a sorted pool lie the W ranges of every
+        // material nobody survived on (the light: thousands of empty ranges), and a tile that straddles them walked
+        // them window by window -- 80 windows of one dependent load each, 60-150 us at the end of every sorted launch.
+        const uint32_t pmin = (uint32_t)__builtin_amdgcn_readlane((int)p, __ffsll((unsigned long long)un) - 1);
+        const uint32_t nxt = find_range(base, dir.nr, pmin);
+        s = nxt > s ? nxt : s + 63;                 // (always ahead: the first unresolved lane lies past this window)
     }
     // the highest active lane holds the tile's last path
     const uint64_t act = ballot64(active);
@@ -800,7 +807,7 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);
     const bool packed = dir_in.mem && nprev_ptr;
-    const uint32_t span = packed ? range_tiles(*nprev_ptr, W) * TILE : 0;
+    const uint32_t span = packed ? range_tiles(*nprev_ptr, dir_in.W) * TILE : 0;
     uint32_t cur = 0;
     if (packed && wid * R < tiles) cur = find_range(dir_in.base(), dir_in.nr, wid * R * TILE);
     auto finish = [&](uint32_t i, int par, const MeshBest &mb) {
@@ -892,63 +899,68 @@ __global__ __launch_bounds__(BLOCK) void k_cull0_mask(SceneDev sc, pt_camera cam
 // (agent scope) and scans the W counts (<= 8 steps of 1024).  Nothing spins; nothing depends
 // on dispatch order.
 __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t *n_out,
-                                                  uint32_t *lds_scan /* >= 8 words */) {
-    // One step covers 8192 entries: thread t owns the `per` consecutive entries [t*per, (t+1)*per) of the step (per =
-    // a multiple of 4, at most 32), loads them with 16-B loads all issued up front, and the 256 partial sums cross
-    // through one wave scan + one LDS exchange.  W <= 8192 waves: one step; K * W ranges (survivors placed by
-    // material): K steps at most, the running total carried from step to step.
+                                                  uint32_t *lds_scan /* >= 4 words */) {
+    // Thread t owns ONE contiguous segment of the nr counts (per = ceil(nr / 256) rounded to a multiple of 4): it sums
+    // the segment with eight 16-B loads in flight at a time, the 256 sums cross through one wave scan + one LDS
+    // exchange (the only barrier), and the segment is read again (L2) and written back as prefixes.  nr = W <= 8192
+    // waves without the material sort, K * runs with it (up to ~10^5): a step-by-step scan with a carried total took
+    // 12 us for 30 720 entries, this takes the latency of two rounds of loads.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t NR = dir.nr;
     const uint4 *count4 = reinterpret_cast<const uint4 *>(dir.count());
     uint4 *base4 = reinterpret_cast<uint4 *>(dir.base());
-    uint32_t carry = 0;
-    for (uint32_t s0 = 0, step = 0; s0 < NR; s0 += 8192u, ++step) {
-        const uint32_t W = min(8192u, NR - s0);                           // entries of this step
-        const uint32_t per4 = ((W + BLOCK - 1) / BLOCK + 3) / 4;          // uint4s per thread, <= 8
-        const uint32_t first = threadIdx.x * per4 * 4;                    // first entry of this thread within the step
+    const uint32_t per4 = ((NR + BLOCK - 1) / BLOCK + 3) / 4;          // uint4s per thread
+    const uint32_t first = threadIdx.x * per4 * 4;                     // first entry of this thread
+    auto load4 = [&](uint32_t k) {                                       // the k-th uint4 of the segment, entries past NR as 0
+        const uint32_t e = first + 4 * k;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < per4 && e < NR) {
+            v = count4[e >> 2];                                          // count[] is padded to a multiple of 4
+            if (e + 1 >= NR) v.y = 0;
+            if (e + 2 >= NR) v.z = 0;
+            if (e + 3 >= NR) v.w = 0;
+        }
+        return v;
+    };
+    uint32_t sum = 0;
+    for (uint32_t k0 = 0; k0 < per4; k0 += 8) {
         uint4 v[8];
-        uint32_t sum = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t e = first + 4 * k;
-            v[k] = make_uint4(0, 0, 0, 0);
-            if (k < per4 && e < W) {
-                v[k] = count4[(s0 + e) >> 2];                                // count[] is padded to a multiple of 4
-                if (e + 1 >= W) v[k].y = 0;
-                if (e + 2 >= W) v[k].z = 0;
-                if (e + 3 >= W) v[k].w = 0;
-            }
-            sum += v[k].x + v[k].y + v[k].z + v[k].w;
-        }
-        uint32_t incl = sum;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t u = __shfl_up(incl, off);
-            if (lane >= off) incl += u;
-        }
-        uint32_t *slot = lds_scan + (step & 1u) * WAVES;
-        if (lane == 63) slot[wave] = incl;
-        __syncthreads();
-        uint32_t wave_off = 0, total = 0;
+        for (uint32_t u = 0; u < 8; ++u) v[u] = load4(k0 + u);
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const uint32_t c = slot[w];
-            if (w < wave) wave_off += c;
-            total += c;
-        }
-        uint32_t run = carry + wave_off + incl - sum;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t e = first + 4 * k;
-            if (k < per4 && e < W) {
-                uint4 b;
-                b.x = run; b.y = b.x + v[k].x; b.z = b.y + v[k].y; b.w = b.z + v[k].z;
-                base4[(s0 + e) >> 2] = b;                                    // base[] has 4 spare entries; steps start at multiples of 8192
-                run = b.w + v[k].w;
-            }
-        }
-        carry += total;
+        for (uint32_t u = 0; u < 8; ++u) sum += v[u].x + v[u].y + v[u].z + v[u].w;
     }
-    if (threadIdx.x == 0) { dir.base()[NR] = carry; *n_out = carry; }
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) lds_scan[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = lds_scan[w];
+        if (w < wave) wave_off += c;
+        total += c;
+    }
+    uint32_t run = wave_off + incl - sum;
+    for (uint32_t k0 = 0; k0 < per4; k0 += 8) {
+        uint4 v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) v[u] = load4(k0 + u);
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t e = first + 4 * (k0 + u);
+            if (k0 + u < per4 && e < NR) {
+                uint4 b;
+                b.x = run; b.y = b.x + v[u].x; b.z = b.y + v[u].y; b.w = b.z + v[u].z;
+                base4[e >> 2] = b;                                       // base[] has 4 spare entries
+                run = b.w + v[u].w;
+            }
+        }
+    }
+    if (threadIdx.x == 0) { dir.base()[NR] = total; *n_out = total; }
 }
 
 // ---------------------------------------------------------------------------
@@ -1691,25 +1703,43 @@ __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH =
     WaveQ q{lc.pw, 0, 0};
     const int lane = threadIdx.x & 63;
     c.lane = lane;
-    const uint32_t W = gridDim.x * WAVES;
-    const uint32_t wid = run_id();
+    const uint32_t Wp = gridDim.x * WAVES;                        // waves of the grid
+    // runs of tiles the pool is cut into: one per wave -- or, with the material sort, several (RangeDir::W = S * Wp).
+    // Consecutive logical tiles of a sorted pool hold paths that all hit the SAME material at the last bounce, and what a
+    // path costs depends on where it has just been (a run of paths that left the glass ball is all sphere candidates):
+    // with one run per wave the launch waited 60-150 us for its slowest wave.  Wave w takes the runs w, Wp + w, ...:
+    // a share of every part of the key space.
+    const uint32_t W = (SORT && COMPACT) ? a.dir_out.W : Wp;
+    const uint32_t runs_per_wave = (SORT && COMPACT) ? W / Wp : 1u;
+    const uint32_t wid0 = run_id();
     c.iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;       // graph replay: arguments are frozen
     c.stamp = batch_stamp(a.fin_stamp, a.ctl);
     const uint32_t n = (COMPACT && !GEN) ? a.ctl->nlive[a.depth] : a.pool_n;
     const uint32_t tiles = (n + TILE - 1) / TILE;
-    const uint32_t R = range_tiles(n, W);                        // logical tiles per wave (one contiguous run)
+    const uint32_t R = range_tiles(n, W);                        // logical tiles per run (contiguous)
     const bool packed_in = COMPACT && !GEN && a.dir_in.mem != nullptr;
-    const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], W) * TILE : 0;
+    const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], a.dir_in.W) * TILE : 0;
     uint32_t traced = 0;
-    uint32_t packed = 0;                                         // survivors this wave has written (wave-uniform; SORT: lane k counts key k)
-    uint32_t cur = 0;                                            // source range of the run's current position
     if (GEN && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = a.pool_n;   // k_raygen's job otherwise
-    if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), a.dir_in.nr, wid * R * TILE);
-    STAMP(2);
-
-    // every wave walks its own run of R consecutive 64-path tiles; no workgroup barrier inside the loop
-    run_tiles<MODE, COMPACT, MESH, GEN, SORT>(a, c, q, a.in, a.out, a.depth, wid * R, R, tiles, n, packed_in, span_in,
-                                              cur, wid * R * TILE, false, WgSpans{}, packed, traced, W * R * TILE);
+    for (uint32_t j = 0; j < runs_per_wave; ++j) {
+        const uint32_t wid = j * Wp + wid0;
+        uint32_t packed = 0;                                     // survivors of this run written so far (wave-uniform; SORT: lane k counts key k)
+        uint32_t cur = 0;                                        // source range of the run's current position
+        if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), a.dir_in.nr, wid * R * TILE);
+        STAMP(2);
+        // the run's R consecutive 64-path tiles; no workgroup barrier inside the loop
+        run_tiles<MODE, COMPACT, MESH, GEN, SORT>(a, c, q, a.in, a.out, a.depth, wid * R, R, tiles, n, packed_in, span_in,
+                                                  cur, wid * R * TILE, false, WgSpans{}, packed, traced, W * R * TILE);
+        if (COMPACT) {
+            // every run publishes its range count(s); the last workgroup out scans them
+            if (SORT) {
+                if ((uint32_t)lane * W < a.dir_out.nr)                    // lane k: the run's key-k survivors, range k * W + run
+                    __hip_atomic_store(&a.dir_out.count()[(uint32_t)lane * W + wid], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (lane == 0)
+                __hip_atomic_store(&a.dir_out.count()[wid], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const uint32_t wid = wid0;
     STAMP(6);
 #ifdef PT_WAVE_TIMES
     if (lane == 0 && a.depth < 8 && wid < 8192) {
@@ -1734,13 +1764,7 @@ __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH =
     }
 
     if (COMPACT) {
-        // every wave publishes its range count(s); the last workgroup out scans them
-        if (SORT) {
-            if ((uint32_t)lane * W < a.dir_out.nr)                        // lane k: the wave's key-k survivors, range k * W + w
-                __hip_atomic_store(&a.dir_out.count()[(uint32_t)lane * W + wid], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (lane == 0)
-            __hip_atomic_store(&a.dir_out.count()[wid], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's count store has left
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's count stores have left
         __syncthreads();
         if (threadIdx.x == 0) {
             const bool last = elect_last(a.ctl->bucket[a.depth][0], &a.ctl->done[a.depth]);

@@ -128,6 +128,7 @@ struct Renderer {
     int grid = 0;                 // persistent grid size
     int grid_sort = 0;            // workgroups of the material-sort kernels (k_sort_hist / k_shade_sorted)
     bool sort_wave = true;        // <= 64 keys: k_shade_sorted_w (PTMI355_SORT_WAVE=0 forces the workgroup-wide kernel)
+    int sort_runs = 1;            // runs of tiles per wave of the fused sort (k_bounce); PTMI355_SORT_RUNS
     int sort_keys = 0;            // > 0: PT_SORT_MATERIAL in its fused form -- survivors placed by material, K = sort_keys ranges per wave (pt_types.hpp: RangeDir)
     bool sorted_isects = false;   // the last bounce was shaded in material order (the intersection planes keep the order the bounce received)
     bool gen_fused = false;       // bounce 0 of the current batch generates its own rays
@@ -258,7 +259,7 @@ int ensure_scratch(size_t bytes) {
 }
 
 RangeDir tile_dir(int depth) {
-    const uint32_t W = (uint32_t)R.grid * WAVES;
+    const uint32_t W = (uint32_t)R.grid * WAVES * (uint32_t)(R.sort_keys > 0 ? R.sort_runs : 1);     // runs of tiles
     const uint32_t nr = W * (uint32_t)std::max(1, R.sort_keys);
     if (depth < 0) return RangeDir{nullptr, W, nr};
     return RangeDir{R.dir_mem + (size_t)depth * R.dir_stride, W, nr};
@@ -1258,18 +1259,21 @@ static int init_impl(const pt_scene_desc *d) {
         if (const char *e = getenv("PTMI355_SORT_FUSED")) on = atoi(e) != 0;
         double budget_gb = 96.0;
         if (const char *e = getenv("PTMI355_SORT_FUSED_GB")) budget_gb = atof(e);
-        const double tiles_k = (double)d->num_materials * ((double)((R.cap + 63) / 64) + 8192.0);
+        R.sort_runs = 1;              // more runs per wave (each wave a share of every part of the key space): measured slower (profiles/r03/variants_sort.log)
+        if (const char *e = getenv("PTMI355_SORT_RUNS")) R.sort_runs = std::max(1, std::min(8, atoi(e)));
+        const double tiles_k = (double)d->num_materials * ((double)((R.cap + 63) / 64) + 8192.0 * R.sort_runs);
         if (on && tiles_k * 2560.0 * 2.0 <= budget_gb * 1e9 && tiles_k * 64.0 < 2147483648.0) R.sort_keys = d->num_materials;
     }
     // pools, intersections, final colours, image, control
     const size_t capz = R.cap;
     const size_t pool_mult = (size_t)std::max(1, R.sort_keys);
+    const size_t run_mult = R.sort_keys > 0 ? (size_t)R.sort_runs : 1;        // every run's span is rounded up to whole tiles
     for (int k = 0; k < 2; ++k) {
         // whole 64-path tiles, plus one tile per wave of the largest grid (W <= 8192): wave w's span starts at slot
         // w * R * 64 with R = ceil(tiles / W), so the spans of the last waves reach up to W tiles past the pool's paths --
         // never written while a wave only packs its own survivors, but k_iteration deals a workgroup's survivors to
         // all four of its waves, whichever of them had paths at bounce 0
-        HIPCHK(hipMalloc(&R.pool_mem[k], pool_mult * (((capz + 63) / 64) + 8192) * 64 * 10 * 4));
+        HIPCHK(hipMalloc(&R.pool_mem[k], pool_mult * (((capz + 63) / 64) + 8192 * run_mult) * 64 * 10 * 4));
         R.pool[k] = carve_pool(R.pool_mem[k], R.cap);
     }
     // the ShadeableIntersection planes exist only where a pipeline materialises them (the fused path keeps them
@@ -1347,7 +1351,7 @@ static int init_impl(const pt_scene_desc *d) {
         HIPCHK(hipMalloc((void **)&R.sort_table, ((size_t)(d->num_materials + 1) * R.grid_sort + 4) * sizeof(uint32_t)));   // + the scan's last 16-B load
     }
     {   // range directory: one count + one base per wave of the persistent grid, per bounce
-        const size_t Wp = ((size_t)R.grid * WAVES * pool_mult + 3) & ~(size_t)3;
+        const size_t Wp = ((size_t)R.grid * WAVES * pool_mult * run_mult + 3) & ~(size_t)3;
         R.dir_stride = 2 * Wp + 8;
         // one directory per bounce up to MAX_DEPTH: traceDepth is re-read on every call and may GROW (pathtrace.cu:286)
         HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)MAX_DEPTH * R.dir_stride * sizeof(uint32_t)));
@@ -1538,7 +1542,7 @@ int pt_export_paths(pt_path_segment *host_paths, int capacity, int *n_live) {
         if (packed) HIPCHK(hipMemcpy(&nprev, &R.ctl->nlive[R.cur_dir], 4, hipMemcpyDeviceToHost));
         hipLaunchKernelGGL(k_export_paths, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.pool[R.cur], R.map, n,
                            live, R.trace_depth - R.step_depth, (pt_path_segment *)R.scratch,
-                           tile_dir(packed ? R.cur_dir : -1), range_tiles(nprev, (uint32_t)R.grid * WAVES) * TILE);
+                           tile_dir(packed ? R.cur_dir : -1), range_tiles(nprev, tile_dir(-1).W) * TILE);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(host_paths, R.scratch, (size_t)n * sizeof(pt_path_segment), hipMemcpyDeviceToHost, R.stream));
         HIPCHK(hipStreamSynchronize(R.stream));
