@@ -47,6 +47,23 @@ BYTES_PER_RAY = 44 + 104 + 4
 BYTES_PER_SURVIVOR = 88
 
 
+def build_digest():
+    """What a counter profile is keyed by: the kernel sources AND how they are compiled (-fno-slp-vectorize
+    changes the instruction mix as much as a source edit does).  A library loaded through PTMI355_LIB (an A/B variant)
+    never matches a committed profile."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(csrc_digest().encode())
+    sys.path.insert(0, os.path.join(ROOT, "project3-cuda-path-tracer_amd"))
+    try:
+        import build as _b
+        h.update(" ".join(_b.HIPCC_FLAGS).encode())
+    except Exception:
+        h.update(b"?")
+    h.update((os.environ.get("PTMI355_LIB") or "").encode())
+    return h.hexdigest()[:16]
+
+
 def csrc_digest():
     """sha256 (first 16 hex digits) over the kernel sources -- comments and white space removed, so that only code
     changes count: counter profiles are only valid for the build they were taken on."""
@@ -251,51 +268,7 @@ def main():
         rank_rays, first = rays1 - rays0, first1 - first0
         prof = pt.get_profile()
         pt.set_profiling(False)
-        survivors = rank_rays - first                 # paths that survived a compaction = rays of bounces >= 1
-        ms, launches = prof["bounce"]
-        # the fused launch does intersect + shade/scatter + compaction; with `unfused`/`sort` the timed
-        # k_bounce launch only shades and compacts (the intersections come from k_intersect): 104 + 4 B/ray
-        fused = not (flags & (pt.PT_UNFUSED | pt.PT_SORT_MATERIAL))
-        per_ray = BYTES_PER_RAY if fused else (104 + 4)
-        algo_bytes = rank_rays * per_ray + survivors * BYTES_PER_SURVIVOR
-        achieved = algo_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        avg_s = ms * 1e-3 / max(1, launches)
-        kernel = "k_bounce<fused,compact>" if args.flags == "compact" else "k_bounce (" + args.flags + ")"
-        hbm_algo = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "bytes_per_launch": int(algo_bytes / max(1, launches)),
-                    "note": "SURVEY 8(d) algorithmic bytes of the unfused reference pipeline (152 B per ray + 88 B per "
-                            "survivor); the fused kernel never moves most of them"}
-        prof_json = counter_profile(args, world)
-        common = {"kernel": kernel, "launches": int(launches),
-                  "pass": "the %d timed steps repeated with per-launch HIP events" % args.steps,
-                  "avg_launch_us": round(avg_s * 1e6, 2),
-                  "stage_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]},
-                  "grays_per_s_in_kernel": round(rank_rays / (ms * 1e-3) / 1e9, 3) if ms > 0 else 0.0,
-                  "hbm_algorithmic": hbm_algo}
-        vm = prof_json.get("valu_model") if prof_json else None
-        if fused and vm and avg_s > 0:
-            # vector issue: counted instructions per class x measured cycles per class, over SIMDs x peak clock x time
-            used = vm["issue_cycles_per_launch"] / avg_s / 1e9                     # G SIMD-cycles of issue per second
-            peak = SIMDS * PEAK_CLOCK_GHZ
-            traffic = prof_json.get("bytes_per_launch")
-            roofline = dict(common, bound="valu-issue", achieved=round(used, 1), peak=round(peak, 1),
-                            unit="G SIMD issue-cycles/s", frac=round(used / peak, 4), traffic=traffic,
-                            source="profiles/traffic.json@csrc:%s (rocprofv3 --pmc passes of this build)" % prof_json.get("csrc_sha16"),
-                            valu={"wave_insts_per_launch": int(vm["wave_insts_per_launch"]),
-                                  "insts_per_ray": round(vm["wave_insts_per_launch"] * 64 / max(1.0, rank_rays / max(1, launches)), 1),
-                                  "issue_cycles_per_launch": int(vm["issue_cycles_per_launch"]), "mix": vm.get("mix"),
-                                  "issue_cost_table": "profiles/r02/valu_peak_r02.json",
-                                  "peak": "%d SIMDs x %.1f GHz (MI355X_MICROARCH.md max clock; ~2.1 GHz is what the chip "
-                                          "holds under this load)" % (SIMDS, PEAK_CLOCK_GHZ)})
-            if traffic:
-                roofline["hbm_measured"] = {"achieved": round(traffic / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4),
-                                            "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch (gfx950 correction)"}
-        else:
-            # no counter profile matches this build / command line: only the algorithmic HBM figure can be stated
-            roofline = dict(common, bound="hbm", achieved=hbm_algo["achieved"], peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=hbm_algo["frac"], traffic=None,
-                            source="no rocprofv3 counter profile for this build and command line (profiles/run_rocprof.sh)")
+        roofline = roofline_object(args, n_tiles if inproc else world, flags, pt, prof, rank_rays, first)
 
     # ---- CPU baseline: the oracle (plain-C port) on this host, rank 0, N = 1 only ----
     cpu = None
@@ -383,19 +356,85 @@ def main():
         dist.destroy_process_group()
 
 
+def roofline_object(args, world, flags, pt, prof, rank_rays, first):
+    """What bounds the dominant kernel(s) of THIS run: launch times measured here with HIP events on the launch stream
+    (the timed steps repeated), against
+      * the vector-issue roof: issue cycles per launch = the kernel's EXECUTED opcode histogram (per-basic-block counts of
+        an instrumented build: profiles/tools/isa_count.py) x the issue cost of each opcode measured one by one
+        (profiles/microbench/gen_issue_ops.py), over SIMDs x 2.4 GHz x time;
+      * HBM: FETCH_SIZE x 2 + WRITE_SIZE per launch (separate rocprofv3 --pmc passes) over 8 TB/s;
+      * fp32: the histogram's floating-point operations x the active-lane fraction (SQ_THREAD_CYCLES_VALU) over 157.3 TF.
+    `bound` is whichever of vector issue and HBM is closer to its roof; `frac` is that fraction, never above 1 by
+    construction.  Without a counter profile of exactly this build and command line (profiles/collect_r03.py ->
+    profiles/traffic.json) the counter-derived fields are null rather than stale."""
+    steps = args.steps
+    stage_ms = {k: v[0] for k, v in prof.items() if v[1]}
+    launches = {k: int(v[1]) for k, v in prof.items() if v[1]}
+    common = {"pass": "the %d timed steps repeated with per-launch HIP events" % steps,
+              "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()}, "launches": launches.get("bounce", 0)}
+    t = counter_profile(args, world)
+    fused = not (flags & pt.PT_UNFUSED) and not ((flags & pt.PT_SORT_MATERIAL) and not (flags & pt.PT_COMPACT))
+    ms_b, n_b = prof["bounce"]
+    if fused and args.config in ("c2", "c3", "c5") and ms_b > 0:
+        # SURVEY 8(d)'s byte model of the UNFUSED reference pipeline, kept beside the measured figures because the
+        # contract names it; the fused kernel never moves most of these bytes, so it is not a bound and never `frac`
+        survivors = rank_rays - first
+        algo = rank_rays * BYTES_PER_RAY + survivors * BYTES_PER_SURVIVOR
+        common["hbm_algorithmic_unfused_model"] = {"gb_per_s": round(algo / (ms_b * 1e-3) / 1e9, 1), "bytes_per_launch": int(algo / max(1, n_b)),
+                                                   "note": "152 B per ray + 88 B per survivor of the reference's separate kernels; not what this kernel moves"}
+    if not t:
+        return dict(common, kernel=None, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
+                    source="no counter profile for this build and command line (python3 profiles/collect_r03.py)")
+    ks = t["kernels"]
+    stages = sorted({k["stage"] for k in ks.values() if k["stage"] in stage_ms}, key=lambda s_: -stage_ms[s_])
+    if not stages:
+        return dict(common, kernel=None, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, source="profile has no stage of this run")
+    st = stages[0]
+    sel = [k for k in ks.values() if k["stage"] == st]
+    per_step_s = stage_ms[st] * 1e-3 / steps
+    nl = sum(k["launches_per_step"] for k in sel)
+    cyc = sum(k["launches_per_step"] * k.get("issue_cycles_per_launch", 0.0) for k in sel)
+    byt = sum(k["launches_per_step"] * k.get("hbm_bytes_per_launch", 0) for k in sel)
+    flops = sum(k["launches_per_step"] * k.get("flops_fp32_per_launch_64_lanes", 0.0) * k.get("active_lane_fraction", 1.0) for k in sel)
+    lanes = sum(k["launches_per_step"] * k.get("issue_cycles_per_launch", 0.0) * k.get("active_lane_fraction", 0.0) for k in sel) / cyc if cyc else None
+    unpriced = max(k.get("unpriced_share_of_cycles", 0.0) for k in sel)
+    issue_frac = cyc / per_step_s / (SIMDS * PEAK_CLOCK_GHZ * 1e9)
+    hbm_frac = byt / per_step_s / (HBM_PEAK_GBS * 1e9)
+    names = " + ".join(sorted({k["name"].split("(")[0] for k in sel}))
+    r = dict(common, kernel=names, stage=st, launches_per_step=nl, avg_launch_us=round(per_step_s / nl * 1e6, 2),
+             traffic=int(byt / nl) if byt else None,
+             source="profiles/traffic.json@build:%s (profiles/collect_r03.py: instrumented-build opcode histogram, rocprofv3 --pmc passes)" % t["build_sha16"],
+             valu_issue={"achieved": round(cyc / per_step_s / 1e9, 1), "peak": round(SIMDS * PEAK_CLOCK_GHZ, 1), "unit": "G SIMD issue-cycles/s",
+                         "frac": round(issue_frac, 4), "issue_cycles_per_launch": int(cyc / nl),
+                         "valu_insts_per_ray": round(64.0 * sum(k["launches_per_step"] * k.get("wave_insts_per_launch", {}).get("valu", 0.0) for k in sel) /
+                                                     max(1.0, rank_rays / steps), 1),
+                         "unpriced_share_of_cycles": round(unpriced, 4),
+                         "issue_cost_table": "profiles/r03/issue_ops_r03.json (one row per opcode)",
+                         "sq_insts_valu_over_counted": [k.get("sq_insts_valu_over_counted") for k in sel]},
+             hbm_measured={"achieved": round(byt / per_step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
+                           "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch (gfx950 correction)"},
+             fp32={"achieved": round(flops / per_step_s / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops / per_step_s / 157.3e12, 4),
+                   "active_lane_fraction": round(lanes, 4) if lanes else None,
+                   "note": "fp32 operations of the executed opcode histogram (fma = 2) x active lanes (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64)"},
+             grays_per_s_in_kernel=round(rank_rays / (stage_ms[st] * 1e-3) / 1e9, 3) if st == "bounce" else None)
+    if issue_frac >= hbm_frac:
+        r.update(bound="valu-issue", achieved=r["valu_issue"]["achieved"], peak=r["valu_issue"]["peak"], unit=r["valu_issue"]["unit"], frac=round(min(1.0, issue_frac), 4))
+    else:
+        r.update(bound="hbm", achieved=r["hbm_measured"]["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(min(1.0, hbm_frac), 4))
+    return r
+
+
 def counter_profile(args, world):
-    """profiles/traffic.json (written by profiles/summarize.py from the rocprofv3 PMC passes) when it belongs to THIS
-    build (hash of the kernel sources) and THIS command line; None otherwise -- stale counters are never reported."""
+    """The entry of profiles/traffic.json (written by profiles/collect_r03.py) for THIS build (hash of the kernel
+    sources and the compile flags) and THIS command line; None otherwise -- stale counters are never reported."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if world != 1 or (args.inproc and args.gpus != 1) or not os.path.exists(path):
+    if world != 1 or not os.path.exists(path):
         return None
     try:
-        t = json.load(open(path))
+        t = json.load(open(path))["configs"]["%s|%s|%d" % (args.config, args.flags, args.batch)]
     except Exception:
         return None
-    if t.get("config") != args.config or t.get("batch") != args.batch or t.get("flags") != args.flags:
-        return None
-    if t.get("csrc_sha16") != csrc_digest():
+    if t.get("build_sha16") != build_digest():
         return None
     return t
 

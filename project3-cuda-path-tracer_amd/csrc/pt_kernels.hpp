@@ -97,10 +97,11 @@ constexpr int GREC_WORDS = 36;       // gather record per geom: inverseTransform
 // per-wave block: candidate ring + two tiles in flight (rays, best keys, winner records)
 constexpr int Q_SLOTS = 128;         // candidate ring entries (a tile's cull adds <= 64 per geom while < 64 wait)
 constexpr int PW_RING = 0;                               // u32[128]: lane | parity << 6 | type << 7 | geom << 9
-constexpr int PW_BEST = PW_RING + Q_SLOTS;               // u64[2][64]: (bits(t) << 32) | geom, ~0 = nothing hit
-constexpr int PW_WIN = PW_BEST + 2 * 64 * 2;             // float4[2][64]: winner's normal xyz, outside flag
-constexpr int PW_RAYS = PW_WIN + 2 * 64 * 4;             // float[2][6][64]: ro.xyz rd.xyz of the tile's paths
-constexpr int PW_WORDS = PW_RAYS + 2 * 6 * 64;           // 1664 dwords = 6.5 KiB per wave
+constexpr int PW_BEST = PW_RING + Q_SLOTS;               // u64[2][64]: (bits(t) << 32) | geom << 1 | outside, ~0 = nothing hit
+constexpr int PW_WIN = PW_BEST + 2 * 64 * 2;             // float[2][3][64]: winner's normal x, y, z (the outside flag rides in the key)
+constexpr int PW_RAYS = PW_WIN + 2 * 64 * 3;             // float[2][6][64]: ro.xyz rd.xyz of the tile's paths
+constexpr int PW_WORDS = PW_RAYS + 2 * 6 * 64;           // 1536 dwords = 6 KiB per wave: six workgroups fit a CU's 160 KiB beside a
+                                                         // Cornell-sized scene block (round 2: 6.5 KiB, float4 winner records, five)
 constexpr int CULL_WORDS = 12;       // per geom, scalar-loaded: lo.x hi.x lo.y hi.y lo.z hi.z | type + (reject mode << 8) | the reject row:
                                      //   m_k0 m_k1 m_k2 m_k3 | spare (48 B: one s_load_dwordx8 + one s_load_dwordx4)
 
@@ -245,7 +246,7 @@ struct WaveQ {                        // wave-uniform ring cursors + the wave's 
     __device__ __forceinline__ unsigned long long *best(int par) const {
         return reinterpret_cast<unsigned long long *>(pw + PW_BEST) + par * 64;
     }
-    __device__ __forceinline__ float4 *win(int par) const { return reinterpret_cast<float4 *>(pw + PW_WIN) + par * 64; }
+    __device__ __forceinline__ float *win(int par) const { return pw + PW_WIN + par * 3 * 64; }
     __device__ __forceinline__ float *rays(int par) const { return pw + PW_RAYS + par * 6 * 64; }
 };
 
@@ -315,12 +316,14 @@ __device__ __forceinline__ void cand_pass1(const WaveQ &q, const SceneAcc &acc, 
             f3 n = ptd::normalize(ptd::mv_dir(m, nv));
             if (type != PT_CUBE && !outside) n = ptd::neg(n);
             if (t > 0.0f) {                                                // pathtrace.cu:192
-                const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | g;
+                // positive floats order like their bit patterns; geom << 1 | outside: the lowest geom wins a tie in t
+                // (the flag belongs to the geom: it cannot reorder two different geoms)
+                const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (g << 1) | (uint32_t)(outside & 1);
                 unsigned long long *bk = q.best(par) + origin;
                 __hip_atomic_fetch_min(bk, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // LDS operations of one wave execute in order: every min of this pass precedes this read
-                if (*bk == key) q.win(par)[origin] = make_float4(n.x, n.y, n.z, __int_as_float(outside));
+                if (*bk == key) { float *w = q.win(par) + origin; w[0] = n.x; w[64] = n.y; w[128] = n.z; }
             }
         }
     }
@@ -689,9 +692,9 @@ __device__ __forceinline__ void tile_result(const WaveQ &q, int par, const Scene
     t = -1.0f; n = ptd::mk(0, 0, 0); mat = 0; outside = 1;
     int geom = -1;
     if (key != ~0ull) {
-        const float4 w = q.win(par)[lane];
-        t = __uint_as_float((uint32_t)(key >> 32)); geom = (int)(uint32_t)key;
-        n = ptd::mk(w.x, w.y, w.z); outside = __float_as_int(w.w);
+        const float *w = q.win(par) + lane;
+        t = __uint_as_float((uint32_t)(key >> 32)); geom = (int)((uint32_t)key >> 1); outside = (int)((uint32_t)key & 1u);
+        n = ptd::mk(w[0], w[64], w[128]);
     }
     if (mb.geom >= 0 && (geom < 0 || t > mb.t || (t == mb.t && mb.geom < geom))) {     // pathtrace.cu:192 across all geoms
         const float *tv = tris + (size_t)mb.tri * TRI_WORDS;
@@ -899,68 +902,63 @@ __global__ __launch_bounds__(BLOCK) void k_cull0_mask(SceneDev sc, pt_camera cam
 // (agent scope) and scans the W counts (<= 8 steps of 1024).  Nothing spins; nothing depends
 // on dispatch order.
 __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t *n_out,
-                                                  uint32_t *lds_scan /* >= 4 words */) {
-    // Thread t owns ONE contiguous segment of the nr counts (per = ceil(nr / 256) rounded to a multiple of 4): it sums
-    // the segment with eight 16-B loads in flight at a time, the 256 sums cross through one wave scan + one LDS
-    // exchange (the only barrier), and the segment is read again (L2) and written back as prefixes.  nr = W <= 8192
-    // waves without the material sort, K * runs with it (up to ~10^5): a step-by-step scan with a carried total took
-    // 12 us for 30 720 entries, this takes the latency of two rounds of loads.
+                                                  uint32_t *lds_scan /* >= 8 words */) {
+    // One step covers 8192 entries: thread t owns the `per` consecutive entries [t*per, (t+1)*per) of the step (per =
+    // a multiple of 4, at most 32), loads them with 16-B loads all issued up front, and the 256 partial sums cross
+    // through one wave scan + one LDS exchange.  W <= 8192 waves: one step; K * W ranges (survivors placed by
+    // material): K steps at most, the running total carried from step to step.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t NR = dir.nr;
     const uint4 *count4 = reinterpret_cast<const uint4 *>(dir.count());
     uint4 *base4 = reinterpret_cast<uint4 *>(dir.base());
-    const uint32_t per4 = ((NR + BLOCK - 1) / BLOCK + 3) / 4;          // uint4s per thread
-    const uint32_t first = threadIdx.x * per4 * 4;                     // first entry of this thread
-    auto load4 = [&](uint32_t k) {                                       // the k-th uint4 of the segment, entries past NR as 0
-        const uint32_t e = first + 4 * k;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (k < per4 && e < NR) {
-            v = count4[e >> 2];                                          // count[] is padded to a multiple of 4
-            if (e + 1 >= NR) v.y = 0;
-            if (e + 2 >= NR) v.z = 0;
-            if (e + 3 >= NR) v.w = 0;
+    uint32_t carry = 0;
+    for (uint32_t s0 = 0, step = 0; s0 < NR; s0 += 8192u, ++step) {
+        const uint32_t W = min(8192u, NR - s0);                           // entries of this step
+        const uint32_t per4 = ((W + BLOCK - 1) / BLOCK + 3) / 4;          // uint4s per thread, <= 8
+        const uint32_t first = threadIdx.x * per4 * 4;                    // first entry of this thread within the step
+        uint4 v[8];
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t e = first + 4 * k;
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (k < per4 && e < W) {
+                v[k] = count4[(s0 + e) >> 2];                                // count[] is padded to a multiple of 4
+                if (e + 1 >= W) v[k].y = 0;
+                if (e + 2 >= W) v[k].z = 0;
+                if (e + 3 >= W) v[k].w = 0;
+            }
+            sum += v[k].x + v[k].y + v[k].z + v[k].w;
         }
-        return v;
-    };
-    uint32_t sum = 0;
-    for (uint32_t k0 = 0; k0 < per4; k0 += 8) {
-        uint4 v[8];
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off);
+            if (lane >= off) incl += u;
+        }
+        uint32_t *slot = lds_scan + (step & 1u) * WAVES;
+        if (lane == 63) slot[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) v[u] = load4(k0 + u);
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c = slot[w];
+            if (w < wave) wave_off += c;
+            total += c;
+        }
+        uint32_t run = carry + wave_off + incl - sum;
 #pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) sum += v[u].x + v[u].y + v[u].z + v[u].w;
-    }
-    uint32_t incl = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t u = __shfl_up(incl, off);
-        if (lane >= off) incl += u;
-    }
-    if (lane == 63) lds_scan[wave] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        const uint32_t c = lds_scan[w];
-        if (w < wave) wave_off += c;
-        total += c;
-    }
-    uint32_t run = wave_off + incl - sum;
-    for (uint32_t k0 = 0; k0 < per4; k0 += 8) {
-        uint4 v[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) v[u] = load4(k0 + u);
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-            const uint32_t e = first + 4 * (k0 + u);
-            if (k0 + u < per4 && e < NR) {
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t e = first + 4 * k;
+            if (k < per4 && e < W) {
                 uint4 b;
-                b.x = run; b.y = b.x + v[u].x; b.z = b.y + v[u].y; b.w = b.z + v[u].z;
-                base4[e >> 2] = b;                                       // base[] has 4 spare entries
-                run = b.w + v[u].w;
+                b.x = run; b.y = b.x + v[k].x; b.z = b.y + v[k].y; b.w = b.z + v[k].z;
+                base4[(s0 + e) >> 2] = b;                                    // base[] has 4 spare entries; steps start at multiples of 8192
+                run = b.w + v[k].w;
             }
         }
+        carry += total;
     }
-    if (threadIdx.x == 0) { dir.base()[NR] = total; *n_out = total; }
+    if (threadIdx.x == 0) { dir.base()[NR] = carry; *n_out = carry; }
 }
 
 // ---------------------------------------------------------------------------

@@ -182,6 +182,10 @@ struct SceneDev {
 };
 
 struct BounceArgs {
+    // FIRST member (kernarg offset 0): where an INSTRUMENTED build of a kernel adds its per-basic-block execution
+    // counts when it ends (profiles/tools/isa_count.py rewrites the device assembly; the library's own code never reads
+    // this field).  nullptr unless PTMI355_DBG_COUNTS is set.
+    unsigned int *dbg_counts;
     Pool in, out;
     Lens lens;
     Isect isect;

@@ -168,6 +168,8 @@ struct Renderer {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
     uint64_t async_calls = 0;
+    unsigned int *dbg_counts = nullptr;   // PTMI355_DBG_COUNTS=<words>: buffer for an instrumented kernel build's block counts (BounceArgs::dbg_counts)
+    size_t dbg_words = 0;
     void *scratch = nullptr;      // export / import staging
     size_t scratch_bytes = 0;
     // stepping state
@@ -267,6 +269,7 @@ RangeDir tile_dir(int depth) {
 
 BounceArgs bounce_args(int depth) {
     BounceArgs a{};
+    a.dbg_counts = R.dbg_counts;
     a.in = R.pool[R.cur];
     a.out = (R.flags & PT_COMPACT) ? R.pool[R.cur ^ 1] : R.pool[R.cur];
     a.isect = R.isect;
@@ -882,6 +885,7 @@ void pt_free(void) {
     if (R.dir_mem) (void)hipFree(R.dir_mem);
     if (R.persist) (void)hipFree(R.persist);
     if (R.scratch) (void)hipFree(R.scratch);
+    if (R.dbg_counts) (void)hipFree(R.dbg_counts);
     if (R.copy_stream) (void)hipStreamSynchronize(R.copy_stream);
     for (auto &h : R.host_regs) (void)hipHostUnregister(h.ptr);
     for (int j = 0; j < 2; ++j) {
@@ -1370,6 +1374,11 @@ static int init_impl(const pt_scene_desc *d) {
             if (rc != PT_OK) return rc;
         }
     }
+    if (const char *e = getenv("PTMI355_DBG_COUNTS")) {
+        R.dbg_words = (size_t)std::max(64, atoi(e));
+        HIPCHK(hipMalloc((void **)&R.dbg_counts, R.dbg_words * 4));
+        HIPCHK(hipMemsetAsync(R.dbg_counts, 0, R.dbg_words * 4, R.stream));
+    }
     HIPCHK(hipStreamSynchronize(R.stream));
     t_err[0] = 0;
     return PT_OK;
@@ -1737,6 +1746,16 @@ int pt_get_stats(pt_stats *stats) {
 }  // namespace one
 
 #include "pt_multi.hpp"
+
+// diagnostics (not in include/ptmi355.h): the block counts an instrumented kernel build has added up since pt_init or the
+// last call (profiles/tools/isa_count.py); reads and clears.  Single-device sessions.
+extern "C" int ptdbg_counts(unsigned int *out, int words) {
+    if (!g_single.live || !g_single.dbg_counts || words < 0 || (size_t)words > g_single.dbg_words) return -1;
+    if (hipStreamSynchronize(g_single.stream) != hipSuccess) return -1;
+    if (hipMemcpy(out, g_single.dbg_counts, (size_t)words * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemset(g_single.dbg_counts, 0, g_single.dbg_words * 4) != hipSuccess) return -1;
+    return words;
+}
 
 #ifdef PT_WAVE_TIMES
 // diagnostic build only (not in include/ptmi355.h): per-wave start / end ticks and hardware ids of k_bounce's last launches

@@ -26,6 +26,28 @@ def run(cmd, timeout=600, per_bounce=True):
     return json.loads(line)
 
 
+def _check_roofline(r):
+    """A fraction comes from measured counters of exactly this build and command line (profiles/traffic.json) and never
+    exceeds 1; without such a profile every counter-derived field is null, never stale, never a model's number."""
+    assert r["bound"] in ("valu-issue", "hbm") and "traffic" in r and "source" in r and "frac" in r
+    if r["frac"] is not None:
+        assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - min(1.0, r["achieved"] / r["peak"])) < 2e-3
+        assert r["traffic"] > 0 and r["valu_issue"]["unpriced_share_of_cycles"] < 0.05
+        assert r["valu_issue"]["frac"] <= 1.0 and r["hbm_measured"]["frac"] <= 1.0 and 0.0 < r["fp32"]["frac"] <= 1.0
+        assert 0.0 < r["fp32"]["active_lane_fraction"] <= 1.0
+    else:
+        assert r["traffic"] is None and r["achieved"] is None
+
+
+def test_default_line_and_its_counter_profile():
+    """The driver's command line (defaults: C2, 64 spp per step): when profiles/traffic.json holds this build's profile
+    the roofline object carries measured fractions; they are checked for consistency either way."""
+    d = run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], per_bounce=False)
+    assert d["config"]["batch_spp"] == 64 and d["value"] > 1000
+    _check_roofline(d["roofline"])
+    assert d["roofline"]["launches"] == 5 * 8
+
+
 def test_single_gpu_line():
     d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
              "--digest", "--pcie"])
@@ -35,14 +57,8 @@ def test_single_gpu_line():
     # the reference's calling pattern (one pathtrace() per iteration with the host image): synchronous and PT_ASYNC_IMAGE
     assert d["config"]["pcie_inclusive_mrays_per_s"] > 100 and d["config"]["pcie_inclusive_async_mrays_per_s"] > 100
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["value"] > 100
-    r = d["roofline"]
-    assert r["bound"] in ("valu-issue", "hbm") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert "traffic" in r and "source" in r and r["hbm_algorithmic"]["unit"] == "GB/s"
-    if r["bound"] == "valu-issue":              # a counter profile of exactly this build and command line exists
-        assert r["traffic"] > 0 and r["valu"]["insts_per_ray"] > 100
-    else:
-        assert r["traffic"] is None             # never a stale number
-    assert r["launches"] == 3 * 8
+    _check_roofline(d["roofline"])
+    assert d["roofline"]["launches"] == 3 * 8
     test_single_gpu_line.md5 = d["image_md5"]
 
 
