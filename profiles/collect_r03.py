@@ -30,7 +30,7 @@ SIMDS, PEAK_GHZ = 1024, 2.4
 COUNTED = {
     "fn": "k_bounceILi0ELb1ELi0ELb1ELb0ELb0E", "fg": "k_bounceILi0ELb1ELi0ELb1ELb1ELb0E",
     "sn": "k_bounceILi0ELb1ELi0ELb1ELb0ELb1E", "sg": "k_bounceILi0ELb1ELi0ELb1ELb1ELb1E",
-    "tn": "k_bounceILi0ELb1ELi1ELb1ELb0ELb0E", "tg": "k_bounceILi0ELb1ELi1ELb1ELb1ELb0E",
+    "tn": "k_bounceILi0ELb1ELi1ELb0ELb0ELb0E", "tg": "k_bounceILi0ELb1ELi1ELb0ELb1ELb0E",
     "pn": "k_bounceILi0ELb1ELi3ELb1ELb0ELb0E", "pg": "k_bounceILi0ELb1ELi3ELb1ELb1ELb0E",
     "km": "k_meshILb1E", "it": "k_iterationILb1E",
 }
@@ -38,7 +38,7 @@ COUNTED = {
 PROF_NAME = {
     "fn": r"k_bounce<0, true, 0, true, false, false>", "fg": r"k_bounce<0, true, 0, true, true, false>",
     "sn": r"k_bounce<0, true, 0, true, false, true>", "sg": r"k_bounce<0, true, 0, true, true, true>",
-    "tn": r"k_bounce<0, true, 1, true, false, false>", "tg": r"k_bounce<0, true, 1, true, true, false>",
+    "tn": r"k_bounce<0, true, 1, false, false, false>", "tg": r"k_bounce<0, true, 1, false, true, false>",
     "pn": r"k_bounce<0, true, 3, true, false, false>", "pg": r"k_bounce<0, true, 3, true, true, false>",
     "km": r"k_mesh<true>", "it": r"k_iteration<true>",
 }
@@ -75,8 +75,6 @@ def rocprof(tag, what, bench_args):
     d = os.path.join(OUT, tag, what.split()[0].replace("--", "").replace("-", "_") if what.startswith("--kernel") else "pmc_" + what.split()[1])
     cmd = ["rocprofv3"] + what.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3", os.path.join(ROOT, "bench.py")] + \
           bench_args.split() + ["--no-cpu-baseline", "--no-roofline"]
-    if "--steps" not in bench_args:
-        cmd += ["--steps", "5", "--warmup", "2"]
     sh(cmd, d + ".log")
     return d
 
@@ -114,16 +112,28 @@ def main(which):
         dsq = rocprof(tag, "--pmc " + SQ_PASS, bench_args)
         dfe = rocprof(tag, "--pmc FETCH_SIZE", bench_args)
         dwr = rocprof(tag, "--pmc WRITE_SIZE", bench_args)
+        # the TIMED launches only: bench.py's warm-up steps run while the clocks still ramp (the first step of a process
+        # is ~15 % slower than the twentieth) and are not in its ms_per_step either
+        m = re.search(r"--steps (\d+)", bench_args)
+        timed_steps = int(m.group(1)) if m else 20
+        rows = sorted(per_kernel_rows(dtrace, "kernel_trace.csv"), key=lambda r: int(r["Start_Timestamp"]))
+        stage_calls = {}
+        for (cb, stage, per_step) in kernels:
+            stage_calls[PROF_NAME[cb]] = timed_steps * per_step
         dur = {}
-        for r in per_kernel_rows(dtrace, "kernel_trace.csv"):
+        for r in rows:
             dur.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for k in list(dur):
+            for name, n in stage_calls.items():
+                if name in k:
+                    dur[k] = dur[k][-n:]
         pmc = {}
         for d in (dsq, dfe, dwr):
             for r in per_kernel_rows(d, "counter_collection.csv"):
                 a = pmc.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], [0.0, 0])
                 a[0] += float(r["Counter_Value"]); a[1] += 1
         total_ns = sum(sum(v) for v in dur.values())
-        lines = ["%-64s %7s %12s %10s %7s" % ("kernel (rocprofv3 --kernel-trace --stats)", "calls", "total_us", "avg_us", "share")]
+        lines = ["%-64s %7s %12s %10s %7s" % ("kernel (rocprofv3 --kernel-trace --stats; timed steps)", "calls", "total_us", "avg_us", "share")]
         for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
             lines.append("%-64s %7d %12.1f %10.2f %6.1f%%" % (re.sub(r"^void |\(anonymous namespace\)::", "", k)[:64], len(v), sum(v) / 1e3,
                                                             sum(v) / len(v) / 1e3, 100.0 * sum(v) / max(1, total_ns)))
@@ -187,10 +197,7 @@ def main(which):
                              100.0 * e.get("unpriced_share_of_cycles", 0), e.get("active_lane_fraction"), e.get("hbm_frac")))
         open(os.path.join(OUT, "rocprof_r03_%s_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
         json.dump(out, open(os.path.join(OUT, "roofline_r03_%s.json" % tag), "w"), indent=1)
-        m = re.search(r"--flags (\S+)", bench_args)
-        b = re.search(r"--batch (\d+)", bench_args)
-        key = "%s|%s|%s" % (ccfg, m.group(1) if m else "compact", b.group(1) if b else "64")
-        traffic["configs"][key] = out
+        traffic["configs"][traffic_key(tag)] = out
         json.dump(traffic, open(tpath, "w"), indent=1)
         print("\n".join(lines), flush=True)
         # the plain bench line, with the roofline object this profile feeds
@@ -199,5 +206,26 @@ def main(which):
                            stderr=subprocess.DEVNULL, timeout=900)
 
 
+def traffic_key(tag):
+    bench_args, (ccfg, _, _, _), _ = CONFIGS[tag]
+    m = re.search(r"--flags (\S+)", bench_args)
+    b = re.search(r"--batch (\d+)", bench_args)
+    return "%s|%s|%s" % (ccfg, m.group(1) if m else "compact", b.group(1) if b else "64")
+
+
+def assemble(src):
+    """profiles/traffic.json from the roofline_r03_*.json of a finished collection (gpurun merges gpurun_out/ back, not profiles/)"""
+    traffic = {"configs": {}}
+    for tag in CONFIGS:
+        f = os.path.join(src, "roofline_r03_%s.json" % tag)
+        if os.path.exists(f):
+            traffic["configs"][traffic_key(tag)] = json.load(open(f))
+    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    print("profiles/traffic.json:", ", ".join(sorted(traffic["configs"])))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:] or list(CONFIGS))
+    if sys.argv[1:2] == ["--assemble"]:
+        assemble(sys.argv[2])
+    else:
+        main(sys.argv[1:] or list(CONFIGS))

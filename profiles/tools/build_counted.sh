@@ -9,7 +9,11 @@ B=/opt/rocm/lib/llvm/bin
 SRC=$ROOT/project3-cuda-path-tracer_amd/csrc/ptmi355.hip
 FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 $*"
 cd "$OUT"
-/opt/rocm/bin/hipcc $FLAGS --cuda-device-only -S -o plain.s "$SRC"
+# the device assembly is the same for every NAME: made once per state of csrc/ and flags
+KEY=$( (cat "$ROOT"/project3-cuda-path-tracer_amd/csrc/*; echo "$FLAGS") | sha256sum | cut -c1-16)
+PLAIN=$ROOT/.ab/plain_$KEY.s
+if [ ! -s "$PLAIN" ]; then /opt/rocm/bin/hipcc $FLAGS --cuda-device-only -S -o "$PLAIN.tmp.$$" "$SRC" && mv "$PLAIN.tmp.$$" "$PLAIN"; fi
+ln -sf "$PLAIN" plain.s
 if [ "${COUNT_MODE:-full}" = none ]; then cp plain.s counted.s; echo "{\"words\": 64}" > map.json; else python3 "$ROOT/profiles/tools/isa_count.py" instrument plain.s "$KERNEL" counted.s map.json ${COUNT_MODE:-full}; fi
 $B/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c counted.s -o dev.o
 $B/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o dev.out dev.o
