@@ -126,6 +126,7 @@ struct Renderer {
     size_t flag_words = 0;                   // mesh pre-pass: 64-bit flag words per parity (one bit per physical pool slot)
     size_t ctl_bytes = 0;         // Control, zeroed per batch
     int grid = 0;                 // persistent grid size
+    int grid_iter = 0;            // k_iteration's own (its register budget differs from the bounce kernels')
     int grid_sort = 0;            // workgroups of the material-sort kernels (k_sort_hist / k_shade_sorted)
     bool sort_wave = true;        // <= 64 keys: k_shade_sorted_w (PTMI355_SORT_WAVE=0 forces the workgroup-wide kernel)
     int sort_runs = 1;            // runs of tiles per wave of the fused sort (k_bounce); PTMI355_SORT_RUNS
@@ -373,6 +374,18 @@ void launch_intersect(const Pool &in, const uint32_t *n_ptr, uint32_t n_fixed, c
 // The instantiations of k_bounce that are ever launched: MODE_ISECT / MODE_CACHE0 intersect nothing (one mesh mode
 // serves them all, no ray generation); the fused kernel reads the results of the mesh pre-pass under PT_MESH_BVH
 // (the hierarchy is never walked inline by k_bounce) and generates bounce 0's rays itself in batches (GEN).
+// the fused compacting kernel that launch_bounce_at picks for (scene in LDS, ray generation, material keys)
+template <int MESH>
+const void *bounce_fn(bool slds, bool gen, bool sorted) {
+    if constexpr (MESH != MESH_PRE) {
+        if (sorted) {
+            if (slds) return gen ? (const void *)k_bounce<MODE_FUSED, true, MESH, true, true, true> : (const void *)k_bounce<MODE_FUSED, true, MESH, true, false, true>;
+            return gen ? (const void *)k_bounce<MODE_FUSED, true, MESH, false, true, true> : (const void *)k_bounce<MODE_FUSED, true, MESH, false, false, true>;
+        }
+    }
+    if (slds) return gen ? (const void *)k_bounce<MODE_FUSED, true, MESH, true, true> : (const void *)k_bounce<MODE_FUSED, true, MESH, true, false>;
+    return gen ? (const void *)k_bounce<MODE_FUSED, true, MESH, false, true> : (const void *)k_bounce<MODE_FUSED, true, MESH, false, false>;
+}
 template <int MODE, bool COMPACT, int MESH, bool GEN>
 void launch_bounce_at(const BounceArgs &a) {
     if constexpr (MODE == MODE_FUSED && COMPACT && MESH != MESH_PRE) {
@@ -522,8 +535,8 @@ int enqueue_batch_direct(int iter0, int count) {
         StageTimer tm(PT_STAGE_BOUNCE);
         BounceArgs a = bounce_args(0);
         if (R.epi_host && count == 1 && !R.capturing) { a.epi_image = R.image; a.epi_host = R.epi_host; R.epi_done = true; }
-        if (R.scene_lds) hipLaunchKernelGGL(k_iteration<true>, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
-        else hipLaunchKernelGGL(k_iteration<false>, dim3(R.grid), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        if (R.scene_lds) hipLaunchKernelGGL(k_iteration<true>, dim3(R.grid_iter), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        else hipLaunchKernelGGL(k_iteration<false>, dim3(R.grid_iter), dim3(BLOCK), R.lds_bytes, R.stream, a);
         HIPCHK(hipGetLastError());
         R.step_depth = R.trace_depth;
         R.whole = true;
@@ -1309,22 +1322,37 @@ static int init_impl(const pt_scene_desc *d) {
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // persistent grid: as many workgroups as are co-resident for the fused kernel (tiles are
     // dealt round-robin, so more workgroups than that only re-stage the scene)
-    int per_cu = 0;
-    if (R.mesh_mode == MESH_BVH)
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH_PRE, true, false>, BLOCK, R.lds_bytes));
-    else if (R.mesh_mode == MESH_TILES)
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH_TILES, true, false>, BLOCK, R.lds_bytes));
-    else
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, (const void *)k_bounce<MODE_FUSED, true, MESH_NONE, true, false>, BLOCK, R.lds_bytes));
+    // ... counted on the variants this session launches (scene in LDS or not, with and without ray generation, with or
+    // without the material keys): they differ in registers, and a grid one workgroup per CU too large for the variant
+    // that runs serialises a whole extra round of workgroups (C3 sorted at 6 per CU instead of its 5: -23 %)
+    int per_cu = 8;
+    {
+        const bool sorted = R.sort_keys > 0;
+        const void *fns[2];
+        if (R.mesh_mode == MESH_BVH) { fns[0] = bounce_fn<MESH_PRE>(R.scene_lds, false, false); fns[1] = bounce_fn<MESH_PRE>(R.scene_lds, true, false); }
+        else if (R.mesh_mode == MESH_TILES) { fns[0] = bounce_fn<MESH_TILES>(R.scene_lds, false, sorted); fns[1] = bounce_fn<MESH_TILES>(R.scene_lds, true, sorted); }
+        else { fns[0] = bounce_fn<MESH_NONE>(R.scene_lds, false, sorted); fns[1] = bounce_fn<MESH_NONE>(R.scene_lds, true, sorted); }
+        for (const void *f : fns) {
+            int n = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, BLOCK, R.lds_bytes));
+            per_cu = std::min(per_cu, n);
+        }
+    }
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     if (const char *e = getenv("PTMI355_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // occupancy experiments
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
     if (R.grid < 1) R.grid = 1;
     if (R.grid * WAVES > 8192) R.grid = 8192 / WAVES;           // the pools' slack and the directory scan are sized for W <= 8192
+    {   // k_iteration has no directory and no cross-workgroup step: its grid is its own co-resident count
+        int n = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &n, R.scene_lds ? (const void *)k_iteration<true> : (const void *)k_iteration<false>, BLOCK, R.lds_bytes));
+        n = std::max(1, std::min(n, 8));
+        if (const char *e = getenv("PTMI355_WGS_PER_CU")) n = std::max(1, std::min(n, atoi(e)));
+        R.grid_iter = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)n);
+        R.grid_iter = std::max(1, std::min(R.grid_iter, 8192 / WAVES));
+    }
     if (R.mesh_mode == MESH_BVH) {
         HIPCHK(hipMalloc((void **)&R.mesh_hit, (size_t)(((capz + 63) / 64) * 64) * sizeof(float4)));
         // k_mesh reads the flags of whole ranges (waves x tiles per range can overshoot the pool by up to one tile per
