@@ -79,6 +79,7 @@ int fail(int code, const char *fmt, ...) {
                         hipGetErrorString(e_));                                                 \
     } while (0)
 
+constexpr int OV_MAX_LANES = 8;
 struct Renderer {
     bool live = false;
     pt_scene_desc desc{};
@@ -140,6 +141,30 @@ struct Renderer {
     std::map<int, BatchGraph> graphs;
     uint64_t whole_max_paths = 6000000;  // batches up to this many paths run as ONE launch (k_iteration); PTMI355_WHOLE_MAX
     bool whole = false;           // the current batch did
+    // Batches whose caller does not wait for them overlap on the device (enqueue_batch_direct): each runs on a LANE --
+    // a launch stream of its own and its own set of the buffers a batch in flight owns
+    struct Bufs {
+        float *pool_mem[2]; Pool pool[2]; float *final_mem; Control *ctl; uint32_t *dir_mem;
+        float4 *mesh_hit; unsigned long long *mesh_flags[2];
+    };
+    struct Lane {
+        hipStream_t stream = nullptr;
+        Bufs b{};                                 // lane 0: the session's own
+        hipEvent_t traced = nullptr, gathered = nullptr;
+        bool gathered_valid = false;
+    } lane[OV_MAX_LANES];
+    Lane *lane_cur = nullptr;     // the lane whose buffers and stream currently stand in for the session's (while its batch is enqueued)
+    hipStream_t lane_main = nullptr;   // ... and the session's launch stream meanwhile
+    size_t pool_bytes = 0, final_bytes = 0, dir_bytes = 0, mesh_hit_bytes = 0;   // of one set (init_impl)
+    int ov_lanes = 4;             // PTMI355_OVERLAP=n: n lanes (0: every batch on the launch stream); 4 measured best, 3 worst (profiles/r03/variants_overlap*.log)
+    double ov_budget_gb = 64.0;   // PTMI355_OVERLAP_GB: HBM the extra lanes may take
+    hipEvent_t ov_enter = nullptr;
+    bool ov_ready = false;        // lanes allocated
+    bool ov_enabled = true;
+    bool ov_ok = false;           // this call does not wait for its own result (async entry points)
+    bool ov_active = false;       // the last thing enqueued was an overlapped batch
+    int ov_next = 0;
+    Control *last_ctl = nullptr;  // the control block of the last batch (collect_stats)
     float *epi_host = nullptr;    // pt_trace: the caller's image, device-mapped, for k_iteration's own gather (this call only)
     bool epi_done = false;        // ... and k_iteration took it
     bool epi_enabled = true;      // PTMI355_HOST_EPILOGUE=0: always copy after the iteration
@@ -302,6 +327,9 @@ BounceArgs bounce_args(int depth) {
 int next_fin_stamp(void) {
     if (++R.fin_serial == 0) {                                    // 2^32 batches later: forget every old stamp
         HIPCHK(hipMemsetAsync(R.final_mem, 0, (size_t)R.cap * 16, R.stream));
+        if (R.ov_ready)
+            for (int j = 1; j < R.ov_lanes; ++j)
+                HIPCHK(hipMemsetAsync(R.lane[j].b.final_mem, 0, R.final_bytes, R.stream));
         R.fin_serial = 1;
     }
     return PT_OK;
@@ -315,6 +343,8 @@ int enqueue_begin(int iter0, int count, bool stepping) {
     if (iter0 < 0 || (int64_t)iter0 + count - 1 > 0x7fffffff)
         return fail(PT_ERR_INVALID, "iteration %d (+%d) outside [0, 2^31)", iter0, count);
     R.step_iter0 = iter0; R.step_count = count; R.step_depth = 0; R.cur = 0; R.cur_dir = -1;
+    R.ov_active = false;          // (every overlapped batch's gather is on the launch stream: what follows is ordered after them)
+    R.last_ctl = R.ctl;
     if (!R.capturing) { const int rc = next_fin_stamp(); if (rc) return rc; }
     R.sorted_isects = false;
     R.mesh_marked = false;
@@ -513,17 +543,132 @@ int enqueue_fake(void) {
 
 int enqueue_end(void) {
     StageTimer tm(PT_STAGE_GATHER);
-    hipLaunchKernelGGL(k_gather, dim3((R.map.tile_pixels + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, R.stream, R.image,
+    hipStream_t gs = R.stream;
+    if (R.lane_cur) {                                         // overlapped batch: gathers stay in call order on the launch stream
+        HIPCHK(hipEventRecord(R.lane_cur->traced, R.stream));
+        HIPCHK(hipStreamWaitEvent(R.lane_main, R.lane_cur->traced, 0));
+        gs = R.lane_main;
+    }
+    hipLaunchKernelGGL(k_gather, dim3((R.map.tile_pixels + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, gs, R.image,
                        R.final_mem, R.cap, R.map,
                        R.step_count, R.ctl, R.persist, (R.flags & PT_FAKE_SHADER) ? 0 : R.trace_depth,
                        (R.flags & PT_FAKE_SHADER) ? (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count : 0u,
                        R.whole ? 1 : 0, R.epi_done ? 1 : 0, R.capturing ? 0u : R.fin_serial);
     R.whole = false;
     HIPCHK(hipGetLastError());
+    if (R.lane_cur) {
+        HIPCHK(hipEventRecord(R.lane_cur->gathered, gs));
+        R.lane_cur->gathered_valid = true;
+    }
     return PT_OK;
 }
 
+// Batches whose caller does not wait for them (pt_trace_batch_async; pt_trace / pt_trace_batch under PT_ASYNC_IMAGE)
+// OVERLAP on the device.  A launch stream runs its kernels one after the other, and every kernel of this library ends
+// with a tail: the persistent grid's waves do not finish together (mean residency 0.84-0.94 of a launch),
+// and one iteration per launch (k_iteration) is a chain of `depth` dependent bounces per wave, ~10 us each at 800x800
+// whatever the number of paths left.  Consecutive batches therefore go to different LANES -- each a launch stream with
+// its own pools, final-colour buffer, control block, directory and mesh pre-pass buffers -- and as the workgroups of
+// one batch's kernel retire, those of another batch's take their slots.  What must stay ordered does: every k_gather
+// runs on the session's launch stream, in call order, after its own batch's last kernel (event), so the image is
+// summed in iteration order bit for bit and whatever is enqueued on the launch stream afterwards (tonemap, image
+// copies, serial batches, pt_synchronize) comes after every batch before it; a lane's next batch waits for the gather
+// of its previous one (it reuses the buffers that gather reads).  While a batch is enqueued its lane's buffers and
+// stream stand in for the session's (put_bufs / R.stream), so the enqueue code is the serial one.
+// Measured (profiles/r03/variants_overlap*.log), C2: 1 spp per call 20.0 -> 25.0 Grays/s, 8 spp 32.4 -> 38.8.
+Renderer::Bufs take_bufs(void) {
+    Renderer::Bufs b{};
+    for (int k = 0; k < 2; ++k) { b.pool_mem[k] = R.pool_mem[k]; b.pool[k] = R.pool[k]; b.mesh_flags[k] = R.mesh_flags[k]; }
+    b.final_mem = R.final_mem; b.ctl = R.ctl; b.dir_mem = R.dir_mem; b.mesh_hit = R.mesh_hit;
+    return b;
+}
+void put_bufs(const Renderer::Bufs &b) {
+    for (int k = 0; k < 2; ++k) { R.pool_mem[k] = b.pool_mem[k]; R.pool[k] = b.pool[k]; R.mesh_flags[k] = b.mesh_flags[k]; }
+    R.final_mem = b.final_mem; R.ctl = b.ctl; R.dir_mem = b.dir_mem; R.mesh_hit = b.mesh_hit;
+}
+
+int ensure_lanes(void) {
+    if (R.ov_ready) return PT_OK;
+    const double per_lane = 2.0 * (double)R.pool_bytes + (double)R.final_bytes + (double)R.dir_bytes + (double)R.mesh_hit_bytes +
+                            2.0 * (double)R.flag_words * 8.0;
+    const int fit = 1 + (int)std::min(16.0, std::floor(R.ov_budget_gb * 1e9 / std::max(1.0, per_lane)));
+    R.ov_lanes = std::min(R.ov_lanes, fit);
+    if (R.ov_lanes == 3) R.ov_lanes = 2;                       // three lanes measured no better than one
+    if (R.ov_lanes < 2) { R.ov_enabled = false; return PT_OK; }
+    R.lane[0].b = take_bufs();
+    for (int j = 1; j < R.ov_lanes; ++j) {
+        Renderer::Bufs &b = R.lane[j].b;
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(hipMalloc((void **)&b.pool_mem[k], R.pool_bytes));
+            b.pool[k] = carve_pool(b.pool_mem[k], R.cap);
+        }
+        HIPCHK(hipMalloc((void **)&b.final_mem, R.final_bytes));
+        HIPCHK(hipMemsetAsync(b.final_mem, 0, R.final_bytes, R.stream));
+        HIPCHK(hipMalloc((void **)&b.ctl, sizeof(Control)));
+        HIPCHK(hipMemsetAsync(b.ctl, 0, sizeof(Control), R.stream));
+        HIPCHK(hipMalloc((void **)&b.dir_mem, R.dir_bytes));
+        if (R.mesh_mode == MESH_BVH) {
+            HIPCHK(hipMalloc((void **)&b.mesh_hit, R.mesh_hit_bytes));
+            for (int k = 0; k < 2; ++k) {
+                HIPCHK(hipMalloc((void **)&b.mesh_flags[k], R.flag_words * sizeof(unsigned long long)));
+                HIPCHK(hipMemsetAsync(b.mesh_flags[k], 0, R.flag_words * sizeof(unsigned long long), R.stream));
+            }
+        }
+    }
+    for (int k = 0; k < R.ov_lanes; ++k) {
+        HIPCHK(hipStreamCreateWithFlags(&R.lane[k].stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&R.lane[k].traced, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&R.lane[k].gathered, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&R.ov_enter, hipEventDisableTiming));
+    R.ov_ready = true;
+    return PT_OK;
+}
+
+// the fused pipelines only: the unfused / two-kernel-sort / fake-shader ones keep intersection planes and sort tables
+// (one set), the first-bounce cache is filled by the first batch that needs it
+bool overlap_eligible(int count) {
+    return R.ov_ok && R.ov_enabled && !R.capturing && !R.use_graphs && !R.profiling && !R.epi_host && !R.dbg_counts &&
+           !(R.flags & (PT_UNFUSED | PT_FAKE_SHADER | PT_CACHE_FIRST)) && (!(R.flags & PT_SORT_MATERIAL) || R.sort_keys > 0) &&
+           count >= 1 && count <= R.max_batch;
+}
+
+int enqueue_batch_serial(int iter0, int count);
+
 int enqueue_batch_direct(int iter0, int count) {
+    if (!overlap_eligible(count)) return enqueue_batch_serial(iter0, count);
+    int rc = ensure_lanes();
+    if (rc) return rc;
+    if (!R.ov_enabled) return enqueue_batch_serial(iter0, count);       // the lanes do not fit the budget
+    if (R.fin_serial == 0xffffffffu) {      // the stamp is about to wrap: nothing may be in flight while every lane's colours are forgotten
+        HIPCHK(hipStreamSynchronize(R.stream));
+        for (int j = 0; j < R.ov_lanes; ++j) HIPCHK(hipMemsetAsync(R.lane[j].b.final_mem, 0, R.final_bytes, R.stream));
+        HIPCHK(hipStreamSynchronize(R.stream));
+        R.fin_serial = 0;
+        R.ov_active = false;
+    }
+    if (!R.ov_active) {
+        // whatever the launch stream holds (uploads, masks, serial batches on the session's buffers) comes first
+        HIPCHK(hipEventRecord(R.ov_enter, R.stream));
+        for (int k = 0; k < R.ov_lanes; ++k) {
+            HIPCHK(hipStreamWaitEvent(R.lane[k].stream, R.ov_enter, 0));
+            R.lane[k].gathered_valid = false;
+        }
+    }
+    Renderer::Lane &l = R.lane[R.ov_next];
+    R.ov_next = (R.ov_next + 1) % R.ov_lanes;
+    if (l.gathered_valid) HIPCHK(hipStreamWaitEvent(l.stream, l.gathered, 0));
+    const Renderer::Bufs home = take_bufs();
+    R.lane_main = R.stream; R.lane_cur = &l;
+    put_bufs(l.b); R.stream = l.stream;
+    rc = enqueue_batch_serial(iter0, count);                            // its gather goes to the launch stream (enqueue_end)
+    R.stream = R.lane_main; put_bufs(home);
+    R.lane_cur = nullptr; R.lane_main = nullptr;
+    R.ov_active = rc == PT_OK;
+    return rc;
+}
+
+int enqueue_batch_serial(int iter0, int count) {
     int rc = enqueue_begin(iter0, count, false);
     if (rc) return rc;
     if (R.flags & PT_FAKE_SHADER) {
@@ -803,7 +948,7 @@ int enqueue_image_copy(float *host) {
 // reads the control block back (after a sync) and folds it into the stats
 int collect_stats(void) {
     Control c;
-    HIPCHK(hipMemcpyAsync(&c, R.ctl, offsetof(Control, bucket), hipMemcpyDeviceToHost, R.stream));
+    HIPCHK(hipMemcpyAsync(&c, R.last_ctl ? R.last_ctl : R.ctl, offsetof(Control, bucket), hipMemcpyDeviceToHost, R.stream));
     HIPCHK(hipStreamSynchronize(R.stream));
     if (c.error) return fail(PT_ERR_INTERNAL, "kernel watchdog tripped: inconsistent tile directory (control.error=%u)", c.error);
     R.stats.bounces = 0; R.stats.rays = 0;
@@ -894,6 +1039,22 @@ void pt_free(void) {
     R.d_cam_mask = nullptr; R.cam_mask_valid = false;
     if (R.d_cull0) (void)hipFree(R.d_cull0);
     R.d_cull0 = nullptr; R.cull0_tiles = 0;
+    if (R.ov_ready) {
+        for (int k = 0; k < R.ov_lanes; ++k) {
+            if (R.lane[k].stream) { (void)hipStreamSynchronize(R.lane[k].stream); (void)hipStreamDestroy(R.lane[k].stream); }
+            if (R.lane[k].traced) (void)hipEventDestroy(R.lane[k].traced);
+            if (R.lane[k].gathered) (void)hipEventDestroy(R.lane[k].gathered);
+        }
+        for (int j = 1; j < R.ov_lanes; ++j) {
+            Renderer::Bufs &b = R.lane[j].b;
+            for (int k = 0; k < 2; ++k) { if (b.pool_mem[k]) (void)hipFree(b.pool_mem[k]); if (b.mesh_flags[k]) (void)hipFree(b.mesh_flags[k]); }
+            if (b.final_mem) (void)hipFree(b.final_mem);
+            if (b.ctl) (void)hipFree(b.ctl);
+            if (b.dir_mem) (void)hipFree(b.dir_mem);
+            if (b.mesh_hit) (void)hipFree(b.mesh_hit);
+        }
+        if (R.ov_enter) (void)hipEventDestroy(R.ov_enter);
+    }
     if (R.ctl) (void)hipFree(R.ctl);
     if (R.dir_mem) (void)hipFree(R.dir_mem);
     if (R.persist) (void)hipFree(R.persist);
@@ -1127,6 +1288,12 @@ static int init_impl(const pt_scene_desc *d) {
     if (const char *ug = getenv("PTMI355_GRAPH")) R.use_graphs = atoi(ug) != 0;
     R.whole_max_paths = 6000000;     // measured at 800x800 (r02): 1 spp +38 %, 4 spp +20 %, 8 spp +8 %, 16 spp -4 %
     if (const char *wm = getenv("PTMI355_WHOLE_MAX")) R.whole_max_paths = strtoull(wm, nullptr, 10);
+    if (const char *e = getenv("PTMI355_OVERLAP")) {           // 0: off; 1: on (default lanes); n >= 2: n lanes
+        const int nl = atoi(e);
+        R.ov_enabled = nl != 0;
+        if (nl >= 2) R.ov_lanes = std::min(nl, OV_MAX_LANES);
+    }
+    if (const char *e = getenv("PTMI355_OVERLAP_GB")) R.ov_budget_gb = atof(e);
     R.epi_enabled = true;
     if (const char *e = getenv("PTMI355_HOST_EPILOGUE")) R.epi_enabled = atoi(e) != 0;
     R.pin_enabled = true;
@@ -1290,7 +1457,8 @@ static int init_impl(const pt_scene_desc *d) {
         // w * R * 64 with R = ceil(tiles / W), so the spans of the last waves reach up to W tiles past the pool's paths --
         // never written while a wave only packs its own survivors, but k_iteration deals a workgroup's survivors to
         // all four of its waves, whichever of them had paths at bounce 0
-        HIPCHK(hipMalloc(&R.pool_mem[k], pool_mult * (((capz + 63) / 64) + 8192 * run_mult) * 64 * 10 * 4));
+        R.pool_bytes = pool_mult * (((capz + 63) / 64) + 8192 * run_mult) * 64 * 10 * 4;
+        HIPCHK(hipMalloc(&R.pool_mem[k], R.pool_bytes));
         R.pool[k] = carve_pool(R.pool_mem[k], R.cap);
     }
     // the ShadeableIntersection planes exist only where a pipeline materialises them (the fused path keeps them
@@ -1299,7 +1467,8 @@ static int init_impl(const pt_scene_desc *d) {
         const int rc = ensure_isect();
         if (rc != PT_OK) return rc;
     }
-    HIPCHK(hipMalloc(&R.final_mem, capz * 4 * 4));
+    R.final_bytes = capz * 4 * 4;
+    HIPCHK(hipMalloc(&R.final_mem, R.final_bytes));
     HIPCHK(hipMemsetAsync(R.final_mem, 0, capz * 4 * 4, R.stream));          // no entry carries a stamp yet (stamps start at 1)
     R.fin_serial = 0;
     if (const char *e = getenv("PTMI355_FIN_SERIAL")) R.fin_serial = (uint32_t)strtoul(e, nullptr, 0);   // tests: start near the wrap
@@ -1354,7 +1523,8 @@ static int init_impl(const pt_scene_desc *d) {
         R.grid_iter = std::max(1, std::min(R.grid_iter, 8192 / WAVES));
     }
     if (R.mesh_mode == MESH_BVH) {
-        HIPCHK(hipMalloc((void **)&R.mesh_hit, (size_t)(((capz + 63) / 64) * 64) * sizeof(float4)));
+        R.mesh_hit_bytes = (size_t)(((capz + 63) / 64) * 64) * sizeof(float4);
+        HIPCHK(hipMalloc((void **)&R.mesh_hit, R.mesh_hit_bytes));
         // k_mesh reads the flags of whole ranges (waves x tiles per range can overshoot the pool by up to one tile per
         // wave) and in chunks of 8 tiles: the words past the pool exist and stay zero
         R.flag_words = (size_t)R.max_tiles + (size_t)R.grid * WAVES + 8;
@@ -1386,7 +1556,8 @@ static int init_impl(const pt_scene_desc *d) {
         const size_t Wp = ((size_t)R.grid * WAVES * pool_mult * run_mult + 3) & ~(size_t)3;
         R.dir_stride = 2 * Wp + 8;
         // one directory per bounce up to MAX_DEPTH: traceDepth is re-read on every call and may GROW (pathtrace.cu:286)
-        HIPCHK(hipMalloc((void **)&R.dir_mem, (size_t)MAX_DEPTH * R.dir_stride * sizeof(uint32_t)));
+        R.dir_bytes = (size_t)MAX_DEPTH * R.dir_stride * sizeof(uint32_t);
+        HIPCHK(hipMalloc((void **)&R.dir_mem, R.dir_bytes));
     }
     {
         const int rc = update_cam_mask();
@@ -1442,6 +1613,7 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
     R.cam = *camera;
     R.trace_depth = trace_depth;
     if (moved || recull) {
+        R.ov_active = false;      // overlapped batches to come wait for what is enqueued here (the launch stream orders it after the ones in flight)
         const int rc = update_cull0();
         if (rc != PT_OK) return rc;
     }
@@ -1486,13 +1658,18 @@ int pt_synchronize(void) {
 int pt_trace_batch_async(int iter0, int count) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_batch_async: not initialised");
     R.in_step = false;
-    return enqueue_batch(iter0, count);
+    R.ov_ok = true;
+    const int rc = enqueue_batch(iter0, count);
+    R.ov_ok = false;
+    return rc;
 }
 
 int pt_trace_batch(int iter0, int count, float *host_image_sum) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_batch: not initialised");
     R.in_step = false;
+    R.ov_ok = host_image_sum && (R.flags & PT_ASYNC_IMAGE);
     int rc = enqueue_batch(iter0, count);
+    R.ov_ok = false;
     if (rc) return rc;
     if (host_image_sum && (R.flags & PT_ASYNC_IMAGE)) return enqueue_async_image(host_image_sum);
     if (host_image_sum) {
@@ -1511,7 +1688,9 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
     R.epi_host = nullptr; R.epi_done = false;
     if (host_image_sum && !(R.flags & PT_ASYNC_IMAGE) && R.epi_enabled && !R.use_graphs && R.map.tile_count == 1)
         R.epi_host = map_host(host_image_sum, (size_t)R.npix * 12);
+    R.ov_ok = host_image_sum && (R.flags & PT_ASYNC_IMAGE);
     int rc = enqueue_batch(iter, 1);
+    R.ov_ok = false;
     const bool gathered = R.epi_done;
     R.epi_host = nullptr; R.epi_done = false;
     if (rc) return rc;
@@ -1615,6 +1794,7 @@ int pt_export_intersections(pt_shadeable_intersection *host_isects, uint8_t *hos
 
 int pt_intersect_once(const pt_path_segment *host_paths, int n, pt_shadeable_intersection *host_isects,
                       uint8_t *host_outside) {
+    R.ov_active = false;
     if (!R.live) return fail(PT_ERR_INVALID, "pt_intersect_once: not initialised");
     if (n < 0 || (uint32_t)n > R.cap) return fail(PT_ERR_INVALID, "pt_intersect_once: n=%d exceeds the pool capacity %u", n, R.cap);
     if (n == 0) return PT_OK;

@@ -326,6 +326,86 @@ def test_async_image_mode(pt, scenes):
     pt.pathtraceFree()
 
 
+def test_overlapped_small_batches(pt, po, scenes, monkeypatch):
+    """Consecutive small batches whose caller does not wait (pt_trace_batch_async, PT_ASYNC_IMAGE) overlap on two
+    launch streams (csrc/ptmi355.hip: enqueue_overlapped).  The image after every call, the ray counters and the
+    per-bounce statistics equal the serial plan's and the oracle's: batch sizes mixed with larger (serial) batches,
+    the camera moved and the trace depth changed in between, synchronous calls in between, a second session."""
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+    cam2 = scene.camera.copy()
+    cam2["position"][0][0] += 0.75
+    plan = [("a", 1, 1), ("a", 2, 1), ("a", 3, 2), ("a", 5, 1), ("a", 6, 1), ("a", 7, 1), ("s", 8, 1), ("a", 9, 1), ("a", 10, 3),
+            ("cam", cam2, s["depth"] - 3), ("a", 13, 1), ("a", 14, 1), ("a", 15, 16), ("a", 31, 1), ("a", 32, 1), ("cam", scene.camera.copy(), s["depth"]),
+            ("a", 33, 1), ("a", 34, 2), ("a", 36, 1)]
+
+    def run(overlap, serial0=None):
+        monkeypatch.setenv("PTMI355_OVERLAP", str(overlap))
+        if serial0 is None:
+            monkeypatch.delenv("PTMI355_FIN_SERIAL", raising=False)
+        else:
+            monkeypatch.setenv("PTMI355_FIN_SERIAL", serial0)     # the final-colour stamp wraps in the middle of the plan
+        out = []
+        for session in range(2):
+            pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=16)
+            for step in plan:
+                if step[0] == "cam":
+                    pt.set_camera(step[1], step[2])
+                elif step[0] == "s":
+                    out.append(pt.pathtrace(None, 0, step[1]).tobytes())
+                else:
+                    pt.trace_batch_async(step[1], step[2])
+            pt.synchronize()
+            out.append(pt.get_image(n).tobytes())
+            out.append(tuple(int(v) for v in pt.counters()))
+            # single calls, each waited for, between overlapped ones
+            pt.trace_batch_async(40, 1)
+            pt.synchronize()
+            img = pt.get_image(n).copy()
+            pt.trace_batch_async(41, 1)
+            pt.trace_batch_async(42, 1)
+            out.append(pt.get_image(n).tobytes())
+            out.append(img.tobytes())
+            pt.pathtraceFree()
+        return out
+
+    serial, overlapped = run(0), run(1)
+    assert serial == overlapped
+    assert run(2) == serial and run(4) == serial                  # two / four lanes (default: three)
+    assert run(3, "0xfffffff8") == serial
+    assert serial[:len(serial) // 2] == serial[len(serial) // 2:]
+    # and the oracle: iterations 1..7 with the first camera
+    tr = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
+    for it in range(1, 9):
+        tr.iterate(it)
+    assert tr.image.tobytes() == overlapped[0]
+
+
+def test_overlapped_async_image(pt, scenes, monkeypatch):
+    """PT_ASYNC_IMAGE + one iteration per call (the shim's asynchronous variant): calls overlap on the device, and every
+    buffer still holds exactly the sum after its own call."""
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+    monkeypatch.setenv("PTMI355_OVERLAP", "0")
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
+    sums = [pt.pathtrace(None, 0, it).copy() for it in range(1, 12)]
+    pt.pathtraceFree()
+    monkeypatch.setenv("PTMI355_OVERLAP", "1")
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_ASYNC_IMAGE)
+    bufs = [np.zeros((n, 3), dtype=np.float32) for _ in range(3)]
+    L = pt.library()
+    for it in range(1, 12):
+        assert L.pt_trace(None, 0, it, bufs[it % 3].ctypes.data) == 0
+        if it >= 2:
+            assert bufs[(it - 1) % 3].tobytes() == sums[it - 2].tobytes()
+    pt.synchronize()
+    assert bufs[11 % 3].tobytes() == sums[10].tobytes()
+    assert pt.counters()[2] == 11
+    pt.pathtraceFree()
+
+
 def test_tiles_equal_whole_frame(pt, scenes):
     """Interleaved row-strip tiles (multi-GPU sharding) reproduce the 1-tile image exactly:
     the RNG is keyed by the global pixelIndex."""
