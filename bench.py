@@ -18,13 +18,19 @@ exchange of BASELINE.json's north_star) as a gather of the packed tile rows (N/k
 --inproc: the same tiling inside the library, one process driving all N devices (include/ptmi355.h:
 pt_scene_desc::devices; RCCL send/recv from C++) -- what a host that links libptmi355.so gets; same JSON line.
 
+Steps are enqueued back to back (pt_trace_batch_async) and the region ends with one synchronisation: consecutive
+steps overlap on the device (the library runs them on alternating launch streams with their own path pools; every
+gather stays in call order, the image is bit-identical), which is what a host that renders many iterations gets.
+
 Extra JSON objects (see the task statement): `roofline` for the dominant kernel and `cpu_baseline` (the plain-C
 oracle on this host's cores, rank 0, N = 1 only).  The kernel is bound by vector-instruction issue, not by HBM:
-`roofline.frac` is the issue utilisation (instruction counts per class from the committed rocprofv3 PMC passes of THIS
-build x the per-class issue costs measured by profiles/microbench/valu_peak.hip, over the launch time measured here
-with HIP events); the HBM figures (algorithmic bytes, and measured FETCH/WRITE_SIZE traffic) ride along.  The counter
-profile is keyed by a hash of the kernel sources: after any kernel change it is dropped (fields null) until
-profiles/run_rocprof.sh has been re-run.
+`roofline.frac` = issue cycles per launch (the EXECUTED opcode histogram of an instrumented build x the issue cost of
+each opcode measured one by one: profiles/tools/isa_count.py, profiles/microbench/gen_issue_ops.py) over 1024 SIMDs x
+2.4 GHz x the launch time measured here with HIP events; the measured HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE), the
+fp32 rate and the active-lane fraction ride along, and `roofline.timed_pass` states the same cycles over the timed
+pass's own time per step.  The counter profile (profiles/traffic.json, written by profiles/collect_r03.py) is keyed
+by a hash of the kernel sources and compile flags: after any kernel change the counter-derived fields are null until
+the collection has been re-run.
 """
 import argparse
 import json
@@ -268,7 +274,7 @@ def main():
         rank_rays, first = rays1 - rays0, first1 - first0
         prof = pt.get_profile()
         pt.set_profiling(False)
-        roofline = roofline_object(args, n_tiles if inproc else world, flags, pt, prof, rank_rays, first)
+        roofline = roofline_object(args, n_tiles if inproc else world, flags, pt, prof, rank_rays, first, dt / args.steps)
 
     # ---- CPU baseline: the oracle (plain-C port) on this host, rank 0, N = 1 only ----
     cpu = None
@@ -356,7 +362,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_object(args, world, flags, pt, prof, rank_rays, first):
+def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s):
     """What bounds the dominant kernel(s) of THIS run: launch times measured here with HIP events on the launch stream
     (the timed steps repeated), against
       * the vector-issue roof: issue cycles per launch = the kernel's EXECUTED opcode histogram (per-basic-block counts of
@@ -366,7 +372,11 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first):
       * fp32: the histogram's floating-point operations x the active-lane fraction (SQ_THREAD_CYCLES_VALU) over 157.3 TF.
     `bound` is whichever of vector issue and HBM is closer to its roof; `frac` is that fraction, never above 1 by
     construction.  Without a counter profile of exactly this build and command line (profiles/collect_r03.py ->
-    profiles/traffic.json) the counter-derived fields are null rather than stale."""
+    profiles/traffic.json) the counter-derived fields are null rather than stale.
+    The event pass runs its steps one after the other on the launch stream; in the timed pass consecutive steps overlap
+    on the device (csrc/ptmi355.hip: enqueue_batch_direct), so `value` can exceed `grays_per_s_in_kernel`.
+    `timed_pass` therefore states the same issue cycles -- of every profiled kernel of a step -- over the timed
+    pass's own time per step: the share of the chip's issue cycles the whole pipeline used while `value` was measured."""
     steps = args.steps
     stage_ms = {k: v[0] for k, v in prof.items() if v[1]}
     launches = {k: int(v[1]) for k, v in prof.items() if v[1]}
@@ -417,6 +427,14 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first):
                    "active_lane_fraction": round(lanes, 4) if lanes else None,
                    "note": "fp32 operations of the executed opcode histogram (fma = 2) x active lanes (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64)"},
              grays_per_s_in_kernel=round(rank_rays / (stage_ms[st] * 1e-3) / 1e9, 3) if st == "bounce" else None)
+    cyc_all = sum(k["launches_per_step"] * k.get("issue_cycles_per_launch", 0.0) for k in ks.values())
+    byt_all = sum(k["launches_per_step"] * k.get("hbm_bytes_per_launch", 0) for k in ks.values())
+    if timed_step_s > 0:
+        r["timed_pass"] = {"ms_per_step": round(timed_step_s * 1e3, 4), "event_pass_ms_per_step": round(sum(stage_ms.values()) / steps, 4),
+                           "valu_issue_frac": round(min(1.0, cyc_all / timed_step_s / (SIMDS * PEAK_CLOCK_GHZ * 1e9)), 4),
+                           "hbm_frac": round(min(1.0, byt_all / timed_step_s / (HBM_PEAK_GBS * 1e9)), 4),
+                           "note": "consecutive steps overlap on the device in the timed pass (serial in the event pass): all profiled kernels' "
+                                   "issue cycles / HBM bytes per step over the timed pass's time per step"}
     if issue_frac >= hbm_frac:
         r.update(bound="valu-issue", achieved=r["valu_issue"]["achieved"], peak=r["valu_issue"]["peak"], unit=r["valu_issue"]["unit"], frac=round(min(1.0, issue_frac), 4))
     else:

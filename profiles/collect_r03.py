@@ -51,7 +51,7 @@ CONFIGS = {
     "c4_loop": ("--config c4 --flags compact --batch 4 --steps 3 --warmup 1", ("c4", "compact", 1, 4), [("tn", "bounce", 7), ("tg", "bounce", 1)]),
     "c4_bvh": ("--config c4 --flags compact,bvh --steps 10 --warmup 2", ("c4", "compact,bvh", 2, 64),
                [("pn", "bounce", 7), ("pg", "bounce", 1), ("km", "mesh", 8)]),
-    "c5": ("--config c5 --batch 4 --steps 5 --warmup 1", ("c5", "compact", 2, 4), [("fn", "bounce", 7), ("fg", "bounce", 1)]),
+    "c5": ("--config c5 --batch 4 --steps 20 --warmup 4", ("c5", "compact", 2, 4), [("fn", "bounce", 7), ("fg", "bounce", 1)]),
 }
 SQ_PASS = "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_SALU"
 
@@ -75,7 +75,9 @@ def rocprof(tag, what, bench_args):
     d = os.path.join(OUT, tag, what.split()[0].replace("--", "").replace("-", "_") if what.startswith("--kernel") else "pmc_" + what.split()[1])
     cmd = ["rocprofv3"] + what.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3", os.path.join(ROOT, "bench.py")] + \
           bench_args.split() + ["--no-cpu-baseline", "--no-roofline"]
-    sh(cmd, d + ".log")
+    # one launch at a time: in the timed pass of bench.py consecutive steps overlap on the device, which stretches every
+    # launch in a trace; the roofline is the kernel's own (bench.py's event pass runs serially too)
+    sh(cmd, d + ".log", env={"PTMI355_OVERLAP": "0"})
     return d
 
 
@@ -133,7 +135,7 @@ def main(which):
                 a = pmc.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], [0.0, 0])
                 a[0] += float(r["Counter_Value"]); a[1] += 1
         total_ns = sum(sum(v) for v in dur.values())
-        lines = ["%-64s %7s %12s %10s %7s" % ("kernel (rocprofv3 --kernel-trace --stats; timed steps)", "calls", "total_us", "avg_us", "share")]
+        lines = ["%-64s %7s %12s %10s %7s" % ("kernel (rocprofv3 --kernel-trace --stats; timed steps, PTMI355_OVERLAP=0)", "calls", "total_us", "avg_us", "share")]
         for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
             lines.append("%-64s %7d %12.1f %10.2f %6.1f%%" % (re.sub(r"^void |\(anonymous namespace\)::", "", k)[:64], len(v), sum(v) / 1e3,
                                                             sum(v) / len(v) / 1e3, 100.0 * sum(v) / max(1, total_ns)))

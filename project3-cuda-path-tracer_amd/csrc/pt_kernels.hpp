@@ -1920,7 +1920,10 @@ __global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a)
 #ifndef PT_MESH_WAVES
 #define PT_MESH_WAVES 4                      // waves per SIMD k_mesh is register-budgeted for
 #endif
-constexpr int MESH_BLOCK = 1024;              // k_mesh: ONE workgroup of 16 waves per CU, so that the CU's waves share one LDS copy
+#ifndef PT_MESH_BLOCK
+#define PT_MESH_BLOCK 1024
+#endif
+constexpr int MESH_BLOCK = PT_MESH_BLOCK;     // k_mesh: ONE workgroup of 16 waves per CU, so that the CU's waves share one LDS copy
 constexpr int MESH_WG_WAVES = MESH_BLOCK / 64;   // of the tops of the trees
 constexpr int MQ_SLOTS = 128;                 // ray ring entries per wave (a tile adds <= 64 while < 64 wait)
 constexpr int TQ_SLOTS = 512;                 // triangle ring entries per wave (a step adds <= 64 * 2 * LEAF_MAX while < 64 wait)
@@ -2165,7 +2168,7 @@ __device__ __forceinline__ uint32_t kth_set_bit(unsigned long long w, uint32_t r
 constexpr uint32_t FLAG_GROUP = 8;            // tiles of a wave whose flag words are read together (flagged launches)
 
 template <bool COMPACT>
-__global__ __launch_bounds__(MESH_BLOCK) void k_mesh(BounceArgs a) {
+__global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     float *mq = lds_raw + (threadIdx.x >> 6) * MQ_WORDS;
     float *tops = lds_raw + MESH_WG_WAVES * MQ_WORDS;

@@ -35,6 +35,7 @@ def _check_roofline(r):
         assert r["traffic"] > 0 and r["valu_issue"]["unpriced_share_of_cycles"] < 0.05
         assert r["valu_issue"]["frac"] <= 1.0 and r["hbm_measured"]["frac"] <= 1.0 and 0.0 < r["fp32"]["frac"] <= 1.0
         assert 0.0 < r["fp32"]["active_lane_fraction"] <= 1.0
+        assert 0.0 < r["timed_pass"]["valu_issue_frac"] <= 1.0 and 0.0 < r["timed_pass"]["hbm_frac"] <= 1.0
     else:
         assert r["traffic"] is None and r["achieved"] is None
 
