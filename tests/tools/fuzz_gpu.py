@@ -28,6 +28,8 @@ def mesh_fuzz(pt, first, count):
     bad = 0
     t0 = time.time()
     for seed in range(first, first + count):
+        if (seed - first) % 25 == 0:
+            print("mesh seed %d (%.0f s, %d mismatches so far)" % (seed, time.time() - t0, bad), flush=True)
         rng = np.random.default_rng(seed)
         if seed % 2:
             tris = mesh_cases.soup(pt.TRI_DT, rng)
@@ -41,9 +43,16 @@ def mesh_fuzz(pt, first, count):
         pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_MESH_BVH, max_batch=2)
         img = np.zeros((64 * 64, 3), dtype=np.float32)
         pt.trace_batch(1, 2, img)
-        pt.pathtraceFree()
         ref.iterate(1); ref.iterate(2)
-        if img.tobytes() != ref.image.tobytes():
+        same = img.tobytes() == ref.image.tobytes()
+        for it0, cnt in ((3, 1), (4, 2), (6, 1), (7, 1)):             # overlapped on the lanes (each with its own mesh buffers)
+            pt.trace_batch_async(it0, cnt)
+        pt.synchronize()
+        for it in range(3, 8):
+            ref.iterate(it)
+        img = pt.get_image(64 * 64)
+        pt.pathtraceFree()
+        if not same or img.tobytes() != ref.image.tobytes():
             bad += 1
             print("mesh seed %d: IMAGE DIFFERS (%d pixels)" % (seed, int((img != ref.image).any(axis=1).sum())), flush=True)
         # aimed rays: vertices, edge midpoints, points just off the surface (tangential), from random origins
@@ -81,6 +90,8 @@ def main():
     bad = 0
     t0 = time.time()
     for seed in range(first, first + count):
+        if (seed - first) % 50 == 0:
+            print("seed %d (%.0f s, %d mismatches so far)" % (seed, time.time() - t0, bad), flush=True)
         rng = np.random.default_rng(seed)
         nm = int(rng.integers(2, 12))
         mats = np.zeros(nm, dtype=pt.MATERIAL_DT)
@@ -139,6 +150,14 @@ def main():
             same = img.tobytes() == ref.image.tobytes()
             got = pt.pathtrace(None, 0, 3)
             ref.iterate(3)
+            same = same and got.tobytes() == ref.image.tobytes()
+            # batches nobody waits for: consecutive ones overlap on the device (lanes), the sums stay in iteration order
+            for it0, cnt in ((4, 1), (5, 1), (6, 2), (8, 1), (9, 1)):
+                pt.trace_batch_async(it0, cnt)
+            pt.synchronize()
+            for it in range(4, 10):
+                ref.iterate(it)
+            got = pt.get_image(64 * 64)
             same = same and got.tobytes() == ref.image.tobytes()
             pt.pathtraceFree()
             if not same:
