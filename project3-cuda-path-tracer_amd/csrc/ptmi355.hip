@@ -563,8 +563,7 @@ int enqueue_end(void) {
     return PT_OK;
 }
 
-// Batches whose caller does not wait for them (pt_trace_batch_async; pt_trace / pt_trace_batch under PT_ASYNC_IMAGE)
-// OVERLAP on the device.  A launch stream runs its kernels one after the other, and every kernel of this library ends
+// Batches whose caller does not wait for them (pt_trace_batch_async) OVERLAP on the device.  A launch stream runs its kernels one after the other, and every kernel of this library ends
 // with a tail: the persistent grid's waves do not finish together (mean residency 0.84-0.94 of a launch),
 // and one iteration per launch (k_iteration) is a chain of `depth` dependent bounces per wave, ~10 us each at 800x800
 // whatever the number of paths left.  Consecutive batches therefore go to different LANES -- each a launch stream with
@@ -1667,7 +1666,7 @@ int pt_trace_batch_async(int iter0, int count) {
 int pt_trace_batch(int iter0, int count, float *host_image_sum) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_batch: not initialised");
     R.in_step = false;
-    R.ov_ok = host_image_sum && (R.flags & PT_ASYNC_IMAGE);
+    R.ov_ok = false;       // (PT_ASYNC_IMAGE calls are bound by their 7.68 MB copy: lanes measured 14.7 against 15.8 Grays/s there)
     int rc = enqueue_batch(iter0, count);
     R.ov_ok = false;
     if (rc) return rc;
@@ -1688,7 +1687,7 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
     R.epi_host = nullptr; R.epi_done = false;
     if (host_image_sum && !(R.flags & PT_ASYNC_IMAGE) && R.epi_enabled && !R.use_graphs && R.map.tile_count == 1)
         R.epi_host = map_host(host_image_sum, (size_t)R.npix * 12);
-    R.ov_ok = host_image_sum && (R.flags & PT_ASYNC_IMAGE);
+    R.ov_ok = false;       // (PT_ASYNC_IMAGE calls are bound by their 7.68 MB copy: lanes measured 14.7 against 15.8 Grays/s there)
     int rc = enqueue_batch(iter, 1);
     R.ov_ok = false;
     const bool gathered = R.epi_done;

@@ -383,8 +383,8 @@ def test_overlapped_small_batches(pt, po, scenes, monkeypatch):
 
 
 def test_overlapped_async_image(pt, scenes, monkeypatch):
-    """PT_ASYNC_IMAGE + one iteration per call (the shim's asynchronous variant): calls overlap on the device, and every
-    buffer still holds exactly the sum after its own call."""
+    """PT_ASYNC_IMAGE + one iteration per call (the shim's asynchronous variant) interleaved with overlapped batches:
+    every buffer still holds exactly the sum after its own call."""
     s = scenes["cornell_64"]
     scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
     n = scene.resolution[0] * scene.resolution[1]
@@ -396,12 +396,21 @@ def test_overlapped_async_image(pt, scenes, monkeypatch):
     pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_ASYNC_IMAGE)
     bufs = [np.zeros((n, 3), dtype=np.float32) for _ in range(3)]
     L = pt.library()
+    last = None                                   # (buffer, iteration) of the previous call that took a host image
+    calls = 0
     for it in range(1, 12):
-        assert L.pt_trace(None, 0, it, bufs[it % 3].ctypes.data) == 0
-        if it >= 2:
-            assert bufs[(it - 1) % 3].tobytes() == sums[it - 2].tobytes()
+        if it in (3, 4, 7, 10):
+            pt.trace_batch_async(it, 1)           # overlapped on the lanes, between the image calls
+            continue
+        buf = bufs[calls % 3]
+        calls += 1
+        assert L.pt_trace(None, 0, it, buf.ctypes.data) == 0
+        if last is not None:                      # the buffer of the previous image call is complete when this one returns
+            assert last[0].tobytes() == sums[last[1] - 1].tobytes()
+        last = (buf, it)
     pt.synchronize()
-    assert bufs[11 % 3].tobytes() == sums[10].tobytes()
+    assert last[0].tobytes() == sums[last[1] - 1].tobytes()
+    assert pt.get_image(n).tobytes() == sums[10].tobytes()
     assert pt.counters()[2] == 11
     pt.pathtraceFree()
 
