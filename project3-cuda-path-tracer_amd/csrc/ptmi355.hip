@@ -586,14 +586,27 @@ void put_bufs(const Renderer::Bufs &b) {
     R.final_mem = b.final_mem; R.ctl = b.ctl; R.dir_mem = b.dir_mem; R.mesh_hit = b.mesh_hit;
 }
 
-int ensure_lanes(void) {
-    if (R.ov_ready) return PT_OK;
-    const double per_lane = 2.0 * (double)R.pool_bytes + (double)R.final_bytes + (double)R.dir_bytes + (double)R.mesh_hit_bytes +
-                            2.0 * (double)R.flag_words * 8.0;
-    const int fit = 1 + (int)std::min(16.0, std::floor(R.ov_budget_gb * 1e9 / std::max(1.0, per_lane)));
-    R.ov_lanes = std::min(R.ov_lanes, fit);
-    if (R.ov_lanes == 3) R.ov_lanes = 2;                       // three lanes measured no better than one
-    if (R.ov_lanes < 2) { R.ov_enabled = false; return PT_OK; }
+void free_lanes(void) {
+    for (int k = 0; k < OV_MAX_LANES; ++k) {
+        Renderer::Lane &l = R.lane[k];
+        if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+        if (l.traced) (void)hipEventDestroy(l.traced);
+        if (l.gathered) (void)hipEventDestroy(l.gathered);
+        if (k > 0) {                                          // lane 0 borrows the session's own buffers
+            for (int j = 0; j < 2; ++j) { if (l.b.pool_mem[j]) (void)hipFree(l.b.pool_mem[j]); if (l.b.mesh_flags[j]) (void)hipFree(l.b.mesh_flags[j]); }
+            if (l.b.final_mem) (void)hipFree(l.b.final_mem);
+            if (l.b.ctl) (void)hipFree(l.b.ctl);
+            if (l.b.dir_mem) (void)hipFree(l.b.dir_mem);
+            if (l.b.mesh_hit) (void)hipFree(l.b.mesh_hit);
+        }
+        l = Renderer::Lane{};
+    }
+    if (R.ov_enter) (void)hipEventDestroy(R.ov_enter);
+    R.ov_enter = nullptr;
+    R.ov_ready = false;
+}
+
+static int alloc_lanes(void) {
     R.lane[0].b = take_bufs();
     for (int j = 1; j < R.ov_lanes; ++j) {
         Renderer::Bufs &b = R.lane[j].b;
@@ -620,6 +633,28 @@ int ensure_lanes(void) {
         HIPCHK(hipEventCreateWithFlags(&R.lane[k].gathered, hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&R.ov_enter, hipEventDisableTiming));
+    return PT_OK;
+}
+
+// The lanes are an optimisation: when their buffers do not fit (the budget, or the device's free memory) or cannot be
+// allocated, the session simply keeps tracing on its launch stream.
+int ensure_lanes(void) {
+    if (R.ov_ready || !R.ov_enabled) return PT_OK;
+    const double per_lane = 2.0 * (double)R.pool_bytes + (double)R.final_bytes + (double)R.dir_bytes + (double)R.mesh_hit_bytes +
+                            2.0 * (double)R.flag_words * 8.0 + (double)sizeof(Control);
+    double budget = R.ov_budget_gb * 1e9;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, 0.5 * (double)free_b);   // leave room for the caller
+    const int fit = 1 + (int)std::min(16.0, std::floor(budget / std::max(1.0, per_lane)));
+    R.ov_lanes = std::min(R.ov_lanes, fit);
+    if (R.ov_lanes == 3) R.ov_lanes = 2;                       // three lanes measured no better than one
+    if (R.ov_lanes < 2) { R.ov_enabled = false; return PT_OK; }
+    if (alloc_lanes() != PT_OK) {
+        (void)hipGetLastError();
+        free_lanes();
+        R.ov_enabled = false;
+        return PT_OK;
+    }
     R.ov_ready = true;
     return PT_OK;
 }
@@ -1038,22 +1073,7 @@ void pt_free(void) {
     R.d_cam_mask = nullptr; R.cam_mask_valid = false;
     if (R.d_cull0) (void)hipFree(R.d_cull0);
     R.d_cull0 = nullptr; R.cull0_tiles = 0;
-    if (R.ov_ready) {
-        for (int k = 0; k < R.ov_lanes; ++k) {
-            if (R.lane[k].stream) { (void)hipStreamSynchronize(R.lane[k].stream); (void)hipStreamDestroy(R.lane[k].stream); }
-            if (R.lane[k].traced) (void)hipEventDestroy(R.lane[k].traced);
-            if (R.lane[k].gathered) (void)hipEventDestroy(R.lane[k].gathered);
-        }
-        for (int j = 1; j < R.ov_lanes; ++j) {
-            Renderer::Bufs &b = R.lane[j].b;
-            for (int k = 0; k < 2; ++k) { if (b.pool_mem[k]) (void)hipFree(b.pool_mem[k]); if (b.mesh_flags[k]) (void)hipFree(b.mesh_flags[k]); }
-            if (b.final_mem) (void)hipFree(b.final_mem);
-            if (b.ctl) (void)hipFree(b.ctl);
-            if (b.dir_mem) (void)hipFree(b.dir_mem);
-            if (b.mesh_hit) (void)hipFree(b.mesh_hit);
-        }
-        if (R.ov_enter) (void)hipEventDestroy(R.ov_enter);
-    }
+    free_lanes();
     if (R.ctl) (void)hipFree(R.ctl);
     if (R.dir_mem) (void)hipFree(R.dir_mem);
     if (R.persist) (void)hipFree(R.persist);

@@ -374,6 +374,9 @@ def test_overlapped_small_batches(pt, po, scenes, monkeypatch):
     assert serial == overlapped
     assert run(2) == serial and run(4) == serial                  # two / four lanes (default: three)
     assert run(3, "0xfffffff8") == serial
+    monkeypatch.setenv("PTMI355_OVERLAP_GB", "0.0001")                # the lanes' buffers do not fit the budget: the launch stream alone
+    assert run(4) == serial
+    monkeypatch.delenv("PTMI355_OVERLAP_GB")
     assert serial[:len(serial) // 2] == serial[len(serial) // 2:]
     # and the oracle: iterations 1..7 with the first camera
     tr = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
