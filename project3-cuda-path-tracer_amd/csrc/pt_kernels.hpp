@@ -1681,7 +1681,7 @@ __device__ uint32_t g_wave_hw[8][8192];
 #endif
 
 template <int MODE, bool COMPACT, int MESH, bool SLDS, bool GEN = false, bool SORT = false>
-__global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
+__global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : (SORT && MODE == MODE_FUSED && MESH == MESH_NONE) ? PT_SORT_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 #ifdef PT_WAVE_TIMES
     const unsigned long long wt0 = __builtin_amdgcn_s_memrealtime();
 #endif

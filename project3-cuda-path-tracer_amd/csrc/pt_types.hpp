@@ -15,6 +15,9 @@ namespace {
 #ifndef PT_PRE_WAVES
 #define PT_PRE_WAVES 5                       // k_bounce<MESH_PRE>: 97 VGPRs unconstrained; budgeted for 5 waves per SIMD (+6 %)
 #endif
+#ifndef PT_SORT_WAVES
+#define PT_SORT_WAVES PT_MIN_WAVES            // k_bounce with material keys: 84 VGPRs unconstrained (five workgroups per CU)
+#endif
 #ifndef PT_LOOP_WAVES
 #define PT_LOOP_WAVES 4                      // k_bounce<MESH_TILES>: measured 41.9 Mrays/s on C4 against 36.9 at 3 and 40.1 at 5 (profiles/r03)
 #endif
