@@ -1801,7 +1801,7 @@ __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH =
 // workgroup runs in CU mode (not tgsplit: a workgroup's waves then share one CU and one L1) -- the mode hipcc
 // compiles for by default and the only one this library is built in (build.py passes no -mtgsplit).
 template <bool SLDS>
-__global__ __launch_bounds__(BLOCK, PT_MIN_WAVES) void k_iteration(BounceArgs a) {
+__global__ __launch_bounds__(BLOCK, PT_ITER_WAVES) void k_iteration(BounceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const LdsCarve lc = carve_lds(lds_raw, a.scene, SLDS);
     TileCtx c;

@@ -13,7 +13,11 @@ namespace {
 #define PT_ISECT_WAVES 4                     // k_intersect (unfused / sorted pipelines)
 #endif
 #ifndef PT_PRE_WAVES
-#define PT_PRE_WAVES 5                       // k_bounce<MESH_PRE>: 97 VGPRs unconstrained; budgeted for 5 waves per SIMD (+6 %)
+#define PT_PRE_WAVES 6                       // k_bounce<MESH_PRE>: 87-97 VGPRs unconstrained; capped at 80 (six workgroups per CU, 3-5 registers
+                                             // spilled): C4 + hierarchy 17.5 -> 18.05 Grays/s against the cap of 96 (profiles/r03/variants_pre_waves.log)
+#endif
+#ifndef PT_ITER_WAVES
+#define PT_ITER_WAVES PT_MIN_WAVES            // k_iteration: 92 VGPRs unconstrained (five workgroups per CU)
 #endif
 #ifndef PT_SORT_WAVES
 #define PT_SORT_WAVES PT_MIN_WAVES            // k_bounce with material keys: 84 VGPRs unconstrained (five workgroups per CU)
