@@ -388,15 +388,22 @@ __device__ __forceinline__ BvhRec bvh_fetch(const float *__restrict__ nodes, int
 // k_mesh: the same record from the LDS copy of the tree tops when it is one of the mesh's first (top >> 16) records.
 // A walk spends its first ~10 steps there; each such fetch is three LDS reads instead of three address-divergent
 // global loads, which are what bounds the walk (64 distinct lines per instruction through the texture path).
-__device__ __forceinline__ BvhRec bvh_fetch_top(const float *__restrict__ nodes, const float *tops, uint32_t top, int node, int oct) {
+// `all_nodes`: every mesh's records back to back (a wave-uniform pointer); the lane's tree starts at record `root`.  The byte offset
+// is 32 bits (upload_bvh refuses more than 4 GiB of records), so the loads take the scalar base + vector offset form:
+// no 64-bit address arithmetic per lane and step.
+__device__ __forceinline__ BvhRec bvh_fetch_top(const float *__restrict__ all_nodes, int root, const float *tops, uint32_t top, int node, int oct) {
+    BvhRec rec;
     if ((uint32_t)node < (top >> 16)) {
         const float *r = tops + ((top & 0xffffu) + (uint32_t)node) * BVH_TOP_STRIDE;
-        BvhRec rec;
         rec.a = *reinterpret_cast<const uint4 *>(r); rec.b = *reinterpret_cast<const uint4 *>(r + 4);
         rec.miss = reinterpret_cast<const int *>(r)[8 + oct];
         return rec;
     }
-    return bvh_fetch(nodes, node, oct);
+    const uint32_t off = ((uint32_t)root + (uint32_t)node) * (uint32_t)(BVH_NODE_WORDS * 4);
+    const char *p = reinterpret_cast<const char *>(all_nodes) + off;
+    rec.a = *reinterpret_cast<const uint4 *>(p); rec.b = *reinterpret_cast<const uint4 *>(p + 16);
+    rec.miss = *reinterpret_cast<const int *>(p + 32 + 4 * oct);
+    return rec;
 }
 // box tests of a fetched record: the record to continue with (< 0: the walk is over) and the hit leaf
 // children as first | count << 24 (-1: none), to be tested by bvh_leaf
@@ -1942,6 +1949,7 @@ static_assert(MESH_LDS_BYTES <= 160 * 1024, "k_mesh: per-wave rings + tree tops 
 constexpr int MQ_STEPS = PT_MQ_STEPS;         // walk steps between two looks at the ray ring
 constexpr int MQ_LEAVE = PT_MQ_LEAVE;         // lanes still busy when the wave goes back to scanning
 static_assert(2 * PT_LEAF_MAX * 64 + 63 <= TQ_SLOTS, "a step's triangles must fit beside the waiting ones");
+constexpr int NT_BITS = 2 * PT_LEAF_MAX < 2 ? 1 : 2 * PT_LEAF_MAX < 4 ? 2 : 2 * PT_LEAF_MAX < 8 ? 3 : 4;   // bits of a step's triangle count per lane
 
 // per-lane state of a walk in flight; it survives across the scanning of further tiles
 struct MeshWalker {
@@ -2020,7 +2028,7 @@ __device__ __forceinline__ uint64_t mesh_refill(MeshWalker &w, float *mq, const 
     const uint64_t idle = ballot64(!w.have);
     const uint32_t avail = rg.q_total - rg.q_head;
     if (idle && avail) {
-        const uint32_t rank = (uint32_t)__popcll((unsigned long long)(idle & below));
+        const uint32_t rank = rank_below(idle);
         if (!w.have && rank < avail) {
             const uint32_t s = (rg.q_head + rank) & (MQ_SLOTS - 1);
             w.src = mi[0 * MQ_SLOTS + s]; w.path = mi[1 * MQ_SLOTS + s];
@@ -2053,7 +2061,7 @@ __device__ __forceinline__ void mesh_steps(MeshWalker &w, float *mq, const float
 #endif
         int leaf_l = -1, leaf_r = -1;
         if (w.have && w.node >= 0) {
-            const BvhRec rec = bvh_fetch_top(a.scene.bvh_nodes + (size_t)w.root * BVH_NODE_WORDS, tops, w.top, w.node, w.ray.oct);
+            const BvhRec rec = bvh_fetch_top(a.scene.bvh_nodes, w.root, tops, w.top, w.node, w.ray.oct);
             // prune against the best bary.z the tested triangles have produced so far (it may lag: conservative)
             const float best = __uint_as_float((uint32_t)(keys[lane] >> 32));
             int skip;
@@ -2098,16 +2106,17 @@ __device__ __forceinline__ void mesh_steps(MeshWalker &w, float *mq, const float
         if (ballot64(nt > 0)) {
             uint32_t pre = 0, tot = 0;
 #pragma unroll
-            for (int bit = 0; bit < 4; ++bit) {                      // exclusive prefix of nt (< 16) over the lanes
+            for (int bit = 0; bit < NT_BITS; ++bit) {                // exclusive prefix of nt (<= 2 * LEAF_MAX) over the lanes
                 const uint64_t bm = ballot64((nt >> bit) & 1);
-                pre += (uint32_t)__popcll((unsigned long long)(bm & below)) << bit;
+                pre += rank_below(bm) << bit;
                 tot += (uint32_t)__popcll((unsigned long long)bm) << bit;
             }
             const uint32_t pos = rg.t_total + pre;
-            for (int j = 0; j < nl; ++j)
-                tq[(pos + (uint32_t)j) & (TQ_SLOTS - 1)] = (uint32_t)lane | ((uint32_t)((leaf_l & 0xffffff) + j) << 6);
-            for (int j = 0; j < nr; ++j)
-                tq[(pos + (uint32_t)(nl + j)) & (TQ_SLOTS - 1)] = (uint32_t)lane | ((uint32_t)((leaf_r & 0xffffff) + j) << 6);
+#pragma unroll
+            for (int j = 0; j < PT_LEAF_MAX; ++j) {                  // predicated stores, no per-lane loops
+                if (j < nl) tq[(pos + (uint32_t)j) & (TQ_SLOTS - 1)] = (uint32_t)lane | ((uint32_t)((leaf_l & 0xffffff) + j) << 6);
+                if (j < nr) tq[(pos + (uint32_t)(nl + j)) & (TQ_SLOTS - 1)] = (uint32_t)lane | ((uint32_t)((leaf_r & 0xffffff) + j) << 6);
+            }
             if (nt > 0) w.ticket = pos + (uint32_t)nt;
             rg.t_total += tot;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2331,7 +2340,7 @@ __global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a
         const uint64_t m = ballot64(cand);
         if (m) {
             if (cand) {
-                const uint32_t s = (rg.q_total + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1)))) & (MQ_SLOTS - 1);
+                const uint32_t s = (rg.q_total + rank_below(m)) & (MQ_SLOTS - 1);
                 mi[0 * MQ_SLOTS + s] = src; mi[1 * MQ_SLOTS + s] = src;
                 mq[2 * MQ_SLOTS + s] = ro.x; mq[3 * MQ_SLOTS + s] = ro.y; mq[4 * MQ_SLOTS + s] = ro.z;
                 mq[5 * MQ_SLOTS + s] = rd.x; mq[6 * MQ_SLOTS + s] = rd.y; mq[7 * MQ_SLOTS + s] = rd.z;

@@ -1156,6 +1156,8 @@ static int upload_bvh(const pt_scene_desc *d, std::vector<float> &grec) {
         R.bvh_info.pad = std::max(R.bvh_info.pad, tree.pad);
     }
     R.bvh_info.prune = prune;
+    if (nodes.size() * 4 >= ((size_t)1 << 32))
+        return fail(PT_ERR_INVALID, "pt_init: PT_MESH_BVH holds at most 4 GiB of hierarchy records (k_mesh addresses them with 32-bit offsets)");
     if (nodes.empty()) nodes.assign(BVH_NODE_WORDS, 0.0f);
     if (btris.empty()) btris.assign(TRI_WORDS, 0.0f);
     HIPCHK(hipMalloc(&R.d_bvh_nodes, nodes.size() * 4));
