@@ -2054,6 +2054,36 @@ __device__ __forceinline__ void mesh_steps(MeshWalker &w, float *mq, const float
     uint32_t *tq = reinterpret_cast<uint32_t *>(mq + MQ_RAY_WORDS);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(mq + MQ_RAY_WORDS + TQ_SLOTS);
     const uint64_t below = (1ull << lane) - 1;
+    // A walk that is over (and whose queued triangles have been tested) folds its mesh's winner and publishes its
+    // result or moves on to the next mesh.  Lanes get new walks only between blocks of MQ_STEPS steps (mesh_drain), so
+    // with ONE mesh this runs once per block, for all the lanes that finished during it together -- per step it ran a
+    // couple of lanes wide on most steps (72 % of them had some lane finishing).  Several meshes: per step, so that a
+    // lane's next mesh starts at once.
+    const bool multi = a.scene.bvh_nmesh > 1;
+    auto finish = [&]() {
+        if (w.have && w.node < 0 && (int32_t)(rg.t_head - w.ticket) >= 0) {    // this mesh is done and fully tested
+            const unsigned long long key = keys[lane];
+            if ((uint32_t)key != 0xffffffffu) {                      // completion spec 8.0: distance to origin + dir * bary.z
+                const float tz = __uint_as_float((uint32_t)(key >> 32));
+                const f3 p = ptd::add(w.ray.ro, ptd::scale(w.ray.rd, tz));
+                const float t = ptd::length(ptd::sub(w.ray.ro, p));
+                if (t > 0.0f && w.best_t > t) { w.best_t = t; w.best_geom = w.geom; w.best_tri = (int)(uint32_t)key; }
+            }
+            if (w.mesh + 1 < a.scene.bvh_nmesh) {
+                mesh_begin(w, mtab, a, w.mesh + 1, w.ray.ro, w.ray.rd);
+#pragma unroll
+                for (int u = 0; u < PT_SKIP_PAIRS; ++u) w.skip[u] = -1;
+                keys[lane] = TRI_KEY_NONE;
+            } else {
+                // flagged slots (marked by the previous bounce) always get a record, a hit or "nothing"; in scan
+                // mode only hits are recorded and flagged here
+                if (w.best_geom >= 0 || !a.mesh_scan)
+                    a.mesh_hit[w.src] = make_float4(w.best_t, __int_as_float(w.best_geom), __int_as_float(w.best_tri), 0.0f);
+                if (w.best_geom >= 0 && a.mesh_scan) atomicOr(&a.mesh_flags_in[w.src >> 6], 1ull << (w.src & 63u));
+                w.have = false;
+            }
+        }
+    };
 #pragma unroll 1
     for (int k = 0; k < MQ_STEPS; ++k) {
 #ifdef PT_STEP_REFILL
@@ -2127,29 +2157,12 @@ __device__ __forceinline__ void mesh_steps(MeshWalker &w, float *mq, const float
             tri_pass(mq, rg.t_head, rg.t_total - rg.t_head, w, a);
             rg.t_head = rg.t_total;
         }
-        if (w.have && w.node < 0 && (int32_t)(rg.t_head - w.ticket) >= 0) {    // this mesh is done and fully tested
-            const unsigned long long key = keys[lane];
-            if ((uint32_t)key != 0xffffffffu) {                      // completion spec 8.0: distance to origin + dir * bary.z
-                const float tz = __uint_as_float((uint32_t)(key >> 32));
-                const f3 p = ptd::add(w.ray.ro, ptd::scale(w.ray.rd, tz));
-                const float t = ptd::length(ptd::sub(w.ray.ro, p));
-                if (t > 0.0f && w.best_t > t) { w.best_t = t; w.best_geom = w.geom; w.best_tri = (int)(uint32_t)key; }
-            }
-            if (w.mesh + 1 < a.scene.bvh_nmesh) {
-                mesh_begin(w, mtab, a, w.mesh + 1, w.ray.ro, w.ray.rd);
-#pragma unroll
-                for (int u = 0; u < PT_SKIP_PAIRS; ++u) w.skip[u] = -1;
-                keys[lane] = TRI_KEY_NONE;
-            } else {
-                // flagged slots (marked by the previous bounce) always get a record, a hit or "nothing"; in scan
-                // mode only hits are recorded and flagged here
-                if (w.best_geom >= 0 || !a.mesh_scan)
-                    a.mesh_hit[w.src] = make_float4(w.best_t, __int_as_float(w.best_geom), __int_as_float(w.best_tri), 0.0f);
-                if (w.best_geom >= 0 && a.mesh_scan) atomicOr(&a.mesh_flags_in[w.src >> 6], 1ull << (w.src & 63u));
-                w.have = false;
-            }
-        }
+        if (multi) finish();
+#ifdef PT_MESH_BREAK
+        else if (!ballot64(w.have && w.node >= 0) && rg.t_total == rg.t_head) break;     // every walk of the block is over
+#endif
     }
+    if (!multi) finish();
 }
 
 __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, const float *tops, const float *mtab, MeshRings &rg, const BounceArgs &a, int leave) {
