@@ -2150,7 +2150,15 @@ __device__ __forceinline__ void mesh_steps(MeshWalker &w, float *mq, const float
             if (nt > 0) w.ticket = pos + (uint32_t)nt;
             rg.t_total += tot;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef PT_TRI_FLUSH
+            // test queued triangles before a whole pass has gathered: the walks' prune distance lags less (experiments)
+            while (rg.t_total - rg.t_head >= PT_TRI_FLUSH) {
+                const uint32_t cnt = min(64u, rg.t_total - rg.t_head);
+                tri_pass(mq, rg.t_head, cnt, w, a); rg.t_head += cnt;
+            }
+#else
             while (rg.t_total - rg.t_head >= 64) { tri_pass(mq, rg.t_head, 64, w, a); rg.t_head += 64; }
+#endif
         }
         // nobody is walking any more but triangles are still queued: test them now, their owners are waiting
         if (rg.t_total != rg.t_head && !ballot64(w.have && w.node >= 0)) {
