@@ -390,19 +390,29 @@ __device__ __forceinline__ BvhRec bvh_fetch(const float *__restrict__ nodes, int
 // global loads, which are what bounds the walk (64 distinct lines per instruction through the texture path).
 // `all_nodes`: every mesh's records back to back (a wave-uniform pointer); the lane's tree starts at record `root`.  The byte offset
 // is 32 bits (upload_bvh refuses more than 4 GiB of records), so the loads take the scalar base + vector offset form:
-// no 64-bit address arithmetic per lane and step.
-__device__ __forceinline__ BvhRec bvh_fetch_top(const float *__restrict__ all_nodes, int root, const float *tops, uint32_t top, int node, int oct) {
+// no 64-bit address arithmetic per lane and step.  `tops_lds` = the LDS byte address of the tree tops: the two sources
+// are read through their own address spaces (ds_read / global_load under the lanes' masks).  Written with generic
+// pointers the compiler merged the two branches into ONE set of flat loads on a selected pointer -- every top record
+// then went through the flat path's address check instead of a plain LDS read (round 3: found in the block listing).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4_t lds_u4_t;
+typedef __attribute__((address_space(3))) const int lds_i32_t;
+typedef __attribute__((address_space(1))) const u32x4_t glb_u4_t;
+typedef __attribute__((address_space(1))) const int glb_i32_t;
+__device__ __forceinline__ uint4 as_uint4(u32x4_t v) { return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ BvhRec bvh_fetch_top(const float *__restrict__ all_nodes, int root, uint32_t tops_lds, uint32_t top, int node, int oct) {
     BvhRec rec;
     if ((uint32_t)node < (top >> 16)) {
-        const float *r = tops + ((top & 0xffffu) + (uint32_t)node) * BVH_TOP_STRIDE;
-        rec.a = *reinterpret_cast<const uint4 *>(r); rec.b = *reinterpret_cast<const uint4 *>(r + 4);
-        rec.miss = reinterpret_cast<const int *>(r)[8 + oct];
+        const uint32_t off = tops_lds + ((top & 0xffffu) + (uint32_t)node) * (uint32_t)(BVH_TOP_STRIDE * 4);
+        lds_u4_t *r = (lds_u4_t *)off;
+        rec.a = as_uint4(r[0]); rec.b = as_uint4(r[1]);
+        rec.miss = ((lds_i32_t *)off)[8 + oct];
         return rec;
     }
     const uint32_t off = ((uint32_t)root + (uint32_t)node) * (uint32_t)(BVH_NODE_WORDS * 4);
     const char *p = reinterpret_cast<const char *>(all_nodes) + off;
-    rec.a = *reinterpret_cast<const uint4 *>(p); rec.b = *reinterpret_cast<const uint4 *>(p + 16);
-    rec.miss = *reinterpret_cast<const int *>(p + 32 + 4 * oct);
+    rec.a = as_uint4(*(glb_u4_t *)p); rec.b = as_uint4(*(glb_u4_t *)(p + 16));
+    rec.miss = *(glb_i32_t *)(p + 32 + 4 * oct);
     return rec;
 }
 // box tests of a fetched record: the record to continue with (< 0: the walk is over) and the hit leaf
@@ -2006,9 +2016,14 @@ __device__ __forceinline__ void tri_pass(float *mq, uint32_t head, uint32_t coun
 // meshes' entries and grids are read from the LDS table k_mesh stages; the rest from the scene buffers.
 __device__ __forceinline__ void mesh_begin(MeshWalker &w, const float *mtab, const BounceArgs &a, int k, f3 ro, f3 rd) {
     if (k < MESH_TAB) {
-        const float *e = mtab + k * MESH_TAB_WORDS;
-        const float4 h = *reinterpret_cast<const float4 *>(e), g0 = *reinterpret_cast<const float4 *>(e + 4);
-        const float2 g1 = *reinterpret_cast<const float2 *>(e + 8);
+        // (read through the LDS address space: with generic pointers the compiler merges this branch and the other into
+        // flat loads on a selected pointer, see bvh_fetch_top)
+        const uint32_t off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)mtab + (uint32_t)k * (uint32_t)(MESH_TAB_WORDS * 4);
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x4_t h = *(__attribute__((address_space(3))) const f32x4_t *)off;
+        const f32x4_t g0 = *(__attribute__((address_space(3))) const f32x4_t *)(off + 16);
+        const f32x2_t g1 = *(__attribute__((address_space(3))) const f32x2_t *)(off + 32);
         w.geom = __float_as_int(h.x); w.root = __float_as_int(h.y); w.top = __float_as_uint(h.z);
         w.ray = bvh_ray(ro, rd, ptd::mk(g0.x, g0.y, g0.z), ptd::mk(g0.w, g1.x, g1.y));
     } else {
@@ -2054,6 +2069,7 @@ __device__ __forceinline__ void mesh_steps(MeshWalker &w, float *mq, const float
     uint32_t *tq = reinterpret_cast<uint32_t *>(mq + MQ_RAY_WORDS);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(mq + MQ_RAY_WORDS + TQ_SLOTS);
     const uint64_t below = (1ull << lane) - 1;
+    const uint32_t tops_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)tops;   // LDS byte address
     // A walk that is over (and whose queued triangles have been tested) folds its mesh's winner and publishes its
     // result or moves on to the next mesh.  Lanes get new walks only between blocks of MQ_STEPS steps (mesh_drain), so
     // with ONE mesh this runs once per block, for all the lanes that finished during it together -- per step it ran a
@@ -2091,7 +2107,7 @@ __device__ __forceinline__ void mesh_steps(MeshWalker &w, float *mq, const float
 #endif
         int leaf_l = -1, leaf_r = -1;
         if (w.have && w.node >= 0) {
-            const BvhRec rec = bvh_fetch_top(a.scene.bvh_nodes, w.root, tops, w.top, w.node, w.ray.oct);
+            const BvhRec rec = bvh_fetch_top(a.scene.bvh_nodes, w.root, tops_lds, w.top, w.node, w.ray.oct);
             // prune against the best bary.z the tested triangles have produced so far (it may lag: conservative)
             const float best = __uint_as_float((uint32_t)(keys[lane] >> 32));
             int skip;
