@@ -404,9 +404,9 @@ __device__ __forceinline__ BvhRec bvh_fetch_top(const float *__restrict__ all_no
     BvhRec rec;
     if ((uint32_t)node < (top >> 16)) {
         const uint32_t off = tops_lds + ((top & 0xffffu) + (uint32_t)node) * (uint32_t)(BVH_TOP_STRIDE * 4);
-        lds_u4_t *r = (lds_u4_t *)off;
+        lds_u4_t *r = (lds_u4_t *)(size_t)off;
         rec.a = as_uint4(r[0]); rec.b = as_uint4(r[1]);
-        rec.miss = ((lds_i32_t *)off)[8 + oct];
+        rec.miss = ((lds_i32_t *)(size_t)off)[8 + oct];
         return rec;
     }
     const uint32_t off = ((uint32_t)root + (uint32_t)node) * (uint32_t)(BVH_NODE_WORDS * 4);
@@ -2021,9 +2021,9 @@ __device__ __forceinline__ void mesh_begin(MeshWalker &w, const float *mtab, con
         const uint32_t off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)mtab + (uint32_t)k * (uint32_t)(MESH_TAB_WORDS * 4);
         typedef float f32x4_t __attribute__((ext_vector_type(4)));
         typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        const f32x4_t h = *(__attribute__((address_space(3))) const f32x4_t *)off;
-        const f32x4_t g0 = *(__attribute__((address_space(3))) const f32x4_t *)(off + 16);
-        const f32x2_t g1 = *(__attribute__((address_space(3))) const f32x2_t *)(off + 32);
+        const f32x4_t h = *(__attribute__((address_space(3))) const f32x4_t *)(size_t)off;
+        const f32x4_t g0 = *(__attribute__((address_space(3))) const f32x4_t *)(size_t)(off + 16);
+        const f32x2_t g1 = *(__attribute__((address_space(3))) const f32x2_t *)(size_t)(off + 32);
         w.geom = __float_as_int(h.x); w.root = __float_as_int(h.y); w.top = __float_as_uint(h.z);
         w.ray = bvh_ray(ro, rd, ptd::mk(g0.x, g0.y, g0.z), ptd::mk(g0.w, g1.x, g1.y));
     } else {
