@@ -7,6 +7,8 @@
         own registers; exec is switched to that lane for one v_add_u32 and restored: no SCC / VCC / live register is
         touched, s[100:101] are free in every kernel of this library), and every s_endpgm first adds the wave's
         counters to BounceArgs::dbg_counts (kernarg offset 0).  map.json = the blocks and their instructions.
+        (mode "lanes": the counters accumulate the blocks' ACTIVE LANES, popcount(exec), instead of their executions;
+        profiles/tools/hot_blocks.py divides the two)
   isa_count.py hist map.json counts.u32 costs.json [launches]
         counts.u32 = what ptdbg_counts() returned after the workload.  Prints the executed opcode histogram and the
         issue cycles per launch (opcode -> cycles from the microbenchmark table costs.json), JSON on the last line.
@@ -93,14 +95,22 @@ def instrument(path, substr, out_path, map_path, mode="full"):
     base = (nv + 7) & ~7
     nreg = max(2, -(-len(blocks) // LANES))
     regs = [base + j for j in range(nreg)]
-    edits = {desc['next_free_vgpr'][0]: '\t\t.amdhsa_next_free_vgpr %d' % (base + nreg),
+    extra = 1 if mode == "lanes" else 0
+    edits = {desc['next_free_vgpr'][0]: '\t\t.amdhsa_next_free_vgpr %d' % (base + nreg + extra),
              desc['next_free_sgpr'][0]: '\t\t.amdhsa_next_free_sgpr 102',
-             desc['accum_offset'][0]: '\t\t.amdhsa_accum_offset %d' % ((base + nreg + 3) & ~3)}
+             desc['accum_offset'][0]: '\t\t.amdhsa_accum_offset %d' % ((base + nreg + extra + 3) & ~3)}
     ins = {}                      # body line index -> lines to insert before it
     for bid, (first, instrs) in enumerate(blocks):
         r, lane = regs[bid // LANES], slot_lane(bid % LANES)
         seq = ['\ts_mov_b64 s[100:101], exec'] + exec_to_lane(lane) + ['\tv_add_u32_e32 v%d, 1, v%d' % (r, r), '\ts_mov_b64 exec, s[100:101]']
-        if mode in ("full", "inc"):
+        if mode == "lanes":
+            # the block's ACTIVE LANES instead of its executions: popcount(exec) added to the same counter (v_bcnt reads the
+            # saved mask as data; one temporary VGPR above the counters; still no SCC / VCC / live register touched)
+            tmp = base + nreg
+            seq = ['\ts_mov_b64 s[100:101], exec'] + exec_to_lane(lane) + [
+                '\tv_bcnt_u32_b32 v%d, s100, 0' % tmp, '\tv_bcnt_u32_b32 v%d, s101, v%d' % (tmp, tmp),
+                '\tv_add_u32_e32 v%d, v%d, v%d' % (r, tmp, r), '\ts_mov_b64 exec, s[100:101]']
+        if mode in ("full", "inc", "lanes"):
             ins.setdefault(first, []).extend(seq)
     # entry: clear the counters, park the kernarg pointer in lane 31 of the first two
     entry = ['\tv_mov_b32_e32 v%d, 0' % r for r in regs]
