@@ -264,7 +264,9 @@ int enqueue_exchange(void) {
 }
 
 // the launches of one call on every device, the packing of the tiles, then the exchange
-int multi_enqueue(int iter0, int count) {
+// `overlap`: the caller does not wait for this call (pt_trace_batch_async): consecutive batches may overlap on each
+// device's lanes (ptmi355.hip: enqueue_batch_direct); their gathers stay on the launch stream, which the packing waits on
+int multi_enqueue(int iter0, int count, bool overlap = false) {
     const int s = (int)(G.exchanges & 1);
     const bool self = G.self_exchange;
     const int prev = s ^ 1;
@@ -273,7 +275,9 @@ int multi_enqueue(int iter0, int count) {
         R.in_step = false;
         // rehearsal with one context: the unpack writes the root's OWN rows; the next gather must come after it
         if (wait_frame) HIPCHK(hipStreamWaitEvent(R.stream, G.ev_frame[prev], 0));
+        R.ov_ok = overlap;
         const int r = enqueue_batch(iter0, count);
+        R.ov_ok = false;
         if (r) return r;
         return worker_pack(w, s);
     });
@@ -512,7 +516,7 @@ int pt_synchronize(void) {
 
 int pt_trace_batch_async(int iter0, int count) {
     if (!G.live) return one::pt_trace_batch_async(iter0, count);
-    return multi_enqueue(iter0, count);
+    return multi_enqueue(iter0, count, true);
 }
 
 // the calls that hand the image back: launches + exchange enqueued on every device, then the frame -> host copy on the
