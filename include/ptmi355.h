@@ -193,7 +193,11 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum);
  * (count <= max_batch); bit-identical image to `count` pt_trace calls. */
 int pt_trace_batch(int iter0, int count, float *host_image_sum);
 
-/* Asynchronous form used by bench.py: enqueue only; pt_synchronize() waits. */
+/* Asynchronous form: enqueue only; pt_synchronize() waits.  Consecutive calls may OVERLAP on the device (each batch on
+ * one of up to four launch streams with its own path pools; their memory is allocated on first use, within
+ * PTMI355_OVERLAP_GB; PTMI355_OVERLAP=0 switches this off): the image is still summed in iteration order, bit for bit,
+ * and everything enqueued afterwards on the session's stream -- pt_trace, pt_get_image, pt_tonemap, pt_synchronize --
+ * comes after every batch enqueued before it. */
 int pt_trace_batch_async(int iter0, int count);
 int pt_synchronize(void);
 
