@@ -385,6 +385,36 @@ def test_overlapped_small_batches(pt, po, scenes, monkeypatch):
     assert tr.image.tobytes() == overlapped[0]
 
 
+@pytest.mark.parametrize("variant", ["jitter_lens", "sort", "no_compaction", "glass_sorted"])
+def test_overlapped_batches_other_pipelines(pt, scenes, monkeypatch, variant):
+    """The lanes under the other fused pipelines: stochastic antialiasing + thin lens (no bounce-0 masks, the lens set
+    between batches), the fused material sort (pools K times as long per lane), no compaction, the glass scene sorted.
+    Overlapped == one stream, call for call."""
+    s = scenes["cornell_glass_64" if variant == "glass_sorted" else "cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+    flags = {"jitter_lens": pt.PT_COMPACT | pt.PT_AA_JITTER, "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL,
+             "no_compaction": 0, "glass_sorted": pt.PT_COMPACT | pt.PT_SORT_MATERIAL}[variant]
+
+    def run(overlap):
+        monkeypatch.setenv("PTMI355_OVERLAP", str(overlap))
+        pt.pathtraceInit(scene, flags=flags, max_batch=4)
+        out = []
+        it = 1
+        for k, cnt in enumerate((1, 1, 2, 1, 4, 1, 1, 3, 1, 1)):
+            if variant == "jitter_lens" and k in (3, 7):
+                pt.set_lens(0.25 if k == 3 else 0.0, 9.0 if k == 3 else 0.0)
+            pt.trace_batch_async(it, cnt)
+            it += cnt
+            if k in (4, 9):
+                out.append(pt.get_image(n).tobytes())
+        out.append(tuple(int(v) for v in pt.counters()))
+        pt.pathtraceFree()
+        return out
+
+    assert run(0) == run(4) == run(2)
+
+
 def test_overlapped_async_image(pt, scenes, monkeypatch):
     """PT_ASYNC_IMAGE + one iteration per call (the shim's asynchronous variant) interleaved with overlapped batches:
     every buffer still holds exactly the sum after its own call."""
