@@ -156,6 +156,52 @@ struct Worker {
     }
 };
 
+// The exchange of a call is a dozen host calls -- a grouped RCCL send / recv costs the issuing thread ~80 us -- and
+// nothing in it needs the caller.  With asynchronous batches (pt_trace_batch_async) it is issued from this thread while
+// the caller already enqueues the next batch's launches: at one exchange per iteration the host, not the device, set
+// the pace.  One job at a time; the caller waits for the previous exchange before it posts the next (whose packing
+// waits on events that exchange records), and before anything else touches the exchange streams.
+struct Exchanger {
+    char err[ERR_BYTES] = "";
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::function<int()> job;
+    std::atomic<uint64_t> posted{0}, finished{0};
+    bool quit = false;
+    int rc = PT_OK;
+    void loop() {
+        t_err = err;
+        uint64_t seen = 0;
+        for (;;) {
+            for (int spin = 0; spin < 4000 && posted.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+            if (posted.load(std::memory_order_acquire) == seen) {
+                std::unique_lock<std::mutex> lk(m);
+                cv_job.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit; });
+                if (quit && posted.load(std::memory_order_acquire) == seen) return;
+            }
+            seen = posted.load(std::memory_order_acquire);
+            rc = job();
+            finished.store(seen, std::memory_order_release);
+            { std::lock_guard<std::mutex> lk(m); }
+            cv_done.notify_one();
+        }
+    }
+    void post(std::function<int()> f) {
+        { std::lock_guard<std::mutex> lk(m); job = std::move(f); posted.fetch_add(1, std::memory_order_release); }
+        cv_job.notify_one();
+    }
+    int wait() {                                  // the last posted exchange has been ENQUEUED (not executed)
+        const uint64_t want = posted.load(std::memory_order_acquire);
+        for (int spin = 0; spin < 4000 && finished.load(std::memory_order_acquire) != want; ++spin) __builtin_ia32_pause();
+        if (finished.load(std::memory_order_acquire) != want) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return finished.load(std::memory_order_acquire) == want; });
+        }
+        return rc;
+    }
+};
+
 struct Group {
     bool live = false;
     int K = 0;
@@ -166,7 +212,9 @@ struct Group {
     std::vector<ncclComm_t> comms;
     hipEvent_t ev_frame[2] = {nullptr, nullptr};    // slot s unpacked into the frame (root's exchange stream)
     bool frame_once[2] = {false, false};
-    uint64_t exchanges = 0;
+    uint64_t exchanges = 0;                     // exchanges enqueued (by whichever thread issues them)
+    uint64_t calls = 0;                         // calls made (caller's thread): call i uses staging slot i & 1
+    std::unique_ptr<Exchanger> x;               // K >= 2: asynchronous batches hand their exchange to this thread
     pt_camera last_cam{};
     int last_depth = -1;
     std::string transport;
@@ -210,8 +258,7 @@ int worker_pack(Worker &w, int s) {
 }
 
 // caller's thread: tiles -> root -> frame, on the exchange streams (nothing here waits on the host)
-int enqueue_exchange(void) {
-    const int s = (int)(G.exchanges & 1);
+int enqueue_exchange(int s) {
     Worker &root = *G.w[0];
     DeviceGuard guard;
     if (G.use_rccl) {
@@ -266,8 +313,16 @@ int enqueue_exchange(void) {
 // the launches of one call on every device, the packing of the tiles, then the exchange
 // `overlap`: the caller does not wait for this call (pt_trace_batch_async): consecutive batches may overlap on each
 // device's lanes (ptmi355.hip: enqueue_batch_direct); their gathers stay on the launch stream, which the packing waits on
+// the exchange thread has enqueued everything it was given (an error of its own is the caller's now)
+int exchange_settled(void) {
+    if (!G.x) return PT_OK;
+    const int r = G.x->wait();
+    if (r < 0) { memcpy(t_err, G.x->err, ERR_BYTES); G.x->rc = PT_OK; }
+    return r;
+}
+
 int multi_enqueue(int iter0, int count, bool overlap = false) {
-    const int s = (int)(G.exchanges & 1);
+    const int s = (int)(G.calls & 1);
     const bool self = G.self_exchange;
     const int prev = s ^ 1;
     const bool wait_frame = self && G.frame_once[prev];
@@ -282,11 +337,19 @@ int multi_enqueue(int iter0, int count, bool overlap = false) {
         return worker_pack(w, s);
     });
     if (rc) return rc;
-    return enqueue_exchange();
+    G.calls++;
+    // the exchange of the call before is enqueued by now or soon: this call's own goes behind it -- from the exchange
+    // thread when the caller does not wait for the batch, from here otherwise
+    rc = exchange_settled();
+    if (rc) return rc;
+    if (G.x && overlap) { G.x->post([s] { return enqueue_exchange(s); }); return PT_OK; }
+    return enqueue_exchange(s);
 }
 
 int multi_sync(void) {
-    int rc = on_all([&](Worker &w) -> int {
+    int rc = exchange_settled();
+    if (rc) return rc;
+    rc = on_all([&](Worker &w) -> int {
         HIPCHK(hipStreamSynchronize(R.stream));
         HIPCHK(hipStreamSynchronize(w.xs));
         return PT_OK;
@@ -296,6 +359,13 @@ int multi_sync(void) {
 
 void multi_free(void) {
     if (!G.live && G.w.empty()) return;
+    if (G.x) {
+        (void)G.x->wait();
+        { std::lock_guard<std::mutex> lk(G.x->m); G.x->quit = true; }
+        G.x->cv_job.notify_one();
+        if (G.x->th.joinable()) G.x->th.join();
+        G.x.reset();
+    }
     for (auto &wp : G.w) {
         Worker *w = wp.get();
         if (!w->th.joinable()) continue;
@@ -435,6 +505,18 @@ int multi_init(const pt_scene_desc *d, const std::vector<int> &devs) {
         if (G.use_rccl) {
             G.comms.assign((size_t)K, nullptr);
             NCCLCHK(g_rccl.CommInitAll(G.comms.data(), K, devs.data()));
+        }
+    }
+    {   // (not in the one-context rehearsal: there the unpack writes the root's own rows, and the next call's gather waits
+        // for an event the exchange records -- the caller has to have it recorded first)
+        // opt-in (PTMI355_XCHG_THREAD=1): with two and four contexts on ONE device -- all this pool can run -- the device, not the
+        // host, sets the pace and it measured the same; it is for hosts that exchange after every iteration over RCCL
+        bool on = false;
+        if (const char *e = getenv("PTMI355_XCHG_THREAD")) on = K >= 2 && atoi(e) != 0;
+        if (on) {
+            G.x.reset(new Exchanger());
+            Exchanger *x = G.x.get();
+            x->th = std::thread([x] { x->loop(); });
         }
     }
     G.last_cam = d->camera; G.last_depth = d->trace_depth;

@@ -85,6 +85,8 @@ def test_contexts_equal_single_device(pt, scenes, pipeline, monkeypatch):
     assert np.isfinite(want[-1]).all() and want[-1].max() > 0
     for devs in device_lists():
         for strip in (8, 5):                                     # 64 rows: 8 strips of 8 (even), 13 of 5 (uneven)
+            # (the uneven runs hand the asynchronous batches' exchanges to the exchange thread: pt_multi.hpp, Exchanger)
+            monkeypatch.setenv("PTMI355_XCHG_THREAD", "1" if strip == 5 else "0")
             got, glive, gcounters, grgba, gdev, gtransport = run_calls(pt, scene, n, devices=devs, tile=(0, 1, strip), **kw)
             assert gdev == len(devs)
             assert gtransport == ("rccl" if len(set(devs)) == len(devs) else "peer")
