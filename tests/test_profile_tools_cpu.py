@@ -1,0 +1,99 @@
+"""profiles/tools/isa_count.py (the basic-block instrumentation behind the exact roofline) on a hand-written
+kernel: blocks are found where control can enter, every block gets exactly one counter increment that touches neither
+SCC / VCC nor a register of the kernel, the descriptor grows by the counter registers, the dump precedes s_endpgm, and
+the histogram arithmetic (counts x opcode costs) comes out as computed by hand.  No GPU, no compiler."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "profiles", "tools", "isa_count.py")
+
+KERNEL = """\t.text
+_Z6k_toyP4Args:
+\ts_load_dwordx2 s[2:3], s[0:1], 0x8
+\tv_mov_b32_e32 v1, 0
+\ts_waitcnt lgkmcnt(0)
+\ts_cmp_eq_u32 s2, 0
+\ts_cbranch_scc1 .LBB0_3
+.LBB0_1:
+\tv_add_f32_e32 v1, v1, v0
+\tv_fma_f32 v1, v1, v0, v1
+\ts_add_i32 s2, s2, -1
+\ts_cmp_lg_u32 s2, 0
+\ts_cbranch_scc1 .LBB0_1
+\tv_mul_f32_e32 v1, v1, v1
+.LBB0_3:
+\tglobal_store_dword v2, v1, s[4:5]
+\ts_endpgm
+\t.section\t.rodata,"a",@progbits
+\t.amdhsa_kernel _Z6k_toyP4Args
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_next_free_vgpr 3
+\t\t.amdhsa_next_free_sgpr 6
+\t\t.amdhsa_accum_offset 4
+\t.end_amdhsa_kernel
+\t.text
+.Lfunc_end0:
+\t.size\t_Z6k_toyP4Args, .Lfunc_end0-_Z6k_toyP4Args
+"""
+
+
+def run(*args):
+    return subprocess.run([sys.executable, TOOL] + list(args), capture_output=True, text=True, check=True).stdout
+
+
+def test_instrument_and_hist(tmp_path):
+    src, out, mp = tmp_path / "k.s", tmp_path / "k_counted.s", tmp_path / "map.json"
+    src.write_text(KERNEL)
+    msg = run("instrument", str(src), "k_toy", str(out), str(mp))
+    m = json.loads(mp.read_text())
+    # four blocks: entry .. branch | loop body .. back edge | fall-through multiply | store + end
+    assert [b[0] for b in m["blocks"]] == ["s_load_dwordx2", "v_add_f32_e32", "v_mul_f32_e32", "global_store_dword"]
+    assert m["blocks"][1][-1] == "s_cbranch_scc1" and m["blocks"][3][-1] == "s_endpgm"
+    assert "4 blocks" in msg and "1 exits" in msg
+    text = out.read_text()
+    lines = text.split("\n")
+    # counters live above the kernel's own registers (3 VGPRs -> v8, v9: two registers hold the kernarg pointer's halves)
+    assert "\t\t.amdhsa_next_free_vgpr 10" in text and "\t\t.amdhsa_next_free_sgpr 102" in text
+    incs = [i for i, l in enumerate(lines) if l.startswith("\tv_add_u32_e32 v8, 1, v8")]
+    assert len(incs) == 4                                            # one increment per block
+    for i in incs:                                                   # exec saved, one lane selected, exec restored
+        assert lines[i - 2] == "\ts_mov_b64 s[100:101], exec" and lines[i - 1].startswith("\ts_mov_b64 exec, 0x")
+        assert lines[i + 1] == "\ts_mov_b64 exec, s[100:101]"
+    lanes = sorted(int(lines[i - 1].split("0x")[1], 16) for i in incs)
+    assert lanes == [1, 2, 4, 8]
+    # nothing the instrumentation adds writes SCC, VCC or a register below v8 / s100 (except v0, used by the dump AFTER the last use)
+    added = [l for l in lines if l not in KERNEL.split("\n")]
+    body_added = [l for l in added if l.startswith("\t") and not l.startswith("\t\t")]
+    dump_at = next(i for i, l in enumerate(lines) if l.startswith("\tv_readlane_b32 s100"))
+    assert dump_at > max(incs) and lines.index("\ts_endpgm") > dump_at
+    for l in body_added:
+        op = l.split()[0]
+        assert not op.startswith(("s_cmp", "s_add", "s_and", "s_or", "v_cmp")) or "s[100:101]" in l or op == "s_cmp_eq_u64", l
+    assert any(l.startswith("\tglobal_atomic_add v0, v8, s[100:101]") for l in lines)
+    # "lanes" mode: popcount(exec) instead of 1, one temporary register more
+    out2, mp2 = tmp_path / "k_lanes.s", tmp_path / "map2.json"
+    run("instrument", str(src), "k_toy", str(out2), str(mp2), "lanes")
+    t2 = out2.read_text()
+    assert t2.count("\tv_bcnt_u32_b32 v10, s100, 0") == 4 and t2.count("\tv_bcnt_u32_b32 v10, s101, v10") == 4
+    assert "\t\t.amdhsa_next_free_vgpr 11" in t2
+    # histogram: the loop body ran 5 times per launch in 2 launches, the others once per launch
+    counts = np.zeros(m["words"], dtype=np.uint32)
+    for bid, n in enumerate((2, 10, 2, 2)):
+        counts[bid] = n
+    cf = tmp_path / "c.u32"
+    counts.tofile(cf)
+    costs = tmp_path / "costs.json"
+    costs.write_text(json.dumps({"cycles": {"v_add_f32": 2.25, "v_fma_f32": 2.5, "v_mov_b32": 2.25}, "default": 4.0}))
+    h = json.loads(run("hist", str(mp), str(cf), str(costs), "2").strip().split("\n")[-1])
+    assert h["valu_per_launch"] == (2 * 1 + 10 * 2 + 2 * 1) / 2
+    want = (2 * 2.25 + 10 * (2.25 + 2.5) + 2 * 4.0) / 2                # v_mul_f32 has no row here: the default, and it is reported
+    assert abs(h["issue_cycles_per_launch"] - want) < 1e-9
+    assert abs(h["unpriced_share_of_cycles"] - (2 * 4.0 / 2) / want) < 1e-9
+    assert h["flops_fp32_per_launch"] == 64.0 * (10 * 1 + 10 * 2 + 2 * 1) / 2
+    assert h["wave_insts_per_launch"]["branch"] == (2 + 10 + 2) / 2     # the two conditional branches and s_endpgm
