@@ -627,16 +627,28 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
     CULL_STAT(0, 1); CULL_STAT(5, __popcll((unsigned long long)ballot64(active && cr.wild))); CULL_STAT(6, __popcll((unsigned long long)ballot64(active)));
     const uint32_t tag = (uint32_t)lane | ((uint32_t)par << 6);
     const int ngeoms = sc.ngeoms;
-    // the records come through wave-uniform scalar loads (s_load_dwordx8 + x4); the next primitive's is requested
-    // before this one's is used, so its latency overlaps the test instead of stalling every iteration
+    // the records come through wave-uniform scalar loads (s_load_dwordx8 + x4).  Round 2 requested the next primitive's
+    // record before using this one's (its latency then overlaps the test); by round 3 the eleven scalar registers that
+    // keeps alive across the loop cost more than the latency -- the kernel spilled 47 scalar values into VGPR lanes and
+    // reloaded 28 of them per tile; without the prefetch it spills 34, and every configuration gained 2-6 %
+    // (profiles/r03/variants_cull_prefetch.log).  -DPT_CULL_PREFETCH brings it back.
+#ifdef PT_CULL_PREFETCH
     float nxt[11];
     {
         cfloat *c0 = as_const(sc.cull);
 #pragma unroll
         for (int k = 0; k < 11; ++k) nxt[k] = ngeoms > 0 ? c0[k] : 0.0f;
     }
+#endif
     for (int g = 0; g < ngeoms; ++g) {
         float cb[11];
+#ifndef PT_CULL_PREFETCH
+        {
+            cfloat *cc = as_const(sc.cull) + g * CULL_WORDS;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) cb[k] = cc[k];
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 11; ++k) cb[k] = nxt[k];
         if (g + 1 < ngeoms) {
@@ -644,6 +656,7 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
 #pragma unroll
             for (int k = 0; k < 11; ++k) nxt[k] = cn[k];
         }
+#endif
         // bounce 0: primitives no camera ray of this tile is a candidate of (k_cull0_mask, bit g of the tile's word)
         if (masked && !((gmask >> (g & 63)) & 1ull)) continue;
         const int tw = __float_as_int(cb[6]);
