@@ -1476,7 +1476,25 @@ __global__ __launch_bounds__(BLOCK, GEN ? 6 : 8) void k_shade_sorted_w(BounceArg
 enum { MODE_FUSED = 0, MODE_ISECT = 1, MODE_CACHE0 = 2 };
 
 // per-launch constants of a wave
+// A field of the kernel's argument block read again where it is used (k_bounce: BounceArgs is the one kernel
+// argument, so the field sits at its offset in the kernarg segment).  The pools' and the final-colour buffer's base
+// pointers are used once per tile; kept in scalar registers across the tile loop they were spilled to VGPR lanes and
+// came back through v_readlane -- vector-issue slots the kernel is bound by -- whereas a scalar load costs this wave
+// a wait and the vector pipe nothing.  The empty asm hides the pointer's origin from the compiler, which would
+// otherwise hoist the load out of the loop and keep the value alive again.
+template <typename T>
+__device__ __forceinline__ T karg_field(size_t offset) {
+    const __attribute__((address_space(4))) char *kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return *(const __attribute__((address_space(4))) T *)(kp + offset);
+}
+// a Pool (base pointer + capacity) of the argument block
+__device__ __forceinline__ Pool karg_pool(size_t offset) {
+    return Pool{karg_field<float *>(offset + offsetof(Pool, base)), karg_field<uint32_t>(offset + offsetof(Pool, cap))};
+}
+
 struct TileCtx {
+    bool kargs = false;         // k_bounce: pools and final colours through karg_field (a compile-time constant after inlining)
     SceneAcc acc;               // per-lane gathers: materials, geom info, matrices (LDS or global)
     float *tri_lds;             // triangle tile (MESH_TILES)
     int lane, iter0;
@@ -1509,7 +1527,7 @@ __device__ __forceinline__ void tile_load(const BounceArgs &a, const TileCtx &c,
             tr.pid = i;
         } else {
             // all ten fields of the slot in one burst of loads (one memory latency per tile)
-            char *p = in.slot(src);
+            char *p = (c.kargs ? karg_pool(offsetof(BounceArgs, in)) : in).slot(src);
             tr.pid = ppid(p);
             ro = ptd::mk(pf(p, 0), pf(p, 1), pf(p, 2));
             rd = ptd::mk(pf(p, 3), pf(p, 4), pf(p, 5));
@@ -1563,7 +1581,7 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
         alive = ptd::shade_scatter(ps, t, nrm, mat, outside, c.acc.mats, c.iter0 + (int)tr.smp, tr.pixel, depth,
                                    depth == a.trace_depth - 1);
         if (!alive) {
-            put_final(a.fin, tr.pid, ps.c, c.stamp);
+            put_final(c.kargs ? karg_field<float *>(offsetof(BounceArgs, fin)) : a.fin, tr.pid, ps.c, c.stamp);
         }
     }
     // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
@@ -1584,7 +1602,7 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
         packed += (uint32_t)__popcll((unsigned long long)bal);
     }
     if (alive) {
-        char *p = out.slot(dst);
+        char *p = (c.kargs ? karg_pool(offsetof(BounceArgs, out)) : out).slot(dst);
         pf(p, 0) = ps.o.x; pf(p, 1) = ps.o.y; pf(p, 2) = ps.o.z;
         pf(p, 3) = ps.d.x; pf(p, 4) = ps.d.y; pf(p, 5) = ps.d.z;
         pf(p, 6) = ps.c.x; pf(p, 7) = ps.c.y; pf(p, 8) = ps.c.z;
@@ -1719,6 +1737,11 @@ __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH =
     uint32_t *sctl = reinterpret_cast<uint32_t *>(lds_raw);
     const LdsCarve lc = carve_lds(lds_raw, a.scene, SLDS);
     TileCtx c;
+#ifndef PT_NO_KARG_RELOAD
+    // C2 +0.9 %, C3 +0.5 %, C3 sorted +2.2 % (ten scalar spills fewer); the every-triangle loop measured 1 % slower with it
+    // (profiles/r03/variants_karg_reload.log)
+    c.kargs = MESH != MESH_TILES;
+#endif
     c.tri_lds = lc.tri;
 #ifdef PT_STAMPS
 #define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.depth == PT_STAMPS) a.ctl->stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
