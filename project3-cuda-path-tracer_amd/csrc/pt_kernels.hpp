@@ -1547,15 +1547,15 @@ __device__ __forceinline__ void tile_load(const BounceArgs &a, const TileCtx &c,
 // that end here and append the survivors at dst_base + packed (wave64 ballot + popcount rank).
 // does the ray reach one of the two root boxes of some mesh?  (wave-uniform scalar loads of the roots; the same
 // conservative box arithmetic the walk uses)
-__device__ __forceinline__ bool mesh_root_candidate(const SceneDev &sc, f3 ro, f3 rd) {
+__device__ __forceinline__ bool mesh_root_candidate(const int4 *bvh_meshes, int bvh_nmesh, const float *geoms, const float *bvh_nodes, f3 ro, f3 rd) {
     bool cand = false;
 #pragma unroll 1
-    for (int k = 0; k < sc.bvh_nmesh; ++k) {
+    for (int k = 0; k < bvh_nmesh; ++k) {
         const __attribute__((address_space(4))) int *mrec =
-            (const __attribute__((address_space(4))) int *)(unsigned long long)(sc.bvh_meshes + k);
-        cfloat *grid = as_const(sc.geoms) + (size_t)mrec[0] * ptd::GEOM_WORDS + ptd::G_INV;
+            (const __attribute__((address_space(4))) int *)(unsigned long long)(bvh_meshes + k);
+        cfloat *grid = as_const(geoms) + (size_t)mrec[0] * ptd::GEOM_WORDS + ptd::G_INV;
         const __attribute__((address_space(4))) uint32_t *b =
-            (const __attribute__((address_space(4))) uint32_t *)(unsigned long long)(sc.bvh_nodes + (size_t)mrec[1] * BVH_NODE_WORDS);
+            (const __attribute__((address_space(4))) uint32_t *)(unsigned long long)(bvh_nodes + (size_t)mrec[1] * BVH_NODE_WORDS);
         const BvhRay br = bvh_ray(ro, rd, ptd::mk(grid[0], grid[1], grid[2]), ptd::mk(grid[3], grid[4], grid[5]));
         float tn, tf;
         bvh_slab(br, b[0], b[1], b[2], tn, tf);
@@ -1564,6 +1564,9 @@ __device__ __forceinline__ bool mesh_root_candidate(const SceneDev &sc, f3 ro, f
         cand |= tn <= tf;
     }
     return cand;
+}
+__device__ __forceinline__ bool mesh_root_candidate(const SceneDev &sc, f3 ro, f3 rd) {
+    return mesh_root_candidate(sc.bvh_meshes, sc.bvh_nmesh, sc.geoms, sc.bvh_nodes, ro, rd);
 }
 
 // SORT (PT_SORT_MATERIAL, fused form): the survivors of key (= material hit) k go to the wave's span of range
@@ -1609,8 +1612,15 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
         ppid(p) = tr.pid;
         // mesh pre-pass of the NEXT bounce: flag the slot when the new ray can reach a mesh at all (~11 % of them on
         // C4), so that k_mesh neither scans nor loads the other 89 %
-        if (MESH == MESH_PRE && mesh_root_candidate(a.scene, ps.o, ps.d))
-            atomicOr(&a.mesh_flags_out[dst >> 6], 1ull << (dst & 63u));
+        if (MESH == MESH_PRE) {
+            constexpr size_t SC = offsetof(BounceArgs, scene);
+            const bool reach = c.kargs
+                ? mesh_root_candidate(karg_field<const int4 *>(SC + offsetof(SceneDev, bvh_meshes)), karg_field<int>(SC + offsetof(SceneDev, bvh_nmesh)),
+                                      karg_field<const float *>(SC + offsetof(SceneDev, geoms)), karg_field<const float *>(SC + offsetof(SceneDev, bvh_nodes)), ps.o, ps.d)
+                : mesh_root_candidate(a.scene, ps.o, ps.d);
+            if (reach)
+                atomicOr(&(c.kargs ? karg_field<unsigned long long *>(offsetof(BounceArgs, mesh_flags_out)) : a.mesh_flags_out)[dst >> 6], 1ull << (dst & 63u));
+        }
     } else if (!COMPACT && tr.have && tr.i < n) {
         out.pid(dst) = DEAD_PID;
     }
@@ -1693,7 +1703,8 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
             const float4 *pre_hit = nullptr;
             if (MESH == MESH_PRE && tr.active) {
                 // slots whose flag is set carry a mesh result from k_mesh (a hit, or "walked, nothing hit")
-                if ((a.mesh_flags_in[src >> 6] >> (src & 63u)) & 1ull) pre_hit = a.mesh_hit + src;
+                const unsigned long long *fl = c.kargs ? karg_field<unsigned long long *>(offsetof(BounceArgs, mesh_flags_in)) : a.mesh_flags_in;
+                if ((fl[src >> 6] >> (src & 63u)) & 1ull) pre_hit = (c.kargs ? karg_field<float4 *>(offsetof(BounceArgs, mesh_hit)) : a.mesh_hit) + src;
             }
             cull_scene<MESH>(a.scene, c.acc, q, par, c.tri_lds, tr.active, ro, rd, tr.mb, pre_hit, masked, gmask);
             const uint32_t ticket = q.total;
