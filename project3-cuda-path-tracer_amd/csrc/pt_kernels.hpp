@@ -1488,6 +1488,20 @@ __device__ __forceinline__ T karg_field(size_t offset) {
     asm volatile("" : "+s"(kp));
     return *(const __attribute__((address_space(4))) T *)(kp + offset);
 }
+// a plain struct of the argument block (camera, lens, tile map), word by word behind ONE hidden pointer: the compiler
+// merges the words into s_load_dwordx4 / x8 / x16
+template <typename T>
+__device__ __forceinline__ T karg_struct(size_t offset) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    const __attribute__((address_space(4))) char *kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    uint32_t w[sizeof(T) / 4];
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; ++k) w[k] = *(const __attribute__((address_space(4))) uint32_t *)(kp + offset + 4 * k);
+    T t;
+    __builtin_memcpy(&t, w, sizeof(T));
+    return t;
+}
 // a Pool (base pointer + capacity) of the argument block
 __device__ __forceinline__ Pool karg_pool(size_t offset) {
     return Pool{karg_field<float *>(offset + offsetof(Pool, base)), karg_field<uint32_t>(offset + offsetof(Pool, cap))};
@@ -1495,6 +1509,7 @@ __device__ __forceinline__ Pool karg_pool(size_t offset) {
 
 struct TileCtx {
     bool kargs = false;         // k_bounce: pools and final colours through karg_field (a compile-time constant after inlining)
+    bool kmisc = false;         // k_iteration: final colours, camera, lens, tile map through karg_field / karg_struct (its pools are locals)
     SceneAcc acc;               // per-lane gathers: materials, geom info, matrices (LDS or global)
     float *tri_lds;             // triangle tile (MESH_TILES)
     int lane, iter0;
@@ -1536,9 +1551,17 @@ __device__ __forceinline__ void tile_load(const BounceArgs &a, const TileCtx &c,
         }
     }
     if (active) {
-        tr.smp = sample_of(a.map, tr.pid);
-        tr.pixel = local_to_pixel(a.map, (int)(tr.pid - tr.smp * (uint32_t)a.map.tile_pixels));
-        if (gen_rays) camera_ray(a.cam, a.lens, a.trace_depth, c.iter0 + (int)tr.smp, tr.pixel, a.map.W, ro, rd);
+        if (c.kmisc) {
+            const TileMap map = karg_struct<TileMap>(offsetof(BounceArgs, map));
+            tr.smp = sample_of(map, tr.pid);
+            tr.pixel = local_to_pixel(map, (int)(tr.pid - tr.smp * (uint32_t)map.tile_pixels));
+            if (gen_rays) camera_ray(karg_struct<pt_camera>(offsetof(BounceArgs, cam)), karg_struct<Lens>(offsetof(BounceArgs, lens)),
+                                     karg_field<int>(offsetof(BounceArgs, trace_depth)), c.iter0 + (int)tr.smp, tr.pixel, map.W, ro, rd);
+        } else {
+            tr.smp = sample_of(a.map, tr.pid);
+            tr.pixel = local_to_pixel(a.map, (int)(tr.pid - tr.smp * (uint32_t)a.map.tile_pixels));
+            if (gen_rays) camera_ray(a.cam, a.lens, a.trace_depth, c.iter0 + (int)tr.smp, tr.pixel, a.map.W, ro, rd);
+        }
     }
     tr.active = active;
 }
@@ -1584,7 +1607,7 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
         alive = ptd::shade_scatter(ps, t, nrm, mat, outside, c.acc.mats, c.iter0 + (int)tr.smp, tr.pixel, depth,
                                    depth == a.trace_depth - 1);
         if (!alive) {
-            put_final(c.kargs ? karg_field<float *>(offsetof(BounceArgs, fin)) : a.fin, tr.pid, ps.c, c.stamp);
+            put_final((c.kargs || c.kmisc) ? karg_field<float *>(offsetof(BounceArgs, fin)) : a.fin, tr.pid, ps.c, c.stamp);
         }
     }
     // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
@@ -1869,6 +1892,10 @@ __global__ __launch_bounds__(BLOCK, PT_ITER_WAVES) void k_iteration(BounceArgs a
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const LdsCarve lc = carve_lds(lds_raw, a.scene, SLDS);
     TileCtx c;
+#ifndef PT_NO_KARG_RELOAD
+    // 71 -> 28 scalar spills, 92 -> 81 VGPRs: 1 spp 26.0 -> 27.3, 4 spp 35.5 -> 36.8 Grays/s (profiles/r03/variants_karg_iter.log)
+    c.kmisc = true;
+#endif
     c.tri_lds = nullptr;
     c.acc = stage_scene<SLDS>(lc.scene, a.scene);
     WaveQ q{lc.pw, 0, 0};
