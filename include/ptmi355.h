@@ -219,6 +219,11 @@ int pt_intersect_once(const pt_path_segment *host_paths, int n,
 int pt_get_image(float *host_image_sum);             /* W*H*3 floats, running sum */
 int pt_tonemap(uint8_t *host_rgba, int iter);        /* sendImageToPBO (pathtrace.cu:48-68) to host */
 int pt_clear_image(void);
+/* Resume an accumulation: the running sum becomes `host_image_sum` (W*H*3 floats, e.g. what pt_get_image / the host's
+ * PFM dump returned after iteration k); tracing iterations k+1.. then yields, bit for bit, the image of the
+ * uninterrupted run -- the running sum is the whole state the reference carries from one iteration to the next
+ * (dev_image, pathtrace.cu:71,84,389; the iteration number is the caller's).  Synchronises the session first. */
+int pt_set_image(const float *host_image_sum);
 float *pt_device_image(void);                        /* device pointer of the accumulation buffer */
 int pt_get_stats(pt_stats *stats);
 /* rays traced since pt_init, read from the device-side counter (includes
@@ -265,6 +270,21 @@ int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxe
  * (glm::intersectRayTriangle + the hit-point test; csrc/ptmi355.hip: make_tri_bounds has the derivation), so the kernel
  * does not run the exact test for the pair.  Returns the number of entries written. */
 int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, float *bounds);
+/* ---- known-answer probes: the DEVICE's own arithmetic on caller data (no session needed, any HIP device) -------
+ * pt_probe_rng: thrust::default_random_engine (minstd_rand) as makeSeededRandomEngine constructs it
+ * (pathtrace.cu:41-45 -> engine(seed)): for each of the n seeds, seed the engine and draw `draws` times through
+ * uniform_real_distribution<float>(0,1) (csrc/pt_device.hpp: lcg_seed, u01); state[i] = the engine's state after the
+ * last draw, u[i] = the last draw's value (both optional).  Known answer (C++ [rand.predef]): seed 1, 10 000 draws ->
+ * state 399268537.
+ * pt_probe_sincos: the shared sin / cos of calculateRandomDirectionInHemisphere (interactions.h:40-41; DESIGN.md
+ * section 4) for n arguments, or -- x == NULL -- for the `n` consecutive binary32 values that start at bit pattern
+ * `first_bits`, reduced to sum[0] = sum over k of bits(sin) * (2k + 1), sum[1] = the same for cos (mod 2^64): the
+ * oracle computes the same two sums on the CPU, so every float of [0, 2 pi] can be compared without moving 9 GB.
+ * pt_probe_hemisphere: calculateRandomDirectionInHemisphere (interactions.h:10-42) for n (normal, engine seed)
+ * pairs; dirs = n x 3 floats. */
+int pt_probe_rng(const uint32_t *seeds, int n, int draws, uint32_t *state, float *u);
+int pt_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, float *s, float *c, uint64_t sum[2]);
+int pt_probe_hemisphere(const float *normals, const uint32_t *seeds, int n, float *dirs);
 /* devices of the current session (0: not initialised) and how their tiles reach devices[0]: "rccl", "peer"
  * (hipMemcpyPeerAsync) or "none" (one device) */
 int pt_num_devices(void);

@@ -163,6 +163,22 @@ void pto_sincos(float x, float *s, float *c) {
     *c = (float)co;
 }
 
+/* The two checksums libptmi355.so's pt_probe_sincos forms on the device (include/ptmi355.h), here on the CPU: over the
+ * n consecutive binary32 values from bit pattern first_bits on, sum[0] = sum of bits(sin) * (2k + 1), sum[1] = the
+ * same for cos (mod 2^64) -- every argument calculateRandomDirectionInHemisphere can form (u01 * TWO_PI, [0, 2 pi])
+ * is compared without storing a value. */
+void pto_sincos_sums(uint32_t first_bits, uint32_t n, uint64_t sum[2]) {
+    uint64_t as = 0, ac = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        union { uint32_t u; float f; } x, sv, cv;
+        x.u = first_bits + k;
+        pto_sincos(x.f, &sv.f, &cv.f);
+        as += (uint64_t)sv.u * (2ull * k + 1ull);
+        ac += (uint64_t)cv.u * (2ull * k + 1ull);
+    }
+    sum[0] = as; sum[1] = ac;
+}
+
 /* ------------------------------------------------------------------------ */
 /* geometry helpers                                                          */
 /* ------------------------------------------------------------------------ */

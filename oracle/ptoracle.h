@@ -99,6 +99,7 @@ float    pto_u01(uint32_t *state);
 
 /* ---- shared trig ---- */
 void pto_sincos(float x, float *s, float *c);
+void pto_sincos_sums(uint32_t first_bits, uint32_t n, uint64_t sum[2]);   /* the checksums of pt_probe_sincos (include/ptmi355.h) */
 
 /* ---- geometry helpers ---- */
 pto_vec3 pto_get_point_on_ray(pto_ray r, float t);                       /* intersections.h:27-29 */

@@ -179,6 +179,14 @@ def sincos(x):
     return s.value, c.value
 
 
+def sincos_sums(first_bits, count):
+    """CPU side of ptmi355.probe_sincos_sums: (sum of bits(sin) * (2k+1), the same for cos) mod 2^64 over `count`
+    consecutive float32 values from bit pattern `first_bits` on."""
+    out = (C.c_uint64 * 2)()
+    lib().pto_sincos_sums(C.c_uint32(first_bits), C.c_uint32(count), out)
+    return int(out[0]), int(out[1])
+
+
 def geom_test(geom_np, rays_np, kind):
     """rays_np: (n,6) float32 -> (n,8) float32 [t, p3, n3, outside]; sentinel -7 where untouched."""
     L = lib()

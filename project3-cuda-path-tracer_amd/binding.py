@@ -142,6 +142,10 @@ def library():
         L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pt_cull_boxes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
         L.pt_tri_bounds.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.pt_set_image.argtypes = [C.c_void_p]
+        L.pt_probe_rng.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.pt_probe_sincos.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pt_probe_hemisphere.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.pt_free.restype = None
         L.pt_exchange_transport.restype = C.c_char_p
         _lib = L
@@ -281,6 +285,12 @@ def clear_image():
     _chk(library().pt_clear_image())
 
 
+def set_image(image_sum):
+    """Resume an accumulation: the running sum becomes `image_sum` (W*H*3 floats)."""
+    img = np.ascontiguousarray(image_sum, dtype=np.float32)
+    _chk(library().pt_set_image(_p(img)))
+
+
 def device_image_ptr():
     return library().pt_device_image()
 
@@ -364,3 +374,38 @@ def counters():
     a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
     _chk(library().pt_get_counters(C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def probe_rng(seeds, draws):
+    """The device's minstd_rand + u01 (csrc/pt_device.hpp): (engine state, last u01) after `draws` draws per seed."""
+    sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+    st = np.zeros(len(sd), dtype=np.uint32)
+    u = np.zeros(len(sd), dtype=np.float32)
+    _chk(library().pt_probe_rng(_p(sd), len(sd), int(draws), _p(st), _p(u)))
+    return st, u
+
+
+def probe_sincos(x):
+    """The device's shared sin / cos for the float32 arguments x."""
+    xs = np.ascontiguousarray(x, dtype=np.float32)
+    s = np.zeros(len(xs), dtype=np.float32)
+    c = np.zeros(len(xs), dtype=np.float32)
+    _chk(library().pt_probe_sincos(_p(xs), 0, len(xs), _p(s), _p(c), None))
+    return s, c
+
+
+def probe_sincos_sums(first_bits, count):
+    """(sum of bits(sin) * (2k+1), the same for cos) mod 2^64 over the `count` consecutive float32 values from bit
+    pattern `first_bits` on -- what oracle.pyoracle.sincos_sums computes on the CPU."""
+    out = np.zeros(2, dtype=np.uint64)
+    _chk(library().pt_probe_sincos(None, int(first_bits), int(count), None, None, _p(out)))
+    return int(out[0]), int(out[1])
+
+
+def probe_hemisphere(normals, seeds):
+    """calculateRandomDirectionInHemisphere on the device for (normal, engine seed) pairs."""
+    nr = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+    sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+    out = np.zeros((len(sd), 3), dtype=np.float32)
+    _chk(library().pt_probe_hemisphere(_p(nr), _p(sd), len(sd), _p(out)))
+    return out

@@ -214,7 +214,10 @@ struct Group {
     bool frame_once[2] = {false, false};
     uint64_t exchanges = 0;                     // exchanges enqueued (by whichever thread issues them)
     uint64_t calls = 0;                         // calls made (caller's thread): call i uses staging slot i & 1
-    std::unique_ptr<Exchanger> x;               // K >= 2: asynchronous batches hand their exchange to this thread
+    std::unique_ptr<Exchanger> x;               // asynchronous batches hand their exchange to this thread
+    float *frame = nullptr;                     // where the tiles are assembled: context 0's accumulation buffer -- except in the
+                                                // one-context RCCL rehearsal, where it is a buffer of its own (self_frame)
+    float *self_frame = nullptr;
     pt_camera last_cam{};
     int last_depth = -1;
     std::string transport;
@@ -300,7 +303,7 @@ int enqueue_exchange(int s) {
     }
     for (int k = G.self_exchange ? 0 : 1; k < G.K; ++k) {
         Worker &p = *G.w[(size_t)k];
-        hipLaunchKernelGGL(k_unpack_tile, dim3((unsigned)((p.floats + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, root.xs, root.ctx.image, p.map,
+        hipLaunchKernelGGL(k_unpack_tile, dim3((unsigned)((p.floats + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, root.xs, G.frame, p.map,
                            p.stage[s]);
         HIPCHK(hipGetLastError());
     }
@@ -323,13 +326,8 @@ int exchange_settled(void) {
 
 int multi_enqueue(int iter0, int count, bool overlap = false) {
     const int s = (int)(G.calls & 1);
-    const bool self = G.self_exchange;
-    const int prev = s ^ 1;
-    const bool wait_frame = self && G.frame_once[prev];
     int rc = on_all([&](Worker &w) -> int {
         R.in_step = false;
-        // rehearsal with one context: the unpack writes the root's OWN rows; the next gather must come after it
-        if (wait_frame) HIPCHK(hipStreamWaitEvent(R.stream, G.ev_frame[prev], 0));
         R.ov_ok = overlap;
         const int r = enqueue_batch(iter0, count);
         R.ov_ok = false;
@@ -386,6 +384,7 @@ void multi_free(void) {
             for (auto &wp : G.w)
                 for (int s = 0; s < 2; ++s) if (wp->stage[s]) (void)hipFree(wp->stage[s]);
             for (int s = 0; s < 2; ++s) if (G.ev_frame[s]) (void)hipEventDestroy(G.ev_frame[s]);
+            if (G.self_frame) (void)hipFree(G.self_frame);
         }
     }
     for (auto &wp : G.w) {
@@ -490,6 +489,17 @@ int multi_init(const pt_scene_desc *d, const std::vector<int> &devs) {
         for (int k = G.self_exchange ? 0 : 1; k < K; ++k)
             for (int s = 0; s < 2; ++s) HIPCHK(hipMalloc(&G.w[(size_t)k]->stage[s], G.w[(size_t)k]->floats * 4));
         for (int s = 0; s < 2; ++s) HIPCHK(hipEventCreateWithFlags(&G.ev_frame[s], hipEventDisableTiming));
+        // The frame is context 0's accumulation buffer: the peers' rows are unpacked beside the rows it sums itself.  In the
+        // one-context rehearsal the "peer" is the root, and unpacking its rows over themselves would make every gather
+        // wait for the previous exchange (a dependency real peers do not have: round 3 measured the rehearsal at 13.5
+        // Grays/s for that reason alone): there the tiles are assembled in a buffer of their own, so the rehearsal costs
+        // what an exchange between devices costs -- pack, grouped send / recv, unpack -- and nothing else.
+        G.frame = root.ctx.image;
+        if (G.self_exchange) {
+            HIPCHK(hipMalloc(&G.self_frame, (size_t)G.npix * 12));
+            HIPCHK(hipMemset(G.self_frame, 0, (size_t)G.npix * 12));
+            G.frame = G.self_frame;
+        }
         if (!G.use_rccl)
             for (int k = 1; k < K; ++k) {
                 const int dk = G.w[(size_t)k]->device;
@@ -507,12 +517,12 @@ int multi_init(const pt_scene_desc *d, const std::vector<int> &devs) {
             NCCLCHK(g_rccl.CommInitAll(G.comms.data(), K, devs.data()));
         }
     }
-    {   // (not in the one-context rehearsal: there the unpack writes the root's own rows, and the next call's gather waits
-        // for an event the exchange records -- the caller has to have it recorded first)
-        // opt-in (PTMI355_XCHG_THREAD=1): with two and four contexts on ONE device -- all this pool can run -- the device, not the
-        // host, sets the pace and it measured the same; it is for hosts that exchange after every iteration over RCCL
-        bool on = false;
-        if (const char *e = getenv("PTMI355_XCHG_THREAD")) on = K >= 2 && atoi(e) != 0;
+    {   // The exchange of an asynchronous batch is issued from a thread of its own (Exchanger), one call behind the tracing:
+        // a grouped RCCL send / recv costs the issuing thread ~80 us, and at one exchange per iteration (the north star's
+        // cadence: 0.1 ms of tracing per iteration at 800x800) the host set the pace, not the device.
+        // PTMI355_XCHG_THREAD=0 issues it from the caller's thread as rounds 1-3 did.
+        bool on = true;
+        if (const char *e = getenv("PTMI355_XCHG_THREAD")) on = atoi(e) != 0;
         if (on) {
             G.x.reset(new Exchanger());
             Exchanger *x = G.x.get();
@@ -611,11 +621,11 @@ static int multi_trace(uint8_t *pbo_rgba, int iter0, int count, float *host_imag
         DeviceGuard guard;
         HIPCHK(hipSetDevice(root.device));
         if (pbo_rgba) {
-            hipLaunchKernelGGL(k_tonemap, dim3((G.npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, root.xs, pbo_rgba, root.ctx.image, G.npix, iter0);
+            hipLaunchKernelGGL(k_tonemap, dim3((G.npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, root.xs, pbo_rgba, G.frame, G.npix, iter0);
             HIPCHK(hipGetLastError());
         }
         if (host_image_sum)
-            HIPCHK(hipMemcpyAsync(host_image_sum, root.ctx.image, (size_t)G.npix * 12, hipMemcpyDeviceToHost, root.xs));
+            HIPCHK(hipMemcpyAsync(host_image_sum, G.frame, (size_t)G.npix * 12, hipMemcpyDeviceToHost, root.xs));
     }
     return on_all([&](Worker &w) -> int {
         const int r = collect_stats();
@@ -659,6 +669,8 @@ int pt_get_image(float *host_image_sum) {
     if (!host_image_sum) return fail(PT_ERR_INVALID, "pt_get_image: null buffer");
     const int rc = multi_sync();
     if (rc) return rc;
+    if (G.self_frame)                                          // the one-context rehearsal assembles the frame beside the sum
+        return on_one(0, [&](Worker &) -> int { HIPCHK(hipMemcpy(host_image_sum, G.self_frame, (size_t)G.npix * 12, hipMemcpyDeviceToHost)); return PT_OK; });
     return on_one(0, [&](Worker &) -> int { return one::pt_get_image(host_image_sum); });      // context 0's buffer is the frame
 }
 
@@ -673,10 +685,25 @@ int pt_clear_image(void) {
     if (!G.live) return one::pt_clear_image();
     const int rc = multi_sync();
     if (rc) return rc;
-    return on_all([&](Worker &) -> int { return one::pt_clear_image(); });
+    return on_all([&](Worker &) -> int {
+        if (G.self_frame) HIPCHK(hipMemset(G.self_frame, 0, (size_t)G.npix * 12));
+        return one::pt_clear_image();
+    });
 }
 
-float *pt_device_image(void) { return G.live ? G.w[0]->ctx.image : one::pt_device_image(); }
+// every context gets the whole frame: it adds to (and packs) its own rows only, and context 0's buffer IS the frame
+int pt_set_image(const float *host_image_sum) {
+    if (!G.live) return one::pt_set_image(host_image_sum);
+    if (!host_image_sum) return fail(PT_ERR_INVALID, "pt_set_image: null buffer");
+    const int rc = multi_sync();
+    if (rc) return rc;
+    return on_all([&](Worker &) -> int {
+        if (G.self_frame) HIPCHK(hipMemcpy(G.self_frame, host_image_sum, (size_t)G.npix * 12, hipMemcpyHostToDevice));
+        return one::pt_set_image(host_image_sum);
+    });
+}
+
+float *pt_device_image(void) { return G.live ? G.frame : one::pt_device_image(); }
 
 long long pt_total_rays(void) {
     if (!G.live) return one::pt_total_rays();
@@ -748,5 +775,10 @@ int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, f
 int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound, float *reject) {
     return one::pt_cull_boxes(geoms, count, eye, boxes, origin_bound, reject);
 }
+int pt_probe_rng(const uint32_t *seeds, int n, int draws, uint32_t *state, float *u) { return one::pt_probe_rng(seeds, n, draws, state, u); }
+int pt_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, float *s, float *c, uint64_t sum[2]) {
+    return one::pt_probe_sincos(x, first_bits, n, s, c, sum);
+}
+int pt_probe_hemisphere(const float *normals, const uint32_t *seeds, int n, float *dirs) { return one::pt_probe_hemisphere(normals, seeds, n, dirs); }
 
 }  // extern "C"

@@ -1870,6 +1870,18 @@ int pt_clear_image(void) {
     return PT_OK;
 }
 
+// Resume an accumulation: the running sum is the whole state the reference carries between iterations (dev_image,
+// pathtrace.cu:71,84,389).  Everything in flight comes first: batches still tracing add into the buffer being replaced.
+int pt_set_image(const float *host_image_sum) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_set_image: not initialised");
+    if (!host_image_sum) return fail(PT_ERR_INVALID, "pt_set_image: null buffer");
+    HIPCHK(hipStreamSynchronize(R.stream));
+    if (R.copy_stream) HIPCHK(hipStreamSynchronize(R.copy_stream));
+    HIPCHK(hipMemcpy(R.image, host_image_sum, (size_t)R.npix * 12, hipMemcpyHostToDevice));
+    R.ov_active = false;
+    return PT_OK;
+}
+
 float *pt_device_image(void) { return R.live ? R.image : nullptr; }
 
 long long pt_total_rays(void) {
@@ -1974,6 +1986,7 @@ int pt_get_stats(pt_stats *stats) {
 
 }  // namespace one
 
+#include "pt_probe.hpp"
 #include "pt_multi.hpp"
 
 // diagnostics (not in include/ptmi355.h): the block counts an instrumented kernel build has added up since pt_init or the

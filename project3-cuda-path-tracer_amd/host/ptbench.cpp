@@ -4,7 +4,12 @@
 //
 //   ptbench SCENEFILE.txt [--iters N] [--batch B] [--out BASENAME] [--sort] [--no-compact]
 //           [--cache-first] [--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D] [--tile R/K] [--strip-rows S]
-//           [--gpus K | --devices D0,D1,...]
+//           [--gpus K | --devices D0,D1,...] [--save-sum] [--resume SUMFILE.pfm [--start N]]
+//
+// --save-sum / --resume: a render across several runs (C5's 5000 spp across GPU leases).  The running sum is the whole
+// state the reference carries from one iteration to the next (dev_image, pathtrace.cu:71,84,389): --save-sum writes it
+// raw (BASE.<N>samp.sum.pfm, exact), --resume loads it (pt_set_image) and continues with iteration N + 1 (N from
+// --start or from the "<N>samp" of the file name) up to --iters: bit for bit the image of the uninterrupted run.
 //
 // --gpus K / --devices LIST: ONE process renders the frame on several GPUs: the library tiles it over the devices
 // (interleaved strips of S rows), traces every tile on its own host thread and gathers the tiles' sums onto the first
@@ -28,12 +33,14 @@ int main(int argc, char **argv) {
     if (argc < 2) {
         printf("Usage: %s SCENEFILE.txt [--iters N] [--batch B] [--out BASE] [--sort] [--no-compact] [--cache-first] "
                "[--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D] [--tile R/K] [--strip-rows S] "
-               "[--gpus K | --devices D0,D1,...]\n", argv[0]);
+               "[--gpus K | --devices D0,D1,...] [--save-sum] [--resume SUMFILE.pfm [--start N]]\n", argv[0]);
         return 1;
     }
     int iters = -1, batch = 1, device = 0, tile_index = 0, tile_count = 1, strip_rows = 8;
     unsigned flags = PT_COMPACT | PT_PIN_IMAGE;          // `image` below lives until pt_free
-    bool pfm = false;
+    bool pfm = false, save_sum = false;
+    std::string resume;
+    int start = -1;
     float lens_radius = 0.0f, focal_distance = 0.0f;
     std::string out;
     std::vector<int32_t> devices;
@@ -50,6 +57,9 @@ int main(int argc, char **argv) {
         else if (a == "--aa") flags |= PT_AA_JITTER;
         else if (a == "--lens" && i + 2 < argc) { lens_radius = (float)atof(argv[++i]); focal_distance = (float)atof(argv[++i]); }
         else if (a == "--pfm") pfm = true;
+        else if (a == "--save-sum") save_sum = true;
+        else if (a == "--resume" && i + 1 < argc) resume = argv[++i];
+        else if (a == "--start" && i + 1 < argc) start = atoi(argv[++i]);
         else if (a == "--tile" && i + 1 < argc) {
             if (sscanf(argv[++i], "%d/%d", &tile_index, &tile_count) != 2 || tile_count < 1 || tile_index < 0 || tile_index >= tile_count) {
                 fprintf(stderr, "--tile wants R/K with 0 <= R < K\n");
@@ -86,8 +96,23 @@ int main(int argc, char **argv) {
     if (pt_init(&d) != PT_OK) { fprintf(stderr, "pathtraceInit: %s\n", pt_last_error()); return 1; }
 
     std::vector<float> image((size_t)W * H * 3, 0.0f);    // scene->state.image
-    const auto t0 = std::chrono::steady_clock::now();
     int iteration = 0;
+    if (!resume.empty()) {
+        if (start < 0) {                                   // BASE.<N>samp.sum.pfm
+            const size_t e = resume.rfind("samp");
+            size_t b = e;
+            while (b != std::string::npos && b > 0 && resume[b - 1] >= '0' && resume[b - 1] <= '9') --b;
+            if (e == std::string::npos || b == e) { fprintf(stderr, "--resume: no <N>samp in %s, say --start N\n", resume.c_str()); return 1; }
+            start = atoi(resume.substr(b, e - b).c_str());
+        }
+        if (start < 0 || start > iters) { fprintf(stderr, "--resume: %d iterations done, %d wanted\n", start, iters); return 1; }
+        if (pth_read_pfm(resume.c_str(), image.data(), W, H) != 0) { fprintf(stderr, "%s\n", pth_last_error()); return 1; }
+        if (pt_set_image(image.data()) != PT_OK) { fprintf(stderr, "pt_set_image: %s\n", pt_last_error()); return 1; }
+        iteration = start;
+        printf("resumed %s: %d iterations done\n", resume.c_str(), start);
+    }
+    const int first_iteration = iteration;
+    const auto t0 = std::chrono::steady_clock::now();
     while (iteration < iters) {                            // runCuda: iteration++ ; pathtrace(pbo, 0, iteration)
         const int n = (iters - iteration < batch) ? iters - iteration : batch;
         const int last = (iteration + n == iters);
@@ -98,8 +123,9 @@ int main(int argc, char **argv) {
     }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const long long rays = pt_total_rays();
-    printf("%d iterations, %lld rays, %.3f s, %.1f Mrays/s on %d device(s), tile exchange: %s\n", iteration, rays, sec, rays / sec / 1e6,
+    printf("%d iterations, %lld rays, %.3f s, %.1f Mrays/s on %d device(s), tile exchange: %s\n", iteration - first_iteration, rays, sec, rays / sec / 1e6,
            pt_num_devices(), pt_exchange_transport());
+    if (iteration == first_iteration && pt_get_image(image.data()) != PT_OK) { fprintf(stderr, "%s\n", pt_last_error()); return 1; }
 
     if (out.empty()) out = std::string(sc->image_name[0] ? sc->image_name : "render");
     char name[512];
@@ -111,6 +137,11 @@ int main(int argc, char **argv) {
     if (pfm) {
         snprintf(name, sizeof name, "%s.%dsamp.pfm", out.c_str(), iteration);
         pth_write_pfm(name, image.data(), W, H, (float)iteration);
+        printf("Saved %s.\n", name);
+    }
+    if (save_sum) {
+        snprintf(name, sizeof name, "%s.%dsamp.sum.pfm", out.c_str(), iteration);
+        if (pth_write_pfm(name, image.data(), W, H, 1.0f) != 0) { fprintf(stderr, "%s\n", pth_last_error()); return 1; }
         printf("Saved %s.\n", name);
     }
     pt_free();

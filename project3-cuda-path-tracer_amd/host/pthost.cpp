@@ -513,4 +513,27 @@ int pth_write_pfm(const char *path, const float *image_sum, int w, int h, float 
     return 0;
 }
 
+// the raw running sum back from a PFM written with samples = 1 (ptbench --save-sum): what pt_set_image resumes from
+int pth_read_pfm(const char *path, float *image_sum, int w, int h) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { snprintf(g_err, sizeof g_err, "cannot read %s", path); return -1; }
+    char magic[3] = {0, 0, 0};
+    int fw = 0, fh = 0;
+    float scale = 0.0f;
+    if (fscanf(f, "%2s %d %d %f", magic, &fw, &fh, &scale) != 4 || strcmp(magic, "PF") != 0 || fgetc(f) != '\n') {
+        fclose(f); snprintf(g_err, sizeof g_err, "%s: not a colour PFM", path); return -1;
+    }
+    if (fw != w || fh != h || !(scale < 0.0f)) {
+        fclose(f); snprintf(g_err, sizeof g_err, "%s: %dx%d scale %g, expected %dx%d little-endian", path, fw, fh, scale, w, h); return -1;
+    }
+    for (int y = h - 1; y >= 0; --y)
+        if (fread(image_sum + (size_t)3 * w * y, sizeof(float), (size_t)3 * w, f) != (size_t)3 * w) {
+            fclose(f); snprintf(g_err, sizeof g_err, "%s: truncated", path); return -1;
+        }
+    fclose(f);
+    if (scale != -1.0f)
+        for (size_t k = 0; k < (size_t)3 * w * h; ++k) image_sum[k] *= -scale;
+    return 0;
+}
+
 }  // extern "C"

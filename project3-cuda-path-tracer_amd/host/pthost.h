@@ -40,6 +40,10 @@ void pth_build_geom_matrices(pt_geom *g);
 void pth_image_to_rgb8(const float *image_sum, int w, int h, float samples, uint8_t *rgb_out);
 int pth_write_png(const char *path, const uint8_t *rgb, int w, int h);          /* stored-deflate PNG */
 int pth_write_pfm(const char *path, const float *image_sum, int w, int h, float samples);
+/* the floats of a little-endian colour PFM of exactly w x h pixels (times |scale|), rows top to bottom as in memory:
+ * with samples = 1 on the writing side this is the running sum itself (the reference keeps nothing else between
+ * iterations, pathtrace.cu:71,84,389), exact */
+int pth_read_pfm(const char *path, float *image_sum, int w, int h);
 
 #ifdef __cplusplus
 }

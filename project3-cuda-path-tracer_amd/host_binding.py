@@ -63,6 +63,7 @@ def host_library():
         L.pth_image_to_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
         L.pth_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         L.pth_write_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.pth_read_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -115,3 +116,11 @@ def save_pfm(path, image_sum, width, height, samples):
     img = np.ascontiguousarray(image_sum, dtype=np.float32).reshape(-1)
     if host_library().pth_write_pfm(os.fsencode(path), img.ctypes.data, width, height, C.c_float(samples)) != 0:
         raise PtError(host_library().pth_last_error().decode())
+
+
+def load_pfm(path, width, height):
+    """The floats of a little-endian colour PFM (a running sum saved with samples = 1 comes back exactly)."""
+    img = np.zeros((width * height, 3), dtype=np.float32)
+    if host_library().pth_read_pfm(os.fsencode(path), img.ctypes.data, width, height) != 0:
+        raise PtError(host_library().pth_last_error().decode())
+    return img

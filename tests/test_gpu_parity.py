@@ -303,6 +303,52 @@ def test_batch_equals_sequential(pt, scenes):
     pt.pathtraceFree()
 
 
+def test_resumed_accumulation_equals_the_uninterrupted_run(pt, po, scenes, tmp_path):
+    """pt_set_image + ptbench --save-sum / --resume (C5's 5000 spp across GPU leases): the running sum is the whole
+    state the reference carries between iterations (dev_image, pathtrace.cu:71,84,389), so 2 x N/2 iterations with the
+    sum taken through host memory (and a PFM file) in between == N iterations, bit for bit -- per call and batched,
+    one device and three contexts, and through the headless host."""
+    import subprocess
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    npix = 64 * 64
+    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
+    for it in range(1, 13):
+        ref.iterate(it)
+    for devices in (None, [0, 0, 0]):
+        pt.pathtraceInit(scene, max_batch=4, devices=devices)
+        for it in range(1, 7):
+            pt.pathtrace(None, 0, it)
+        half = pt.get_image(npix)
+        pt.pathtraceFree()
+        path = str(tmp_path / "half.6samp.sum.pfm")
+        pt.save_pfm(path, half, 64, 64, 1.0)
+        pt.pathtraceInit(scene, max_batch=4, devices=devices)           # a new session: nothing survives but the file
+        pt.set_image(pt.load_pfm(path, 64, 64))
+        pt.trace_batch(7, 4)
+        pt.pathtrace(None, 0, 11)
+        img = pt.pathtrace(None, 0, 12).copy()
+        pt.pathtraceFree()
+        assert img.tobytes() == ref.image.tobytes(), devices
+    with pytest.raises(pt.PtError):
+        pt.set_image(half)                                              # no session
+    # the headless host: 5 + 7 iterations in two processes == 12 in one
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         64 64")
+    scene_file = tmp_path / "cornell64.txt"
+    scene_file.write_text(txt)
+    exe = pt.build_ptbench()
+    run = lambda *a: subprocess.run([exe, str(scene_file)] + list(a), capture_output=True, text=True, timeout=300)
+    p = run("--iters", "5", "--batch", "2", "--out", str(tmp_path / "a"), "--save-sum")
+    assert p.returncode == 0, p.stdout + p.stderr
+    p = run("--iters", "12", "--batch", "3", "--out", str(tmp_path / "a"), "--resume", str(tmp_path / "a.5samp.sum.pfm"), "--save-sum")
+    assert p.returncode == 0 and "resumed" in p.stdout, p.stdout + p.stderr
+    got = pt.load_pfm(str(tmp_path / "a.12samp.sum.pfm"), 64, 64)
+    assert got.tobytes() == ref.image.tobytes()
+    p = run("--iters", "3", "--resume", str(tmp_path / "a.5samp.sum.pfm"))
+    assert p.returncode != 0                                            # 5 iterations done, 3 wanted
+
+
 def test_async_image_mode(pt, scenes):
     """PT_ASYNC_IMAGE: pathtrace() returns without waiting for its own copy; the running sum reaches the host while
     the next call traces.  When call i+1 returns the buffer of call i is complete; pt_synchronize completes the last
@@ -1307,11 +1353,15 @@ def test_mesh_bvh_c4_equals_every_triangle(pt, scenes):
     assert out["loop"][1][1] > 100000
 
 
-def test_c4_strip_against_the_oracle(pt, po, scenes):
+@pytest.mark.parametrize("r", [37, 26])
+def test_c4_strip_against_the_oracle(pt, po, scenes, r):
     """BASELINE config C4 at full size (800x800, depth 8, 100 032 triangles) held against the ORACLE, not against
     itself: a whole-frame oracle iteration is 2.5 * 10^11 triangle tests, but every path is keyed by (iteration, global
-    pixelIndex, depth), so one 16-row strip -- tile (37, 50, 16), the rows the mesh's centre projects to -- is the same
-    12 800 paths in both and costs the oracle seconds.  Loop over every triangle and hierarchy: image and live counts."""
+    pixelIndex, depth), so one 16-row strip is the same 12 800 paths in both and costs the oracle seconds.  Strip 37
+    (rows 592-607) sees the mesh only through bounces; strip 26 (rows 416-431) runs THROUGH THE MESH'S SILHOUETTE: the
+    camera rays of rows 421 and up hit it, those of rows 416-420 pass its limb (the mesh covers rows 421-551, columns
+    290-390 of the frame), so grazing camera rays, first-bounce mesh hits and their scattered rays are all in it.
+    Loop over every triangle and hierarchy: image and live counts."""
     import os
     s = scenes["cornell"]
     tris = pt.meshes.uv_sphere()
@@ -1319,11 +1369,18 @@ def test_c4_strip_against_the_oracle(pt, po, scenes):
     geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
     scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
     W, H = scene.resolution
-    r, strip = 37, 16
+    strip = 16
     rows = slice(r * strip * W, (r + 1) * strip * W)
     ref = po.Tracer(geoms, s["materials"], s["camera"], s["depth"], tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
     st = ref.iterate_rows(1, r * strip, (r + 1) * strip, threads=min(32, os.cpu_count() or 8))
     assert st.live[0] == strip * W and st.live[1] > 0
+    if r == 26:
+        # the strip does cross the limb: some of its camera rays hit the mesh (they differ from the mesh-less scene's), most do not
+        cam = po.generate_rays(s["camera"], s["depth"])[rows]
+        with_mesh, _ = po.compute_intersections(cam.view(po.PATH_DT), geoms.view(po.GEOM_DT), tris.view(po.TRI_DT), meshes.view(po.MESH_DT))
+        without, _ = po.compute_intersections(cam.view(po.PATH_DT), s["geoms"].view(po.GEOM_DT))
+        on_mesh = (with_mesh["t"] != without["t"]).reshape(strip, W).sum(axis=1)
+        assert on_mesh[:5].sum() == 0 and on_mesh[5] > 0 and on_mesh[-1] > on_mesh[5], on_mesh
     for flags in (pt.PT_COMPACT, pt.PT_COMPACT | pt.PT_MESH_BVH):
         pt.pathtraceInit(scene, flags=flags, tile=(r, H // strip, strip))
         img = pt.pathtrace(None, 0, 1).copy()

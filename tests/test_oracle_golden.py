@@ -40,6 +40,28 @@ def test_lcg_and_u01(po, golden):
     assert po.lib().pto_lcg_seed(2147483648) == 1 and po.lib().pto_lcg_seed(0xffffffff) == 1
 
 
+def test_minstd_rand_published_known_answer(po):
+    """A pin nobody here compiled: the C++ standard's check value for minstd_rand ([rand.predef]: the 10 000th
+    consecutive invocation of a default-constructed object -- seed 1 -- produces 399268537), and minstd_rand0's
+    predecessor constant for contrast (a = 16807 would give 1043618065).  thrust::default_random_engine is
+    minstd_rand (thrust/random/linear_congruential_engine.h:274); rocThrust, through which the golden vectors of
+    rng.npz were generated, is thereby tied to a published constant."""
+    st = C.c_uint32(po.lib().pto_lcg_seed(1))
+    assert st.value == 1
+    x = 0
+    for _ in range(10000):
+        x = po.lib().pto_lcg_next(C.byref(st))
+    assert x == 399268537
+    # the same through the uniform_real_distribution path (u01 advances the engine exactly once per draw)
+    st = C.c_uint32(po.lib().pto_lcg_seed(1))
+    for _ in range(10000):
+        u = po.lib().pto_u01(C.byref(st))
+    assert st.value == 399268537
+    assert np.float32(u) == np.float32(np.float32(399268536) / np.float32(2147483648.0))
+    # closed form: 48271^10000 mod (2^31 - 1)
+    assert pow(48271, 10000, 2147483647) == 399268537
+
+
 def test_make_seeded_engine(po, golden):
     z = golden["rng"]
     for (it, idx, d), want in zip(z["key"], z["first_raw"]):
@@ -108,6 +130,18 @@ def test_shared_sincos_accuracy(po):
         s, c = po.sincos(float(x))
         bad += (np.float32(s) != np.float32(np.sin(np.float64(x)))) + (np.float32(c) != np.float32(np.cos(np.float64(x))))
     assert bad == 0
+
+
+def test_sincos_sums_are_the_probe_checksums(po):
+    """pto_sincos_sums (what the GPU suite holds pt_probe_sincos against) is the plain sum over pto_sincos."""
+    first, n = 0x40000000, 257                                       # 2.0 ...
+    xs = (np.arange(n, dtype=np.uint32) + np.uint32(first)).view(np.float32)
+    ss = sc = 0
+    for k, x in enumerate(xs):
+        s, c = po.sincos(float(x))
+        ss = (ss + int(np.float32(s).view(np.uint32)) * (2 * k + 1)) % (1 << 64)
+        sc = (sc + int(np.float32(c).view(np.uint32)) * (2 * k + 1)) % (1 << 64)
+    assert po.sincos_sums(first, n) == (ss, sc)
 
 
 def test_raygen(po, golden, scenes):
