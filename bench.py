@@ -93,6 +93,252 @@ def load_scene(pt, name):
     return pt.Scene(g("geoms"), g("materials"), g("camera"), int(g("depth")), name=name)
 
 
+class Ctx:
+    """What every measurement of one bench.py run shares: the process group, the scene, the flags."""
+
+
+def setup(args):
+    # dmabuf IPC (the pool's driver has no legacy IPC): must be in the environment BEFORE the HIP runtime initialises,
+    # i.e. before torch is imported; launchers normally export it already
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    c = Ctx()
+    c.args, c.torch, c.dist = args, torch, dist
+    c.rank = int(os.environ.get("RANK", "0"))
+    c.world = int(os.environ.get("WORLD_SIZE", "1"))
+    c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    c.inproc = args.inproc
+    if c.inproc and c.world != 1:
+        raise SystemExit("--inproc is one process: do not launch it through torch.distributed.run")
+    if c.world != args.gpus and not c.inproc:
+        if c.world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = c.world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.same_device:
+        c.local_rank = 0
+    torch.cuda.set_device(c.local_rank)
+    c.dist_on = (c.world > 1 or args.force_dist) and not c.inproc
+    c.n_tiles = args.gpus if c.inproc else c.world          # GPUs the frame is tiled over
+    if c.dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if args.backend == "nccl":      # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", rank=c.rank, world_size=c.world,
+                                    device_id=torch.device("cuda", c.local_rank))
+        else:
+            dist.init_process_group("gloo", rank=c.rank, world_size=c.world)
+
+    pt = c.pt = ge.load_package()
+    pt.library()
+    c.scene_name = {"c2": "cornell", "c3": "cornell_glass", "c4": "cornell", "c5": "cornell_4k"}[args.config]
+    scene = load_scene(pt, c.scene_name)
+    if args.config == "c4":       # BASELINE configs[3]: naive loop over a 100 032-triangle UV sphere, material 1
+        tris = pt.meshes.uv_sphere(n_lat=97, n_lon=521)
+        assert len(tris) == 100032
+        geoms, tris, meshes = pt.meshes.add_mesh(scene.geoms, tris, material_id=1)
+        scene = pt.Scene(geoms, scene.materials, scene.camera, scene.traceDepth, triangles=tris, meshes=meshes,
+                         name="cornell+mesh")
+    c.scene = scene
+    c.W, c.H = scene.resolution
+    c.npix = c.W * c.H
+    c.flags = 0
+    for f in args.flags.split(","):
+        c.flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED,
+                    "cache": pt.PT_CACHE_FIRST, "bvh": pt.PT_MESH_BVH, "aa": pt.PT_AA_JITTER, "": 0}[f]
+    # an explicit (non-null) torch stream: the library launches on it, torch copies / RCCL order against it
+    c.stream = torch.cuda.Stream()
+    torch.cuda.set_stream(c.stream)
+    return c
+
+
+class Session:
+    """One pathtraceInit ... pathtraceFree with the exchange plumbing of its cadence.
+
+    scaling / reduce_every as on the command line; exchange=False traces at the same cadence (same batch sizes, same
+    number of calls) without moving the tiles -- the reference rate an exchange is held against; threaded: the tile
+    gather of the process form is issued from sharding.TileGatherThread (None: whenever there is more than one exchange
+    per step -- at one per step the two-slot TileGather on the tracing thread costs nothing)."""
+
+    def __init__(self, c, scaling, reduce_every, exchange=True, threaded=None, it0=0):
+        args, torch, pt = c.args, c.torch, c.pt
+        self.c, self.scaling, self.do_exchange = c, scaling, exchange and (c.dist_on or c.inproc)
+        self.per_step_iters = pt.sharding.step_iterations(0, args.batch, c.n_tiles, scaling)[1]
+        self.every = self.per_step_iters if (reduce_every <= 0 or not (c.dist_on or c.inproc)) else min(reduce_every, self.per_step_iters)
+        self.exchanges_per_step = -(-self.per_step_iters // self.every)
+        self.image = torch.zeros(c.npix * 3, dtype=torch.float32, device="cuda")     # accumulation buffer (torch-owned)
+        self.frame = torch.zeros_like(self.image) if c.dist_on else None           # rank 0: the assembled frame / reduce staging
+        torch.cuda.synchronize()
+        if c.inproc:
+            # the library owns every device's stream and buffers; device 0 assembles the frame after every batch
+            devices = [0] * args.gpus if args.same_device else list(range(args.gpus))
+            pt.pathtraceInit(c.scene, flags=c.flags, tile=(0, 1, args.strip_rows), max_batch=self.every, devices=devices)
+        else:
+            pt.pathtraceInit(c.scene, flags=c.flags, device=c.local_rank, stream=c.stream.cuda_stream,
+                             tile=(c.rank, c.world, args.strip_rows), max_batch=self.every,
+                             device_image=self.image.data_ptr())
+        self.transport = pt.exchange_transport() if c.inproc else None
+        self.gather = self.gather_thread = None
+        if c.dist_on and self.do_exchange and args.collective == "gather":
+            if threaded is None:
+                threaded = self.exchanges_per_step > 1 and not args.no_exchange_thread
+            cls = pt.sharding.TileGatherThread if threaded else pt.sharding.TileGather
+            g = cls(torch, c.dist, c.rank, c.world, args.strip_rows, c.W, c.H, torch.device("cuda", c.local_rank),
+                    via_host=(args.backend == "gloo"))
+            if threaded:
+                self.gather_thread = g
+            else:
+                self.gather = g
+        self.bytes_per_rank = (self.gather or self.gather_thread).bytes_per_rank if (self.gather or self.gather_thread) else c.npix * 12
+        self.pending = None
+        self.exchanges = 0
+        self.it = it0
+
+    def exchange(self):
+        """tiles' running sums -> rank 0, overlapped with whatever is traced next"""
+        k = self.exchanges
+        self.exchanges += 1
+        if self.gather_thread is not None:
+            self.gather_thread.exchange(self.image, self.frame)
+        elif self.gather is not None:
+            self.gather.finish(self.frame, k & 1)                  # the gather issued two exchanges ago used this slot
+            self.gather.start(self.image, k & 1)
+        else:
+            if self.pending is not None:
+                self.pending.wait()
+            self.frame.copy_(self.image)
+            self.pending = self.c.dist.reduce(self.frame, dst=0, op=self.c.dist.ReduceOp.SUM, async_op=True)
+
+    def step(self):
+        c, pt = self.c, self.c.pt
+        iter0, count = pt.sharding.step_iterations(self.it, c.args.batch, c.n_tiles, self.scaling)
+        self.it += 1
+        for j in range(0, count, self.every):
+            pt.trace_batch_async(iter0 + j, min(self.every, count - j))          # enqueue only
+            if c.dist_on and self.do_exchange:
+                self.exchange()
+
+    def barrier(self):
+        c, torch = self.c, self.c.torch
+        if c.dist_on:
+            if self.gather_thread is not None:
+                self.gather_thread.drain()
+            if self.gather is not None:
+                self.gather.drain(self.frame)
+            if self.pending is not None:
+                self.pending.wait()
+                self.pending = None
+            torch.cuda.synchronize()
+            c.dist.barrier()
+        if c.inproc:
+            c.pt.synchronize()                     # every device's launch and exchange stream
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        """W untimed steps, then exactly K steps between two barriers; max over ranks of the time, sum of the rays."""
+        c, torch, pt = self.c, self.c.torch, self.c.pt
+        for _ in range(warmup):
+            self.step()
+        self.barrier()
+        rays0, first0, _ = pt.counters()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        rays1, first1, _ = pt.counters()
+        rays, first = rays1 - rays0, first1 - first0
+        rank_rays = rays
+        if c.dist_on:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda"); c.dist.all_reduce(tmax, op=c.dist.ReduceOp.MAX)
+            rsum = torch.tensor([float(rays)], dtype=torch.float64, device="cuda"); c.dist.all_reduce(rsum, op=c.dist.ReduceOp.SUM)
+            dt, rays = float(tmax.item()), float(rsum.item())
+        return dt, rays, first, rank_rays
+
+    def close(self):
+        if self.gather_thread is not None:
+            self.gather_thread.close()
+        self.c.pt.pathtraceFree()
+
+
+def per_call_rates(c, n_it=128):
+    """The drop-in calling pattern (src/main.cpp:130-140): ONE pathtrace() per iteration.  `mrays_per_s`: the calls
+    alone, enqueued back to back (pt_trace_batch_async(iter, 1): what a host gets that does not look at state.image
+    between iterations); `pcie_inclusive_sync`: every call hands the running sum back in host memory before it returns
+    (pathtrace.cu:389-392: the reference's exact semantics, 7.68 MB over PCIe per call at 800x800);
+    `pcie_inclusive_async`: PT_ASYNC_IMAGE (the copy of call i overlaps the tracing of call i+1)."""
+    pt, torch = c.pt, c.torch
+    out = {}
+    host = np.zeros((c.npix, 3), dtype=np.float32)
+    L = pt.library()
+
+    def run(flags, call):
+        pt.pathtraceInit(c.scene, flags=flags, device=c.local_rank, stream=c.stream.cuda_stream, max_batch=1)
+        for k in range(16):
+            call(1 + k)
+        pt.synchronize()
+        r0 = pt.total_rays()
+        t1 = time.perf_counter()
+        for k in range(n_it):
+            call(17 + k)
+        pt.synchronize()
+        el = time.perf_counter() - t1
+        rate = round((pt.total_rays() - r0) / el / 1e6, 2)
+        pt.pathtraceFree()
+        return rate, round(el / n_it * 1e3, 4)
+
+    out["mrays_per_s"], out["ms_per_call"] = run(c.flags, lambda it: pt.trace_batch_async(it, 1))
+    out["pcie_inclusive_sync"], out["pcie_inclusive_sync_ms_per_call"] = run(c.flags, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
+    if c.args.digest:
+        import hashlib
+        out["host_image_md5"] = hashlib.md5(host.tobytes()).hexdigest()       # the host image after the synchronous calls
+    out["pcie_inclusive_async"], _ = run(c.flags | pt.PT_ASYNC_IMAGE, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
+    out["calls"] = n_it
+    out["note"] = ("one pathtrace() per iteration (src/main.cpp:130-140), 1 spp per call, max_batch = 1: mrays_per_s = calls enqueued back to back "
+                   "(no host image); pcie_inclusive_sync = the running sum in host memory when each call returns (pathtrace.cu:389-392); "
+                   "pcie_inclusive_async = PT_ASYNC_IMAGE")
+    return out
+
+
+def sub_measurements(c, steps, warmup):
+    """N > 1: the north star's questions answered in the default line.  `per_iteration_exchange`: the
+    tiles' sums travel to rank 0 after EVERY iteration (1 spp batches), next to the same cadence without the exchange;
+    `strong`: the frame gets `batch` iterations per step whatever N (total work fixed)."""
+    args = c.args
+    out = {}
+    iters = args.sub_iters
+    n_steps = max(1, -(-iters // c.pt.sharding.step_iterations(0, args.batch, c.n_tiles, args.scaling)[1]))
+    rates = {}
+    for key, exch in (("exchange", True), ("no_exchange", False)):
+        if c.inproc and not exch:
+            continue                                  # the in-library form exchanges after every call by construction
+        s = Session(c, args.scaling, 1, exchange=exch)
+        dt, rays, _, _ = s.timed(n_steps, 1)
+        rates[key] = (rays / dt / 1e6, dt / (n_steps * s.per_step_iters) * 1e3, s)
+        s.close()
+    r, ms, s = rates["exchange"]
+    out["per_iteration_exchange"] = {
+        "mrays_per_s": round(r, 2), "ms_per_iteration": round(ms, 4), "iterations": n_steps * s.per_step_iters,
+        "transport": s.transport or ("%s %s from %s" % (args.backend, args.collective, "an exchange thread (sharding.TileGatherThread)" if s.gather_thread else "the tracing thread")),
+        "mb_per_rank_per_exchange": round(s.bytes_per_rank / 1e6, 3),
+        "note": "%s scaling, 1 spp per batch, every rank's tile sums to rank 0 after every iteration (BASELINE north_star)" % args.scaling}
+    if "no_exchange" in rates:
+        out["per_iteration_exchange"]["no_exchange_mrays_per_s"] = round(rates["no_exchange"][0], 2)
+        out["per_iteration_exchange"]["ratio"] = round(r / rates["no_exchange"][0], 3)
+    if c.n_tiles > 1:
+        s = Session(c, "strong", args.reduce_every)
+        dt, rays, _, _ = s.timed(steps, warmup)
+        out["strong"] = {"mrays_per_s": round(rays / dt / 1e6, 2), "ms_per_step": round(dt * 1e3 / steps, 4),
+                         "spp_per_step_per_frame": args.batch, "paths_per_rank_per_step": int(args.batch * c.npix / c.n_tiles),
+                         "note": "the frame gets %d spp per step whatever N: per-GPU work shrinks with N" % args.batch}
+        s.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,136 +372,27 @@ def main():
                     help="rehearsal on a 1-GPU box: run the N > 1 code path (process group, tile exchange, max / sum over "
                          "ranks) with a world of ONE rank, so that the RCCL calls themselves execute on hardware")
     ap.add_argument("--digest", action="store_true", help="add the md5 of the (reduced) accumulation image")
-    ap.add_argument("--pcie", action="store_true",
-                    help="also time the reference's own calling pattern: one pathtrace() per iteration with the "
-                         "running sum copied to host memory every call (pathtrace.cu:389-390); reported as "
-                         "config.pcie_inclusive_mrays_per_s, never as value")
+    ap.add_argument("--pcie", action="store_true", help="(kept for old command lines: config.per_call is in every N = 1 line now)")
+    ap.add_argument("--no-per-call", action="store_true",
+                    help="N = 1: skip config.per_call (the reference's one pathtrace() per iteration, with and without the host image)")
+    ap.add_argument("--no-sub", action="store_true",
+                    help="N > 1: skip config.per_iteration_exchange / config.strong (the sub-measurements after the main pass)")
+    ap.add_argument("--sub-iters", type=int, default=256, help="iterations of the per-iteration-exchange sub-measurement")
+    ap.add_argument("--sub-timeout", type=float, default=120.0,
+                    help="seconds the sub-measurements may take before the main line is printed without them")
+    ap.add_argument("--no-exchange-thread", action="store_true",
+                    help="process form: issue every tile gather from the tracing thread (rounds 1-3), also at more than one exchange per step")
     args = ap.parse_args()
 
-    # dmabuf IPC (the pool's driver has no legacy IPC): must be in the environment BEFORE the HIP runtime initialises,
-    # i.e. before torch is imported; launchers normally export it already
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    import torch
-    import torch.distributed as dist
+    c = setup(args)
+    pt, torch, dist, rank, world = c.pt, c.torch, c.dist, c.rank, c.world
+    inproc, dist_on, n_tiles, scene = c.inproc, c.dist_on, c.n_tiles, c.scene
+    W, H, npix, flags = c.W, c.H, c.npix, c.flags
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    inproc = args.inproc
-    if inproc and world != 1:
-        raise SystemExit("--inproc is one process: do not launch it through torch.distributed.run")
-    if world != args.gpus and not inproc:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    if args.same_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist_on = (world > 1 or args.force_dist) and not inproc
-    n_tiles = args.gpus if inproc else world          # GPUs the frame is tiled over
-    if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        if args.backend == "nccl":      # "nccl" is RCCL on ROCm
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    pt = ge.load_package()
-    pt.library()
-    scene_name = {"c2": "cornell", "c3": "cornell_glass", "c4": "cornell", "c5": "cornell_4k"}[args.config]
-    scene = load_scene(pt, scene_name)
-    if args.config == "c4":       # BASELINE configs[3]: naive loop over a 100 032-triangle UV sphere, material 1
-        tris = pt.meshes.uv_sphere(n_lat=97, n_lon=521)
-        assert len(tris) == 100032
-        geoms, tris, meshes = pt.meshes.add_mesh(scene.geoms, tris, material_id=1)
-        scene = pt.Scene(geoms, scene.materials, scene.camera, scene.traceDepth, triangles=tris, meshes=meshes,
-                         name="cornell+mesh")
-    W, H = scene.resolution
-    npix = W * H
-    flags = 0
-    for f in args.flags.split(","):
-        flags |= {"compact": pt.PT_COMPACT, "sort": pt.PT_SORT_MATERIAL, "unfused": pt.PT_UNFUSED,
-                  "cache": pt.PT_CACHE_FIRST, "bvh": pt.PT_MESH_BVH, "aa": pt.PT_AA_JITTER, "": 0}[f]
-    per_step_iters = pt.sharding.step_iterations(0, args.batch, n_tiles, args.scaling)[1]
-    every = per_step_iters if (args.reduce_every <= 0 or not (dist_on or inproc)) else min(args.reduce_every, per_step_iters)
-
-    # an explicit (non-null) torch stream: the library launches on it, torch copies / RCCL order against it
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    image = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")     # accumulation buffer (torch-owned)
-    frame = torch.zeros_like(image) if dist_on else None                # rank 0: the assembled frame / reduce staging
-    torch.cuda.synchronize()
-    if inproc:
-        # the library owns every device's stream and buffers; device 0 assembles the frame after every batch
-        devices = [0] * args.gpus if args.same_device else list(range(args.gpus))
-        pt.pathtraceInit(scene, flags=flags, tile=(0, 1, args.strip_rows), max_batch=every, devices=devices)
-    else:
-        pt.pathtraceInit(scene, flags=flags, device=local_rank, stream=stream.cuda_stream,
-                         tile=(rank, world, args.strip_rows), max_batch=every,
-                         device_image=image.data_ptr())
-    gather = None
-    if dist_on and args.collective == "gather":
-        gather = pt.sharding.TileGather(torch, dist, rank, world, args.strip_rows, W, H, torch.device("cuda"),
-                                        via_host=(args.backend == "gloo"))
-    pending = [None]
-    exchanges = [0]
-
-    def exchange():
-        """tiles' running sums -> rank 0, overlapped with whatever is traced next"""
-        k = exchanges[0]
-        exchanges[0] += 1
-        if gather is not None:
-            gather.finish(frame, k & 1)                       # the gather issued two exchanges ago used this slot
-            gather.start(image, k & 1)
-        else:
-            if pending[0] is not None:
-                pending[0].wait()
-            frame.copy_(image)
-            pending[0] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)
-
-    def step(i):
-        iter0, count = pt.sharding.step_iterations(i, args.batch, n_tiles, args.scaling)
-        for j in range(0, count, every):
-            pt.trace_batch_async(iter0 + j, min(every, count - j))          # enqueue only
-            if dist_on:
-                exchange()
-
-    def barrier():
-        if dist_on:
-            if gather is not None:
-                gather.drain(frame)
-            if pending[0] is not None:
-                pending[0].wait()
-                pending[0] = None
-            torch.cuda.synchronize()
-            dist.barrier()
-        if inproc:
-            pt.synchronize()                       # every device's launch and exchange stream
-        torch.cuda.synchronize()
-
-    it = 0
-    for _ in range(args.warmup):
-        step(it); it += 1
-    barrier()
+    s = Session(c, args.scaling, args.reduce_every)
+    per_step_iters, every = s.per_step_iters, s.every
     profile_on = not args.no_roofline and args.steps * (scene.traceDepth + 2) * -(-per_step_iters // every) <= 2000
-    rays0, first0, _ = pt.counters()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(it); it += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    rays1, first1, _ = pt.counters()
-    rays, first = rays1 - rays0, first1 - first0
-    rank_rays = rays
-    if dist_on:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        rsum = torch.tensor([float(rays)], dtype=torch.float64, device="cuda"); dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
-        dt, rays = float(tmax.item()), float(rsum.item())
+    dt, rays, first, rank_rays = s.timed(args.steps, args.warmup)
     value = rays / dt / 1e6
 
     # ---- roofline of the dominant kernel: the timed region is run a second time, identically, with HIP
@@ -266,62 +403,36 @@ def main():
     if profile_on:
         pt.set_profiling(True)
         rays0, first0, _ = pt.counters()
-        barrier()
+        s.barrier()
         for _ in range(args.steps):
-            step(it); it += 1
-        barrier()
+            s.step()
+        s.barrier()
         rays1, first1, _ = pt.counters()
         rank_rays, first = rays1 - rays0, first1 - first0
         prof = pt.get_profile()
         pt.set_profiling(False)
         roofline = roofline_object(args, n_tiles if inproc else world, flags, pt, prof, rank_rays, first, dt / args.steps)
 
-    # ---- CPU baseline: the oracle (plain-C port) on this host, rank 0, N = 1 only ----
-    cpu = None
-    if rank == 0 and world == 1 and not inproc and not args.no_cpu_baseline:
-        cpu = cpu_baseline(scene)
-
-    pcie = pcie_async = pcie_md5 = None
-    if args.pcie and world == 1 and not inproc:
-        # the reference's calling pattern: one pathtrace() per iteration, the running sum in host memory after every
-        # call (pathtrace.cu:389-390).  Synchronous (the default: exact reference semantics, host buffer page-locked by
-        # the library) and with PT_ASYNC_IMAGE (the copy of call i overlaps the tracing of call i+1).
-        host = np.zeros((npix, 3), dtype=np.float32)
-        n_it = 128
-        for mode_flags in (flags, flags | pt.PT_ASYNC_IMAGE):
-            pt.pathtraceFree()
-            pt.pathtraceInit(scene, flags=mode_flags, device=local_rank, stream=stream.cuda_stream, max_batch=1)
-            for k in range(8):
-                pt.library().pt_trace(None, 0, 1 + k, host.ctypes.data)
-            pt.synchronize()
-            r0 = pt.total_rays()
-            t1 = time.perf_counter()
-            for k in range(n_it):
-                pt.library().pt_trace(None, 0, 9 + k, host.ctypes.data)
-            pt.synchronize()
-            el = time.perf_counter() - t1
-            rate = round((pt.total_rays() - r0) / el / 1e6, 2)
-            if mode_flags == flags:
-                pcie = rate
-                if args.digest:
-                    import hashlib
-                    pcie_md5 = hashlib.md5(host.tobytes()).hexdigest()   # the host image after the synchronous calls
-            else:
-                pcie_async = rate
     digest = None
     if args.digest:
         import hashlib
-        barrier()
-        final = image
+        s.barrier()
+        final = s.image
         if inproc:
             final = torch.from_numpy(pt.get_image(npix))        # the frame device 0 assembled
         if dist_on:
             # the frame rank 0 holds after the last exchange IS the result (gather: copies; reduce: sum with zeros)
-            final = frame
+            final = s.frame
         torch.cuda.synchronize()
         if rank == 0:
             digest = hashlib.md5(final.cpu().numpy().tobytes()).hexdigest()
-    pt.pathtraceFree()
+    gather_desc = ("a gather of the packed tile rows (%.2f MB per rank)" % (s.bytes_per_rank / 1e6)) if (s.gather or s.gather_thread) \
+        else "reduce(SUM) of the zero-padded frames (%.2f MB per rank)" % (npix * 12 / 1e6)
+    transport = s.transport
+    exchanges_per_step = s.exchanges_per_step
+    s.close()
+
+    out = None
     if rank == 0:
         out = {
             "metric": "Mrays/sec (live paths x bounces) at 800x800 Cornell depth 8" if args.config == "c2" else
@@ -331,32 +442,62 @@ def main():
             "higher_is_better": True, "scaling": args.scaling if n_tiles > 1 else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "scenes/cornell.txt (%s) %dx%d depth %d, compaction on, %d spp per step per GPU-tile"
-                                   % (scene_name, W, H, scene.traceDepth, per_step_iters),
+                                   % (c.scene_name, W, H, scene.traceDepth, per_step_iters),
                        "batch_spp": args.batch, "flags": args.flags,
                        "sharding": ("in the library (one process): interleaved %d-row strips over %d devices, one host thread and "
                                     "stream per device; %s scaling; after every batch of %d iterations the tiles' running sums "
                                     "travel to device 0 (%s) and are unpacked into the frame, overlapped with the next batch"
-                                    % (args.strip_rows, n_tiles, args.scaling, every, pt.exchange_transport())) if inproc else
+                                    % (args.strip_rows, n_tiles, args.scaling, every, transport)) if inproc else
                        "whole frame" if not dist_on else
                        "interleaved %d-row strips over %d GPUs; %s scaling; tiles' running sums to rank 0 every %d "
                        "iterations by %s, overlapped with the next batch"
-                       % (args.strip_rows, world, args.scaling, every,
-                          "a gather of the packed tile rows (%.2f MB per rank)" % (gather.bytes_per_rank / 1e6) if gather
-                          else "reduce(SUM) of the zero-padded frames (%.2f MB per rank)" % (npix * 12 / 1e6)),
-                       "exchanges_per_step": 0 if not (dist_on or inproc) else -(-per_step_iters // every),
+                       % (args.strip_rows, world, args.scaling, every, gather_desc),
+                       "exchanges_per_step": 0 if not (dist_on or inproc) else exchanges_per_step,
                        "rays_per_step": int(rays / args.steps)},
         }
         if digest:
             out["image_md5"] = digest
-        if pcie:
-            out["config"]["pcie_inclusive_mrays_per_s"] = pcie
-            out["config"]["pcie_inclusive_async_mrays_per_s"] = pcie_async
-            if pcie_md5:
-                out["config"]["pcie_host_image_md5"] = pcie_md5
         if roofline:
             out["roofline"] = roofline
-        if cpu:
-            out["cpu_baseline"] = cpu
+
+    # ---- CPU baseline: the oracle (plain-C port) on this host, rank 0, N = 1 only ----
+    if rank == 0 and world == 1 and not inproc and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene)
+
+    # ---- the drop-in calling pattern, N = 1: one pathtrace() per iteration ----
+    if world == 1 and not inproc and not args.force_dist and not args.no_per_call and args.config in ("c2", "c3", "c5") \
+            and not (flags & ~(pt.PT_COMPACT | pt.PT_SORT_MATERIAL)):
+        pc = per_call_rates(c)
+        out["config"]["per_call"] = pc
+        out["config"]["pcie_inclusive_mrays_per_s"] = pc["pcie_inclusive_sync"]           # (the names of rounds 1-3)
+        out["config"]["pcie_inclusive_async_mrays_per_s"] = pc["pcie_inclusive_async"]
+        if "host_image_md5" in pc:
+            out["config"]["pcie_host_image_md5"] = pc["host_image_md5"]
+
+    # ---- N > 1 (or its one-rank rehearsal): per-iteration exchange and strong scaling beside the main number.  A
+    # collective that never returns must not cost the main line: after --sub-timeout seconds every rank gives up (its own
+    # watchdog, same deadline), rank 0 prints the line without the sub-measurements and the processes exit.
+    if (dist_on or inproc) and not args.no_sub:
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if done.wait(args.sub_timeout):
+                return
+            if rank == 0:
+                out["config"]["sub_measurements"] = "gave up after %.0f s" % args.sub_timeout
+                print(json.dumps(out), flush=True)
+            os._exit(0 if rank == 0 else 3)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            sub = sub_measurements(c, args.steps, args.warmup)
+            if rank == 0:
+                out["config"].update(sub)
+        except Exception as e:                 # a sub-measurement must never break the bench line
+            if rank == 0:
+                out["config"]["sub_measurements"] = "failed: %s" % str(e)[:300]
+        done.set()
+    if rank == 0:
         print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()
@@ -486,10 +627,24 @@ def usable_cpus():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(scene):
-    """The oracle (plain-C port of the reference's path) on every host hardware thread: one whole iteration per
-    thread (iterations are independent -- the same decomposition the GPU batch uses), images summed in iteration
-    order.  ~0.1 GB of scratch per thread, so the thread count is also bounded by the free memory."""
+    """The oracle (plain-C port of the reference's path) on this host's CPUs, SURVEY 8(d): (i) ONE thread, (ii) every
+    CPU the process may use, with the core count and the CPU model stated.  `value` is the multi-thread figure in the
+    decomposition the GPU batch uses -- one whole iteration per thread (iterations are independent), images summed in
+    iteration order; `path_ranges` is the other decomposition BASELINE.md section 4 describes, threads over contiguous path
+    ranges of ONE iteration (a barrier per bounce).  ~0.1 GB of scratch per thread, so the thread count is also bounded
+    by the free memory."""
     from oracle import pyoracle as po
     ncores = usable_cpus()
     try:
@@ -500,16 +655,35 @@ def cpu_baseline(scene):
     tr = po.Tracer(scene.geoms.view(po.GEOM_DT), scene.materials.view(po.MATERIAL_DT),
                    scene.camera.view(po.CAMERA_DT), scene.traceDepth, flags=po.F_COMPACT,
                    trig=po.TRIG_SHARED)
+    t0 = time.perf_counter()
+    st1 = tr.iterate(1)                                     # (i) one thread, one iteration
+    el1 = time.perf_counter() - t0
+    one = {"value": round(st1.rays / el1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+           "sample": "iteration 1 of the same workload (%.1f s), oracle/ptoracle.c, single thread" % el1}
     rays, t0, iters = 0, time.perf_counter(), 0
     while True:
-        rays += tr.iterate_parallel(1 + iters, ncores, ncores)
+        rays += tr.iterate_parallel(2 + iters, ncores, ncores)
         iters += ncores
         el = time.perf_counter() - t0
         if el > 10.0 or iters >= 4 * ncores:
             break
-    out = {"value": round(rays / el / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "kind": "port",
+    out = {"value": round(rays / el / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "kind": "port", "cpu_model": cpu_model(),
+           "decomposition": "one whole iteration per thread",
            "sample": "%d iterations of the same 800x800 depth-8 Cornell workload (%.1f s), oracle/ptoracle.c, one "
-                     "whole iteration per thread on %d pthreads" % (iters, el, ncores)}
+                     "whole iteration per thread on %d pthreads" % (iters, el, ncores),
+           "one_thread": one}
+    try:
+        t0 = time.perf_counter()
+        r2, n2 = 0, 0
+        while n2 < 8 and time.perf_counter() - t0 < 5.0:
+            r2 += tr.iterate(2 + iters + n2, threads=ncores).rays
+            n2 += 1
+        el2 = time.perf_counter() - t0
+        out["path_ranges"] = {"value": round(r2 / el2 / 1e6, 3), "unit": "Mrays/s", "cores": ncores,
+                              "sample": "%d iterations (%.1f s), %d pthreads over contiguous path ranges of one iteration "
+                                        "(BASELINE.md section 4's decomposition)" % (n2, el2, ncores)}
+    except Exception as e:
+        out["path_ranges"] = {"error": str(e)[:200]}
     ref = reference_headers_baseline(scene, po)
     if ref:
         out["reference_headers"] = ref

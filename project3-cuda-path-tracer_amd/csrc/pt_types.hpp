@@ -102,9 +102,13 @@ struct Control {         // zeroed from `stamp` on by one hipMemsetAsync per bat
     uint32_t pad[512 - 16 - 32 - 2 * (MAX_DEPTH + 1) - 3 * MAX_DEPTH - 1];
     // first-level election counters: 32 buckets per bounce, one 64-B line apart
     uint32_t bucket[MAX_DEPTH][2][32 * 16];       // [bounce][bounce kernel | sort histogram][bucket * 16]
+    // NOT part of the per-batch clear: k_iteration's own last-workgroup election (elect_last_self_clearing) -- 32 buckets
+    // one 64-B line apart, then the top counter; the last arriver of each puts it back to zero, so that a batch that runs
+    // as one launch needs no hipMemsetAsync in front of it
+    uint32_t ticket[33 * 16];
 };
 constexpr int ELECT_BUCKETS = 32;
-static_assert(sizeof(Control) == 2048 + 2 * MAX_DEPTH * 32 * 16 * 4, "Control is one memset block");
+static_assert(offsetof(Control, ticket) == 2048 + 2 * MAX_DEPTH * 32 * 16 * 4, "Control up to `ticket` is one memset block");
 static_assert(sizeof(Control) % 16 == 0, "memset block is a multiple of 16 B");
 
 // Last-workgroup-out election without hammering one address: a same-address atomic costs ~12 ns at
@@ -121,6 +125,23 @@ __device__ __forceinline__ bool elect_last(uint32_t *buckets /* [32*16] */, uint
     if (old != members - 1) return false;
     const uint32_t t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return t == used - 1;
+}
+
+// The same election on counters nobody clears (Control::ticket): the last arriver of a bucket puts it back to zero, the
+// last of the launch the top counter too.  Valid because the launches that share a control block are stream-ordered:
+// the next launch's first workgroup arrives after this launch has ended.
+__device__ __forceinline__ bool elect_last_self_clearing(uint32_t *ticket /* [33*16] */) {
+    const uint32_t G = gridDim.x;
+    const uint32_t k = blockIdx.x % ELECT_BUCKETS;
+    const uint32_t members = (G - k + ELECT_BUCKETS - 1) / ELECT_BUCKETS;
+    const uint32_t used = G < ELECT_BUCKETS ? G : ELECT_BUCKETS;
+    const uint32_t old = __hip_atomic_fetch_add(&ticket[k * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old != members - 1) return false;
+    __hip_atomic_store(&ticket[k * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t t = __hip_atomic_fetch_add(&ticket[32 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != used - 1) return false;
+    __hip_atomic_store(&ticket[32 * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
 }
 
 // Range directory of one bounce's OUTPUT pool.  Wave w of the persistent grid owns the
@@ -163,6 +184,15 @@ struct Persist {         // survives the per-batch memset
     unsigned long long rays;        // sum over bounces of paths traced since pt_init
     unsigned long long iterations;
     unsigned long long first_rays;  // paths traced at bounce 0 (rays - first_rays = compaction survivors)
+};
+
+// What pt_trace / pt_trace_batch hand back as pt_stats, written by the last workgroup of k_iteration straight into
+// page-locked host memory (device-mapped): the synchronous call then needs no device-to-host copy of the control block
+// after its stream synchronisation -- at one iteration per call that copy was a tenth of the call.
+struct HostStats {
+    uint32_t alive[MAX_DEPTH + 1];
+    uint32_t error;
+    uint32_t serial;                // the batch stamp of the launch that wrote this (collect_stats checks it)
 };
 
 // camera extensions of the completion spec (the TODO at pathtrace.cu:134)
@@ -222,9 +252,15 @@ struct BounceArgs {
     // those pixels is a cull candidate of (k_cull0_mask); nullptr: test every primitive
     const unsigned long long *cull0;
     uint32_t cull0_tiles;  // words in cull0 = tile_pixels / 64
-    // k_iteration at 1 spp with a host image: every wave gathers its own pixels into epi_image (the device's running
-    // sum) and writes the new sums to epi_host (the caller's page-locked image, device-mapped); nullptr: k_gather does it
+    // k_iteration at 1 spp, launches that do not overlap others: every wave gathers its own pixels into epi_image (the
+    // device's running sum: finalGather inside the launch, no k_gather) and, with a host image, writes the new sums to
+    // epi_host (the caller's page-locked image, device-mapped); epi_image == nullptr: k_gather does it
     float *epi_image, *epi_host;
+    // k_iteration: per-workgroup traced counts [bounce][workgroup] (plain stores, nothing to clear), folded by the
+    // launch's last workgroup into Control::alive, Persist and (synchronous calls) the host's pt_stats block
+    uint32_t *iter_counts;
+    Persist *persist;
+    HostStats *host_stats;
     // material sort, two-kernel form: table[key][workgroup] of k_sort_hist / k_shade_sorted; keys = materials + 1 (misses)
     uint32_t *sort_table;
     int nbins;

@@ -47,8 +47,9 @@ class TileGather:
     rank's full-frame accumulation buffer (only its own rows are non-zero), `frame` rank 0's assembled frame.
     torch is passed in: this module stays importable without it."""
 
-    def __init__(self, torch, dist, rank, world, strip_rows, width, height, device, via_host=False):
+    def __init__(self, torch, dist, rank, world, strip_rows, width, height, device, via_host=False, slots=2):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.slots = slots
         self.W3 = width * 3
         self.H = height
         self.via_host = via_host                 # gloo (debug / CPU tests): collectives on host tensors
@@ -57,24 +58,35 @@ class TileGather:
         self.max_rows = max(self.nrows)
         self.my_rows = torch.as_tensor(rows[rank], dtype=torch.int64, device=device)
         cdev = "cpu" if via_host else device
-        self.staging = [torch.zeros(self.max_rows * self.W3, dtype=torch.float32, device=device) for _ in range(2)]
-        self.host_staging = [torch.zeros(self.max_rows * self.W3, dtype=torch.float32) for _ in range(2)] if via_host else None
+        self.staging = [torch.zeros(self.max_rows * self.W3, dtype=torch.float32, device=device) for _ in range(slots)]
+        self.host_staging = [torch.zeros(self.max_rows * self.W3, dtype=torch.float32) for _ in range(slots)] if via_host else None
         self.recv = None
-        self.all_rows = None
+        self.recv_all = None
+        self.frame_src = None
         if rank == 0:
-            self.recv = [[torch.zeros(self.max_rows * self.W3, dtype=torch.float32, device=cdev) for _ in range(world)]
-                         for _ in range(2)]
-            self.all_rows = [torch.as_tensor(r, dtype=torch.int64, device=device) for r in rows]
-        self.pending = [None, None]
-        self.seq = [0, 0]                        # issue order of the slots' gathers (the newer sum must land last)
+            # one receive buffer per slot, [world][max_rows][W*3]; the gather list is its world slices.  Row y of the
+            # frame is row frame_src[y] of that buffer seen as world * max_rows rows: ONE index_select assembles the
+            # frame (round 3 issued one index_copy_ per rank -- eight launches per exchange on the root at N = 8)
+            self.recv_all = [torch.zeros(world * self.max_rows * self.W3, dtype=torch.float32, device=cdev) for _ in range(slots)]
+            self.recv = [[b[r * self.max_rows * self.W3:(r + 1) * self.max_rows * self.W3] for r in range(world)] for b in self.recv_all]
+            src = np.zeros(height, dtype=np.int64)
+            for r in range(world):
+                src[rows[r]] = r * self.max_rows + np.arange(len(rows[r]))
+            self.frame_src = torch.as_tensor(src, dtype=torch.int64, device=device)
+        self.pending = [None] * slots
+        self.seq = [0] * slots                   # issue order of the slots' gathers (the newer sum must land last)
         self.issued = 0
         self.bytes_per_rank = self.nrows[rank] * self.W3 * 4
 
-    def start(self, image, slot):
-        """Pack this rank's rows (on the current stream, i.e. after the trace enqueued so far) and start the gather."""
-        torch = self.torch
+    def pack(self, image, slot):
+        """This rank's rows -> the slot's staging buffer, on the current stream (i.e. after the trace enqueued so far)."""
         st = self.staging[slot][: self.nrows[self.rank] * self.W3].view(self.nrows[self.rank], self.W3)
-        torch.index_select(image.view(self.H, self.W3), 0, self.my_rows, out=st)
+        self.torch.index_select(image.view(self.H, self.W3), 0, self.my_rows, out=st)
+
+    def start(self, image, slot, packed=False):
+        """Pack this rank's rows (unless the caller already has) and start the gather."""
+        if not packed:
+            self.pack(image, slot)
         if self.via_host:
             self.host_staging[slot].copy_(self.staging[slot])            # synchronises: debug path
             send = self.host_staging[slot]
@@ -93,13 +105,101 @@ class TileGather:
         work.wait()
         self.pending[slot] = None
         if self.rank == 0:
-            fv = frame.view(self.H, self.W3)
-            for r in range(self.world):
-                t = self.recv[slot][r][: self.nrows[r] * self.W3].view(self.nrows[r], self.W3)
-                if self.via_host:
-                    t = t.to(frame.device)
-                fv.index_copy_(0, self.all_rows[r], t)
+            t = self.recv_all[slot]
+            if self.via_host:
+                t = t.to(frame.device)
+            self.torch.index_select(t.view(self.world * self.max_rows, self.W3), 0, self.frame_src, out=frame.view(self.H, self.W3))
 
     def drain(self, frame):
-        for slot in sorted((0, 1), key=lambda k: self.seq[k]):
+        for slot in sorted(range(self.slots), key=lambda k: self.seq[k]):
             self.finish(frame, slot)
+
+
+class TileGatherThread:
+    """TileGather with the collective issued from a thread of its own, one or more exchanges behind the tracing.
+
+    At one exchange per iteration (BASELINE's north star: "reduce ... once per iteration") an iteration is 0.1 ms of GPU
+    time at 800x800, while issuing a gather, waiting for the previous one and copying its tiles into the frame costs the
+    calling thread about as much again in host time: the host, not the device, set the pace.  Here the tracing thread
+    only packs its rows (one kernel, stream-ordered after the iteration's finalGather -- the packed tile is the running
+    sum after exactly that iteration) and records an event; this thread waits for the event ON A SIDE STREAM, issues
+    the gather there, and rank 0 copies the tiles into the frame behind it, in issue order.  `slots` staging buffers:
+    the tracing thread runs up to `slots` exchanges ahead.  On CPU tensors (gloo, the N > 1 tests) there are no
+    streams: the pack is synchronous and the thread's gather blocks, same order."""
+
+    def __init__(self, torch, dist, rank, world, strip_rows, width, height, device, via_host=False, slots=4):
+        import queue
+        import threading
+        self.torch = torch
+        self.g = TileGather(torch, dist, rank, world, strip_rows, width, height, device, via_host=via_host, slots=slots)
+        self.slots = slots
+        self.device = device
+        self.cuda = getattr(device, "type", str(device)) == "cuda"
+        self.bytes_per_rank = self.g.bytes_per_rank
+        if self.cuda:
+            self.side = torch.cuda.Stream(device)
+            self.ev_packed = [torch.cuda.Event() for _ in range(slots)]
+            self.ev_free = [torch.cuda.Event() for _ in range(slots)]
+        self.jobs = queue.SimpleQueue()
+        self.cond = threading.Condition()
+        self.issued = 0          # exchanges handed over (tracing thread)
+        self.enqueued = 0        # exchanges this thread has issued
+        self.error = None
+        self.th = threading.Thread(target=self._loop, name="tile-exchange", daemon=True)
+        self.th.start()
+
+    def _wait_enqueued(self, n):
+        with self.cond:
+            while self.enqueued < n and self.error is None:
+                self.cond.wait(0.05)
+        if self.error is not None:
+            raise self.error
+
+    def exchange(self, image, frame):
+        """Tracing thread: after the batch just enqueued, this rank's rows -> rank 0's frame."""
+        k = self.issued
+        slot = k % self.slots
+        self._wait_enqueued(k - self.slots + 1)              # the slot's previous exchange has been issued (its event recorded)
+        if self.cuda:
+            if k >= self.slots:
+                self.torch.cuda.current_stream().wait_event(self.ev_free[slot])    # ... and has consumed the staging buffer
+            self.g.pack(image, slot)
+            self.ev_packed[slot].record()
+        else:
+            self.g.pack(image, slot)
+        self.issued += 1
+        self.jobs.put((slot, image, frame))
+
+    def _loop(self):
+        torch = self.torch
+        if self.cuda:
+            torch.cuda.set_device(self.device)
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            slot, image, frame = job
+            try:
+                if self.cuda:
+                    with torch.cuda.stream(self.side):
+                        self.side.wait_event(self.ev_packed[slot])
+                        self.g.start(image, slot, packed=True)
+                        self.g.finish(frame, slot)                   # the side stream waits for the collective, not the host
+                        self.ev_free[slot].record(self.side)
+                else:
+                    self.g.start(image, slot, packed=True)
+                    self.g.finish(frame, slot)
+            except BaseException as e:                               # surfaced by the tracing thread
+                self.error = e
+            with self.cond:
+                self.enqueued += 1
+                self.cond.notify_all()
+
+    def drain(self, frame=None):
+        self._wait_enqueued(self.issued)
+        if self.cuda:
+            self.side.synchronize()
+
+    def close(self):
+        self.jobs.put(None)
+        self.th.join(timeout=10.0)

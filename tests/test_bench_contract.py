@@ -55,8 +55,10 @@ def test_single_gpu_line():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
-    # the reference's calling pattern (one pathtrace() per iteration with the host image): synchronous and PT_ASYNC_IMAGE
+    # the reference's calling pattern (one pathtrace() per iteration): without the host image, with it synchronously, PT_ASYNC_IMAGE
     assert d["config"]["pcie_inclusive_mrays_per_s"] > 100 and d["config"]["pcie_inclusive_async_mrays_per_s"] > 100
+    pc = d["config"]["per_call"]
+    assert pc["mrays_per_s"] > pc["pcie_inclusive_sync"] > 100 and pc["pcie_inclusive_async"] > 100 and pc["calls"] >= 64
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["value"] > 100
     _check_roofline(d["roofline"])
     assert d["roofline"]["launches"] == 3 * 8
@@ -79,7 +81,7 @@ def test_one_iteration_per_call_with_the_host_image():
 def _two(port, *extra, backend="gloo", same_device=True):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--no-roofline", "--backend", backend, "--digest"] + list(extra)
+           "--warmup", "1", "--no-roofline", "--backend", backend, "--digest", "--sub-iters", "8"] + list(extra)
     if same_device:
         cmd.append("--same-device")
     return run(cmd)
@@ -98,12 +100,18 @@ def test_two_ranks_same_frame():
         assert two["n_gpus"] == 2 and two["scaling"] == ("strong" if "strong" in extra else "weak")
         assert two["config"]["rays_per_step"] == one["config"]["rays_per_step"], extra      # same 4 iterations per step
         assert two["image_md5"] == one["image_md5"], extra
+        # the north star's questions ride along in every N > 1 line: the exchange after every iteration (issued from the
+        # exchange thread, next to the same cadence without it) and strong scaling
+        pie, strong = two["config"]["per_iteration_exchange"], two["config"]["strong"]
+        assert pie["mrays_per_s"] > 10 and pie["no_exchange_mrays_per_s"] > 10 and pie["iterations"] >= 8, pie
+        assert "exchange thread" in pie["transport"] or extra == ["--batch", "2", "--collective", "reduce"], pie
+        assert strong["mrays_per_s"] > 10 and strong["spp_per_step_per_frame"] == int(extra[1]), strong
 
 
 def _ranks(n, port, *extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(n), "--steps", "2",
-           "--warmup", "1", "--no-roofline", "--backend", "gloo", "--same-device", "--digest"] + list(extra)
+           "--warmup", "1", "--no-roofline", "--backend", "gloo", "--same-device", "--digest", "--sub-iters", "8"] + list(extra)
     return run(cmd, timeout=900)
 
 
@@ -136,10 +144,12 @@ def test_one_rank_rccl():
         os.environ["MASTER_PORT"] = env_port
         try:
             d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
-                     "--no-roofline", "--digest", "--force-dist", "--backend", "nccl"] + extra)
+                     "--no-roofline", "--digest", "--force-dist", "--backend", "nccl", "--sub-iters", "16"] + extra)
         finally:
             os.environ.pop("MASTER_PORT", None)
         assert d["n_gpus"] == 1 and d["config"]["exchanges_per_step"] >= 1, extra
+        pie = d["config"]["per_iteration_exchange"]                    # RCCL gather per iteration from the exchange thread
+        assert pie["mrays_per_s"] > 10 and 0.05 < pie["ratio"] < 20.0 and pie["iterations"] >= 16, pie
         assert d["config"]["rays_per_step"] == one["config"]["rays_per_step"], extra
         assert d["image_md5"] == one["image_md5"], extra
 

@@ -231,7 +231,7 @@ def test_inproc_bench_line(pt):
     """bench.py --gpus 2 --inproc (one process, the library's own tiling) prints the contract's JSON line and the
     image of the single-device run."""
     import json
-    args = ["--steps", "2", "--warmup", "1", "--batch", "2", "--no-roofline", "--no-cpu-baseline", "--digest"]
+    args = ["--steps", "2", "--warmup", "1", "--batch", "2", "--no-roofline", "--no-cpu-baseline", "--digest", "--sub-iters", "8"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--batch", "4"], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     a = json.loads(one.stdout.strip().splitlines()[-1])
@@ -245,3 +245,5 @@ def test_inproc_bench_line(pt):
     # weak scaling: 2 x 2 iterations per step on two tiles == 4 per step on the whole frame
     assert b["config"]["rays_per_step"] == a["config"]["rays_per_step"]
     assert b["image_md5"] == a["image_md5"]
+    # the sub-measurements of every N > 1 line: an exchange after every iteration (the library's exchange thread) and strong scaling
+    assert b["config"]["per_iteration_exchange"]["mrays_per_s"] > 10 and b["config"]["strong"]["mrays_per_s"] > 10

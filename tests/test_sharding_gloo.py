@@ -38,7 +38,8 @@ def _worker(rank, world, port, strip_rows, out_path, mode):
     frame = torch.zeros_like(image)
     tr = po.Tracer(geoms, mats, cam, depth)
     gather = None
-    for step in range(3):
+    nsteps = 5 if mode == "thread" else 3        # more exchanges than the thread's three staging slots
+    for step in range(nsteps):
         iter0, count = pt.sharding.step_iterations(step, batch, world)
         for it in range(iter0, iter0 + count):
             tr.iterate(it)
@@ -48,6 +49,10 @@ def _worker(rank, world, port, strip_rows, out_path, mode):
         image.copy_(torch.from_numpy(mine.reshape(-1)))
         if mode == "reduce":
             pt.sharding.reduce_frame(dist, image, frame, dst=0)
+        elif mode == "thread":                   # the gather issued from the exchange thread, up to three exchanges behind
+            if gather is None:
+                gather = pt.sharding.TileGatherThread(torch, dist, rank, world, strip_rows, W, H, torch.device("cpu"), via_host=True, slots=3)
+            gather.exchange(image, frame)
         else:                                    # the gather of packed tile rows, two slots in flight
             if gather is None:
                 gather = pt.sharding.TileGather(torch, dist, rank, world, strip_rows, W, H, torch.device("cpu"), via_host=True)
@@ -55,6 +60,9 @@ def _worker(rank, world, port, strip_rows, out_path, mode):
             gather.start(image, step & 1)
     if gather is not None:
         gather.drain(frame)
+        if mode == "thread":
+            assert gather.enqueued == nsteps and gather.error is None
+            gather.close()
     if rank == 0:
         np.save(out_path, frame.numpy().reshape(-1, 3))
         np.save(out_path + ".ref.npy", tr.image)
@@ -62,7 +70,7 @@ def _worker(rank, world, port, strip_rows, out_path, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["reduce", "gather"])
+@pytest.mark.parametrize("mode", ["reduce", "gather", "thread"])
 @pytest.mark.parametrize("strip_rows", [4, 7])
 def test_two_rank_reduce_equals_single(tmp_path, strip_rows, mode):
     import torch.multiprocessing as mp
@@ -81,6 +89,17 @@ def test_eight_ranks_uneven_strips(tmp_path):
     out = str(tmp_path / "frame.npy")
     port = _free_port()
     mp.spawn(_worker, args=(8, port, 5, out, "gather"), nprocs=8, join=True)
+    got, want = np.load(out), np.load(out + ".ref.npy")
+    assert got.tobytes() == want.tobytes()
+
+
+def test_eight_ranks_exchange_thread(tmp_path):
+    """The per-iteration cadence of bench.py's sub-measurement at N = 8: every rank hands its exchanges to
+    sharding.TileGatherThread; more exchanges than staging slots, uneven strips."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "frame.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, 5, out, "thread"), nprocs=8, join=True)
     got, want = np.load(out), np.load(out + ".ref.npy")
     assert got.tobytes() == want.tobytes()
 
