@@ -1917,7 +1917,7 @@ __global__ __launch_bounds__(BLOCK, PT_ITER_WAVES) void k_iteration(BounceArgs a
     // the w-th quarter of the tiles of the four spans read as one sequence (WgSpans).  Left with its own survivors only,
     // a wave ran half-empty tiles from bounce 2 on (36 paths in a tile of 64 at bounce 5): 11 tile passes per wave and
     // iteration at 1 spp instead of 8.5.  Slots alternate by bounce parity, so one barrier per bounce is enough.
-    uint32_t *xcnt = reinterpret_cast<uint32_t *>(lds_raw);      // [2][WAVES] (the LDS control words; unused by this kernel)
+    uint32_t *xcnt = reinterpret_cast<uint32_t *>(lds_raw);      // [2][survivors of WAVES | traced by WAVES] (the 16 LDS control words)
     const int wave = threadIdx.x >> 6;
     WgSpans ws{};
     ws.b0 = (0u * gridDim.x + blockIdx.x) * R * TILE; ws.b1 = (1u * gridDim.x + blockIdx.x) * R * TILE;
@@ -1936,19 +1936,30 @@ __global__ __launch_bounds__(BLOCK, PT_ITER_WAVES) void k_iteration(BounceArgs a
             run_tiles<MODE_FUSED, true, MESH_NONE, false>(a, c, q, in, out, d, first, mine, tiles, n, false, 0, cur, base, true, ws,
                                                           packed, traced);
         }
-        if (lane == 0 && traced)
-            atomicAdd(&a.ctl->bucket[d][1][(wid % ELECT_BUCKETS) * 16], traced);
         // this wave's survivors are read by the workgroup's other waves at the next bounce, through the CU's vector L1
         // that the write-through stores went through: workgroup scope (CU mode, see above); an agent-scope fence writes
         // back / invalidates the L2 and made the launch 4x slower
-        uint32_t *slot = xcnt + (d & 1) * WAVES;
-        if (lane == 0) slot[wave] = packed;
+        uint32_t *slot = xcnt + (d & 1) * (2 * WAVES);
+        if (lane == 0) { slot[wave] = packed; slot[WAVES + wave] = traced; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();                                                     // every wave, every bounce: exits are uniform
         const uint32_t c0 = slot[0], c1 = slot[1], c2 = slot[2], c3 = slot[3];
         ws.p1 = c0; ws.p2 = c0 + c1; ws.p3 = c0 + c1 + c2; ws.total = c0 + c1 + c2 + c3;
-        if (ws.total == 0) break;
+        // paths this workgroup traced at bounce d: one plain (write-through) store into its own word of
+        // iter_counts[bounce][workgroup] -- nothing to clear before the launch, no same-address atomics; the launch's
+        // last workgroup adds the columns up.  A workgroup that runs out of paths writes the zeros of its later bounces.
+        // (the pointers this kernel needs once per bounce or once at its end are read from the kernel-argument segment
+        // where they are used, like the camera: kept in scalar registers across the tile loops they were spilled)
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&karg_field<uint32_t *>(offsetof(BounceArgs, iter_counts))[(uint32_t)d * gridDim.x + blockIdx.x],
+                               slot[WAVES] + slot[WAVES + 1] + slot[WAVES + 2] + slot[WAVES + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ws.total == 0) {
+            if ((int)threadIdx.x > d && (int)threadIdx.x < karg_field<int>(offsetof(BounceArgs, trace_depth)))
+                __hip_atomic_store(&karg_field<uint32_t *>(offsetof(BounceArgs, iter_counts))[threadIdx.x * gridDim.x + blockIdx.x], 0u,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
         const Pool tmp = in; in = out; out = tmp;
     }
     // pathtrace() per call with a host image (the reference's pattern, pathtrace.cu:380-392): at 1 spp a wave owns the
@@ -1958,8 +1969,12 @@ __global__ __launch_bounds__(BLOCK, PT_ITER_WAVES) void k_iteration(BounceArgs a
     // that used to cross PCIe AFTER the iteration now cross during it.  The 192 dwords of a tile's 64 float3 pixels
     // are transposed through the wave's LDS block so that every store instruction writes 256 contiguous bytes
     // (whole lines for the PCIe write combiner), not 64 dwords 12 bytes apart.
-    if (a.epi_host) {
+    float *const epi_image = karg_field<float *>(offsetof(BounceArgs, epi_image));
+    if (epi_image) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's final colours have left the CU
+        float *const epi_host = karg_field<float *>(offsetof(BounceArgs, epi_host));
+        const float *const fin = karg_field<float *>(offsetof(BounceArgs, fin));
+        const TileMap map = karg_struct<TileMap>(offsetof(BounceArgs, map));
         float *tr = lc.pw;                                          // the wave's LDS block is free now
         for (uint32_t r = 0; r < R; ++r) {
             const uint32_t tile = wid * R + r;
@@ -1967,7 +1982,7 @@ __global__ __launch_bounds__(BLOCK, PT_ITER_WAVES) void k_iteration(BounceArgs a
             const uint32_t j = tile * TILE + lane;                  // one sample: pid == local pixel
             float cx = 0.0f, cy = 0.0f, cz = 0.0f;
             if (j < n) {                                            // agent-scope loads: from the L2 the stores went to
-                const float *f = a.fin + (size_t)j * 4;
+                const float *f = fin + (size_t)j * 4;
                 if (__float_as_uint(__hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == c.stamp) {
                     cx = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     cy = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1982,13 +1997,62 @@ __global__ __launch_bounds__(BLOCK, PT_ITER_WAVES) void k_iteration(BounceArgs a
                 const uint32_t jl = w / 3u;
                 const uint32_t jj = tile * TILE + jl;
                 if (jj < n) {
-                    const size_t idx = (size_t)local_to_pixel(a.map, (int)jj) * 3 + (w - jl * 3u);
-                    const float v = a.epi_image[idx] + tr[w];
-                    a.epi_image[idx] = v;
-                    a.epi_host[idx] = v;
+                    const size_t idx = (size_t)local_to_pixel(map, (int)jj) * 3 + (w - jl * 3u);
+                    const float v = epi_image[idx] + tr[w];
+                    epi_image[idx] = v;
+                    if (epi_host) epi_host[idx] = v;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    // ---- the launch's last workgroup folds the traced counts (what k_gather's thread 0 did after a per-batch clear of
+    // 32 x depth atomic buckets: one hipMemsetAsync and one more launch around every iteration at 1 spp per call) ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's count (and image) stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool last = elect_last_self_clearing(karg_field<Control *>(offsetof(BounceArgs, ctl))->ticket);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        xcnt[0] = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (xcnt[0]) {
+        // thread t sums its share of every bounce's column; the four waves' sums cross through the LDS control words
+        const uint32_t *const counts = karg_field<uint32_t *>(offsetof(BounceArgs, iter_counts));
+        Control *const ctl = karg_field<Control *>(offsetof(BounceArgs, ctl));
+        HostStats *const hs = karg_field<HostStats *>(offsetof(BounceArgs, host_stats));
+        const int depth = karg_field<int>(offsetof(BounceArgs, trace_depth));
+        unsigned long long rays = 0;
+        uint32_t first = 0;
+        for (int d = 0; d < depth; ++d) {
+            uint32_t sum = 0;
+            for (uint32_t b = threadIdx.x; b < gridDim.x; b += BLOCK)
+                sum += __hip_atomic_load(&counts[(uint32_t)d * gridDim.x + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+            if (lane == 0) xcnt[4 + wave] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t tot = xcnt[4] + xcnt[5] + xcnt[6] + xcnt[7];
+                ctl->alive[d] = tot;
+                if (hs) hs->alive[d] = tot;
+                rays += tot;
+                if (d == 0) first = tot;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            Persist *const per = karg_field<Persist *>(offsetof(BounceArgs, persist));
+            atomicAdd(&per->rays, rays);
+            atomicAdd(&per->iterations, (unsigned long long)(n / (uint32_t)karg_field<int>(offsetof(BounceArgs, map) + offsetof(TileMap, tile_pixels))));
+            atomicAdd(&per->first_rays, (unsigned long long)first);
+            if (hs) {
+                for (int d = depth; d <= MAX_DEPTH; ++d) hs->alive[d] = 0;
+                hs->error = 0;
+                __hip_atomic_store(&hs->serial, c.stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -2535,20 +2599,16 @@ __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin
                                                   int count, Control *ctl, Persist *per, int depths,
                                                   uint32_t fake_rays, int partial_counts, int counters_only, uint32_t stamp_arg) {
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j == 0) {                    // fold this batch's ray count into the persistent counter
-        if (partial_counts)          // k_iteration left 32 partial sums per bounce
-            for (int d = 0; d < depths; ++d) {
-                uint32_t s = 0;
-                for (int k = 0; k < ELECT_BUCKETS; ++k) s += ctl->bucket[d][1][k * 16];
-                ctl->alive[d] = s;
-            }
+    if (j == 0 && !partial_counts) { // fold this batch's ray count into the persistent counter (k_iteration's last workgroup
+                                     // has done it for its batch: partial_counts; batches of different lanes may run
+                                     // side by side, hence atomics)
         unsigned long long r = fake_rays;
         for (int d = 0; d < depths; ++d) r += ctl->alive[d];
-        per->rays += r;
-        per->iterations += (unsigned long long)count;
-        per->first_rays += depths > 0 ? ctl->alive[0] : fake_rays;
+        atomicAdd(&per->rays, r);
+        atomicAdd(&per->iterations, (unsigned long long)count);
+        atomicAdd(&per->first_rays, (unsigned long long)(depths > 0 ? ctl->alive[0] : fake_rays));
     }
-    if (counters_only || j >= (uint32_t)map.tile_pixels) return;       // k_iteration gathered its own pixels (epi_host)
+    if (counters_only || j >= (uint32_t)map.tile_pixels) return;
     const int pix = local_to_pixel(map, (int)j);
     float r = image[3 * pix + 0], g = image[3 * pix + 1], b = image[3 * pix + 2];
     // samples are added in iteration order (one add per pixel per iteration, as the reference does); the loads of

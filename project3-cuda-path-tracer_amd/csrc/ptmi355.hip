@@ -120,6 +120,12 @@ struct Renderer {
     size_t lds_bytes = 0;
     Control *ctl = nullptr;
     Persist *persist = nullptr;
+    uint32_t *iter_counts = nullptr;       // k_iteration: traced counts [bounce][workgroup] (BounceArgs::iter_counts); one per lane
+    size_t iter_counts_bytes = 0;
+    HostStats *h_stats = nullptr, *d_stats = nullptr;   // page-locked, device-mapped: the last workgroup of a synchronous call's k_iteration writes pt_stats' numbers here
+    bool want_host_stats = false;          // this call ends in collect_stats (pt_trace / pt_trace_batch)
+    uint32_t host_stats_serial = 0;        // != 0: the batch just enqueued leaves its counts in h_stats under this serial
+    bool self_gathered = false;            // the batch just enqueued did finalGather inside k_iteration (no k_gather)
     uint32_t *dir_mem = nullptr;  // per bounce: count[Wp], base[Wp+4]
     size_t dir_stride = 0;        // words per bounce
     int cur_dir = -1;             // bounce whose directory describes pool[cur] (-1: dense)
@@ -145,7 +151,7 @@ struct Renderer {
     // a launch stream of its own and its own set of the buffers a batch in flight owns
     struct Bufs {
         float *pool_mem[2]; Pool pool[2]; float *final_mem; Control *ctl; uint32_t *dir_mem;
-        float4 *mesh_hit; unsigned long long *mesh_flags[2];
+        float4 *mesh_hit; unsigned long long *mesh_flags[2]; uint32_t *iter_counts;
     };
     struct Lane {
         hipStream_t stream = nullptr;
@@ -186,7 +192,7 @@ struct Renderer {
     pt_bvh_info bvh_info{};
     // host buffers the caller hands to pt_trace (scene->state.image): page-locked once so that the per-call copy of
     // the running sum (pathtrace.cu:389-390) runs at PCIe speed instead of through the runtime's staging
-    struct HostReg { void *ptr; size_t bytes; };
+    struct HostReg { void *ptr; size_t bytes; void *dev; };   // dev: the device's address of the mapping (looked up once)
     std::vector<HostReg> host_regs;
     // PT_ASYNC_IMAGE: snapshot of the running sum per call (device), copied out on a second stream while the next
     // call traces
@@ -319,6 +325,8 @@ BounceArgs bounce_args(int depth) {
     const bool same_rays = !R.lens.aa && !(R.lens.radius > 0.0f);
     a.cull0 = (R.cull0_tiles && same_rays) ? R.d_cull0 : nullptr;
     a.cull0_tiles = R.cull0_tiles;
+    a.iter_counts = R.iter_counts;
+    a.persist = R.persist;
     return a;
 }
 
@@ -335,7 +343,9 @@ int next_fin_stamp(void) {
     return PT_OK;
 }
 
-int enqueue_begin(int iter0, int count, bool stepping) {
+// `clear`: the per-batch clear of the control block (live counts, election counters).  A batch that runs as ONE launch
+// (k_iteration) needs none: its counts are plain per-workgroup stores and its election puts its counters back itself.
+int enqueue_begin(int iter0, int count, bool stepping, bool clear = true) {
     if (count < 1 || count > R.max_batch)
         return fail(PT_ERR_INVALID, "batch count %d outside [1, max_batch=%d]", count, R.max_batch);
     // makeSeededRandomEngine ORs the iteration into a word that holds the depth from bit 22 up (pathtrace.cu:41-45);
@@ -348,7 +358,8 @@ int enqueue_begin(int iter0, int count, bool stepping) {
     if (!R.capturing) { const int rc = next_fin_stamp(); if (rc) return rc; }
     R.sorted_isects = false;
     R.mesh_marked = false;
-    HIPCHK(hipMemsetAsync(&R.ctl->stamp, 0, R.ctl_bytes, R.stream));      // everything but Control::iter0
+    R.self_gathered = false; R.host_stats_serial = 0;
+    if (clear) HIPCHK(hipMemsetAsync(&R.ctl->stamp, 0, R.ctl_bytes, R.stream));      // everything but Control::iter0
     if (R.mesh_mode == MESH_BVH)
         for (int k = 0; k < 2; ++k)
             HIPCHK(hipMemsetAsync(R.mesh_flags[k], 0, R.flag_words * sizeof(unsigned long long), R.stream));
@@ -542,6 +553,7 @@ int enqueue_fake(void) {
 }
 
 int enqueue_end(void) {
+    if (R.self_gathered) { R.whole = false; return PT_OK; }   // finalGather and the counters were done inside k_iteration
     StageTimer tm(PT_STAGE_GATHER);
     hipStream_t gs = R.stream;
     if (R.lane_cur) {                                         // overlapped batch: gathers stay in call order on the launch stream
@@ -578,12 +590,12 @@ int enqueue_end(void) {
 Renderer::Bufs take_bufs(void) {
     Renderer::Bufs b{};
     for (int k = 0; k < 2; ++k) { b.pool_mem[k] = R.pool_mem[k]; b.pool[k] = R.pool[k]; b.mesh_flags[k] = R.mesh_flags[k]; }
-    b.final_mem = R.final_mem; b.ctl = R.ctl; b.dir_mem = R.dir_mem; b.mesh_hit = R.mesh_hit;
+    b.final_mem = R.final_mem; b.ctl = R.ctl; b.dir_mem = R.dir_mem; b.mesh_hit = R.mesh_hit; b.iter_counts = R.iter_counts;
     return b;
 }
 void put_bufs(const Renderer::Bufs &b) {
     for (int k = 0; k < 2; ++k) { R.pool_mem[k] = b.pool_mem[k]; R.pool[k] = b.pool[k]; R.mesh_flags[k] = b.mesh_flags[k]; }
-    R.final_mem = b.final_mem; R.ctl = b.ctl; R.dir_mem = b.dir_mem; R.mesh_hit = b.mesh_hit;
+    R.final_mem = b.final_mem; R.ctl = b.ctl; R.dir_mem = b.dir_mem; R.mesh_hit = b.mesh_hit; R.iter_counts = b.iter_counts;
 }
 
 void free_lanes(void) {
@@ -597,6 +609,7 @@ void free_lanes(void) {
             if (l.b.final_mem) (void)hipFree(l.b.final_mem);
             if (l.b.ctl) (void)hipFree(l.b.ctl);
             if (l.b.dir_mem) (void)hipFree(l.b.dir_mem);
+            if (l.b.iter_counts) (void)hipFree(l.b.iter_counts);
             if (l.b.mesh_hit) (void)hipFree(l.b.mesh_hit);
         }
         l = Renderer::Lane{};
@@ -619,6 +632,7 @@ static int alloc_lanes(void) {
         HIPCHK(hipMalloc((void **)&b.ctl, sizeof(Control)));
         HIPCHK(hipMemsetAsync(b.ctl, 0, sizeof(Control), R.stream));
         HIPCHK(hipMalloc((void **)&b.dir_mem, R.dir_bytes));
+        HIPCHK(hipMalloc((void **)&b.iter_counts, R.iter_counts_bytes));
         if (R.mesh_mode == MESH_BVH) {
             HIPCHK(hipMalloc((void **)&b.mesh_hit, R.mesh_hit_bytes));
             for (int k = 0; k < 2; ++k) {
@@ -703,17 +717,28 @@ int enqueue_batch_direct(int iter0, int count) {
 }
 
 int enqueue_batch_serial(int iter0, int count) {
-    int rc = enqueue_begin(iter0, count, false);
+    // small batch: every bounce in one launch (k_iteration)
+    const bool whole = !(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER | PT_CACHE_FIRST)) && (R.flags & PT_COMPACT) &&
+                       R.mesh_mode == MESH_NONE && R.sort_keys == 0 && count >= 1 &&
+                       (uint64_t)R.map.tile_pixels * (uint64_t)count <= R.whole_max_paths;
+    int rc = enqueue_begin(iter0, count, false, !whole);
     if (rc) return rc;
     if (R.flags & PT_FAKE_SHADER) {
         rc = enqueue_fake();
         if (rc) return rc;
-    } else if (R.gen_fused && (R.flags & PT_COMPACT) && !(R.flags & PT_CACHE_FIRST) && R.mesh_mode == MESH_NONE && R.sort_keys == 0 &&
-               (uint64_t)R.map.tile_pixels * (uint64_t)count <= R.whole_max_paths) {
-        // small batch: every bounce in one launch (k_iteration)
+    } else if (whole) {
         StageTimer tm(PT_STAGE_BOUNCE);
         BounceArgs a = bounce_args(0);
-        if (R.epi_host && count == 1 && !R.capturing) { a.epi_image = R.image; a.epi_host = R.epi_host; R.epi_done = true; }
+        // One iteration, and no other launch of this session running beside it (the lanes of pt_trace_batch_async): the
+        // workgroup that traces a pixel's path also does finalGather for it -- image[pixel] += colour inside the launch
+        // (a second launch's waves adding to the same pixels at the same time would lose updates, and the order of the
+        // float additions is part of the result) -- and, with a page-locked host image, writes the new sums there.
+        if (count == 1 && !R.lane_cur && !R.capturing && !R.use_graphs && R.epi_enabled) {
+            a.epi_image = R.image; a.epi_host = R.epi_host;
+            if (R.epi_host) R.epi_done = true;
+            R.self_gathered = true;
+        }
+        if (R.want_host_stats && !R.capturing && !R.use_graphs && R.d_stats) { a.host_stats = R.d_stats; R.host_stats_serial = R.fin_serial; }
         if (R.scene_lds) hipLaunchKernelGGL(k_iteration<true>, dim3(R.grid_iter), dim3(BLOCK), R.lds_bytes, R.stream, a);
         else hipLaunchKernelGGL(k_iteration<false>, dim3(R.grid_iter), dim3(BLOCK), R.lds_bytes, R.stream, a);
         HIPCHK(hipGetLastError());
@@ -929,7 +954,7 @@ bool pin_host(void *ptr, size_t bytes) {
         (void)hipHostUnregister(R.host_regs.front().ptr);
         R.host_regs.erase(R.host_regs.begin());
     }
-    if (hipHostRegister(ptr, bytes, hipHostRegisterMapped) == hipSuccess) { R.host_regs.push_back({ptr, bytes}); return true; }
+    if (hipHostRegister(ptr, bytes, hipHostRegisterMapped) == hipSuccess) { R.host_regs.push_back({ptr, bytes, nullptr}); return true; }
     (void)hipGetLastError();
     return false;
 }
@@ -938,9 +963,12 @@ bool pin_host(void *ptr, size_t bytes) {
 // back to a copy)
 float *map_host(float *host, size_t bytes) {
     if (!pin_host(host, bytes)) return nullptr;
-    void *dev = nullptr;
-    if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return (float *)dev;
+    for (auto &h : R.host_regs)
+        if (h.ptr == host) {
+            if (!h.dev && hipHostGetDevicePointer(&h.dev, host, 0) != hipSuccess) { (void)hipGetLastError(); h.dev = nullptr; }
+            return (float *)h.dev;
+        }
+    return nullptr;
 }
 
 // PT_ASYNC_IMAGE: the running sum after this call is snapshotted on the launch stream (device to device, microseconds)
@@ -982,8 +1010,19 @@ int enqueue_image_copy(float *host) {
 // reads the control block back (after a sync) and folds it into the stats
 int collect_stats(void) {
     Control c;
-    HIPCHK(hipMemcpyAsync(&c, R.last_ctl ? R.last_ctl : R.ctl, offsetof(Control, bucket), hipMemcpyDeviceToHost, R.stream));
-    HIPCHK(hipStreamSynchronize(R.stream));
+    if (R.host_stats_serial) {
+        // the launch's last workgroup wrote the counts into page-locked host memory: nothing to copy
+        HIPCHK(hipStreamSynchronize(R.stream));
+        if (R.h_stats->serial != R.host_stats_serial)
+            return fail(PT_ERR_INTERNAL, "k_iteration left no statistics (serial %u, expected %u)", R.h_stats->serial, R.host_stats_serial);
+        memset(&c, 0, offsetof(Control, bucket));
+        memcpy(c.alive, R.h_stats->alive, sizeof c.alive);
+        c.error = R.h_stats->error;
+        R.host_stats_serial = 0;
+    } else {
+        HIPCHK(hipMemcpyAsync(&c, R.last_ctl ? R.last_ctl : R.ctl, offsetof(Control, bucket), hipMemcpyDeviceToHost, R.stream));
+        HIPCHK(hipStreamSynchronize(R.stream));
+    }
     if (c.error) return fail(PT_ERR_INTERNAL, "kernel watchdog tripped: inconsistent tile directory (control.error=%u)", c.error);
     R.stats.bounces = 0; R.stats.rays = 0;
     memset(R.stats.live, 0, sizeof R.stats.live);
@@ -1077,6 +1116,8 @@ void pt_free(void) {
     if (R.ctl) (void)hipFree(R.ctl);
     if (R.dir_mem) (void)hipFree(R.dir_mem);
     if (R.persist) (void)hipFree(R.persist);
+    if (R.iter_counts) (void)hipFree(R.iter_counts);
+    if (R.h_stats) (void)hipHostFree(R.h_stats);
     if (R.scratch) (void)hipFree(R.scratch);
     if (R.dbg_counts) (void)hipFree(R.dbg_counts);
     if (R.copy_stream) (void)hipStreamSynchronize(R.copy_stream);
@@ -1504,7 +1545,7 @@ static int init_impl(const pt_scene_desc *d) {
     R.ctl_bytes = offsetof(Control, bucket) - offsetof(Control, stamp) +
                   (size_t)R.trace_depth * sizeof(((Control *)nullptr)->bucket[0]);
     HIPCHK(hipMalloc((void **)&R.ctl, sizeof(Control)));
-
+    HIPCHK(hipMemsetAsync(R.ctl, 0, sizeof(Control), R.stream));      // incl. Control::ticket, which no batch clears
     HIPCHK(hipMalloc((void **)&R.persist, sizeof(Persist)));
     HIPCHK(hipMemsetAsync(R.persist, 0, sizeof(Persist), R.stream));
     hipDeviceProp_t prop;
@@ -1542,6 +1583,18 @@ static int init_impl(const pt_scene_desc *d) {
         if (const char *e = getenv("PTMI355_WGS_PER_CU")) n = std::max(1, std::min(n, atoi(e)));
         R.grid_iter = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)n);
         R.grid_iter = std::max(1, std::min(R.grid_iter, 8192 / WAVES));
+        // its traced counts, [bounce][workgroup], and the page-locked block its last workgroup writes a synchronous call's
+        // statistics to (if the host allocation cannot be mapped the control block is copied back as before)
+        R.iter_counts_bytes = (size_t)MAX_DEPTH * (size_t)R.grid_iter * 4;
+        HIPCHK(hipMalloc((void **)&R.iter_counts, R.iter_counts_bytes));
+        void *hs = nullptr, *ds = nullptr;
+        if (hipHostMalloc(&hs, sizeof(HostStats), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&ds, hs, 0) == hipSuccess) {
+            memset(hs, 0, sizeof(HostStats));
+            R.h_stats = (HostStats *)hs; R.d_stats = (HostStats *)ds;
+        } else {
+            (void)hipGetLastError();
+            if (hs) (void)hipHostFree(hs);
+        }
     }
     if (R.mesh_mode == MESH_BVH) {
         R.mesh_hit_bytes = (size_t)(((capz + 63) / 64) * 64) * sizeof(float4);
@@ -1689,8 +1742,9 @@ int pt_trace_batch(int iter0, int count, float *host_image_sum) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_batch: not initialised");
     R.in_step = false;
     R.ov_ok = false;       // (PT_ASYNC_IMAGE calls are bound by their 7.68 MB copy: lanes measured 14.7 against 15.8 Grays/s there)
+    R.want_host_stats = !(host_image_sum && (R.flags & PT_ASYNC_IMAGE));
     int rc = enqueue_batch(iter0, count);
-    R.ov_ok = false;
+    R.ov_ok = false; R.want_host_stats = false;
     if (rc) return rc;
     if (host_image_sum && (R.flags & PT_ASYNC_IMAGE)) return enqueue_async_image(host_image_sum);
     if (host_image_sum) {
@@ -1710,8 +1764,9 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
     if (host_image_sum && !(R.flags & PT_ASYNC_IMAGE) && R.epi_enabled && !R.use_graphs && R.map.tile_count == 1)
         R.epi_host = map_host(host_image_sum, (size_t)R.npix * 12);
     R.ov_ok = false;       // (PT_ASYNC_IMAGE calls are bound by their 7.68 MB copy: lanes measured 14.7 against 15.8 Grays/s there)
+    R.want_host_stats = !(host_image_sum && (R.flags & PT_ASYNC_IMAGE));
     int rc = enqueue_batch(iter, 1);
-    R.ov_ok = false;
+    R.ov_ok = false; R.want_host_stats = false;
     const bool gathered = R.epi_done;
     R.epi_host = nullptr; R.epi_done = false;
     if (rc) return rc;
