@@ -123,44 +123,53 @@ uint32_t pto_make_seeded_engine(int iter, int index, int depth) {
 /* ------------------------------------------------------------------------ */
 /* shared sin/cos (build-defined; DESIGN.md "shared trig")                   */
 /* ------------------------------------------------------------------------ */
-/* sin/cos of a float argument evaluated in binary64 with only + - * and
- * a round-to-int by the 1.5*2^52 trick, then rounded once to binary32.  The
- * HIP kernels implement the identical sequence (no FMA), so the result is
- * bit-identical on host and device; it equals the correctly rounded
- * sinf/cosf except where the binary64 value falls within ~1e-16 relative of
- * a binary32 rounding boundary.  Valid for |x| < 1e5 (the path tracer only
- * needs [0, 2*pi]).  Polynomial coefficients: fdlibm k_sin.c / k_cos.c. */
+/* sin/cos of a float argument in binary32 with explicit fused multiply-adds -- fmaf() here, v_fma_f32 in the HIP
+ * kernels (csrc/pt_device.hpp: sincos_shared), the same sequence operation for operation, so the result is
+ * bit-identical on host and device (checked on EVERY float of [0, 2 pi]: tests/test_gpu_pins.py).
+ *   k  = x * 2/pi rounded to nearest (1.5 * 2^23 trick);   r + rl = x - k pi/2 in two floats (three-constant Cody-Waite,
+ *        every step one fma: exact to 2^-36);
+ *   sin(r) = r + (r z (S1 + z (S2 + z (S3 + z S4))) + rl (1 - z/2)),          z = r r, S = minimax fit on [-pi/4, pi/4]
+ *   cos(r) = w + (z z (C1 + z (C2 + z C3)) + ((1 - w) - z/2 - ze/2 - rl sin r)),  w = fl(1 - z/2), ze = r r - z exactly
+ * and the quadrant k mod 4 picks and signs the two.  Within 1 ulp of the correctly rounded value on every float of
+ * [0, 2 pi] and correctly rounded on 98.6 % of a uniform grid over it (oracle test_shared_sincos_accuracy) -- what the
+ * libms the reference can bind to deliver (CUDA's sinf / cosf: 1 ulp; glibc's: < 1 ulp).  Rounds 1-3 evaluated fdlibm's
+ * binary64 polynomials instead: ~40 binary64 instructions at twice the issue cost inside the kernels' scatter block
+ * (9 % of k_bounce's issue cycles).  Valid for |x| < 2^22 (the path tracer needs [0, 2 pi]). */
 void pto_sincos(float x, float *s, float *c) {
-    static const double TWO_OVER_PI = 6.36619772367581382433e-01; /* 0x3FE45F306DC9C883 */
-    static const double PIO2_1  = 1.57079632673412561417e+00;     /* first 33 bits of pi/2 */
-    static const double PIO2_1T = 6.07710050650619224932e-11;     /* pi/2 - PIO2_1 */
-    static const double MAGIC = 6755399441055744.0;               /* 1.5 * 2^52 */
-    static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                        S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                        S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                        C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                        C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double xd = (double)x;
-    double kd = (xd * TWO_OVER_PI + MAGIC) - MAGIC;   /* nearest integer, ties-to-even */
-    double r = (xd - kd * PIO2_1) - kd * PIO2_1T;
-    double z = r * r;
-    /* sin(r) = r + r*z*(S1 + z*(S2 + z*(S3 + z*(S4 + z*(S5 + z*S6))))) */
-    double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
-    double sn = r + (r * z) * ps;
-    /* cos(r) = 1 - z/2 + z*z*(C1 + z*(C2 + ... )) */
-    double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
-    double cs = (1.0 - 0.5 * z) + (z * z) * pc;
-    int q = (int)kd & 3;
-    double so, co;
+    static const float TWO_OVER_PI = 0.636619772367581343f;      /* 0x3f22f983 */
+    static const float MAGIC = 12582912.0f;                       /* 1.5 * 2^23 */
+    static const float P1 = 1.57079625129699707031f;             /* 0x3fc90fda: pi/2 truncated to 24 bits */
+    static const float P2 = 7.54978941586159635335e-08f;          /* 0x33a22168: fl(pi/2 - P1) */
+    static const float P3 = 5.39030285815811905290e-15f;          /* 0x27c234c4: fl(pi/2 - P1 - P2) */
+    static const float S1 = -1.66666671633720398e-01f, S2 = 8.33333190530538559e-03f,      /* 0xbe2aaaab 0x3c088887 */
+                       S3 = -1.98401714442297816e-04f, S4 = 2.72681563728838228e-06f;      /* 0xb9500a0e 0x3636fe56 */
+    static const float C1 = 4.16666530072689056e-02f, C2 = -1.38876168057322502e-03f,      /* 0x3d2aaaa7 0xbab6071c */
+                       C3 = 2.44678121816832572e-05f;                                       /* 0x37cd403a */
+    float kf = fmaf(x, TWO_OVER_PI, MAGIC) - MAGIC;   /* nearest integer, ties-to-even */
+    float r1 = fmaf(-kf, P1, x);
+    float r = fmaf(-kf, P2, r1);
+    float rl = fmaf(-kf, P3, fmaf(-kf, P2, r1 - r));
+    float z = r * r;
+    float ze = fmaf(r, r, -z);
+    float ps = fmaf(z, fmaf(z, fmaf(z, S4, S3), S2), S1);
+    float pc = fmaf(z, fmaf(z, C3, C2), C1);
+    float hz = 0.5f * z;
+    float w = 1.0f - hz;
+    float e = (1.0f - w) - hz;
+    e = fmaf(-0.5f, ze, e);
+    float u = (r * z) * ps;
+    float sn = r + fmaf(rl, w, u);
+    float cs = w + fmaf(z * z, pc, fmaf(-rl, sn, e));
+    int q = (int)kf & 3;
+    float so, co;
     switch (q) {
     case 0: so = sn;  co = cs;  break;
     case 1: so = cs;  co = -sn; break;
     case 2: so = -sn; co = -cs; break;
     default: so = -cs; co = sn; break;
     }
-    *s = (float)so;
-    *c = (float)co;
+    *s = so;
+    *c = co;
 }
 
 /* The two checksums libptmi355.so's pt_probe_sincos forms on the device (include/ptmi355.h), here on the CPU: over the

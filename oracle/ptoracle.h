@@ -78,7 +78,7 @@ typedef struct { int geom_index, first_tri, tri_count; } pto_mesh;
 /* trig binding for calculateRandomDirectionInHemisphere (interactions.h:40-41):
  * the reference calls unqualified cos/sin, which bind to the platform libm.
  * PTO_TRIG_LIBM binds to this host's libm (sinf/cosf); PTO_TRIG_SHARED binds
- * to pto_sincos(), the double-precision polynomial that the HIP kernels also
+ * to pto_sincos(), the fused-multiply-add binary32 sequence that the HIP kernels also
  * implement op-for-op, so CPU and GPU agree bit-for-bit. */
 enum { PTO_TRIG_LIBM = 0, PTO_TRIG_SHARED = 1 };
 
