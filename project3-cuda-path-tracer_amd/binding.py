@@ -142,10 +142,14 @@ def library():
         L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pt_cull_boxes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
         L.pt_tri_bounds.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
-        L.pt_set_image.argtypes = [C.c_void_p]
-        L.pt_probe_rng.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        L.pt_probe_sincos.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.pt_probe_hemisphere.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        try:
+            L.pt_set_image.argtypes = [C.c_void_p]
+            L.pt_probe_rng.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            L.pt_probe_sincos.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.pt_probe_hemisphere.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        except AttributeError:
+            if not os.environ.get("PTMI355_LIB"):        # only an older A/B build (profiles/tools/ab.sh) may lack them
+                raise
         L.pt_free.restype = None
         L.pt_exchange_transport.restype = C.c_char_p
         _lib = L

@@ -1763,7 +1763,7 @@ __device__ uint32_t g_wave_hw[8][8192];
 #endif
 
 template <int MODE, bool COMPACT, int MESH, bool SLDS, bool GEN = false, bool SORT = false>
-__global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : (SORT && MODE == MODE_FUSED && MESH == MESH_NONE) ? PT_SORT_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
+__global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH == MESH_PRE && PT_PRE_WAVES > PT_MIN_WAVES) ? PT_PRE_WAVES : (SORT && MODE == MODE_FUSED && MESH == MESH_NONE) ? PT_SORT_WAVES : (MODE == MODE_FUSED && COMPACT && MESH == MESH_NONE && !SORT && PT_FUSED_WAVES > PT_MIN_WAVES) ? PT_FUSED_WAVES : PT_MIN_WAVES) void k_bounce(BounceArgs a) {
 #ifdef PT_WAVE_TIMES
     const unsigned long long wt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1868,6 +1868,47 @@ __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH =
 #ifdef PT_STAMPS
             if (threadIdx.x == 0 && a.depth == PT_STAMPS) { a.ctl->stamp[8] = t0; a.ctl->stamp[9] = __builtin_amdgcn_s_memrealtime(); }
 #endif
+        }
+    }
+}
+
+// k_iteration's traced counts, iter_counts[bounce][workgroup] (plain stores, nothing cleared beforehand), added up by ONE
+// workgroup of BLOCK threads: Control::alive[bounce], the session's persistent counters and -- synchronous calls -- the
+// page-locked pt_stats block.  Eight bounces per pass: thread t takes bounce t / 32 and every 32nd workgroup from t % 32
+// on, the 32 partial sums of a bounce meet in a half-wave shuffle.  (A serial loop over the bounces with two barriers
+// each, tried first at the end of k_iteration, cost every launch ~30 us of tail: 1 spp per call 27.3 -> 24.8 Grays/s.)
+__device__ __forceinline__ void fold_iter_counts(const uint32_t *counts, uint32_t G, int depth, Control *ctl, Persist *per, HostStats *hs,
+                                                 uint32_t iterations, uint32_t serial, uint32_t *lds /* >= BLOCK / 32 words */) {
+    constexpr int PER_PASS = BLOCK / 32;
+    unsigned long long rays = 0;
+    uint32_t first = 0;
+    for (int d0 = 0; d0 < depth; d0 += PER_PASS) {
+        const int d = d0 + (int)(threadIdx.x >> 5);
+        uint32_t sum = 0;
+        if (d < depth)
+            for (uint32_t b = threadIdx.x & 31u; b < G; b += 32u)
+                sum += __hip_atomic_load(&counts[(uint32_t)d * G + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int off = 16; off > 0; off >>= 1) sum += __shfl_down(sum, off, 32);
+        if ((threadIdx.x & 31u) == 0) lds[threadIdx.x >> 5] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int k = 0; k < PER_PASS && d0 + k < depth; ++k) {
+                const uint32_t tot = lds[k];
+                ctl->alive[d0 + k] = tot;
+                if (hs) hs->alive[d0 + k] = tot;
+                rays += tot;
+                if (d0 + k == 0) first = tot;
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&per->rays, rays);
+        atomicAdd(&per->iterations, (unsigned long long)iterations);
+        atomicAdd(&per->first_rays, (unsigned long long)first);
+        if (hs) {
+            for (int d = depth; d <= MAX_DEPTH; ++d) hs->alive[d] = 0;
+            hs->error = 0;
+            __hip_atomic_store(&hs->serial, serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -2006,54 +2047,25 @@ __global__ __launch_bounds__(BLOCK, PT_ITER_WAVES) void k_iteration(BounceArgs a
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
-    // ---- the launch's last workgroup folds the traced counts (what k_gather's thread 0 did after a per-batch clear of
-    // 32 x depth atomic buckets: one hipMemsetAsync and one more launch around every iteration at 1 spp per call) ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's count (and image) stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const bool last = elect_last_self_clearing(karg_field<Control *>(offsetof(BounceArgs, ctl))->ticket);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        xcnt[0] = last ? 1u : 0u;
-    }
-    __syncthreads();
-    if (xcnt[0]) {
-        // thread t sums its share of every bounce's column; the four waves' sums cross through the LDS control words
-        const uint32_t *const counts = karg_field<uint32_t *>(offsetof(BounceArgs, iter_counts));
-        Control *const ctl = karg_field<Control *>(offsetof(BounceArgs, ctl));
-        HostStats *const hs = karg_field<HostStats *>(offsetof(BounceArgs, host_stats));
-        const int depth = karg_field<int>(offsetof(BounceArgs, trace_depth));
-        unsigned long long rays = 0;
-        uint32_t first = 0;
-        for (int d = 0; d < depth; ++d) {
-            uint32_t sum = 0;
-            for (uint32_t b = threadIdx.x; b < gridDim.x; b += BLOCK)
-                sum += __hip_atomic_load(&counts[(uint32_t)d * gridDim.x + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
-            if (lane == 0) xcnt[4 + wave] = sum;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const uint32_t tot = xcnt[4] + xcnt[5] + xcnt[6] + xcnt[7];
-                ctl->alive[d] = tot;
-                if (hs) hs->alive[d] = tot;
-                rays += tot;
-                if (d == 0) first = tot;
-            }
-            __syncthreads();
-        }
+    // ---- a launch that did its own finalGather also folds its traced counts: its last workgroup out adds the columns
+    // of iter_counts up (fold_iter_counts) -- no k_gather runs behind it.  Otherwise k_gather's first workgroup does.
+    if (epi_image) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's count and image stores have left
+        __syncthreads();
         if (threadIdx.x == 0) {
-            Persist *const per = karg_field<Persist *>(offsetof(BounceArgs, persist));
-            atomicAdd(&per->rays, rays);
-            atomicAdd(&per->iterations, (unsigned long long)(n / (uint32_t)karg_field<int>(offsetof(BounceArgs, map) + offsetof(TileMap, tile_pixels))));
-            atomicAdd(&per->first_rays, (unsigned long long)first);
-            if (hs) {
-                for (int d = depth; d <= MAX_DEPTH; ++d) hs->alive[d] = 0;
-                hs->error = 0;
-                __hip_atomic_store(&hs->serial, c.stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const bool last = elect_last_self_clearing(karg_field<Control *>(offsetof(BounceArgs, ctl))->ticket);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            xcnt[0] = last ? 1u : 0u;
         }
+        __syncthreads();
+        if (xcnt[0])
+            fold_iter_counts(karg_field<uint32_t *>(offsetof(BounceArgs, iter_counts)), gridDim.x, karg_field<int>(offsetof(BounceArgs, trace_depth)),
+                             karg_field<Control *>(offsetof(BounceArgs, ctl)), karg_field<Persist *>(offsetof(BounceArgs, persist)),
+                             karg_field<HostStats *>(offsetof(BounceArgs, host_stats)),
+                             n / (uint32_t)karg_field<int>(offsetof(BounceArgs, map) + offsetof(TileMap, tile_pixels)), c.stamp, xcnt + 4);
     }
 }
 
@@ -2597,11 +2609,15 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fake(Pool p, Isect is, const fl
 // pixel per iteration, samples added in iteration order
 __global__ __launch_bounds__(BLOCK) void k_gather(float *image, const float *fin, uint32_t cap, TileMap map,
                                                   int count, Control *ctl, Persist *per, int depths,
-                                                  uint32_t fake_rays, int partial_counts, int counters_only, uint32_t stamp_arg) {
+                                                  uint32_t fake_rays, int partial_counts, int counters_only, uint32_t stamp_arg,
+                                                  const uint32_t *iter_counts, uint32_t iter_grid, HostStats *host_stats) {
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j == 0 && !partial_counts) { // fold this batch's ray count into the persistent counter (k_iteration's last workgroup
-                                     // has done it for its batch: partial_counts; batches of different lanes may run
-                                     // side by side, hence atomics)
+    if (partial_counts) {            // the batch ran as ONE launch (k_iteration): its per-workgroup counts are added up here
+        __shared__ uint32_t fold_lds[BLOCK / 32];
+        if (blockIdx.x == 0)
+            fold_iter_counts(iter_counts, iter_grid, depths, ctl, per, host_stats, (uint32_t)count, batch_stamp(stamp_arg, ctl), fold_lds);
+    } else if (j == 0) {             // fold this batch's ray count into the persistent counters (batches of different lanes may
+                                     // run side by side, hence atomics)
         unsigned long long r = fake_rays;
         for (int d = 0; d < depths; ++d) r += ctl->alive[d];
         atomicAdd(&per->rays, r);

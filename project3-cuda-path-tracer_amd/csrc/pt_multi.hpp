@@ -99,6 +99,11 @@ struct RcclApi {
                         g_rccl.GetErrorString(r_));                                                \
     } while (0)
 
+// staging slots per context: call i uses slot i % XSLOTS, so the tracing runs up to XSLOTS exchanges ahead of the slowest
+// one (round 3 had two: at one exchange per iteration the LATENCY of an exchange -- pack, RCCL's own bookkeeping copies
+// and clears, its kernel, the unpack, ~0.3 ms end to end -- then paced the iterations, not its throughput)
+constexpr int XSLOTS = 4;
+
 // ---- one host thread per device context ------------------------------------------------------------------------
 struct Worker {
     Renderer ctx;
@@ -113,11 +118,11 @@ struct Worker {
     int rc = PT_OK;
     // exchange state of this context (device `device`)
     hipStream_t xs = nullptr;                   // exchange stream
-    float *pack[2] = {nullptr, nullptr};         // packed tile rows, two slots
-    hipEvent_t ev_packed[2] = {nullptr, nullptr};   // slot s packed (launch stream)
-    hipEvent_t ev_sent[2] = {nullptr, nullptr};     // slot s has left this device (exchange stream)
-    bool sent_once[2] = {false, false};
-    float *stage[2] = {nullptr, nullptr};        // ON THE ROOT DEVICE: where this context's rows land
+    float *pack[XSLOTS] = {};                    // packed tile rows, one per slot
+    hipEvent_t ev_packed[XSLOTS] = {};           // slot s packed (launch stream)
+    hipEvent_t ev_sent[XSLOTS] = {};             // slot s has left this device (exchange stream)
+    bool sent_once[XSLOTS] = {};
+    float *stage[XSLOTS] = {};                   // ON THE ROOT DEVICE: where this context's rows land
     size_t floats = 0;                           // tile_pixels * 3
     TileMap map{};
 
@@ -210,10 +215,10 @@ struct Group {
     bool use_rccl = false;
     bool self_exchange = false;                 // K == 1 over RCCL (rehearsal: every RCCL call with a communicator of one)
     std::vector<ncclComm_t> comms;
-    hipEvent_t ev_frame[2] = {nullptr, nullptr};    // slot s unpacked into the frame (root's exchange stream)
-    bool frame_once[2] = {false, false};
+    hipEvent_t ev_frame[XSLOTS] = {};           // slot s unpacked into the frame (root's exchange stream)
+    bool frame_once[XSLOTS] = {};
     uint64_t exchanges = 0;                     // exchanges enqueued (by whichever thread issues them)
-    uint64_t calls = 0;                         // calls made (caller's thread): call i uses staging slot i & 1
+    uint64_t calls = 0;                         // calls made (caller's thread): call i uses staging slot i % XSLOTS
     std::unique_ptr<Exchanger> x;               // asynchronous batches hand their exchange to this thread
     float *frame = nullptr;                     // where the tiles are assembled: context 0's accumulation buffer -- except in the
                                                 // one-context RCCL rehearsal, where it is a buffer of its own (self_frame)
@@ -325,7 +330,7 @@ int exchange_settled(void) {
 }
 
 int multi_enqueue(int iter0, int count, bool overlap = false) {
-    const int s = (int)(G.calls & 1);
+    const int s = (int)(G.calls % XSLOTS);
     int rc = on_all([&](Worker &w) -> int {
         R.in_step = false;
         R.ov_ok = overlap;
@@ -382,8 +387,8 @@ void multi_free(void) {
         if (!G.w.empty()) {
             (void)hipSetDevice(G.w[0]->device);
             for (auto &wp : G.w)
-                for (int s = 0; s < 2; ++s) if (wp->stage[s]) (void)hipFree(wp->stage[s]);
-            for (int s = 0; s < 2; ++s) if (G.ev_frame[s]) (void)hipEventDestroy(G.ev_frame[s]);
+                for (int s = 0; s < XSLOTS; ++s) if (wp->stage[s]) (void)hipFree(wp->stage[s]);
+            for (int s = 0; s < XSLOTS; ++s) if (G.ev_frame[s]) (void)hipEventDestroy(G.ev_frame[s]);
             if (G.self_frame) (void)hipFree(G.self_frame);
         }
     }
@@ -391,7 +396,7 @@ void multi_free(void) {
         Worker *w = wp.get();
         if (!w->th.joinable()) continue;
         w->post([w] {
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < XSLOTS; ++s) {
                 if (w->pack[s]) (void)hipFree(w->pack[s]);
                 if (w->ev_packed[s]) (void)hipEventDestroy(w->ev_packed[s]);
                 if (w->ev_sent[s]) (void)hipEventDestroy(w->ev_sent[s]);
@@ -473,8 +478,18 @@ int multi_init(const pt_scene_desc *d, const std::vector<int> &devs) {
         if (r) return r;
         w.map = R.map;
         w.floats = (size_t)R.map.tile_pixels * 3;
-        HIPCHK(hipStreamCreateWithFlags(&w.xs, hipStreamNonBlocking));
-        for (int s = 0; s < 2; ++s) {
+        {   // the exchange stream outranks the launch streams: its kernels (the pack's successor RCCL kernel, the unpack) are
+            // a few workgroups each and must not queue behind the persistent grids of the batches in flight, whose
+            // workgroups otherwise take every slot a retiring workgroup frees
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+            if (getenv("PTMI355_XCHG_PRIO") && atoi(getenv("PTMI355_XCHG_PRIO")) == 0) hi = lo = 0;
+            if (hipStreamCreateWithPriority(&w.xs, hipStreamNonBlocking, hi) != hipSuccess) {
+                (void)hipGetLastError();
+                HIPCHK(hipStreamCreateWithFlags(&w.xs, hipStreamNonBlocking));
+            }
+        }
+        for (int s = 0; s < XSLOTS; ++s) {
             if (w.index != 0 || G.self_exchange) HIPCHK(hipMalloc(&w.pack[s], w.floats * 4));
             HIPCHK(hipEventCreateWithFlags(&w.ev_packed[s], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&w.ev_sent[s], hipEventDisableTiming));
@@ -487,8 +502,8 @@ int multi_init(const pt_scene_desc *d, const std::vector<int> &devs) {
         Worker &root = *G.w[0];
         HIPCHK(hipSetDevice(root.device));
         for (int k = G.self_exchange ? 0 : 1; k < K; ++k)
-            for (int s = 0; s < 2; ++s) HIPCHK(hipMalloc(&G.w[(size_t)k]->stage[s], G.w[(size_t)k]->floats * 4));
-        for (int s = 0; s < 2; ++s) HIPCHK(hipEventCreateWithFlags(&G.ev_frame[s], hipEventDisableTiming));
+            for (int s = 0; s < XSLOTS; ++s) HIPCHK(hipMalloc(&G.w[(size_t)k]->stage[s], G.w[(size_t)k]->floats * 4));
+        for (int s = 0; s < XSLOTS; ++s) HIPCHK(hipEventCreateWithFlags(&G.ev_frame[s], hipEventDisableTiming));
         // The frame is context 0's accumulation buffer: the peers' rows are unpacked beside the rows it sums itself.  In the
         // one-context rehearsal the "peer" is the root, and unpacking its rows over themselves would make every gather
         // wait for the previous exchange (a dependency real peers do not have: round 3 measured the rehearsal at 13.5

@@ -9,6 +9,11 @@ namespace {
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4                     // waves per SIMD the bounce kernels are register-budgeted for
 #endif
+#ifndef PT_FUSED_WAVES
+#define PT_FUSED_WAVES 6                     // the plain fused k_bounce (no mesh, no material keys): 79 VGPRs when left alone in round 3 -- six
+                                             // workgroups per CU -- and 82 after the scatter block changed in round 4; capped at 80 the register
+                                             // allocator finds the 79 again without a spill
+#endif
 #ifndef PT_ISECT_WAVES
 #define PT_ISECT_WAVES 4                     // k_intersect (unfused / sorted pipelines)
 #endif

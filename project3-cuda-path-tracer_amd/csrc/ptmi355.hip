@@ -565,7 +565,8 @@ int enqueue_end(void) {
                        R.final_mem, R.cap, R.map,
                        R.step_count, R.ctl, R.persist, (R.flags & PT_FAKE_SHADER) ? 0 : R.trace_depth,
                        (R.flags & PT_FAKE_SHADER) ? (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count : 0u,
-                       R.whole ? 1 : 0, R.epi_done ? 1 : 0, R.capturing ? 0u : R.fin_serial);
+                       R.whole ? 1 : 0, R.epi_done ? 1 : 0, R.capturing ? 0u : R.fin_serial, R.iter_counts, (uint32_t)R.grid_iter,
+                       (R.whole && R.host_stats_serial) ? R.d_stats : (HostStats *)nullptr);
     R.whole = false;
     HIPCHK(hipGetLastError());
     if (R.lane_cur) {
@@ -738,6 +739,8 @@ int enqueue_batch_serial(int iter0, int count) {
             if (R.epi_host) R.epi_done = true;
             R.self_gathered = true;
         }
+        // a synchronous call's statistics go straight to page-locked host memory: written by whoever folds the counts, this
+        // launch's last workgroup (own finalGather) or k_gather's first
         if (R.want_host_stats && !R.capturing && !R.use_graphs && R.d_stats) { a.host_stats = R.d_stats; R.host_stats_serial = R.fin_serial; }
         if (R.scene_lds) hipLaunchKernelGGL(k_iteration<true>, dim3(R.grid_iter), dim3(BLOCK), R.lds_bytes, R.stream, a);
         else hipLaunchKernelGGL(k_iteration<false>, dim3(R.grid_iter), dim3(BLOCK), R.lds_bytes, R.stream, a);

@@ -1667,6 +1667,53 @@ def test_c5_tile_of_4k_frame(pt, po, scenes):
     assert not img[other].any()                           # zero-padded elsewhere: reduce(SUM) is exact
 
 
+def c5_pooled_statistic(img_sum, samples, golden):
+    """BASELINE C5 against the reference's only rendered artefact: the 4K frame has the 800x800 scene's FOVY, so its
+    central 2160x2160 square IS that view (2.7 x finer); saveImage's x-flip, clamp and 8-bit quantisation, then the 50x50
+    pooled means of tests/golden/png_stat.npz (bins of 43.2 pixels, edges rounded), ball / reflection / shadow masked."""
+    W, H = 3840, 2160
+    img = (np.asarray(img_sum, dtype=np.float32).reshape(H, W, 3) / np.float32(samples))[:, ::-1, :]
+    img = np.floor(np.clip(img, 0, 1) * 255.0) / 255.0
+    sq = img[:, (W - H) // 2:(W + H) // 2, :]
+    edges = np.round(np.arange(51) * (H / 50.0)).astype(int)
+    rows = np.add.reduceat(sq, edges[:-1], axis=0)
+    cells = np.add.reduceat(rows, edges[:-1], axis=1)
+    area = np.diff(edges)[:, None] * np.diff(edges)[None, :]
+    pooled = cells / area[:, :, None]
+    want = golden["png_stat"]["pooled"]
+    mask = np.ones((50, 50), dtype=bool)
+    mask[22:40, 12:32] = False
+    return float(np.sqrt(((pooled - want)[mask] ** 2).sum()) / np.sqrt((want[mask] ** 2).sum()))
+
+
+def test_c5_as_stated_5000spp_through_eight_contexts(pt, golden, tmp_path, launch_plan):
+    """BASELINE config C5 AS STATED, on the one GPU of this box: scenes/cornell_4k.txt (3840x2160, depth 8) for its 5000
+    iterations through the headless host with the frame tiled over EIGHT contexts (`ptbench --devices 0,0,0,0,0,0,0,0`:
+    interleaved 8-row strips, a tile exchange after every batch, as on eight GPUs) -- 1.6 * 10^11 rays.  The image meets
+    the reference's 5000-sample PNG (pooled statistic, relative L2 <= 0.05), and a second render of the same frame --
+    ONE context, other batch size, interrupted after 2500 iterations and resumed from its saved sum in a new process
+    (`--save-sum` / `--resume`) -- gives the same running sum bit for bit."""
+    import subprocess
+    if launch_plan != "small batches in one launch":
+        pytest.skip("one 5000-spp 4K render per suite: the launch plans meet at this batch size")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = pt.build_ptbench()
+    scene = os.path.join(root, "scenes", "cornell_4k.txt")
+    run = lambda *a: subprocess.run([exe, scene] + list(a), capture_output=True, text=True, timeout=900)
+    p = run("--devices", "0,0,0,0,0,0,0,0", "--batch", "4", "--out", str(tmp_path / "m"), "--save-sum")
+    assert p.returncode == 0 and "5000 iterations" in p.stdout and "on 8 device(s)" in p.stdout, p.stdout + p.stderr
+    full = pt.load_pfm(str(tmp_path / "m.5000samp.sum.pfm"), 3840, 2160)
+    stat = c5_pooled_statistic(full, 5000, golden)
+    assert stat <= 0.05, stat
+    assert np.isfinite(full).all() and full.min() >= 0.0
+    p = run("--iters", "2500", "--batch", "5", "--out", str(tmp_path / "s"), "--save-sum")
+    assert p.returncode == 0, p.stdout + p.stderr
+    p = run("--batch", "5", "--out", str(tmp_path / "s"), "--resume", str(tmp_path / "s.2500samp.sum.pfm"), "--save-sum")
+    assert p.returncode == 0 and "resumed" in p.stdout, p.stdout + p.stderr
+    again = pt.load_pfm(str(tmp_path / "s.5000samp.sum.pfm"), 3840, 2160)
+    assert again.tobytes() == full.tobytes()
+
+
 def test_division_fast_path_gates(pt, po, scenes, golden):
     """The rescale-free divide / sqrt sequences (csrc/pt_device.hpp: div_by_rcp, sqrt_normal_range) are
     gated per wave; rays on both sides of every gate (direction components around 2^-40, origins around
