@@ -28,7 +28,7 @@ oracle on this host's cores, rank 0, N = 1 only).  The kernel is bound by vector
 each opcode measured one by one: profiles/tools/isa_count.py, profiles/microbench/gen_issue_ops.py) over 1024 SIMDs x
 2.4 GHz x the launch time measured here with HIP events; the measured HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE), the
 fp32 rate and the active-lane fraction ride along, and `roofline.timed_pass` states the same cycles over the timed
-pass's own time per step.  The counter profile (profiles/traffic.json, written by profiles/collect_r03.py) is keyed
+pass's own time per step.  The counter profile (profiles/traffic.json, written by profiles/collect.py) is keyed
 by a hash of the kernel sources and compile flags: after any kernel change the counter-derived fields are null until
 the collection has been re-run.
 """
@@ -512,7 +512,7 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
       * HBM: FETCH_SIZE x 2 + WRITE_SIZE per launch (separate rocprofv3 --pmc passes) over 8 TB/s;
       * fp32: the histogram's floating-point operations x the active-lane fraction (SQ_THREAD_CYCLES_VALU) over 157.3 TF.
     `bound` is whichever of vector issue and HBM is closer to its roof; `frac` is that fraction, never above 1 by
-    construction.  Without a counter profile of exactly this build and command line (profiles/collect_r03.py ->
+    construction.  Without a counter profile of exactly this build and command line (profiles/collect.py ->
     profiles/traffic.json) the counter-derived fields are null rather than stale.
     The event pass runs its steps one after the other on the launch stream; in the timed pass consecutive steps overlap
     on the device (csrc/ptmi355.hip: enqueue_batch_direct), so `value` can exceed `grays_per_s_in_kernel`.
@@ -535,7 +535,7 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
                                                    "note": "152 B per ray + 88 B per survivor of the reference's separate kernels; not what this kernel moves"}
     if not t:
         return dict(common, kernel=None, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
-                    source="no counter profile for this build and command line (python3 profiles/collect_r03.py)")
+                    source="no counter profile for this build and command line (python3 profiles/collect.py)")
     ks = t["kernels"]
     stages = sorted({k["stage"] for k in ks.values() if k["stage"] in stage_ms}, key=lambda s_: -stage_ms[s_])
     if not stages:
@@ -554,7 +554,7 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
     names = " + ".join(sorted({k["name"].split("(")[0] for k in sel}))
     r = dict(common, kernel=names, stage=st, launches_per_step=nl, avg_launch_us=round(per_step_s / nl * 1e6, 2),
              traffic=int(byt / nl) if byt else None,
-             source="profiles/traffic.json@build:%s (profiles/collect_r03.py: instrumented-build opcode histogram, rocprofv3 --pmc passes)" % t["build_sha16"],
+             source="profiles/traffic.json@build:%s (profiles/collect.py: instrumented-build opcode histogram, rocprofv3 --pmc passes)" % t["build_sha16"],
              valu_issue={"achieved": round(cyc / per_step_s / 1e9, 1), "peak": round(SIMDS * PEAK_CLOCK_GHZ, 1), "unit": "G SIMD issue-cycles/s",
                          "frac": round(issue_frac, 4), "issue_cycles_per_launch": int(cyc / nl),
                          "valu_insts_per_ray": round(64.0 * sum(k["launches_per_step"] * k.get("wave_insts_per_launch", {}).get("valu", 0.0) for k in sel) /
@@ -584,7 +584,7 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
 
 
 def counter_profile(args, world):
-    """The entry of profiles/traffic.json (written by profiles/collect_r03.py) for THIS build (hash of the kernel
+    """The entry of profiles/traffic.json (written by profiles/collect.py) for THIS build (hash of the kernel
     sources and the compile flags) and THIS command line; None otherwise -- stale counters are never reported."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if world != 1 or not os.path.exists(path):

@@ -54,6 +54,63 @@ __global__ __launch_bounds__(256) void k_write_rows(float *pool, uint32_t tiles_
         packed += keep;
     }
 }
+// 5b/5c/5d: the survivor stores as k_bounce really issues them -- the surviving lanes are SCATTERED over the wave (here: a
+// hash keeps ~70 %), their destinations are consecutive (packed + rank among the survivors).  keys = 1: one stream, the
+// plain kernel.  keys = 4: every survivor carries a material key, destination = key's own span + the wave's count for
+// that key + rank among the tile's survivors with that key -- four interleaved streams, the material-keyed kernel
+// (PT_SORT_MATERIAL, fused form).  staged: the tile's survivors are first sorted by key through the wave's LDS strip, so
+// that lane i stores the i-th survivor in (key, lane) order and every stream is a run of ADJACENT lanes.
+__device__ __forceinline__ uint32_t rank_below64(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+template <int KEYS, bool STAGED>
+__global__ __launch_bounds__(256) void k_write_keyed(float *pool, uint32_t tiles_per_wave, uint32_t key_stride, unsigned long long *written) {
+    __shared__ float stage[4][11 * 64];
+    const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    float *st = stage[threadIdx.x >> 6];
+    uint32_t have[KEYS];
+#pragma unroll
+    for (int k = 0; k < KEYS; ++k) have[k] = 0;
+    const uint32_t base = wave * tiles_per_wave * 64;
+    unsigned long long total = 0;
+    for (uint32_t t = 0; t < tiles_per_wave; ++t) {
+        uint32_t h = (wave * 8191u + t * 64u + lane) * 2654435761u;
+        h ^= h >> 13;
+        const bool alive = (h % 10u) < 7u;
+        const int key = KEYS == 1 ? 0 : (int)((h >> 20) % (uint32_t)KEYS);
+        uint32_t dst = 0, pos = 0, before = 0;
+#pragma unroll
+        for (int k = 0; k < KEYS; ++k) {
+            const uint64_t m = __builtin_amdgcn_ballot_w64(alive && key == k);
+            if (alive && key == k) { dst = (uint32_t)k * key_stride + base + have[k] + rank_below64(m); pos = before + rank_below64(m); }
+            have[k] += (uint32_t)__popcll((unsigned long long)m);
+            before += (uint32_t)__popcll((unsigned long long)m);
+        }
+        total += before;
+        float f[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) f[k] = (float)(t + k) + (float)lane;
+        if (!STAGED) {
+            if (alive) {
+                char *p = slot(pool, dst);
+#pragma unroll
+                for (int k = 0; k < 10; ++k) *reinterpret_cast<float *>(p + k * 256) = f[k];
+            }
+        } else {
+            if (alive) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) st[k * 64 + pos] = f[k];
+                st[10 * 64 + pos] = __uint_as_float(dst);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < before) {
+                char *p = slot(pool, __float_as_uint(st[10 * 64 + lane]));
+#pragma unroll
+                for (int k = 0; k < 10; ++k) *reinterpret_cast<float *>(p + k * 256) = st[k * 64 + lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    if (lane == 0) atomicAdd(written, total);
+}
 // 6: final colours: one 16-B store per ENDING path with a non-zero colour, index = pid.  `every`: one lane in `every`
 // stores (pids ascend with the lane: neighbours in the wave are `every` entries apart on average, hashed a little)
 __global__ __launch_bounds__(256) void k_write_fin(float4 *fin, size_t n, uint32_t every, uint32_t salt) {
@@ -86,6 +143,9 @@ int main() {
     CHECK(hipMemset(pool, 0, pool_bytes));
     CHECK(hipMemset(fin, 0, nfin * 16));
     CHECK(hipDeviceSynchronize());
+    unsigned long long *written;
+    CHECK(hipMalloc(&written, 64));
+    CHECK(hipMemset(written, 0, 64));
     const int grid = 256 * 6;
     const uint32_t waves = grid * 4;
     const uint32_t tpw = tiles / waves;
@@ -98,6 +158,10 @@ int main() {
         hipLaunchKernelGGL(k_write_rows, dim3(grid), dim3(256), 0, 0, pool, tpw, 64u);
         hipLaunchKernelGGL(k_write_rows, dim3(grid), dim3(256), 0, 0, pool, tpw, 45u);
         hipLaunchKernelGGL(k_write_dword, dim3(grid), dim3(256), 0, 0, pool, (size_t)tiles * TILE_BYTES / 4);
+        hipLaunchKernelGGL((k_write_keyed<1, false>), dim3(grid), dim3(256), 0, 0, pool, tpw, 0u, written + 0);
+        hipLaunchKernelGGL((k_write_keyed<1, true>), dim3(grid), dim3(256), 0, 0, pool, tpw, 0u, written + 1);
+        hipLaunchKernelGGL((k_write_keyed<4, false>), dim3(grid), dim3(256), 0, 0, pool, tpw / 4, waves * (tpw / 4) * 64, written + 2);
+        hipLaunchKernelGGL((k_write_keyed<4, true>), dim3(grid), dim3(256), 0, 0, pool, tpw / 4, waves * (tpw / 4) * 64, written + 3);
         hipLaunchKernelGGL(k_write_fin, dim3(grid), dim3(256), 0, 0, fin, nfin, 5u, 1u + rep);
         hipLaunchKernelGGL(k_write_fin, dim3(grid), dim3(256), 0, 0, fin, nfin, 1u, 3u + rep);
         hipLaunchKernelGGL(k_read_16, dim3(grid), dim3(256), 0, 0, (const float4 *)fin, nfin, sink);
@@ -114,6 +178,12 @@ int main() {
     printf("ALGO write_rows_keep64      read_MB 0 write_MB %.1f\n", mb((double)waves * tpw * 64 * 40));
     printf("ALGO write_rows_keep45      read_MB 0 write_MB %.1f\n", mb((double)waves * tpw * 45 * 40));
     printf("ALGO write_dword_pool       read_MB 0 write_MB %.1f\n", mb((double)tiles * TILE_BYTES));
+    unsigned long long wr[4];
+    CHECK(hipMemcpy(wr, written, 32, hipMemcpyDeviceToHost));
+    printf("ALGO write_sparse70_1key     read_MB 0 write_MB %.1f\n", mb((double)wr[0] / 2 * 40));
+    printf("ALGO write_sparse70_1key_lds read_MB 0 write_MB %.1f\n", mb((double)wr[1] / 2 * 40));
+    printf("ALGO write_sparse70_4key     read_MB 0 write_MB %.1f\n", mb((double)wr[2] / 2 * 40));
+    printf("ALGO write_sparse70_4key_lds read_MB 0 write_MB %.1f\n", mb((double)wr[3] / 2 * 40));
     printf("ALGO write_fin_one_in_5     read_MB 0 write_MB %.1f\n", mb((double)fin5 * 16));
     printf("ALGO write_fin_all          read_MB 0 write_MB %.1f\n", mb((double)nfin * 16));
     printf("ALGO read_16B_fin           read_MB %.1f write_MB 0\n", mb((double)nfin * 16));

@@ -36,22 +36,31 @@ def main():
         rows = []
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if r.get("Counter_Name") == ctr:
+                if r.get("Counter_Name") == ctr and ("k_read" in r["Kernel_Name"] or "k_write" in r["Kernel_Name"]):
                     rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
         # one row per (dispatch, XCD/instance) possibly: sum per dispatch
         per = {}
         for did, name, v in rows:
             per.setdefault(did, [name, 0.0])[1] += v
         readings[ctr] = [per[k] for k in sorted(per)]
+    # durations: a kernel trace of its own (never combined with counters)
+    d = os.path.join(OUT, "trace")
+    subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", exe], cwd="/tmp", env=env,
+                   stdout=open(os.path.join(OUT, "trace.log"), "w"), stderr=subprocess.STDOUT, timeout=600)
+    durs = []
+    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if ("k_read" in r["Kernel_Name"] or "k_write" in r["Kernel_Name"]))
+        durs = [(e - s0) / 1e3 for s0, e in rows]
     n = len(algo)
-    lines = ["%-24s %12s %14s %8s %12s %14s %8s" % ("pattern", "read MB", "FETCH_SIZE MB", "ratio", "write MB", "WRITE_SIZE MB", "ratio")]
+    lines = ["%-26s %10s %13s %7s %10s %13s %7s %9s %8s" % ("pattern", "read MB", "FETCH_SIZE MB", "ratio", "write MB", "WRITE_SIZE MB", "ratio", "us", "GB/s")]
     for rep in range(2):
         for i, (name, rmb, wmb) in enumerate(algo):
             k = rep * n + i
             f = readings["FETCH_SIZE"][k][1] * 1024 / 1e6 if k < len(readings["FETCH_SIZE"]) else float("nan")
             w = readings["WRITE_SIZE"][k][1] * 1024 / 1e6 if k < len(readings["WRITE_SIZE"]) else float("nan")
-            lines.append("%-24s %12.1f %14.1f %8s %12.1f %14.1f %8s" % (name + ("" if rep == 0 else " (2)"), rmb, f, "%.3f" % (f / rmb) if rmb else "-",
-                                                                      wmb, w, "%.3f" % (w / wmb) if wmb else "-"))
+            us = durs[k] if k < len(durs) else float("nan")
+            lines.append("%-26s %10.1f %13.1f %7s %10.1f %13.1f %7s %9.1f %8.0f" % (name + ("" if rep == 0 else " (2)"), rmb, f, "%.3f" % (f / rmb) if rmb else "-",
+                                                                                  wmb, w, "%.3f" % (w / wmb) if wmb else "-", us, (rmb + wmb) / us * 1e3 if us == us else 0))
     text = "\n".join(lines) + "\n"
     open(os.path.join(OUT, "hbm_calibration.txt"), "w").write(text)
     print(text)

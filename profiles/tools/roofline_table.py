@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Markdown table of a finished collection (profiles/collect_r03.py): one row per (configuration, kernel).
+"""Markdown table of a finished collection (profiles/collect.py): one row per (configuration, kernel).
 
   roofline_table.py profiles/r03
 
@@ -19,7 +19,7 @@ def main(d):
     print("| configuration | kernel | µs / launch | VALU insts / launch (PMC ÷ counted) | issue cycles / launch | issue frac | unpriced | "
           "active lanes | fp32 TFLOP/s | HBM MB / launch | HBM frac |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
-    for f in sorted(glob.glob(os.path.join(d, "roofline_r03_*.json"))):
+    for f in sorted(glob.glob(os.path.join(d, "roofline_r0*_*.json"))):
         r = json.load(open(f))
         for cb, k in r["kernels"].items():
             name = k["name"].split("(")[0]

@@ -137,7 +137,9 @@ class TileGatherThread:
         self.cuda = getattr(device, "type", str(device)) == "cuda"
         self.bytes_per_rank = self.g.bytes_per_rank
         if self.cuda:
-            self.side = torch.cuda.Stream(device)
+            # high priority: the pack's successors (RCCL's kernel, the frame assembly) are a few workgroups each and must not
+            # queue behind the persistent grids of the batches in flight (in-library form: csrc/pt_multi.hpp, same reason)
+            self.side = torch.cuda.Stream(device, priority=-1)
             self.ev_packed = [torch.cuda.Event() for _ in range(slots)]
             self.ev_free = [torch.cuda.Event() for _ in range(slots)]
         self.jobs = queue.SimpleQueue()
