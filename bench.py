@@ -277,7 +277,8 @@ def per_call_rates(c, n_it=128):
     L = pt.library()
 
     def run(flags, call):
-        pt.pathtraceInit(c.scene, flags=flags, device=c.local_rank, stream=c.stream.cuda_stream, max_batch=1)
+        # (the library's own launch stream, as a host that links libptmi355.so gets it -- not torch's)
+        pt.pathtraceInit(c.scene, flags=flags, device=c.local_rank, max_batch=1)
         for k in range(16):
             call(1 + k)
         pt.synchronize()

@@ -221,7 +221,7 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
                                           int depth, uint32_t first_tile, uint32_t count, uint32_t tiles,
                                           uint32_t n, bool packed_in, uint32_t span_in, uint32_t &cur, uint32_t dst_base,
                                           bool own_span, const WgSpans &ws, uint32_t &packed, uint32_t &traced,
-                                          uint32_t key_stride = 0) {
+                                          uint32_t key_stride = 0, bool aligned = false) {
     const int lane = c.lane;
     bool pending = false;
     TileRegs prev{};
@@ -250,6 +250,18 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
             if (L >= ws.p2) { off = L - ws.p2; b = ws.b2; }
             if (L >= ws.p3) { off = L - ws.p3; b = ws.b3; }
             src = b + off; i = src;
+        } else if (aligned) {
+            // tile `tile` of the range-aligned sequence (RangeDir): whole rows of ONE physical tile of the source pool
+            have = tile < tiles;
+            active = false; i = 0; src = 0;
+            if (have) {
+                const uint32_t *tb = a.dir_in.tbase();
+                while (tile >= tb[cur + 1]) ++cur;               // wave-uniform; empty ranges are stepped over
+                const uint32_t t64 = (tile - tb[cur]) * TILE + (uint32_t)lane;
+                active = t64 < a.dir_in.count()[cur];
+                src = cur * span_in + t64;
+                i = a.dir_in.base()[cur] + t64;
+            }
         } else {
             have = tile < tiles;
             i = tile * TILE + lane;                        // logical path index
@@ -338,21 +350,25 @@ __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH =
     c.iter0 = a.iter0 >= 0 ? a.iter0 : (int)a.ctl->iter0;       // graph replay: arguments are frozen
     c.stamp = batch_stamp(a.fin_stamp, a.ctl);
     const uint32_t n = (COMPACT && !GEN) ? a.ctl->nlive[a.depth] : a.pool_n;
-    const uint32_t tiles = (n + TILE - 1) / TILE;
-    const uint32_t R = range_tiles(n, W);                        // logical tiles per run (contiguous)
     const bool packed_in = COMPACT && !GEN && a.dir_in.mem != nullptr;
-    const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], a.dir_in.W) * TILE : 0;
+    // an unsorted packed pool is read in tiles aligned to its ranges (pt_types.hpp: RangeDir): `tiles` counts those
+    constexpr bool ALIGNED = PT_ALIGNED_TILES && MODE == MODE_FUSED && COMPACT && !GEN && !SORT;
+    const bool aligned = ALIGNED && packed_in;
+    const uint32_t tiles = aligned ? a.dir_in.tbase()[a.dir_in.nr] : (n + TILE - 1) / TILE;
+    const uint32_t R = (tiles + W - 1) / W;                      // tiles per run (contiguous)
+    const uint32_t span_in = packed_in ? *a.dir_in.span() : 0;   // slots per range, as the producer wrote it down
     uint32_t traced = 0;
     if (GEN && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->nlive[0] = a.pool_n;   // k_raygen's job otherwise
     for (uint32_t j = 0; j < runs_per_wave; ++j) {
         const uint32_t wid = j * Wp + wid0;
         uint32_t packed = 0;                                     // survivors of this run written so far (wave-uniform; SORT: lane k counts key k)
         uint32_t cur = 0;                                        // source range of the run's current position
-        if (packed_in && wid * R < tiles) cur = find_range(a.dir_in.base(), a.dir_in.nr, wid * R * TILE);
+        if (packed_in && wid * R < tiles)
+            cur = aligned ? find_range(a.dir_in.tbase(), a.dir_in.nr, wid * R) : find_range(a.dir_in.base(), a.dir_in.nr, wid * R * TILE);
         STAMP(2);
         // the run's R consecutive 64-path tiles; no workgroup barrier inside the loop
         run_tiles<MODE, COMPACT, MESH, GEN, SORT>(a, c, q, a.in, a.out, a.depth, wid * R, R, tiles, n, packed_in, span_in,
-                                                  cur, wid * R * TILE, false, WgSpans{}, packed, traced, W * R * TILE);
+                                                  cur, wid * R * TILE, false, WgSpans{}, packed, traced, W * R * TILE, aligned);
         if (COMPACT) {
             // every run publishes its range count(s); the last workgroup out scans them
             if (SORT) {
@@ -401,7 +417,7 @@ __global__ __launch_bounds__(BLOCK, MESH == MESH_TILES ? PT_LOOP_WAVES : (MESH =
         STAMP(7);
         if (sctl[0]) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            scan_range_counts(a.dir_out, &a.ctl->nlive[a.depth + 1], sctl + 2);
+            scan_range_counts(a.dir_out, &a.ctl->nlive[a.depth + 1], sctl + 16, R * TILE, PT_ALIGNED_TILES && !SORT);
             if (threadIdx.x == 0) a.ctl->scan_ticks[a.depth] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
 #ifdef PT_STAMPS
             if (threadIdx.x == 0 && a.depth == PT_STAMPS) { a.ctl->stamp[8] = t0; a.ctl->stamp[9] = __builtin_amdgcn_s_memrealtime(); }

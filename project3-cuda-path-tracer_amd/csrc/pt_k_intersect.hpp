@@ -170,7 +170,7 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
     const uint32_t tiles = (n + TILE - 1) / TILE;
     const uint32_t R = range_tiles(n, W);
     const bool packed = dir_in.mem && nprev_ptr;
-    const uint32_t span = packed ? range_tiles(*nprev_ptr, dir_in.W) * TILE : 0;
+    const uint32_t span = packed ? *dir_in.span() : 0;            // slots per range, as the producer wrote it down
     uint32_t cur = 0;
     if (packed && wid * R < tiles) cur = find_range(dir_in.base(), dir_in.nr, wid * R * TILE);
     auto finish = [&](uint32_t i, int par, const MeshBest &mb) {

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a
     const uint32_t R = range_tiles(n, W);
     const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
     const uint32_t Wd = a.dir_in.W;                               // waves of the grid that packed the pool
-    const uint32_t span_in = packed_in ? range_tiles(a.ctl->nlive[a.depth - 1], Wd) * TILE : 0;
+    const uint32_t span_in = packed_in ? *a.dir_in.span() : 0;    // slots per range, as the producer wrote it down
     MeshRings rg{0, 0, 0, 0};
     MeshWalker w;
     w.have = false; w.src = 0; w.path = 0; w.ray = bvh_ray(ptd::mk(0, 0, 0), ptd::mk(0, 0, 1), ptd::mk(0, 0, 0), ptd::mk(1, 1, 1));

@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t sp
 // (agent scope) and scans the W counts (<= 8 steps of 1024).  Nothing spins; nothing depends
 // on dispatch order.
 __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t *n_out,
-                                                  uint32_t *lds_scan /* >= 8 words */) {
+                                                  uint32_t *lds_scan /* >= 16 words */, uint32_t span_out, bool with_tiles) {
     // One step covers 8192 entries: thread t owns the `per` consecutive entries [t*per, (t+1)*per) of the step (per =
     // a multiple of 4, at most 32), loads them with 16-B loads all issued up front, and the 256 partial sums cross
     // through one wave scan + one LDS exchange.  W <= 8192 waves: one step; K * W ranges (survivors placed by
@@ -96,54 +96,68 @@ __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t 
     const uint32_t NR = dir.nr;
     const uint4 *count4 = reinterpret_cast<const uint4 *>(dir.count());
     uint4 *base4 = reinterpret_cast<uint4 *>(dir.base());
-    uint32_t carry = 0;
+    uint4 *tbase4 = reinterpret_cast<uint4 *>(dir.tbase());         // with_tiles: the same scan over ceil(count / 64) (RangeDir)
+    uint32_t carry = 0, tcarry = 0;
     for (uint32_t s0 = 0, step = 0; s0 < NR; s0 += 8192u, ++step) {
         const uint32_t W = min(8192u, NR - s0);                           // entries of this step
         const uint32_t per4 = ((W + BLOCK - 1) / BLOCK + 3) / 4;          // uint4s per thread, <= 8
         const uint32_t first = threadIdx.x * per4 * 4;                    // first entry of this thread within the step
-        uint4 v[8];
-        uint32_t sum = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
+        // (the counts are read twice -- once for the sums, again, from the L2, for the prefixes -- instead of being held in
+        // 32 registers across the barrier: this code runs once per launch in one workgroup, but its registers count
+        // against the whole kernel's budget, and at six workgroups per CU there are none to spare)
+        uint32_t sum = 0, tsum = 0;
+        auto tl = [](uint32_t c) { return (c + (uint32_t)TILE - 1u) / (uint32_t)TILE; };
+        auto load = [&](uint32_t k) {
             const uint32_t e = first + 4 * k;
-            v[k] = make_uint4(0, 0, 0, 0);
+            uint4 v = make_uint4(0, 0, 0, 0);
             if (k < per4 && e < W) {
-                v[k] = count4[(s0 + e) >> 2];                                // count[] is padded to a multiple of 4
-                if (e + 1 >= W) v[k].y = 0;
-                if (e + 2 >= W) v[k].z = 0;
-                if (e + 3 >= W) v[k].w = 0;
+                v = count4[(s0 + e) >> 2];                                   // count[] is padded to a multiple of 4
+                if (e + 1 >= W) v.y = 0;
+                if (e + 2 >= W) v.z = 0;
+                if (e + 3 >= W) v.w = 0;
             }
-            sum += v[k].x + v[k].y + v[k].z + v[k].w;
+            return v;
+        };
+        for (uint32_t k = 0; k < per4; ++k) {
+            const uint4 v = load(k);
+            sum += v.x + v.y + v.z + v.w;
+            tsum += tl(v.x) + tl(v.y) + tl(v.z) + tl(v.w);
         }
-        uint32_t incl = sum;
+        uint32_t incl = sum, tincl = tsum;
         for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t u = __shfl_up(incl, off);
-            if (lane >= off) incl += u;
+            const uint32_t u = __shfl_up(incl, off), tu = __shfl_up(tincl, off);
+            if (lane >= off) { incl += u; tincl += tu; }
         }
-        uint32_t *slot = lds_scan + (step & 1u) * WAVES;
-        if (lane == 63) slot[wave] = incl;
+        uint32_t *slot = lds_scan + (step & 1u) * (2 * WAVES);
+        if (lane == 63) { slot[wave] = incl; slot[WAVES + wave] = tincl; }
         __syncthreads();
-        uint32_t wave_off = 0, total = 0;
+        uint32_t wave_off = 0, total = 0, twave_off = 0, ttotal = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
-            const uint32_t c = slot[w];
-            if (w < wave) wave_off += c;
-            total += c;
+            const uint32_t c = slot[w], tc = slot[WAVES + w];
+            if (w < wave) { wave_off += c; twave_off += tc; }
+            total += c; ttotal += tc;
         }
-        uint32_t run = carry + wave_off + incl - sum;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
+        uint32_t run = carry + wave_off + incl - sum, trun = tcarry + twave_off + tincl - tsum;
+        for (uint32_t k = 0; k < per4; ++k) {
             const uint32_t e = first + 4 * k;
-            if (k < per4 && e < W) {
+            if (e < W) {
+                const uint4 v = load(k);
                 uint4 b;
-                b.x = run; b.y = b.x + v[k].x; b.z = b.y + v[k].y; b.w = b.z + v[k].z;
+                b.x = run; b.y = b.x + v.x; b.z = b.y + v.y; b.w = b.z + v.z;
                 base4[(s0 + e) >> 2] = b;                                    // base[] has 4 spare entries; steps start at multiples of 8192
-                run = b.w + v[k].w;
+                run = b.w + v.w;
+                if (with_tiles) {
+                    uint4 t;
+                    t.x = trun; t.y = t.x + tl(v.x); t.z = t.y + tl(v.y); t.w = t.z + tl(v.z);
+                    tbase4[(s0 + e) >> 2] = t;
+                    trun = t.w + tl(v.w);
+                }
             }
         }
-        carry += total;
+        carry += total; tcarry += ttotal;
     }
-    if (threadIdx.x == 0) { dir.base()[NR] = carry; *n_out = carry; }
+    if (threadIdx.x == 0) { dir.base()[NR] = carry; *n_out = carry; if (with_tiles) dir.tbase()[NR] = tcarry; *dir.span() = span_out; }
 }
 
 }  // namespace

@@ -16,7 +16,7 @@ namespace {
 // loads from global memory; what lanes gather individually (the matrices of the primitive a candidate names,
 // the material of a winner) is staged in LDS when the scene fits (SLDS) and read from global memory through
 // the vector cache when it does not (any number of primitives / materials).
-constexpr int LDS_CTL_WORDS = 16;    // [0] last-block flag, [2..5] scan scratch, [8..11] traced counts
+constexpr int LDS_CTL_WORDS = 32;    // [0] last-block flag, [8..11] traced counts, [16..31] the last workgroup's scan scratch (two steps x two sums x four waves)
 constexpr int GREC_WORDS = 36;       // gather record per geom: inverseTransform[12] transform[12] invTranspose[12], each
                                      // 4 columns x 3 rows.  Stride 36 words: records of 16 consecutive geoms start in
                                      // distinct 4-bank slots, so a ds_read_b128 by 64 lanes naming different geoms does

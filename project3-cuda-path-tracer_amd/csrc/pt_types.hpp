@@ -25,7 +25,9 @@ namespace {
 #define PT_ITER_WAVES PT_MIN_WAVES            // k_iteration: 92 VGPRs unconstrained (five workgroups per CU)
 #endif
 #ifndef PT_SORT_WAVES
-#define PT_SORT_WAVES PT_MIN_WAVES            // k_bounce with material keys: 84 VGPRs unconstrained (five workgroups per CU)
+#define PT_SORT_WAVES 6                      // k_bounce with material keys: 84-87 VGPRs unconstrained (five workgroups per CU); capped at 80 (six, 2-9
+                                             // registers spilled) C3 sorted 37.6 -> 38.4 Grays/s within one box (profiles/r04/ab_sincos_iter_cap.log:
+                                             // `all6`; round 3 had measured the cap neutral)
 #endif
 #ifndef PT_LOOP_WAVES
 #define PT_LOOP_WAVES 4                      // k_bounce<MESH_TILES>: measured 41.9 Mrays/s on C4 against 36.9 at 3 and 40.1 at 5 (profiles/r03)
@@ -163,13 +165,31 @@ __device__ __forceinline__ bool elect_last_self_clearing(uint32_t *ticket /* [33
 // front of a span of their own (same stride R*64: the pool is K times as large -- 288 GB of HBM are there to be
 // used), and the exclusive scan of count[] in that order is the sorted order.  Readers are unchanged: logical path i
 // lives in slot r*R*64 + (i - base[r]).  Nothing is moved to be sorted, and nothing extra is read or written.
+//
+// Round 4 -- tiles ALIGNED to the ranges.  Cutting the logical sequence into tiles of 64 wherever they fall makes almost
+// every tile straddle two physical tiles of the source pool (logical i sits at offset i - base[r] in its range): each of
+// its ten rows is then 64-B sectors of two 256-B rows, the sectors at the seam are fetched twice -- by this tile and by
+// its neighbour -- and they have often left the L2 in between (measured: 1.34 x the necessary reads; the microbenchmark
+// profiles/microbench/hbm_patterns.hip reproduces 1.24 x).  So the readers of an unsorted packed pool walk it in tiles
+// that start at the range starts: range r holds ceil(count[r] / 64) tiles, tbase[] is their exclusive scan (made by the
+// same last-workgroup scan as base[]), tile T lies in the range r with tbase[r] <= T < tbase[r + 1] and reads the slots
+// r * span + 64 (T - tbase[r]) + lane: whole rows, except in the last tile of a range.  The order is the logical order
+// (ranges in order, tiles in order), so the stable partition is untouched; the price is up to one partly filled tile per
+// range (W of ~260 000 tiles per launch on C2).  span (slots per range) is what the PRODUCER used: it is written into the
+// directory (it no longer follows from the live count alone).
+#ifndef PT_ALIGNED_TILES
+#define PT_ALIGNED_TILES 1
+#endif
 struct RangeDir {
-    uint32_t *mem;       // count[nrp] | base[nrp+4]  (nrp = nr rounded up to 4); nullptr = dense pool
+    uint32_t *mem;       // count[nrp] | base[nrp+4] | tbase[nrp+4] | span  (nrp = nr rounded up to 4); nullptr = dense pool
     uint32_t W;          // waves in the persistent grid
     uint32_t nr;         // ranges = W, or K * W when survivors are placed by material
     __device__ __forceinline__ uint32_t *count() const { return mem; }
     __device__ __forceinline__ uint32_t *base() const { return mem + ((nr + 3u) & ~3u); }
+    __device__ __forceinline__ uint32_t *tbase() const { return mem + 2u * ((nr + 3u) & ~3u) + 4u; }   // nr + 1 entries
+    __device__ __forceinline__ uint32_t *span() const { return mem + 3u * ((nr + 3u) & ~3u) + 8u; }     // slots per range, written by the producer
 };
+__host__ __device__ constexpr size_t range_dir_words(size_t nr) { return 3u * ((nr + 3u) & ~(size_t)3u) + 12u; }
 
 // Which run of tiles a wave owns: wave j of workgroup b takes run j*G + b, so the first G runs go
 // to G different workgroups.  When a bounce has fewer runs than waves (small pools, late

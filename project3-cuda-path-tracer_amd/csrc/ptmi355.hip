@@ -993,13 +993,14 @@ int enqueue_async_image(float *host) {
     HIPCHK(hipMemcpyAsync(R.snap[k], R.image, bytes, hipMemcpyDeviceToDevice, R.stream));
     HIPCHK(hipEventRecord(R.ev_snap[k], R.stream));
     HIPCHK(hipStreamWaitEvent(R.copy_stream, R.ev_snap[k], 0));
-    // The snapshot leaves the device through a few workgroups that store into the page-locked buffer's device mapping, as
-    // k_iteration's own epilogue does for synchronous calls: on this pool's boxes the copy engine moved the 7.68 MB of an
-    // 800x800 frame in ~0.25 ms (9.2 Grays/s PCIe-inclusive, below the SYNCHRONOUS calls' 10.5), kernel stores in ~0.14 ms.
-    // Buffers that cannot be mapped take the runtime's copy.
-    float *mapped = map_host(host, bytes);
-    if (mapped && ((uintptr_t)mapped & 15u) == 0 && !getenv("PTMI355_ASYNC_DMA")) {
-        hipLaunchKernelGGL(k_copy_out, dim3(64), dim3(BLOCK), 0, R.copy_stream, reinterpret_cast<float4 *>(mapped),
+    // The copy engine moves the 7.68 MB of an 800x800 frame in ~0.15 ms beside the next call's tracing (15.9 Grays/s
+    // PCIe-inclusive).  PTMI355_ASYNC_COPY_WGS=n hands the snapshot over through n workgroups that store into the buffer's
+    // device mapping instead (as k_iteration's epilogue does for synchronous calls): measured slower -- 64 workgroups
+    // 0.25 ms (profiles/r04/ab_async_copy.log) -- and kept as an experiment switch only.
+    const int copy_wgs = getenv("PTMI355_ASYNC_COPY_WGS") ? atoi(getenv("PTMI355_ASYNC_COPY_WGS")) : 0;
+    float *mapped = copy_wgs > 0 ? map_host(host, bytes) : nullptr;
+    if (mapped && ((uintptr_t)mapped & 15u) == 0) {
+        hipLaunchKernelGGL(k_copy_out, dim3((unsigned)copy_wgs), dim3(BLOCK), 0, R.copy_stream, reinterpret_cast<float4 *>(mapped),
                            reinterpret_cast<const float4 *>(R.snap[k]), (uint32_t)(bytes / 16), mapped + (bytes / 16) * 4, R.snap[k] + (bytes / 16) * 4,
                            (uint32_t)((bytes % 16) / 4));
         HIPCHK(hipGetLastError());
@@ -1534,7 +1535,9 @@ static int init_impl(const pt_scene_desc *d) {
         // w * R * 64 with R = ceil(tiles / W), so the spans of the last waves reach up to W tiles past the pool's paths --
         // never written while a wave only packs its own survivors, but k_iteration deals a workgroup's survivors to
         // all four of its waves, whichever of them had paths at bounce 0
-        R.pool_bytes = pool_mult * (((capz + 63) / 64) + 8192 * run_mult) * 64 * 10 * 4;
+        // ... and, with tiles aligned to the ranges (pt_types.hpp: RangeDir), one more: a reader's run is R' = ceil((tiles + up
+        // to one partly filled tile per range) / W) tiles long, and its survivors' span is as long as its run
+        R.pool_bytes = pool_mult * (((capz + 63) / 64) + 2 * 8192 * run_mult) * 64 * 10 * 4;
         HIPCHK(hipMalloc(&R.pool_mem[k], R.pool_bytes));
         R.pool[k] = carve_pool(R.pool_mem[k], R.cap);
     }
@@ -1616,7 +1619,7 @@ static int init_impl(const pt_scene_desc *d) {
         HIPCHK(hipMalloc((void **)&R.mesh_hit, R.mesh_hit_bytes));
         // k_mesh reads the flags of whole ranges (waves x tiles per range can overshoot the pool by up to one tile per
         // wave) and in chunks of 8 tiles: the words past the pool exist and stay zero
-        R.flag_words = (size_t)R.max_tiles + (size_t)R.grid * WAVES + 8;
+        R.flag_words = (size_t)R.max_tiles + 2 * (size_t)R.grid * WAVES + 8;
         for (int k = 0; k < 2; ++k) {
             HIPCHK(hipMalloc((void **)&R.mesh_flags[k], R.flag_words * sizeof(unsigned long long)));
             HIPCHK(hipMemsetAsync(R.mesh_flags[k], 0, R.flag_words * sizeof(unsigned long long), R.stream));
@@ -1643,7 +1646,7 @@ static int init_impl(const pt_scene_desc *d) {
     }
     {   // range directory: one count + one base per wave of the persistent grid, per bounce
         const size_t Wp = ((size_t)R.grid * WAVES * pool_mult * run_mult + 3) & ~(size_t)3;
-        R.dir_stride = 2 * Wp + 8;
+        R.dir_stride = range_dir_words(Wp);
         // one directory per bounce up to MAX_DEPTH: traceDepth is re-read on every call and may GROW (pathtrace.cu:286)
         R.dir_bytes = (size_t)MAX_DEPTH * R.dir_stride * sizeof(uint32_t);
         HIPCHK(hipMalloc((void **)&R.dir_mem, R.dir_bytes));
@@ -1844,12 +1847,15 @@ int pt_export_paths(pt_path_segment *host_paths, int capacity, int *n_live) {
     int rc = ensure_scratch((size_t)n * sizeof(pt_path_segment));
     if (rc) return rc;
     if (n) {
-        uint32_t nprev = 0;
+        uint32_t span = 0;                                  // slots per range, as the bounce that packed the pool wrote it down
         const bool packed = (R.flags & PT_COMPACT) && R.cur_dir >= 0;
-        if (packed) HIPCHK(hipMemcpy(&nprev, &R.ctl->nlive[R.cur_dir], 4, hipMemcpyDeviceToHost));
+        if (packed) {
+            const size_t nrp = ((size_t)tile_dir(R.cur_dir).nr + 3) & ~(size_t)3;
+            HIPCHK(hipMemcpy(&span, tile_dir(R.cur_dir).mem + 3 * nrp + 8, 4, hipMemcpyDeviceToHost));
+        }
         hipLaunchKernelGGL(k_export_paths, dim3((n + 255) / 256), dim3(256), 0, R.stream, R.pool[R.cur], R.map, n,
                            live, R.trace_depth - R.step_depth, (pt_path_segment *)R.scratch,
-                           tile_dir(packed ? R.cur_dir : -1), range_tiles(nprev, tile_dir(-1).W) * TILE);
+                           tile_dir(packed ? R.cur_dir : -1), span);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(host_paths, R.scratch, (size_t)n * sizeof(pt_path_segment), hipMemcpyDeviceToHost, R.stream));
         HIPCHK(hipStreamSynchronize(R.stream));
