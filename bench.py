@@ -265,7 +265,7 @@ class Session:
         self.c.pt.pathtraceFree()
 
 
-def per_call_rates(c, n_it=128):
+def per_call_rates(c, n_it=256):
     """The drop-in calling pattern (src/main.cpp:130-140): ONE pathtrace() per iteration.  `mrays_per_s`: the calls
     alone, enqueued back to back (pt_trace_batch_async(iter, 1): what a host gets that does not look at state.image
     between iterations); `pcie_inclusive_sync`: every call hands the running sum back in host memory before it returns
@@ -279,13 +279,13 @@ def per_call_rates(c, n_it=128):
     def run(flags, call):
         # (the library's own launch stream, as a host that links libptmi355.so gets it -- not torch's)
         pt.pathtraceInit(c.scene, flags=flags, device=c.local_rank, max_batch=1)
-        for k in range(16):
+        for k in range(32):
             call(1 + k)
         pt.synchronize()
         r0 = pt.total_rays()
         t1 = time.perf_counter()
         for k in range(n_it):
-            call(17 + k)
+            call(33 + k)
         pt.synchronize()
         el = time.perf_counter() - t1
         rate = round((pt.total_rays() - r0) / el / 1e6, 2)
@@ -390,6 +390,14 @@ def main():
     inproc, dist_on, n_tiles, scene = c.inproc, c.dist_on, c.n_tiles, c.scene
     W, H, npix, flags = c.W, c.H, c.npix, c.flags
 
+    # ---- the drop-in calling pattern, N = 1: one pathtrace() per iteration.  Measured FIRST, in the
+    # state a host finds the device in (after a 64-spp session -- 20 GB of pools on five streams -- the copy engine
+    # moved PT_ASYNC_IMAGE's snapshots at 60 % of the rate it reaches in a fresh process). ----
+    pc = None
+    if world == 1 and not inproc and not args.force_dist and not args.no_per_call and args.config in ("c2", "c3", "c5") \
+            and not (flags & ~(pt.PT_COMPACT | pt.PT_SORT_MATERIAL)):
+        pc = per_call_rates(c)
+
     s = Session(c, args.scaling, args.reduce_every)
     per_step_iters, every = s.per_step_iters, s.every
     profile_on = not args.no_roofline and args.steps * (scene.traceDepth + 2) * -(-per_step_iters // every) <= 2000
@@ -465,10 +473,7 @@ def main():
     if rank == 0 and world == 1 and not inproc and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene)
 
-    # ---- the drop-in calling pattern, N = 1: one pathtrace() per iteration ----
-    if world == 1 and not inproc and not args.force_dist and not args.no_per_call and args.config in ("c2", "c3", "c5") \
-            and not (flags & ~(pt.PT_COMPACT | pt.PT_SORT_MATERIAL)):
-        pc = per_call_rates(c)
+    if pc:
         out["config"]["per_call"] = pc
         out["config"]["pcie_inclusive_mrays_per_s"] = pc["pcie_inclusive_sync"]           # (the names of rounds 1-3)
         out["config"]["pcie_inclusive_async_mrays_per_s"] = pc["pcie_inclusive_async"]

@@ -36,6 +36,9 @@ for op in ("v_fma_f32 v_min3_f32 v_max3_f32 v_med3_f32 v_add3_u32 v_lshl_add_u32
            "v_xad_u32 v_bfe_u32 v_bfi_b32 v_alignbit_b32 v_mad_u32_u24 v_mad_i32_i24 v_div_fixup_f32 v_perm_b32").split():
     OPS[op] = vop3(op)
 OPS["v_fmac_f32"] = "v_fmac_f32 %s, %s, %s" % (A, B, C)
+# fused multiply-add with a 32-bit literal (round 4: the polynomial constants of the binary32 shared sin / cos)
+OPS["v_fmamk_f32"] = "v_fmamk_f32 %s, %s, 0x3e2aaaab, %s" % (A, A, B)
+OPS["v_fmaak_f32"] = "v_fmaak_f32 %s, %s, %s, 0x3e2aaaab" % (A, A, B)
 OPS["v_cndmask_b32_e32"] = "v_cndmask_b32 %s, %s, %s, vcc" % (A, A, B)
 OPS["v_cndmask_b32_e64"] = "v_cndmask_b32_e64 %s, %s, %s, %s" % (A, A, B, S64)
 OPS["v_div_scale_f32"] = "v_div_scale_f32 %s, vcc, %s, %s, %s" % (A, B, B, A)
