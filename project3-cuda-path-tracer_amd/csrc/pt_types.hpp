@@ -59,17 +59,37 @@ __device__ __forceinline__ T &at(T *plane, uint32_t i) {
 // as ten consecutive 256-B rows, 2560 B per tile.  A wave reads/writes whole rows (coalesced),
 // and all ten fields of slot s sit at one per-lane address plus the immediates 0, 256, ... 2304:
 // one address computation per path instead of ten, and no plane base pointers in SGPRs.
+#ifndef PT_POOL_PAIRS
+#define PT_POOL_PAIRS 1
+#endif
 struct Pool {
     float *base;
     uint32_t cap;        // slots, a multiple of 64
+#if PT_POOL_PAIRS
+    // Round 4: the ten fields of a tile sit as FIVE 512-B rows of field PAIRS (ox oy | oz dx | dy dz | cr cg | cb pid): a
+    // wave moves a tile with five 8-B-per-lane loads or stores instead of ten 4-B ones -- same bytes, same tile size, half
+    // the memory instructions and, where a row store is several interleaved runs (survivors placed by material), runs
+    // twice as long.
+    __device__ __forceinline__ char *slot(uint32_t s) const {
+        return reinterpret_cast<char *>(base) + (size_t)(s >> 6) * 2560u + ((s & 63u) << 3);
+    }
+    __device__ __forceinline__ float &f(uint32_t s, int k) const { return *reinterpret_cast<float *>(slot(s) + (k >> 1) * 512 + (k & 1) * 4); }
+    __device__ __forceinline__ uint32_t &pid(uint32_t s) const { return *reinterpret_cast<uint32_t *>(slot(s) + 4 * 512 + 4); }
+#else
     __device__ __forceinline__ char *slot(uint32_t s) const {
         return reinterpret_cast<char *>(base) + (size_t)(s >> 6) * 2560u + ((s & 63u) << 2);
     }
     __device__ __forceinline__ float &f(uint32_t s, int k) const { return *reinterpret_cast<float *>(slot(s) + k * 256); }
     __device__ __forceinline__ uint32_t &pid(uint32_t s) const { return *reinterpret_cast<uint32_t *>(slot(s) + 9 * 256); }
+#endif
 };
+#if PT_POOL_PAIRS
+__device__ __forceinline__ float &pf(char *slot, int k) { return *reinterpret_cast<float *>(slot + (k >> 1) * 512 + (k & 1) * 4); }
+__device__ __forceinline__ uint32_t &ppid(char *slot) { return *reinterpret_cast<uint32_t *>(slot + 4 * 512 + 4); }
+#else
 __device__ __forceinline__ float &pf(char *slot, int k) { return *reinterpret_cast<float *>(slot + k * 256); }
 __device__ __forceinline__ uint32_t &ppid(char *slot) { return *reinterpret_cast<uint32_t *>(slot + 9 * 256); }
+#endif
 
 struct Isect {           // ShadeableIntersection planes t nx ny nz mat (unfused / sort / fake-shader modes)
     float *base;         // mat: bit 31 carries the winning test's !outside
