@@ -80,7 +80,7 @@ __device__ __forceinline__ void tile_load(const BounceArgs &a, const TileCtx &c,
             tr.pid = i;
         } else {
             // all ten fields of the slot in one burst of loads (one memory latency per tile)
-            char *p = (c.kargs ? karg_pool(offsetof(BounceArgs, in)) : in).slot(src);
+            const SlotPtr p = (c.kargs ? karg_pool(offsetof(BounceArgs, in)) : in).slot(src);
             tr.pid = ppid(p);
             ro = ptd::mk(pf(p, 0), pf(p, 1), pf(p, 2));
             rd = ptd::mk(pf(p, 3), pf(p, 4), pf(p, 5));
@@ -166,7 +166,7 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
         packed += (uint32_t)__popcll((unsigned long long)bal);
     }
     if (alive) {
-        char *p = (c.kargs ? karg_pool(offsetof(BounceArgs, out)) : out).slot(dst);
+        const SlotPtr p = (c.kargs ? karg_pool(offsetof(BounceArgs, out)) : out).slot(dst);
         pf(p, 0) = ps.o.x; pf(p, 1) = ps.o.y; pf(p, 2) = ps.o.z;
         pf(p, 3) = ps.d.x; pf(p, 4) = ps.d.y; pf(p, 5) = ps.d.z;
         pf(p, 6) = ps.c.x; pf(p, 7) = ps.c.y; pf(p, 8) = ps.c.z;

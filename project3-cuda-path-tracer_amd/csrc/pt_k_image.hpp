@@ -20,7 +20,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(Pool p, pt_camera cam, Lens le
     if (iter0 < 0) iter0 = (int)ctl->iter0;                  // graph replay
     f3 o, d;
     camera_ray(cam, lens, trace_depth, iter0 + (int)smp, local_to_pixel(map, (int)j), map.W, o, d);
-    char *q = p.slot(i);
+    const SlotPtr q = p.slot(i);
     pf(q, 0) = o.x; pf(q, 1) = o.y; pf(q, 2) = o.z;
     pf(q, 3) = d.x; pf(q, 4) = d.y; pf(q, 5) = d.z;
     pf(q, 6) = 1.0f; pf(q, 7) = 1.0f; pf(q, 8) = 1.0f;

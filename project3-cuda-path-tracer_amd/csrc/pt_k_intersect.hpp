@@ -209,7 +209,7 @@ __global__ __launch_bounds__(BLOCK, PT_ISECT_WAVES) void k_intersect(Pool in, Is
             const int it0 = gen.iter0 >= 0 ? gen.iter0 : (int)ctl->iter0;
             camera_ray(gen.cam, gen.lens, gen.trace_depth, it0 + (int)smp, pixel, gen.map.W, ro, rd);
         } else if (!GEN && active) {
-            char *p = in.slot(src);
+            const SlotPtr p = in.slot(src);
             if (ppid(p) == DEAD_PID) active = false;
             ro = ptd::mk(pf(p, 0), pf(p, 1), pf(p, 2));
             rd = ptd::mk(pf(p, 3), pf(p, 4), pf(p, 5));

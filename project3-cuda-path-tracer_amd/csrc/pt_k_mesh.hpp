@@ -404,7 +404,7 @@ __global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a
                     p_take = min(64u, total - done);
                     if ((uint32_t)lane < p_take) {
                         p_src = (((g_cur * FLAG_GROUP + tj) * W + wid) << 6) + kth_set_bit(word, i - base);
-                        char *q = a.in.slot(p_src);
+                        const SlotPtr q = a.in.slot(p_src);
                         p_ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
                         p_rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
                     }
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a
                     const int pixel = local_to_pixel(a.map, (int)(i - smp * (uint32_t)a.map.tile_pixels));
                     camera_ray(a.cam, a.lens, a.trace_depth, iter0 + (int)smp, pixel, a.map.W, ro, rd);
                 } else {
-                    char *q = a.in.slot(src);
+                    const SlotPtr q = a.in.slot(src);
                     if (ppid(q) == DEAD_PID) active = false;
                     ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
                     rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
                 key = keyl[e];
                 i = chunk_base + e;
                 dst = gbase[key] + (p - kstart[key]);
-                char *q = a.in.slot(i);
+                const SlotPtr q = a.in.slot(i);
                 pid = ppid(q);
                 ro = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
                 rd = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_sorted(BounceArgs a) {
             }
             traced += (uint32_t)__popcll((unsigned long long)ballot64(active));
             if (alive) {
-                char *q = a.out.slot(dst);
+                const SlotPtr q = a.out.slot(dst);
                 pf(q, 0) = ps.o.x; pf(q, 1) = ps.o.y; pf(q, 2) = ps.o.z;
                 pf(q, 3) = ps.d.x; pf(q, 4) = ps.d.y; pf(q, 5) = ps.d.z;
                 pf(q, 6) = ps.c.x; pf(q, 7) = ps.c.y; pf(q, 8) = ps.c.z;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(BLOCK, GEN ? 6 : 8) void k_shade_sorted_w(BounceArg
                     const int pixel = local_to_pixel(a.map, (int)(pid[s] - smp * (uint32_t)a.map.tile_pixels));
                     camera_ray(a.cam, a.lens, a.trace_depth, iter0 + (int)smp, pixel, a.map.W, ro[s], rd[s]);
                 } else {
-                    char *q = a.in.slot(idx[s]);
+                    const SlotPtr q = a.in.slot(idx[s]);
                     pid[s] = ppid(q);
                     ro[s] = ptd::mk(pf(q, 0), pf(q, 1), pf(q, 2));
                     rd[s] = ptd::mk(pf(q, 3), pf(q, 4), pf(q, 5));
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(BLOCK, GEN ? 6 : 8) void k_shade_sorted_w(BounceArg
             }
             traced += (uint32_t)__popcll((unsigned long long)ballot64(active));
             if (alive) {
-                char *q = a.out.slot(dst[s]);
+                const SlotPtr q = a.out.slot(dst[s]);
                 pf(q, 0) = ps.o.x; pf(q, 1) = ps.o.y; pf(q, 2) = ps.o.z;
                 pf(q, 3) = ps.d.x; pf(q, 4) = ps.d.y; pf(q, 5) = ps.d.z;
                 pf(q, 6) = ps.c.x; pf(q, 7) = ps.c.y; pf(q, 8) = ps.c.z;

@@ -59,36 +59,45 @@ __device__ __forceinline__ T &at(T *plane, uint32_t i) {
 // as ten consecutive 256-B rows, 2560 B per tile.  A wave reads/writes whole rows (coalesced),
 // and all ten fields of slot s sit at one per-lane address plus the immediates 0, 256, ... 2304:
 // one address computation per path instead of ten, and no plane base pointers in SGPRs.
-#ifndef PT_POOL_PAIRS
-#define PT_POOL_PAIRS 1
+#ifndef PT_POOL_QUADS
+#define PT_POOL_QUADS 1
 #endif
+#if PT_POOL_QUADS
+// Round 4: the ten fields of a tile sit as THREE rows -- [ox oy oz dx] and [dy dz cr cg], 16 B per lane (1024-B rows), and
+// [cb pid], 8 B per lane (512 B): a wave moves a tile with three loads or stores instead of ten dword ones -- same
+// bytes, same 2560-B tile, a third of the memory instructions, and where a row store is several interleaved runs
+// (survivors placed by material) the runs are four times as long.  (Field pairs -- five 8-B rows -- were the first step:
+// C2 +3.0 %, C3 sorted +6 %, profiles/r04/ab_pool_pairs.log.)
+struct SlotPtr { char *q, *c; };        // the lane's place in the two 16-B rows / in the 8-B row of its tile
 struct Pool {
     float *base;
     uint32_t cap;        // slots, a multiple of 64
-#if PT_POOL_PAIRS
-    // Round 4: the ten fields of a tile sit as FIVE 512-B rows of field PAIRS (ox oy | oz dx | dy dz | cr cg | cb pid): a
-    // wave moves a tile with five 8-B-per-lane loads or stores instead of ten 4-B ones -- same bytes, same tile size, half
-    // the memory instructions and, where a row store is several interleaved runs (survivors placed by material), runs
-    // twice as long.
+    __device__ __forceinline__ SlotPtr slot(uint32_t s) const {
+        char *t = reinterpret_cast<char *>(base) + (size_t)(s >> 6) * 2560u;
+        return SlotPtr{t + ((s & 63u) << 4), t + 2048u + ((s & 63u) << 3)};
+    }
+    __device__ __forceinline__ float &f(uint32_t s, int k) const {
+        const SlotPtr p = slot(s);
+        return *reinterpret_cast<float *>(k < 8 ? p.q + (k >> 2) * 1024 + (k & 3) * 4 : p.c);
+    }
+    __device__ __forceinline__ uint32_t &pid(uint32_t s) const { return *reinterpret_cast<uint32_t *>(slot(s).c + 4); }
+};
+__device__ __forceinline__ float &pf(const SlotPtr &p, int k) { return *reinterpret_cast<float *>(k < 8 ? p.q + (k >> 2) * 1024 + (k & 3) * 4 : p.c); }
+__device__ __forceinline__ uint32_t &ppid(const SlotPtr &p) { return *reinterpret_cast<uint32_t *>(p.c + 4); }
+#else
+typedef char *SlotPtr;
+struct Pool {
+    float *base;
+    uint32_t cap;        // slots, a multiple of 64
+    // the ten fields of a tile as FIVE 512-B rows of field PAIRS (ox oy | oz dx | dy dz | cr cg | cb pid)
     __device__ __forceinline__ char *slot(uint32_t s) const {
         return reinterpret_cast<char *>(base) + (size_t)(s >> 6) * 2560u + ((s & 63u) << 3);
     }
     __device__ __forceinline__ float &f(uint32_t s, int k) const { return *reinterpret_cast<float *>(slot(s) + (k >> 1) * 512 + (k & 1) * 4); }
     __device__ __forceinline__ uint32_t &pid(uint32_t s) const { return *reinterpret_cast<uint32_t *>(slot(s) + 4 * 512 + 4); }
-#else
-    __device__ __forceinline__ char *slot(uint32_t s) const {
-        return reinterpret_cast<char *>(base) + (size_t)(s >> 6) * 2560u + ((s & 63u) << 2);
-    }
-    __device__ __forceinline__ float &f(uint32_t s, int k) const { return *reinterpret_cast<float *>(slot(s) + k * 256); }
-    __device__ __forceinline__ uint32_t &pid(uint32_t s) const { return *reinterpret_cast<uint32_t *>(slot(s) + 9 * 256); }
-#endif
 };
-#if PT_POOL_PAIRS
 __device__ __forceinline__ float &pf(char *slot, int k) { return *reinterpret_cast<float *>(slot + (k >> 1) * 512 + (k & 1) * 4); }
 __device__ __forceinline__ uint32_t &ppid(char *slot) { return *reinterpret_cast<uint32_t *>(slot + 4 * 512 + 4); }
-#else
-__device__ __forceinline__ float &pf(char *slot, int k) { return *reinterpret_cast<float *>(slot + k * 256); }
-__device__ __forceinline__ uint32_t &ppid(char *slot) { return *reinterpret_cast<uint32_t *>(slot + 9 * 256); }
 #endif
 
 struct Isect {           // ShadeableIntersection planes t nx ny nz mat (unfused / sort / fake-shader modes)
