@@ -55,10 +55,10 @@ __device__ __forceinline__ T &at(T *plane, uint32_t i) {
     return *reinterpret_cast<T *>(reinterpret_cast<char *>(plane) + (i << 2));
 }
 
-// Path pool: SoA *per 64-path tile* -- tile T holds its ten planes (ox oy oz dx dy dz cr cg cb pid)
-// as ten consecutive 256-B rows, 2560 B per tile.  A wave reads/writes whole rows (coalesced),
-// and all ten fields of slot s sit at one per-lane address plus the immediates 0, 256, ... 2304:
-// one address computation per path instead of ten, and no plane base pointers in SGPRs.
+// Path pool: SoA *per 64-path tile* -- tile T holds the ten fields (ox oy oz dx dy dz cr cg cb pid) of its 64 paths in
+// 2560 consecutive bytes.  A wave reads / writes whole rows (coalesced), and every field of slot s sits at a per-lane
+// address plus an immediate: no plane base pointers in SGPRs.  Rounds 1-3: ten 256-B dword rows; now three rows of field
+// quads / a pair (below).
 #ifndef PT_POOL_QUADS
 #define PT_POOL_QUADS 1
 #endif
