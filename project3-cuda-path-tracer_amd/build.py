@@ -45,10 +45,18 @@ def build(force=False, verbose=False):
     want = source_digest()
     have = open(STAMP).read().strip() if os.path.exists(STAMP) else ""
     if force or not os.path.exists(LIB) or have != want:
-        cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB, SOURCES[0]]
+        # built beside the target and renamed into place: a process that loads the library while another one builds it
+        # (several ranks starting at once) sees the old file or the new one, never half of one
+        tmp = "%s.tmp%d" % (LIB, os.getpid())
+        cmd = [hipcc()] + HIPCC_FLAGS + ["-o", tmp, SOURCES[0]]
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True, cwd=HERE)
+        try:
+            subprocess.run(cmd, check=True, cwd=HERE)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
         with open(STAMP, "w") as f:
             f.write(want + "\n")
     return LIB

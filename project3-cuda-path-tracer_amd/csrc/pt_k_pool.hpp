@@ -84,51 +84,51 @@ __device__ __forceinline__ uint32_t resolve_src(const RangeDir &dir, uint32_t sp
 // Hand-off (guide G16): each wave stores its range count with an agent-scope atomic
 // (write-through) store and drains it (s_waitcnt vmcnt(0)); after the workgroup's barrier one
 // lane adds 1 to done[depth]; the workgroup whose add returns grid-1 is last, acquires once
-// (agent scope) and scans the W counts (<= 8 steps of 1024).  Nothing spins; nothing depends
+// (agent scope) and scans the counts.  Nothing spins; nothing depends
 // on dispatch order.
 __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t *n_out,
                                                   uint32_t *lds_scan /* >= 16 words */, uint32_t span_out, bool with_tiles) {
-    // One step covers 8192 entries: thread t owns the `per` consecutive entries [t*per, (t+1)*per) of the step (per =
-    // a multiple of 4, at most 32), loads them with 16-B loads all issued up front, and the 256 partial sums cross
-    // through one wave scan + one LDS exchange.  W <= 8192 waves: one step; K * W ranges (survivors placed by
-    // material): K steps at most, the running total carried from step to step.
+    // ONE pass over all NR entries (W waves, or K * W ranges when survivors are placed by material): thread t owns the
+    // `per4` consecutive uint4s from t * per4, sums them (16-B loads, four in flight), the 256 partial sums cross through one
+    // wave scan + one LDS exchange, and the thread writes its prefixes.  (Up to round 4 this ran in steps of 8192 entries
+    // with the total carried from step to step: five dependent steps, 12 us per launch, for C3's six materials.)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t NR = dir.nr;
     const uint4 *count4 = reinterpret_cast<const uint4 *>(dir.count());
     uint4 *base4 = reinterpret_cast<uint4 *>(dir.base());
     uint4 *tbase4 = reinterpret_cast<uint4 *>(dir.tbase());         // with_tiles: the same scan over ceil(count / 64) (RangeDir)
     uint32_t carry = 0, tcarry = 0;
-    for (uint32_t s0 = 0, step = 0; s0 < NR; s0 += 8192u, ++step) {
-        const uint32_t W = min(8192u, NR - s0);                           // entries of this step
-        const uint32_t per4 = ((W + BLOCK - 1) / BLOCK + 3) / 4;          // uint4s per thread, <= 8
-        const uint32_t first = threadIdx.x * per4 * 4;                    // first entry of this thread within the step
+    {
+        const uint32_t per4 = ((NR + BLOCK - 1) / BLOCK + 3) / 4;         // uint4s per thread
+        const uint32_t first = threadIdx.x * per4 * 4;                    // this thread's first entry
         // (the counts are read twice -- once for the sums, again, from the L2, for the prefixes -- instead of being held in
-        // 32 registers across the barrier: this code runs once per launch in one workgroup, but its registers count
+        // registers across the barrier: this code runs once per launch in one workgroup, but its registers count
         // against the whole kernel's budget, and at six workgroups per CU there are none to spare)
         uint32_t sum = 0, tsum = 0;
         auto tl = [](uint32_t c) { return (c + (uint32_t)TILE - 1u) / (uint32_t)TILE; };
         auto load = [&](uint32_t k) {
             const uint32_t e = first + 4 * k;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (k < per4 && e < W) {
-                v = count4[(s0 + e) >> 2];                                   // count[] is padded to a multiple of 4
-                if (e + 1 >= W) v.y = 0;
-                if (e + 2 >= W) v.z = 0;
-                if (e + 3 >= W) v.w = 0;
+            if (k < per4 && e < NR) {
+                v = count4[e >> 2];                                          // count[] is padded to a multiple of 4
+                if (e + 1 >= NR) v.y = 0;
+                if (e + 2 >= NR) v.z = 0;
+                if (e + 3 >= NR) v.w = 0;
             }
             return v;
         };
-        for (uint32_t k = 0; k < per4; ++k) {
-            const uint4 v = load(k);
-            sum += v.x + v.y + v.z + v.w;
-            tsum += tl(v.x) + tl(v.y) + tl(v.z) + tl(v.w);
+        for (uint32_t k = 0; k < per4; k += 4) {
+            const uint4 v0 = load(k), v1 = load(k + 1), v2 = load(k + 2), v3 = load(k + 3);
+            sum += (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w) + (v2.x + v2.y + v2.z + v2.w) + (v3.x + v3.y + v3.z + v3.w);
+            tsum += tl(v0.x) + tl(v0.y) + tl(v0.z) + tl(v0.w) + tl(v1.x) + tl(v1.y) + tl(v1.z) + tl(v1.w) +
+                    tl(v2.x) + tl(v2.y) + tl(v2.z) + tl(v2.w) + tl(v3.x) + tl(v3.y) + tl(v3.z) + tl(v3.w);
         }
         uint32_t incl = sum, tincl = tsum;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t u = __shfl_up(incl, off), tu = __shfl_up(tincl, off);
             if (lane >= off) { incl += u; tincl += tu; }
         }
-        uint32_t *slot = lds_scan + (step & 1u) * (2 * WAVES);
+        uint32_t *slot = lds_scan;
         if (lane == 63) { slot[wave] = incl; slot[WAVES + wave] = tincl; }
         __syncthreads();
         uint32_t wave_off = 0, total = 0, twave_off = 0, ttotal = 0;
@@ -138,24 +138,27 @@ __device__ __forceinline__ void scan_range_counts(const RangeDir &dir, uint32_t 
             if (w < wave) { wave_off += c; twave_off += tc; }
             total += c; ttotal += tc;
         }
-        uint32_t run = carry + wave_off + incl - sum, trun = tcarry + twave_off + tincl - tsum;
-        for (uint32_t k = 0; k < per4; ++k) {
+        uint32_t run = wave_off + incl - sum, trun = twave_off + tincl - tsum;
+        auto put = [&](uint32_t k, const uint4 &v) {
             const uint32_t e = first + 4 * k;
-            if (e < W) {
-                const uint4 v = load(k);
+            if (k < per4 && e < NR) {
                 uint4 b;
                 b.x = run; b.y = b.x + v.x; b.z = b.y + v.y; b.w = b.z + v.z;
-                base4[(s0 + e) >> 2] = b;                                    // base[] has 4 spare entries; steps start at multiples of 8192
+                base4[e >> 2] = b;                                           // base[] has 4 spare entries
                 run = b.w + v.w;
                 if (with_tiles) {
                     uint4 t;
                     t.x = trun; t.y = t.x + tl(v.x); t.z = t.y + tl(v.y); t.w = t.z + tl(v.z);
-                    tbase4[(s0 + e) >> 2] = t;
+                    tbase4[e >> 2] = t;
                     trun = t.w + tl(v.w);
                 }
             }
+        };
+        for (uint32_t k = 0; k < per4; k += 4) {
+            const uint4 v0 = load(k), v1 = load(k + 1), v2 = load(k + 2), v3 = load(k + 3);
+            put(k, v0); put(k + 1, v1); put(k + 2, v2); put(k + 3, v3);
         }
-        carry += total; tcarry += ttotal;
+        carry = total; tcarry = ttotal;
     }
     if (threadIdx.x == 0) { dir.base()[NR] = carry; *n_out = carry; if (with_tiles) dir.tbase()[NR] = tcarry; *dir.span() = span_out; }
 }

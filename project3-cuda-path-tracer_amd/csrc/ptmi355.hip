@@ -133,7 +133,12 @@ struct Renderer {
     size_t flag_words = 0;                   // mesh pre-pass: 64-bit flag words per parity (one bit per physical pool slot)
     size_t ctl_bytes = 0;         // Control, zeroed per batch
     int grid = 0;                 // persistent grid size
-    int grid_iter = 0;            // k_iteration's own (its register budget differs from the bounce kernels')
+    int grid_iter = 0;            // k_iteration's own (its register budget differs from the bounce kernels'): the co-resident maximum
+    int grid_iter_cur = 0;        // ... and what the batch just enqueued was launched with (iter_grid_for)
+    int iter_tpw = 8;             // under the lanes k_iteration's grid is sized for this many tiles per wave (0: always the whole grid; PTMI355_ITER_TPW) ...
+    int iter_wgs_per_cu_all = 15; // ... but not below this many workgroups per CU over all lanes together (PTMI355_ITER_WGS_ALL)
+    bool ov_lanes_set = false;    // PTMI355_OVERLAP named a lane count
+    int cus = 0;
     int grid_sort = 0;            // workgroups of the material-sort kernels (k_sort_hist / k_shade_sorted)
     bool sort_wave = true;        // <= 64 keys: k_shade_sorted_w (PTMI355_SORT_WAVE=0 forces the workgroup-wide kernel)
     int sort_runs = 1;            // runs of tiles per wave of the fused sort (k_bounce); PTMI355_SORT_RUNS
@@ -565,7 +570,7 @@ int enqueue_end(void) {
                        R.final_mem, R.cap, R.map,
                        R.step_count, R.ctl, R.persist, (R.flags & PT_FAKE_SHADER) ? 0 : R.trace_depth,
                        (R.flags & PT_FAKE_SHADER) ? (uint32_t)R.map.tile_pixels * (uint32_t)R.step_count : 0u,
-                       R.whole ? 1 : 0, R.epi_done ? 1 : 0, R.capturing ? 0u : R.fin_serial, R.iter_counts, (uint32_t)R.grid_iter,
+                       R.whole ? 1 : 0, R.epi_done ? 1 : 0, R.capturing ? 0u : R.fin_serial, R.iter_counts, (uint32_t)R.grid_iter_cur,
                        (R.whole && R.host_stats_serial) ? R.d_stats : (HostStats *)nullptr);
     R.whole = false;
     HIPCHK(hipGetLastError());
@@ -660,6 +665,8 @@ int ensure_lanes(void) {
     double budget = R.ov_budget_gb * 1e9;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, 0.5 * (double)free_b);   // leave room for the caller
+    // a session whose every batch runs as one launch (k_iteration) shares the device between six of them (iter_grid_for)
+    if (!R.ov_lanes_set && (uint64_t)R.cap <= R.whole_max_paths && (R.flags & PT_COMPACT) && !(R.flags & PT_SORT_MATERIAL) && R.mesh_mode == MESH_NONE) R.ov_lanes = 6;
     const int fit = 1 + (int)std::min(16.0, std::floor(budget / std::max(1.0, per_lane)));
     R.ov_lanes = std::min(R.ov_lanes, fit);
     if (R.ov_lanes == 3) R.ov_lanes = 2;                       // three lanes measured no better than one
@@ -717,6 +724,20 @@ int enqueue_batch_direct(int iter0, int count) {
     return rc;
 }
 
+// k_iteration's grid.  A launch of its own wants every co-resident workgroup (latency: 121 us at 800x800).  Under the
+// lanes several launches share the device, and a workgroup of a full grid holds its slot for all eight bounces with two
+// tiles per wave at bounce 0 and less than one from bounce 3 on.  Measured at 800x800 (profiles/r04/ab_iter_grid*.log):
+// what counts is the workgroups the lanes ask for together -- best at ~15 per CU, three times what is co-resident, so
+// that the slots turn over between the launches (5 per CU x 4 lanes = 20: 29.2 Grays/s at 1 spp per call; 2.5 x 6 = 15:
+// 31.3; 2 x 4 = 8: 25.7) -- as long as a wave still has a few tiles (4 spp per call: the full grid is best again).
+int iter_grid_for(uint64_t paths, bool shared) {
+    if (!shared || R.iter_tpw <= 0) return R.grid_iter;
+    const uint64_t tiles = (paths + TILE - 1) / TILE;
+    const uint64_t by_tiles = (tiles + (uint64_t)(WAVES * R.iter_tpw) - 1) / (uint64_t)(WAVES * R.iter_tpw);
+    const uint64_t floor_g = ((uint64_t)R.iter_wgs_per_cu_all * (uint64_t)R.cus + (uint64_t)R.ov_lanes - 1) / (uint64_t)std::max(1, R.ov_lanes);
+    return (int)std::min<uint64_t>(std::max(by_tiles, floor_g), (uint64_t)R.grid_iter);
+}
+
 int enqueue_batch_serial(int iter0, int count) {
     // small batch: every bounce in one launch (k_iteration)
     const bool whole = !(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER | PT_CACHE_FIRST)) && (R.flags & PT_COMPACT) &&
@@ -742,8 +763,9 @@ int enqueue_batch_serial(int iter0, int count) {
         // a synchronous call's statistics go straight to page-locked host memory: written by whoever folds the counts, this
         // launch's last workgroup (own finalGather) or k_gather's first
         if (R.want_host_stats && !R.capturing && !R.use_graphs && R.d_stats) { a.host_stats = R.d_stats; R.host_stats_serial = R.fin_serial; }
-        if (R.scene_lds) hipLaunchKernelGGL(k_iteration<true>, dim3(R.grid_iter), dim3(BLOCK), R.lds_bytes, R.stream, a);
-        else hipLaunchKernelGGL(k_iteration<false>, dim3(R.grid_iter), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        R.grid_iter_cur = iter_grid_for((uint64_t)R.map.tile_pixels * (uint64_t)count, R.lane_cur != nullptr);
+        if (R.scene_lds) hipLaunchKernelGGL(k_iteration<true>, dim3(R.grid_iter_cur), dim3(BLOCK), R.lds_bytes, R.stream, a);
+        else hipLaunchKernelGGL(k_iteration<false>, dim3(R.grid_iter_cur), dim3(BLOCK), R.lds_bytes, R.stream, a);
         HIPCHK(hipGetLastError());
         R.step_depth = R.trace_depth;
         R.whole = true;
@@ -1369,7 +1391,7 @@ static int init_impl(const pt_scene_desc *d) {
     if (const char *e = getenv("PTMI355_OVERLAP")) {           // 0: off; 1: on (default lanes); n >= 2: n lanes
         const int nl = atoi(e);
         R.ov_enabled = nl != 0;
-        if (nl >= 2) R.ov_lanes = std::min(nl, OV_MAX_LANES);
+        if (nl >= 2) { R.ov_lanes = std::min(nl, OV_MAX_LANES); R.ov_lanes_set = true; }
     }
     if (const char *e = getenv("PTMI355_OVERLAP_GB")) R.ov_budget_gb = atof(e);
     R.epi_enabled = true;
@@ -1601,6 +1623,9 @@ static int init_impl(const pt_scene_desc *d) {
         if (const char *e = getenv("PTMI355_WGS_PER_CU")) n = std::max(1, std::min(n, atoi(e)));
         R.grid_iter = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)n);
         R.grid_iter = std::max(1, std::min(R.grid_iter, 8192 / WAVES));
+        R.grid_iter_cur = R.grid_iter; R.cus = cus;
+        if (const char *e = getenv("PTMI355_ITER_TPW")) R.iter_tpw = std::max(0, atoi(e));
+        if (const char *e = getenv("PTMI355_ITER_WGS_ALL")) R.iter_wgs_per_cu_all = std::max(1, atoi(e));
         // its traced counts, [bounce][workgroup], and the page-locked block its last workgroup writes a synchronous call's
         // statistics to (if the host allocation cannot be mapped the control block is copied back as before)
         R.iter_counts_bytes = (size_t)MAX_DEPTH * (size_t)R.grid_iter * 4;
