@@ -31,7 +31,9 @@
 #include <rccl/rccl.h>      // types and prototypes only: nothing links against librccl
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -112,10 +114,11 @@ struct Worker {
     std::thread th;
     std::mutex m;
     std::condition_variable cv_job, cv_done;
-    std::function<int()> job;
+    std::deque<std::function<int()>> jobs;      // FIFO: an asynchronous batch is posted and not waited for (multi_enqueue)
     std::atomic<uint64_t> posted{0}, finished{0};
     bool quit = false;
-    int rc = PT_OK;
+    int rc = PT_OK;                              // of the last job run
+    std::atomic<int> sticky{PT_OK};              // first failure of a job (its message stays in err): reported by the next wait
     // exchange state of this context (device `device`)
     hipStream_t xs = nullptr;                   // exchange stream
     float *pack[XSLOTS] = {};                    // packed tile rows, one per slot
@@ -134,77 +137,94 @@ struct Worker {
         for (;;) {
             // a batch follows a batch within microseconds: look for the next job for a moment before sleeping
             for (int spin = 0; spin < 4000 && posted.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
-            if (posted.load(std::memory_order_acquire) == seen) {
+            std::function<int()> f;
+            {
                 std::unique_lock<std::mutex> lk(m);
-                cv_job.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit; });
-                if (quit && posted.load(std::memory_order_acquire) == seen) return;
+                cv_job.wait(lk, [&] { return !jobs.empty() || quit; });
+                if (jobs.empty()) return;                                   // quit, nothing left to run
+                f = std::move(jobs.front());
+                jobs.pop_front();
             }
-            seen = posted.load(std::memory_order_acquire);
-            rc = job();
-            finished.store(seen, std::memory_order_release);
+            const int r = f();
+            rc = r;
+            if (r < 0) { int none = PT_OK; sticky.compare_exchange_strong(none, r); }
+            finished.store(++seen, std::memory_order_release);
             { std::lock_guard<std::mutex> lk(m); }
-            cv_done.notify_one();
+            cv_done.notify_all();
         }
     }
-    void post(std::function<int()> f) {
-        { std::lock_guard<std::mutex> lk(m); job = std::move(f); posted.fetch_add(1, std::memory_order_release); }
+    uint64_t post(std::function<int()> f) {
+        uint64_t seq;
+        { std::lock_guard<std::mutex> lk(m); jobs.push_back(std::move(f)); seq = posted.fetch_add(1, std::memory_order_release) + 1; }
         cv_job.notify_one();
+        return seq;
     }
-    int wait() {
-        const uint64_t want = posted.load(std::memory_order_acquire);
-        for (int spin = 0; spin < 4000 && finished.load(std::memory_order_acquire) != want; ++spin) __builtin_ia32_pause();
-        if (finished.load(std::memory_order_acquire) != want) {
+    // job number `seq` (and every job before it) has run; a failure of any job so far is returned, and forgotten if `clear`
+    int wait_seq(uint64_t seq, bool clear) {
+        for (int spin = 0; spin < 4000 && finished.load(std::memory_order_acquire) < seq; ++spin) __builtin_ia32_pause();
+        if (finished.load(std::memory_order_acquire) < seq) {
             std::unique_lock<std::mutex> lk(m);
-            cv_done.wait(lk, [&] { return finished.load(std::memory_order_acquire) == want; });
+            cv_done.wait(lk, [&] { return finished.load(std::memory_order_acquire) >= seq; });
         }
-        return rc;
+        const int e = clear ? sticky.exchange(PT_OK) : sticky.load();
+        return e;
+    }
+    int wait() {                                   // everything posted has run: the last job's result, or an earlier failure
+        const int e = wait_seq(posted.load(std::memory_order_acquire), true);
+        return e < 0 ? e : rc;
     }
 };
 
 // The exchange of a call is a dozen host calls -- a grouped RCCL send / recv costs the issuing thread ~80 us -- and
 // nothing in it needs the caller.  With asynchronous batches (pt_trace_batch_async) it is issued from this thread while
 // the caller already enqueues the next batch's launches: at one exchange per iteration the host, not the device, set
-// the pace.  One job at a time; the caller waits for the previous exchange before it posts the next (whose packing
-// waits on events that exchange records), and before anything else touches the exchange streams.
+// the pace.  Jobs run in order; the caller posts up to XSLOTS - 1 exchanges ahead (a call's packing waits on events the
+// exchange XSLOTS calls earlier records) and waits for all of them before anything else touches the exchange streams.
 struct Exchanger {
     char err[ERR_BYTES] = "";
     std::thread th;
     std::mutex m;
     std::condition_variable cv_job, cv_done;
-    std::function<int()> job;
+    std::deque<std::function<int()>> jobs;      // FIFO: the caller runs up to XSLOTS - 1 exchanges ahead (multi_enqueue)
     std::atomic<uint64_t> posted{0}, finished{0};
     bool quit = false;
-    int rc = PT_OK;
+    std::atomic<int> sticky{PT_OK};              // first failure (its message stays in err): reported by the next wait
     void loop() {
         t_err = err;
         uint64_t seen = 0;
         for (;;) {
-            for (int spin = 0; spin < 4000 && posted.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
-            if (posted.load(std::memory_order_acquire) == seen) {
+            for (int spin = 0; spin < 8000 && posted.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+            std::function<int()> f;
+            {
                 std::unique_lock<std::mutex> lk(m);
-                cv_job.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit; });
-                if (quit && posted.load(std::memory_order_acquire) == seen) return;
+                cv_job.wait(lk, [&] { return !jobs.empty() || quit; });
+                if (jobs.empty()) return;
+                f = std::move(jobs.front());
+                jobs.pop_front();
             }
-            seen = posted.load(std::memory_order_acquire);
-            rc = job();
-            finished.store(seen, std::memory_order_release);
+            const int r = f();
+            if (r < 0) { int none = PT_OK; sticky.compare_exchange_strong(none, r); }
+            finished.store(++seen, std::memory_order_release);
             { std::lock_guard<std::mutex> lk(m); }
-            cv_done.notify_one();
+            cv_done.notify_all();
         }
     }
-    void post(std::function<int()> f) {
-        { std::lock_guard<std::mutex> lk(m); job = std::move(f); posted.fetch_add(1, std::memory_order_release); }
+    uint64_t post(std::function<int()> f) {
+        uint64_t seq;
+        { std::lock_guard<std::mutex> lk(m); jobs.push_back(std::move(f)); seq = posted.fetch_add(1, std::memory_order_release) + 1; }
         cv_job.notify_one();
+        return seq;
     }
-    int wait() {                                  // the last posted exchange has been ENQUEUED (not executed)
-        const uint64_t want = posted.load(std::memory_order_acquire);
-        for (int spin = 0; spin < 4000 && finished.load(std::memory_order_acquire) != want; ++spin) __builtin_ia32_pause();
-        if (finished.load(std::memory_order_acquire) != want) {
+    // exchange number `seq` (and every one before it) has been ENQUEUED (not executed); a failure so far is returned
+    int wait_seq(uint64_t seq, bool clear) {
+        for (int spin = 0; spin < 8000 && finished.load(std::memory_order_acquire) < seq; ++spin) __builtin_ia32_pause();
+        if (finished.load(std::memory_order_acquire) < seq) {
             std::unique_lock<std::mutex> lk(m);
-            cv_done.wait(lk, [&] { return finished.load(std::memory_order_acquire) == want; });
+            cv_done.wait(lk, [&] { return finished.load(std::memory_order_acquire) >= seq; });
         }
-        return rc;
+        return clear ? sticky.exchange(PT_OK) : sticky.load();
     }
+    int wait() { return wait_seq(posted.load(std::memory_order_acquire), true); }
 };
 
 struct Group {
@@ -219,6 +239,7 @@ struct Group {
     bool frame_once[XSLOTS] = {};
     uint64_t exchanges = 0;                     // exchanges enqueued (by whichever thread issues them)
     uint64_t calls = 0;                         // calls made (caller's thread): call i uses staging slot i % XSLOTS
+    uint64_t xseq[XSLOTS] = {};                 // the exchange-thread job that last used slot s (0: none outstanding)
     std::unique_ptr<Exchanger> x;               // asynchronous batches hand their exchange to this thread
     float *frame = nullptr;                     // where the tiles are assembled: context 0's accumulation buffer -- except in the
                                                 // one-context RCCL rehearsal, where it is a buffer of its own (self_frame)
@@ -268,6 +289,7 @@ int worker_pack(Worker &w, int s) {
 // caller's thread: tiles -> root -> frame, on the exchange streams (nothing here waits on the host)
 int enqueue_exchange(int s) {
     Worker &root = *G.w[0];
+    if (G.K == 1 && !G.self_exchange) { G.exchanges++; return PT_OK; }     // one context, nothing to move: its buffer is the frame
     DeviceGuard guard;
     if (G.use_rccl) {
         for (auto &wp : G.w) {
@@ -325,12 +347,69 @@ int enqueue_exchange(int s) {
 int exchange_settled(void) {
     if (!G.x) return PT_OK;
     const int r = G.x->wait();
-    if (r < 0) { memcpy(t_err, G.x->err, ERR_BYTES); G.x->rc = PT_OK; }
+    for (int s = 0; s < XSLOTS; ++s) G.xseq[s] = 0;
+    if (r < 0) memcpy(t_err, G.x->err, ERR_BYTES);
     return r;
 }
 
+// PTMI355_XCHG_STATS=1: host time per asynchronous call, by thread, printed by pt_free (where the pace of one exchange per
+// iteration is set when the device is not the limit)
+struct XStats {
+    std::atomic<uint64_t> calls{0}, main_ns{0}, worker_ns{0}, xwait_ns{0}, xissue_ns{0};
+    bool on = false;
+} g_xstats;
+static inline uint64_t now_ns(void) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int multi_enqueue(int iter0, int count, bool overlap = false) {
     const int s = (int)(G.calls % XSLOTS);
+    if (G.x && overlap) {
+        // The caller does not wait for this batch: it does not wait for the contexts' threads to have ENQUEUED it either.
+        // Each worker gets the job (launches + packing of slot s) and the exchange thread the exchange, which first waits
+        // until every worker has run that job (the events it makes the exchange streams wait for are recorded by then).
+        // The caller runs up to XSLOTS - 1 calls ahead of both (a slot is reused when its last exchange has been issued); a
+        // failure of a posted job is reported by a later call or by pt_synchronize.  (With the caller one call ahead
+        // every call was a chain of three thread wake-ups -- caller -> worker -> exchange thread -> caller: 0.100 ms per
+        // iteration with NOTHING to exchange against 0.081 without the threads, profiles/r04/x_*.json.)
+        int rc = PT_OK;
+        const uint64_t t_main = g_xstats.on ? now_ns() : 0;
+        // the slot's last exchange has been issued: its events are what this call's packing waits for
+        if (G.xseq[s]) {
+            rc = G.x->wait_seq(G.xseq[s], false);
+            if (rc < 0) { (void)G.x->wait(); memcpy(t_err, G.x->err, ERR_BYTES); return rc; }
+        }
+        std::vector<uint64_t> seq((size_t)G.K);
+        for (auto &wp : G.w) {
+            Worker *w = wp.get();
+            if (w->posted.load(std::memory_order_acquire) - w->finished.load(std::memory_order_acquire) >= (uint64_t)XSLOTS) {
+                rc = w->wait_seq(w->posted.load(std::memory_order_acquire) - 1, false);
+                if (rc < 0) { (void)w->wait_seq(0, true); memcpy(t_err, w->err, ERR_BYTES); return rc; }
+            }
+            seq[(size_t)w->index] = w->post([w, iter0, count, s] {
+                const uint64_t t0 = g_xstats.on ? now_ns() : 0;
+                R.in_step = false;
+                R.ov_ok = true;
+                int r = enqueue_batch(iter0, count);
+                R.ov_ok = false;
+                if (!r) r = worker_pack(*w, s);
+                if (g_xstats.on && w->index == 0) g_xstats.worker_ns += now_ns() - t0;
+                return r;
+            });
+        }
+        G.calls++;
+        G.xseq[s] = G.x->post([s, seq] {
+            const uint64_t t0 = g_xstats.on ? now_ns() : 0;
+            for (auto &wp : G.w) {
+                const int r = wp->wait_seq(seq[(size_t)wp->index], false);
+                if (r < 0) { memcpy(t_err, wp->err, ERR_BYTES); return r; }
+            }
+            const uint64_t t1 = g_xstats.on ? now_ns() : 0;
+            const int r = enqueue_exchange(s);
+            if (g_xstats.on) { g_xstats.xwait_ns += t1 - t0; g_xstats.xissue_ns += now_ns() - t1; }
+            return r;
+        });
+        if (g_xstats.on) { g_xstats.main_ns += now_ns() - t_main; g_xstats.calls++; }
+        return PT_OK;
+    }
     int rc = on_all([&](Worker &w) -> int {
         R.in_step = false;
         R.ov_ok = overlap;
@@ -341,11 +420,8 @@ int multi_enqueue(int iter0, int count, bool overlap = false) {
     });
     if (rc) return rc;
     G.calls++;
-    // the exchange of the call before is enqueued by now or soon: this call's own goes behind it -- from the exchange
-    // thread when the caller does not wait for the batch, from here otherwise
     rc = exchange_settled();
     if (rc) return rc;
-    if (G.x && overlap) { G.x->post([s] { return enqueue_exchange(s); }); return PT_OK; }
     return enqueue_exchange(s);
 }
 
@@ -362,6 +438,13 @@ int multi_sync(void) {
 
 void multi_free(void) {
     if (!G.live && G.w.empty()) return;
+    if (g_xstats.on && g_xstats.calls.load()) {
+        const double n = (double)g_xstats.calls.load();
+        fprintf(stderr, "[ptmi355] %llu asynchronous calls: caller %.1f us, worker 0 %.1f us, exchange thread waits %.1f us + issues %.1f us per call (%s)\n",
+                (unsigned long long)g_xstats.calls.load(), g_xstats.main_ns.load() / n / 1e3, g_xstats.worker_ns.load() / n / 1e3,
+                g_xstats.xwait_ns.load() / n / 1e3, g_xstats.xissue_ns.load() / n / 1e3, G.transport.c_str());
+        g_xstats.calls = 0; g_xstats.main_ns = 0; g_xstats.worker_ns = 0; g_xstats.xwait_ns = 0; g_xstats.xissue_ns = 0;
+    }
     if (G.x) {
         (void)G.x->wait();
         { std::lock_guard<std::mutex> lk(G.x->m); G.x->quit = true; }
@@ -545,6 +628,7 @@ int multi_init(const pt_scene_desc *d, const std::vector<int> &devs) {
         }
     }
     G.last_cam = d->camera; G.last_depth = d->trace_depth;
+    g_xstats.on = getenv("PTMI355_XCHG_STATS") && atoi(getenv("PTMI355_XCHG_STATS")) != 0;
     t_err[0] = 0;
     return PT_OK;
 }

@@ -135,9 +135,10 @@ struct Renderer {
     int grid = 0;                 // persistent grid size
     int grid_iter = 0;            // k_iteration's own (its register budget differs from the bounce kernels'): the co-resident maximum
     int grid_iter_cur = 0;        // ... and what the batch just enqueued was launched with (iter_grid_for)
-    int iter_tpw = 8;             // under the lanes k_iteration's grid is sized for this many tiles per wave (0: always the whole grid; PTMI355_ITER_TPW) ...
+    int iter_tpw = 4;             // under the lanes k_iteration's grid is sized for this many tiles per wave (0: always the whole grid; PTMI355_ITER_TPW) ...
     int iter_wgs_per_cu_all = 15; // ... but not below this many workgroups per CU over all lanes together (PTMI355_ITER_WGS_ALL)
     bool ov_lanes_set = false;    // PTMI355_OVERLAP named a lane count
+    int ov_streams = 2;           // launch streams the lanes share (lane k uses stream k % ov_streams); PTMI355_LANE_STREAMS
     int cus = 0;
     int grid_sort = 0;            // workgroups of the material-sort kernels (k_sort_hist / k_shade_sorted)
     bool sort_wave = true;        // <= 64 keys: k_shade_sorted_w (PTMI355_SORT_WAVE=0 forces the workgroup-wide kernel)
@@ -584,9 +585,15 @@ int enqueue_end(void) {
 // Batches whose caller does not wait for them (pt_trace_batch_async) OVERLAP on the device.  A launch stream runs its kernels one after the other, and every kernel of this library ends
 // with a tail: the persistent grid's waves do not finish together (mean residency 0.84-0.94 of a launch),
 // and one iteration per launch (k_iteration) is a chain of `depth` dependent bounces per wave, ~10 us each at 800x800
-// whatever the number of paths left.  Consecutive batches therefore go to different LANES -- each a launch stream with
-// its own pools, final-colour buffer, control block, directory and mesh pre-pass buffers -- and as the workgroups of
-// one batch's kernel retire, those of another batch's take their slots.  What must stay ordered does: every k_gather
+// whatever the number of paths left.  Consecutive batches therefore go to different LANES -- each a set of pools,
+// final-colour buffer, control block, directory and mesh pre-pass buffers, on one of TWO launch streams (lanes 0 and 2 on
+// one, 1 and 3 on the other) -- and as the workgroups of one batch's kernel retire, those of another batch's take their
+// slots.  Two streams, not one per lane: how many launches really run side by side is then this library's decision and
+// not the runtime's -- it maps streams onto four hardware queues in creation order, kernels of streams that share a
+// queue run one after the other, and with a stream per lane 1 spp per call measured anything between 15 and 34
+// Grays/s depending on how many streams the process had created before (profiles/r04/ab_hw_queues*.log; four lanes
+// on two streams: 29.4-30.2 in every combination tried).  A stream's second lane has its launch queued behind the first's
+// while that one's gather is still to come.  What must stay ordered does: every k_gather
 // runs on the session's launch stream, in call order, after its own batch's last kernel (event), so the image is
 // summed in iteration order bit for bit and whatever is enqueued on the launch stream afterwards (tonemap, image
 // copies, serial batches, pt_synchronize) comes after every batch before it; a lane's next batch waits for the gather
@@ -607,7 +614,7 @@ void put_bufs(const Renderer::Bufs &b) {
 void free_lanes(void) {
     for (int k = 0; k < OV_MAX_LANES; ++k) {
         Renderer::Lane &l = R.lane[k];
-        if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+        if (l.stream && k < R.ov_streams) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }   // lanes k, k + ov_streams, ... share one
         if (l.traced) (void)hipEventDestroy(l.traced);
         if (l.gathered) (void)hipEventDestroy(l.gathered);
         if (k > 0) {                                          // lane 0 borrows the session's own buffers
@@ -647,8 +654,10 @@ static int alloc_lanes(void) {
             }
         }
     }
+    R.ov_streams = std::max(1, std::min(R.ov_streams, R.ov_lanes));
     for (int k = 0; k < R.ov_lanes; ++k) {
-        HIPCHK(hipStreamCreateWithFlags(&R.lane[k].stream, hipStreamNonBlocking));
+        if (k < R.ov_streams) HIPCHK(hipStreamCreateWithFlags(&R.lane[k].stream, hipStreamNonBlocking));
+        else R.lane[k].stream = R.lane[k % R.ov_streams].stream;
         HIPCHK(hipEventCreateWithFlags(&R.lane[k].traced, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&R.lane[k].gathered, hipEventDisableTiming));
     }
@@ -665,8 +674,6 @@ int ensure_lanes(void) {
     double budget = R.ov_budget_gb * 1e9;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, 0.5 * (double)free_b);   // leave room for the caller
-    // a session whose every batch runs as one launch (k_iteration) shares the device between six of them (iter_grid_for)
-    if (!R.ov_lanes_set && (uint64_t)R.cap <= R.whole_max_paths && (R.flags & PT_COMPACT) && !(R.flags & PT_SORT_MATERIAL) && R.mesh_mode == MESH_NONE) R.ov_lanes = 6;
     const int fit = 1 + (int)std::min(16.0, std::floor(budget / std::max(1.0, per_lane)));
     R.ov_lanes = std::min(R.ov_lanes, fit);
     if (R.ov_lanes == 3) R.ov_lanes = 2;                       // three lanes measured no better than one
@@ -726,10 +733,10 @@ int enqueue_batch_direct(int iter0, int count) {
 
 // k_iteration's grid.  A launch of its own wants every co-resident workgroup (latency: 121 us at 800x800).  Under the
 // lanes several launches share the device, and a workgroup of a full grid holds its slot for all eight bounces with two
-// tiles per wave at bounce 0 and less than one from bounce 3 on.  Measured at 800x800 (profiles/r04/ab_iter_grid*.log):
-// what counts is the workgroups the lanes ask for together -- best at ~15 per CU, three times what is co-resident, so
-// that the slots turn over between the launches (5 per CU x 4 lanes = 20: 29.2 Grays/s at 1 spp per call; 2.5 x 6 = 15:
-// 31.3; 2 x 4 = 8: 25.7) -- as long as a wave still has a few tiles (4 spp per call: the full grid is best again).
+// tiles per wave at bounce 0 and less than one from bounce 3 on.  Measured at 800x800 (profiles/r04/ab_iter_grid*.log,
+// ab_lane_streams2.log): what counts is the workgroups the lanes ask for together -- best at ~15 per CU, three times
+// what is co-resident, so that the slots turn over between the launches -- as long as a wave still has a few tiles
+// (from 2 spp per call on the full grid is best again): 1 spp per call 28.6 -> 30.1 Grays/s.
 int iter_grid_for(uint64_t paths, bool shared) {
     if (!shared || R.iter_tpw <= 0) return R.grid_iter;
     const uint64_t tiles = (paths + TILE - 1) / TILE;
@@ -1394,6 +1401,7 @@ static int init_impl(const pt_scene_desc *d) {
         if (nl >= 2) { R.ov_lanes = std::min(nl, OV_MAX_LANES); R.ov_lanes_set = true; }
     }
     if (const char *e = getenv("PTMI355_OVERLAP_GB")) R.ov_budget_gb = atof(e);
+    if (const char *e = getenv("PTMI355_LANE_STREAMS")) R.ov_streams = std::max(1, atoi(e));
     R.epi_enabled = true;
     if (const char *e = getenv("PTMI355_HOST_EPILOGUE")) R.epi_enabled = atoi(e) != 0;
     R.pin_enabled = true;
@@ -1426,7 +1434,22 @@ static int init_impl(const pt_scene_desc *d) {
         return fail(PT_ERR_INVALID, "pt_init: max_batch * tile pixels must stay below 2^30 (32-bit byte offsets into the planes)");
     R.cap = (uint32_t)R.max_batch * (uint32_t)R.map.tile_pixels;
     if (d->stream) { R.stream = (hipStream_t)d->stream; R.own_stream = false; }
-    else { HIPCHK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking)); R.own_stream = true; }
+    else {
+        // The library's own launch stream ranks above the lanes' streams.  What runs on it between overlapped batches are
+        // their gathers, a few microseconds each, and a lane's next batch waits for one.  Priority classes have hardware
+        // queues of their own: at the default priority the launch stream shares one of the runtime's four queues with
+        // whichever lanes were created fourth, eighth, ... after it, and a gather then waits behind a whole k_iteration
+        // launch of such a lane (or not, depending on how many streams the process had made before: 1 spp per call
+        // measured anything between 15 and 31 Grays/s with 2-8 lanes and 4 / 8 queues, profiles/r04/ab_hw_queues.log).
+        int lo = 0, hi = 0;
+        const char *pe = getenv("PTMI355_MAIN_PRIO");
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        if ((pe && atoi(pe) == 0) || hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, hi) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+        }
+        R.own_stream = true;
+    }
     R.live = true;
 
     // scene -> device records
