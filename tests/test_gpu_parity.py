@@ -212,6 +212,37 @@ def test_c2_forty_iterations_in_batches(pt, po, scenes):
     assert img.tobytes() == ref.image.tobytes()
 
 
+def test_c2_one_iteration_per_call_overlapped(pt, scenes, monkeypatch):
+    """C2 at full size through the reference's call pattern, enqueued back to back: every call is ONE k_iteration launch on a
+    PARTIAL grid (csrc/ptmi355.hip: iter_grid_for) overlapping its neighbours on the lanes.  Image, ray count and per-bounce
+    live counts equal those of the same calls waited for one by one (whole grid, in-launch finalGather), which
+    test_c2_full_iteration pins to the oracle and the golden image."""
+    s = scenes["cornell"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = scene.resolution[0] * scene.resolution[1]
+
+    def run(overlapped, env=()):
+        for k, v in env:
+            monkeypatch.setenv(k, v)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=1)
+        for it in range(1, 14):
+            if overlapped:
+                pt.trace_batch_async(it, 1)
+            else:
+                pt.pathtrace(None, 0, it)
+        pt.synchronize()
+        out = (pt.get_image(n).tobytes(), tuple(int(v) for v in pt.counters()))
+        pt.pathtraceFree()
+        for k, _ in env:
+            monkeypatch.delenv(k)
+        return out
+
+    serial = run(False)
+    assert run(True) == serial
+    assert run(True, (("PTMI355_ITER_TPW", "1"), ("PTMI355_ITER_WGS_ALL", "2"))) == serial      # a quarter of a workgroup per CU
+    assert run(True, (("PTMI355_ITER_TPW", "0"),)) == serial                                     # the whole grid
+
+
 def test_c2_compaction_order_hash(pt, po, scenes, golden):
     z = golden["completion"]
     s = scenes["cornell"]
@@ -373,8 +404,8 @@ def test_async_image_mode(pt, scenes):
 
 
 def test_overlapped_small_batches(pt, po, scenes, monkeypatch):
-    """Consecutive small batches whose caller does not wait (pt_trace_batch_async, PT_ASYNC_IMAGE) overlap on two
-    launch streams (csrc/ptmi355.hip: enqueue_overlapped).  The image after every call, the ray counters and the
+    """Consecutive small batches whose caller does not wait (pt_trace_batch_async, PT_ASYNC_IMAGE) overlap on lanes
+    that share two launch streams (csrc/ptmi355.hip: enqueue_batch_direct).  The image after every call, the ray counters and the
     per-bounce statistics equal the serial plan's and the oracle's: batch sizes mixed with larger (serial) batches,
     the camera moved and the trace depth changed in between, synchronous calls in between, a second session."""
     s = scenes["cornell_64"]
@@ -418,8 +449,20 @@ def test_overlapped_small_batches(pt, po, scenes, monkeypatch):
 
     serial, overlapped = run(0), run(1)
     assert serial == overlapped
-    assert run(2) == serial and run(4) == serial                  # two / four lanes (default: three)
+    assert run(2) == serial and run(4) == serial                  # two / four lanes
     assert run(3, "0xfffffff8") == serial
+    # the lanes share two launch streams by default; one stream for all, one per lane, lanes that do not divide evenly, and
+    # k_iteration's grid under the lanes (whole grid / a tile per wave) change nothing either
+    for lanes, streams, tpw, wgs in ((3, 1, "0", "15"), (6, 6, "8", "15"), (5, 3, "1", "4"), (8, 2, "2", "40")):
+        monkeypatch.setenv("PTMI355_LANE_STREAMS", str(streams))
+        monkeypatch.setenv("PTMI355_ITER_TPW", tpw)
+        monkeypatch.setenv("PTMI355_ITER_WGS_ALL", wgs)
+        assert run(lanes) == serial, (lanes, streams, tpw, wgs)
+    for k in ("PTMI355_LANE_STREAMS", "PTMI355_ITER_TPW", "PTMI355_ITER_WGS_ALL"):
+        monkeypatch.delenv(k)
+    monkeypatch.setenv("PTMI355_MAIN_PRIO", "0")                      # the library's own launch stream at default priority
+    assert run(4) == serial
+    monkeypatch.delenv("PTMI355_MAIN_PRIO")
     monkeypatch.setenv("PTMI355_OVERLAP_GB", "0.0001")                # the lanes' buffers do not fit the budget: the launch stream alone
     assert run(4) == serial
     monkeypatch.delenv("PTMI355_OVERLAP_GB")
