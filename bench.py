@@ -493,7 +493,9 @@ def main():
             if rank == 0:
                 out["config"]["sub_measurements"] = "gave up after %.0f s" % args.sub_timeout
                 print(json.dumps(out), flush=True)
-            os._exit(0 if rank == 0 else 3)
+            else:
+                time.sleep(2.0)                # rank 0's line first: a launcher that sees a rank exit tears the others down
+            os._exit(0)                        # the line says what happened; the timed region was complete
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             sub = sub_measurements(c, args.steps, args.warmup)
