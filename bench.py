@@ -160,8 +160,8 @@ class Session:
 
     scaling / reduce_every as on the command line; exchange=False traces at the same cadence (same batch sizes, same
     number of calls) without moving the tiles -- the reference rate an exchange is held against; threaded: the tile
-    gather of the process form is issued from sharding.TileGatherThread (None: whenever there is more than one exchange
-    per step -- at one per step the two-slot TileGather on the tracing thread costs nothing)."""
+    gather of the process form is issued from sharding.TileGatherThread (None: only with --exchange-thread and more than
+    one exchange per step; otherwise the two-slot TileGather on the tracing thread)."""
 
     def __init__(self, c, scaling, reduce_every, exchange=True, threaded=None, it0=0):
         args, torch, pt = c.args, c.torch, c.pt
@@ -184,7 +184,7 @@ class Session:
         self.gather = self.gather_thread = None
         if c.dist_on and self.do_exchange and args.collective == "gather":
             if threaded is None:
-                threaded = self.exchanges_per_step > 1 and not args.no_exchange_thread
+                threaded = self.exchanges_per_step > 1 and args.exchange_thread and not args.no_exchange_thread
             cls = pt.sharding.TileGatherThread if threaded else pt.sharding.TileGather
             g = cls(torch, c.dist, c.rank, c.world, args.strip_rows, c.W, c.H, torch.device("cuda", c.local_rank),
                     via_host=(args.backend == "gloo"))
@@ -381,8 +381,11 @@ def main():
     ap.add_argument("--sub-iters", type=int, default=256, help="iterations of the per-iteration-exchange sub-measurement")
     ap.add_argument("--sub-timeout", type=float, default=120.0,
                     help="seconds the sub-measurements may take before the main line is printed without them")
-    ap.add_argument("--no-exchange-thread", action="store_true",
-                    help="process form: issue every tile gather from the tracing thread (rounds 1-3), also at more than one exchange per step")
+    ap.add_argument("--exchange-thread", action="store_true",
+                    help="process form: issue the tile gathers from sharding.TileGatherThread when there is more than one per step "
+                         "(measured SLOWER than the tracing thread's own two-slot gather once the device was no longer the limit: "
+                         "two Python threads take turns at the interpreter lock; profiles/r04/sub_exchange_check.log)")
+    ap.add_argument("--no-exchange-thread", action="store_true", help="(the default now; kept for old command lines)")
     args = ap.parse_args()
 
     c = setup(args)

@@ -125,7 +125,11 @@ class TileGatherThread:
     sum after exactly that iteration) and records an event; this thread waits for the event ON A SIDE STREAM, issues
     the gather there, and rank 0 copies the tiles into the frame behind it, in issue order.  `slots` staging buffers:
     the tracing thread runs up to `slots` exchanges ahead.  On CPU tensors (gloo, the N > 1 tests) there are no
-    streams: the pack is synchronous and the thread's gather blocks, same order."""
+    streams: the pack is synchronous and the thread's gather blocks, same order.
+
+    Measured on one MI355X (bench.py --force-dist, profiles/r04/sub_exchange_check.log): once the device was no longer the
+    limit this form is SLOWER than TileGather on the tracing thread (0.36-0.39 x the no-exchange rate against 0.94-0.95 x):
+    two Python threads take turns at the interpreter lock.  bench.py uses it only with --exchange-thread."""
 
     def __init__(self, torch, dist, rank, world, strip_rows, width, height, device, via_host=False, slots=4):
         import queue

@@ -95,16 +95,19 @@ def test_two_ranks_same_frame():
     # weak scaling, 2 x 2 iterations per step: gather once per step; gather every iteration; full-frame reduce
     for k, extra in enumerate((["--batch", "2"], ["--batch", "2", "--reduce-every", "1"],
                                ["--batch", "2", "--collective", "reduce"],
-                               ["--batch", "4", "--scaling", "strong", "--reduce-every", "3"])):
+                               ["--batch", "4", "--scaling", "strong", "--reduce-every", "3"],
+                               ["--batch", "2", "--reduce-every", "1", "--exchange-thread"])):
         two = _two(29533 + k, *extra)
         assert two["n_gpus"] == 2 and two["scaling"] == ("strong" if "strong" in extra else "weak")
         assert two["config"]["rays_per_step"] == one["config"]["rays_per_step"], extra      # same 4 iterations per step
         assert two["image_md5"] == one["image_md5"], extra
-        # the north star's questions ride along in every N > 1 line: the exchange after every iteration (issued from the
-        # exchange thread, next to the same cadence without it) and strong scaling
+        # the north star's questions ride along in every N > 1 line: the exchange after every iteration (next to the same
+        # cadence without it; issued from the tracing thread, or from sharding.TileGatherThread with --exchange-thread)
+        # and strong scaling
         pie, strong = two["config"]["per_iteration_exchange"], two["config"]["strong"]
         assert pie["mrays_per_s"] > 10 and pie["no_exchange_mrays_per_s"] > 10 and pie["iterations"] >= 8, pie
-        assert "exchange thread" in pie["transport"] or extra == ["--batch", "2", "--collective", "reduce"], pie
+        assert ("exchange thread" if "--exchange-thread" in extra else "tracing thread") in pie["transport"] \
+            or extra == ["--batch", "2", "--collective", "reduce"], pie
         assert strong["mrays_per_s"] > 10 and strong["spp_per_step_per_frame"] == int(extra[1]), strong
 
 
@@ -148,7 +151,7 @@ def test_one_rank_rccl():
         finally:
             os.environ.pop("MASTER_PORT", None)
         assert d["n_gpus"] == 1 and d["config"]["exchanges_per_step"] >= 1, extra
-        pie = d["config"]["per_iteration_exchange"]                    # RCCL gather per iteration from the exchange thread
+        pie = d["config"]["per_iteration_exchange"]                    # RCCL gather per iteration
         assert pie["mrays_per_s"] > 10 and 0.05 < pie["ratio"] < 20.0 and pie["iterations"] >= 16, pie
         assert d["config"]["rays_per_step"] == one["config"]["rays_per_step"], extra
         assert d["image_md5"] == one["image_md5"], extra
