@@ -111,7 +111,10 @@ enum pt_flags {
                                     allocated at its address until pt_free (the reference's scene->state.image is: sized at
                                     load, scene.cpp:145-147).  The library then page-locks it on first use and, when an
                                     iteration runs as one launch, lets the kernel write the new sums into it over PCIe
-                                    while it is still tracing.  Without the flag every call copies into whatever buffer
+                                    while it is still tracing -- from the second consecutive pt_trace on only the pixels
+                                    whose sum changed (a path that ends with colour 0 adds nothing): the buffer is the
+                                    library's to keep current, the host READS it between calls and does not write to it
+                                    (a host that does: PTMI355_HOST_SPARSE=0, every pixel every call).  Without the flag every call copies into whatever buffer
                                     it is given (pageable path), exactly like the reference's cudaMemcpy
                                     (pathtrace.cu:389-390): buffers may be freed or reallocated between calls. */
     PT_ASYNC_IMAGE   = 1u << 7   /* opt-in: pt_trace / pt_trace_batch return without waiting; the copy of the

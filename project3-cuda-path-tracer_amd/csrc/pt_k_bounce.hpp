@@ -48,6 +48,7 @@ __device__ __forceinline__ Pool karg_pool(size_t offset) {
 struct TileCtx {
     bool kargs = false;         // k_bounce: pools and final colours through karg_field (a compile-time constant after inlining)
     bool kmisc = false;         // k_iteration: final colours, camera, lens, tile map through karg_field / karg_struct (its pools are locals)
+    bool epi_direct = false;    // k_iteration doing its own finalGather path by path (BounceArgs::epi_direct)
     SceneAcc acc;               // per-lane gathers: materials, geom info, matrices (LDS or global)
     float *tri_lds;             // triangle tile (MESH_TILES)
     int lane, iter0;
@@ -145,7 +146,20 @@ __device__ __forceinline__ void tile_shade(const BounceArgs &a, const TileCtx &c
         alive = ptd::shade_scatter(ps, t, nrm, mat, outside, c.acc.mats, c.iter0 + (int)tr.smp, tr.pixel, depth,
                                    depth == a.trace_depth - 1);
         if (!alive) {
-            put_final((c.kargs || c.kmisc) ? karg_field<float *>(offsetof(BounceArgs, fin)) : a.fin, tr.pid, ps.c, c.stamp);
+            if (c.epi_direct) {
+                // finalGather for this path, here (pathtrace.cu:380-392 at one sample per pixel): image[pixel] += colour, the
+                // same single addition per channel; colour 0 leaves the sum as it is (x + 0 = x exactly, sums are never -0)
+                // and as the host has it.  NaN compares false: added.
+                if (!(ps.c.x == 0.0f && ps.c.y == 0.0f && ps.c.z == 0.0f)) {
+                    float *img = karg_field<float *>(offsetof(BounceArgs, epi_image)) + 3 * (size_t)tr.pixel;
+                    const float r = img[0] + ps.c.x, g = img[1] + ps.c.y, b = img[2] + ps.c.z;
+                    img[0] = r; img[1] = g; img[2] = b;
+                    float *host = karg_field<float *>(offsetof(BounceArgs, epi_host));
+                    if (host) { host += 3 * (size_t)tr.pixel; host[0] = r; host[1] = g; host[2] = b; }
+                }
+            } else {
+                put_final((c.kargs || c.kmisc) ? karg_field<float *>(offsetof(BounceArgs, fin)) : a.fin, tr.pid, ps.c, c.stamp);
+            }
         }
     }
     // ---- survivors append to the wave's packed run (wave64 ballot + popcount rank) ----
@@ -492,6 +506,7 @@ __global__ __launch_bounds__(BLOCK, PT_ITER_WAVES) void k_iteration(BounceArgs a
     c.kmisc = true;
 #endif
     c.tri_lds = nullptr;
+    c.epi_direct = a.epi_direct != 0;
     c.acc = stage_scene<SLDS>(lc.scene, a.scene);
     WaveQ q{lc.pw, 0, 0};
     const int lane = threadIdx.x & 63;
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(BLOCK, PT_ITER_WAVES) void k_iteration(BounceArgs a
     // are transposed through the wave's LDS block so that every store instruction writes 256 contiguous bytes
     // (whole lines for the PCIe write combiner), not 64 dwords 12 bytes apart.
     float *const epi_image = karg_field<float *>(offsetof(BounceArgs, epi_image));
-    if (epi_image) {
+    if (epi_image && !c.epi_direct) {                               // (epi_direct: every ending path has done it for its pixel)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's final colours have left the CU
         float *const epi_host = karg_field<float *>(offsetof(BounceArgs, epi_host));
         const float *const fin = karg_field<float *>(offsetof(BounceArgs, fin));

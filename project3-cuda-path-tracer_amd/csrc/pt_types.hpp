@@ -310,6 +310,10 @@ struct BounceArgs {
     // device's running sum: finalGather inside the launch, no k_gather) and, with a host image, writes the new sums to
     // epi_host (the caller's page-locked image, device-mapped); epi_image == nullptr: k_gather does it
     float *epi_image, *epi_host;
+    // ... and epi_direct: no final-colour buffer in between -- the path that ends with a colour adds it to its pixel of
+    // epi_image itself (one path per pixel in such a launch) and, with a host image, writes that pixel's new sum to
+    // epi_host; the pixels of paths that end with colour 0 are not touched: their sums are what the host already has
+    int epi_direct;
     // k_iteration: per-workgroup traced counts [bounce][workgroup] (plain stores, nothing to clear), folded by the
     // launch's last workgroup into Control::alive, Persist and (synchronous calls) the host's pt_stats block
     uint32_t *iter_counts;

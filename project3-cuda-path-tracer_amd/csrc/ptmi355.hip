@@ -179,6 +179,11 @@ struct Renderer {
     Control *last_ctl = nullptr;  // the control block of the last batch (collect_stats)
     float *epi_host = nullptr;    // pt_trace: the caller's image, device-mapped, for k_iteration's own gather (this call only)
     bool epi_done = false;        // ... and k_iteration took it
+    bool epi_direct_enabled = true;   // PTMI355_EPI_DIRECT=0: such launches keep the final-colour buffer and gather per wave at their end
+    bool host_sparse_enabled = true;  // PTMI355_HOST_SPARSE=0: ... when a host image is written (every pixel, every call)
+    uint64_t image_epoch = 0;     // bumped by everything that changes the accumulation buffer
+    float *host_synced = nullptr; // the (device-mapped) host image that held exactly the buffer's content at epoch host_epoch
+    uint64_t host_epoch = 0;
     bool epi_enabled = true;      // PTMI355_HOST_EPILOGUE=0: always copy after the iteration
     bool pin_enabled = true;      // PTMI355_PIN=0: never page-lock caller buffers (copies take the runtime's pageable path)
     bool use_graphs = false;      // PTMI355_GRAPH=1 turns replay on (measured slower than direct launches on ROCm 7.2: DESIGN.md 6.10)
@@ -574,6 +579,7 @@ int enqueue_end(void) {
                        R.whole ? 1 : 0, R.epi_done ? 1 : 0, R.capturing ? 0u : R.fin_serial, R.iter_counts, (uint32_t)R.grid_iter_cur,
                        (R.whole && R.host_stats_serial) ? R.d_stats : (HostStats *)nullptr);
     R.whole = false;
+    R.image_epoch++;
     HIPCHK(hipGetLastError());
     if (R.lane_cur) {
         HIPCHK(hipEventRecord(R.lane_cur->gathered, gs));
@@ -764,7 +770,13 @@ int enqueue_batch_serial(int iter0, int count) {
         // float additions is part of the result) -- and, with a page-locked host image, writes the new sums there.
         if (count == 1 && !R.lane_cur && !R.capturing && !R.use_graphs && R.epi_enabled) {
             a.epi_image = R.image; a.epi_host = R.epi_host;
-            if (R.epi_host) R.epi_done = true;
+            // path by path (BounceArgs::epi_direct) when nothing but this library has written the accumulation buffer since
+            // the host's copy was complete -- otherwise every pixel is written once more by the launch's epilogue.  A
+            // caller-owned device buffer (pt_scene_desc.device_image) can change behind the library's back.
+            const bool host_current = R.host_sparse_enabled && R.own_image && R.host_synced == R.epi_host && R.host_epoch == R.image_epoch;
+            a.epi_direct = (R.epi_direct_enabled && (!R.epi_host || host_current)) ? 1 : 0;
+            R.image_epoch++;
+            if (R.epi_host) { R.epi_done = true; R.host_synced = R.epi_host; R.host_epoch = R.image_epoch; }
             R.self_gathered = true;
         }
         // a synchronous call's statistics go straight to page-locked host memory: written by whoever folds the counts, this
@@ -1404,6 +1416,8 @@ static int init_impl(const pt_scene_desc *d) {
     if (const char *e = getenv("PTMI355_LANE_STREAMS")) R.ov_streams = std::max(1, atoi(e));
     R.epi_enabled = true;
     if (const char *e = getenv("PTMI355_HOST_EPILOGUE")) R.epi_enabled = atoi(e) != 0;
+    if (const char *e = getenv("PTMI355_EPI_DIRECT")) R.epi_direct_enabled = atoi(e) != 0;
+    if (const char *e = getenv("PTMI355_HOST_SPARSE")) R.host_sparse_enabled = atoi(e) != 0;
     R.pin_enabled = true;
     if (const char *e = getenv("PTMI355_PIN")) R.pin_enabled = atoi(e) != 0;
     R.npix = W * H;
@@ -1991,6 +2005,7 @@ int pt_clear_image(void) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_clear_image: not initialised");
     HIPCHK(hipMemsetAsync(R.image, 0, (size_t)R.npix * 12, R.stream));
     HIPCHK(hipStreamSynchronize(R.stream));
+    R.image_epoch++;
     return PT_OK;
 }
 
@@ -2003,6 +2018,7 @@ int pt_set_image(const float *host_image_sum) {
     if (R.copy_stream) HIPCHK(hipStreamSynchronize(R.copy_stream));
     HIPCHK(hipMemcpy(R.image, host_image_sum, (size_t)R.npix * 12, hipMemcpyHostToDevice));
     R.ov_active = false;
+    R.image_epoch++;
     return PT_OK;
 }
 

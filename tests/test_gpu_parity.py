@@ -672,6 +672,57 @@ def test_host_image_freed_and_reallocated_between_calls(pt, po, scenes):
     pt.pathtraceFree()
 
 
+def test_host_image_kept_current_incrementally(pt, scenes, monkeypatch):
+    """pathtrace() per call with a long-lived page-locked host image (PT_PIN_IMAGE): from the second call on, the launch
+    adds every ending path's colour to its pixel itself and writes only those pixels to the host (BounceArgs::epi_direct;
+    the others still hold their sums).  After every call the host buffer IS the device's running sum, whatever else
+    happened in between: overlapped batches (k_gather wrote the buffer), pt_clear_image, pt_set_image, a second host
+    buffer, a camera move; and the whole sequence equals the one with every pixel written every call."""
+    s = scenes["cornell"]
+    cam = _resized(s["camera"], 400, 300)                  # 1.44 MB of image: above the 1 MiB from which PT_PIN_IMAGE page-locks
+    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
+    n = 400 * 300
+    L = pt.library()
+    cam2 = cam.copy()
+    cam2["position"][0][1] += 0.5
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE, pin_image=False)
+        a = np.full((n, 3), -7.0, dtype=np.float32)
+        b = np.full((n, 3), -9.0, dtype=np.float32)
+        out = []
+
+        def call(buf, it):
+            assert L.pt_trace(None, 0, it, buf.ctypes.data) == 0
+            assert buf.tobytes() == pt.get_image(n).tobytes(), it
+            out.append(buf.tobytes())
+
+        for it in (1, 2, 3):
+            call(a, it)
+        pt.trace_batch_async(4, 1); pt.trace_batch_async(5, 1)            # the buffer changes behind the host's copy
+        call(a, 6); call(a, 7)
+        pt.clear_image()
+        call(a, 8); call(a, 9)
+        call(b, 10); call(a, 11); call(a, 12); call(b, 13)               # two host buffers in turn
+        pt.set_image(np.ascontiguousarray(np.frombuffer(out[2], dtype=np.float32).reshape(n, 3)))
+        call(a, 14); call(a, 15)
+        pt.set_camera(cam2, s["depth"] - 2)
+        call(a, 16); call(a, 17)
+        pt.trace_batch(18, 1, None)                                      # a synchronous batch without a host image
+        call(a, 19)
+        pt.pathtraceFree()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    ref = run({"PTMI355_EPI_DIRECT": "0"})
+    assert run({}) == ref
+    assert run({"PTMI355_HOST_SPARSE": "0"}) == ref
+    assert run({"PTMI355_HOST_EPILOGUE": "0"}) == ref
+
+
 @pytest.mark.parametrize("flags_name", ["loop", "bvh"])
 def test_unit_mesh_seen_from_far_away(pt, po, scenes, flags_name):
     """A unit-size mesh viewed from 300 and then from 5000 units away: the hierarchy's box padding and the
