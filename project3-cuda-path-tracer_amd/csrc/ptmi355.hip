@@ -152,6 +152,7 @@ struct Renderer {
     struct BatchGraph { hipGraphExec_t exec; int cur, cur_dir, step_depth; bool sorted_isects, gen_fused; };
     std::map<int, BatchGraph> graphs;
     uint64_t whole_max_paths = 6000000;  // batches up to this many paths run as ONE launch (k_iteration); PTMI355_WHOLE_MAX
+    uint64_t whole_max_host_paths = 16000000;   // ... one iteration with a page-locked host image: up to this many (PTMI355_WHOLE_MAX_HOST)
     bool whole = false;           // the current batch did
     // Batches whose caller does not wait for them overlap on the device (enqueue_batch_direct): each runs on a LANE --
     // a launch stream of its own and its own set of the buffers a batch in flight owns
@@ -753,9 +754,12 @@ int iter_grid_for(uint64_t paths, bool shared) {
 
 int enqueue_batch_serial(int iter0, int count) {
     // small batch: every bounce in one launch (k_iteration)
+    // (one iteration straight into a page-locked host image: the launch hides the PCIe transfer under its tracing, which
+    // a kernel per bounce + a copy cannot: worth it for larger frames too -- 3840x2160: 2.49 -> see profiles/r04/ab_percall_4k.log)
+    const uint64_t whole_limit = (count == 1 && R.epi_host) ? std::max(R.whole_max_paths, R.whole_max_host_paths) : R.whole_max_paths;
     const bool whole = !(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER | PT_CACHE_FIRST)) && (R.flags & PT_COMPACT) &&
                        R.mesh_mode == MESH_NONE && R.sort_keys == 0 && count >= 1 &&
-                       (uint64_t)R.map.tile_pixels * (uint64_t)count <= R.whole_max_paths;
+                       (uint64_t)R.map.tile_pixels * (uint64_t)count <= whole_limit;
     int rc = enqueue_begin(iter0, count, false, !whole);
     if (rc) return rc;
     if (R.flags & PT_FAKE_SHADER) {
@@ -1407,6 +1411,9 @@ static int init_impl(const pt_scene_desc *d) {
     if (const char *ug = getenv("PTMI355_GRAPH")) R.use_graphs = atoi(ug) != 0;
     R.whole_max_paths = 6000000;     // measured at 800x800 (r02): 1 spp +38 %, 4 spp +20 %, 8 spp +8 %, 16 spp -4 %
     if (const char *wm = getenv("PTMI355_WHOLE_MAX")) R.whole_max_paths = strtoull(wm, nullptr, 10);
+    R.whole_max_host_paths = 16000000;
+    if (const char *wm = getenv("PTMI355_WHOLE_MAX_HOST")) R.whole_max_host_paths = strtoull(wm, nullptr, 10);
+    if (getenv("PTMI355_WHOLE_MAX") && !getenv("PTMI355_WHOLE_MAX_HOST")) R.whole_max_host_paths = R.whole_max_paths;   // (tests pin the launch plan with it)
     if (const char *e = getenv("PTMI355_OVERLAP")) {           // 0: off; 1: on (default lanes); n >= 2: n lanes
         const int nl = atoi(e);
         R.ov_enabled = nl != 0;

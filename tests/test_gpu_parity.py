@@ -723,6 +723,35 @@ def test_host_image_kept_current_incrementally(pt, scenes, monkeypatch):
     assert run({"PTMI355_HOST_EPILOGUE": "0"}) == ref
 
 
+def test_4k_one_iteration_per_call_into_the_host_image(pt, scenes, monkeypatch):
+    """C5's frame (3840 x 2160 = 8.3 M paths) through pathtrace() per call with a page-locked host image: one launch per
+    iteration although the frame is above the 6 M paths up to which batches run as one launch (the launch hides the PCIe
+    transfer).  Host image == device sum after every call == the kernel-per-bounce plan with a copy per call."""
+    s = scenes["cornell"]
+    cam = _resized(s["camera"], 3840, 2160)
+    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
+    n = 3840 * 2160
+    L = pt.library()
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE, pin_image=False)
+        host = np.full((n, 3), -3.0, dtype=np.float32)
+        out = []
+        for it in (1, 2, 3):
+            assert L.pt_trace(None, 0, it, host.ctypes.data) == 0
+            out.append(hashlib.md5(host.tobytes()).hexdigest())
+        assert host.tobytes() == pt.get_image(n).tobytes()
+        out.append(tuple(int(v) for v in pt.counters()))
+        pt.pathtraceFree()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    assert run({}) == run({"PTMI355_WHOLE_MAX_HOST": "0"})
+
+
 @pytest.mark.parametrize("flags_name", ["loop", "bvh"])
 def test_unit_mesh_seen_from_far_away(pt, po, scenes, flags_name):
     """A unit-size mesh viewed from 300 and then from 5000 units away: the hierarchy's box padding and the
