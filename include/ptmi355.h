@@ -120,7 +120,9 @@ enum pt_flags {
     PT_ASYNC_IMAGE   = 1u << 7   /* opt-in: pt_trace / pt_trace_batch return without waiting; the copy of the
                                     running sum into host_image_sum overlaps the NEXT call's tracing and is
                                     complete when the next pt_trace / pt_trace_batch returns, or after
-                                    pt_synchronize, pt_get_image or pt_free (pt_get_stats needs pt_synchronize).  Off = the reference's synchronous pathtrace()
+                                    pt_synchronize, pt_get_image or pt_free (pt_get_stats needs pt_synchronize).  (pt_trace: the launch
+                                    writes the page-locked buffer itself, as under PT_PIN_IMAGE, and the same rule holds: the host
+                                    reads the buffer, it does not write to it.)  Off = the reference's synchronous pathtrace()
                                     (pathtrace.cu:389-392).  Implies the lifetime rule of PT_PIN_IMAGE for the buffers
                                     handed over (they are read by a copy that is still running when the call returns). */
 };

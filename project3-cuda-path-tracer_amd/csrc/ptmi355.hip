@@ -212,6 +212,13 @@ struct Renderer {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
     uint64_t async_calls = 0;
+    // PT_ASYNC_IMAGE through the launch's own host writes (pt_trace, one launch per iteration): completion events of such
+    // launches, the event the NEXT asynchronous call waits for before it returns (a copy's or a launch's), and the last
+    // copy-engine transfer a launch that writes the host buffer itself has to come after
+    hipEvent_t ev_direct[2] = {nullptr, nullptr};
+    int direct_k = 0;
+    hipEvent_t async_prev = nullptr, dma_last = nullptr;
+    bool async_direct_enabled = true;     // PTMI355_ASYNC_DIRECT=0: always snapshot + copy engine
     unsigned int *dbg_counts = nullptr;   // PTMI355_DBG_COUNTS=<words>: buffer for an instrumented kernel build's block counts (BounceArgs::dbg_counts)
     size_t dbg_words = 0;
     void *scratch = nullptr;      // export / import staging
@@ -1055,8 +1062,12 @@ int enqueue_async_image(float *host) {
     HIPCHK(hipEventRecord(R.ev_copied[k], R.copy_stream));
     // the buffer handed over by the PREVIOUS call is complete when this call returns (its copy has been running
     // beside this call's tracing, which is already enqueued)
-    if (R.async_calls >= 1) HIPCHK(hipEventSynchronize(R.ev_copied[k ^ 1]));
+    if (R.async_prev) HIPCHK(hipEventSynchronize(R.async_prev));
+    R.async_prev = R.ev_copied[k]; R.dma_last = R.ev_copied[k];
     R.async_calls++;
+    // once this copy has landed the buffer holds the sum as of now: a later launch that writes the host itself (after
+    // dma_last) only has to write what changes
+    R.host_synced = R.own_image ? map_host(host, bytes) : nullptr; R.host_epoch = R.image_epoch;
     return PT_OK;
 }
 
@@ -1425,6 +1436,7 @@ static int init_impl(const pt_scene_desc *d) {
     if (const char *e = getenv("PTMI355_HOST_EPILOGUE")) R.epi_enabled = atoi(e) != 0;
     if (const char *e = getenv("PTMI355_EPI_DIRECT")) R.epi_direct_enabled = atoi(e) != 0;
     if (const char *e = getenv("PTMI355_HOST_SPARSE")) R.host_sparse_enabled = atoi(e) != 0;
+    if (const char *e = getenv("PTMI355_ASYNC_DIRECT")) R.async_direct_enabled = atoi(e) != 0;
     R.pin_enabled = true;
     if (const char *e = getenv("PTMI355_PIN")) R.pin_enabled = atoi(e) != 0;
     R.npix = W * H;
@@ -1848,8 +1860,13 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
     // synchronous host image: when this iteration runs as one launch, its waves write the new sums into the caller's
     // (page-locked, device-mapped) buffer as they finish, under the tracing of the others (k_iteration's epilogue)
     R.epi_host = nullptr; R.epi_done = false;
-    if (host_image_sum && !(R.flags & PT_ASYNC_IMAGE) && R.epi_enabled && !R.use_graphs && R.map.tile_count == 1)
+    const bool async_image = host_image_sum && (R.flags & PT_ASYNC_IMAGE);
+    if (host_image_sum && (!async_image || R.async_direct_enabled) && R.epi_enabled && !R.use_graphs && R.map.tile_count == 1)
         R.epi_host = map_host(host_image_sum, (size_t)R.npix * 12);
+    if (R.epi_host && R.dma_last) {                        // a copy-engine transfer into a host buffer may still be running
+        HIPCHK(hipStreamWaitEvent(R.stream, R.dma_last, 0));
+        R.dma_last = nullptr;
+    }
     R.ov_ok = false;       // (PT_ASYNC_IMAGE calls are bound by their 7.68 MB copy: lanes measured 14.7 against 15.8 Grays/s there)
     R.want_host_stats = !(host_image_sum && (R.flags & PT_ASYNC_IMAGE));
     int rc = enqueue_batch(iter, 1);
@@ -1862,7 +1879,19 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
                            R.image, R.npix, iter);
         HIPCHK(hipGetLastError());
     }
-    if (host_image_sum && (R.flags & PT_ASYNC_IMAGE)) return enqueue_async_image(host_image_sum);
+    if (async_image && gathered) {
+        // PT_ASYNC_IMAGE and the launch wrote the host image itself: nothing to copy.  The buffer is complete when the launch
+        // is; this call returns without waiting for it, but not before the PREVIOUS call's buffer is complete.
+        for (int j = 0; j < 2; ++j)
+            if (!R.ev_direct[j]) HIPCHK(hipEventCreateWithFlags(&R.ev_direct[j], hipEventDisableTiming));
+        hipEvent_t mine = R.ev_direct[R.direct_k];
+        R.direct_k ^= 1;
+        HIPCHK(hipEventRecord(mine, R.stream));
+        if (R.async_prev && R.async_prev != mine) HIPCHK(hipEventSynchronize(R.async_prev));
+        R.async_prev = mine;
+        return PT_OK;
+    }
+    if (async_image) return enqueue_async_image(host_image_sum);
     if (host_image_sum && !gathered) {
         rc = enqueue_image_copy(host_image_sum);
         if (rc) return rc;

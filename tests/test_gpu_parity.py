@@ -723,6 +723,62 @@ def test_host_image_kept_current_incrementally(pt, scenes, monkeypatch):
     assert run({"PTMI355_HOST_EPILOGUE": "0"}) == ref
 
 
+def test_async_image_written_by_the_launch(pt, scenes, monkeypatch):
+    """PT_ASYNC_IMAGE with a page-lockable image (400 x 300 x 12 B > 1 MiB): pt_trace returns without waiting and the
+    launch writes the host buffer itself (only the pixels that changed when the buffer is the one it wrote last).  The
+    contract of the flag holds call for call: a buffer is complete when the NEXT call returns (or after pt_synchronize)
+    and then holds exactly the sum after its own call -- one buffer reused, two buffers in turn, a batch call (snapshot
+    + copy engine) in between -- and equals the copy-engine-only plan and the synchronous sums."""
+    s = scenes["cornell"]
+    cam = _resized(s["camera"], 400, 300)
+    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
+    n = 400 * 300
+    L = pt.library()
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, pin_image=False)
+    want = {}
+    for it in range(1, 15):
+        want[it] = pt.pathtrace(None, 0, it).tobytes()
+    pt.pathtraceFree()
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_ASYNC_IMAGE, pin_image=False)
+        a = np.full((n, 3), -1.0, dtype=np.float32)
+        b = np.full((n, 3), -2.0, dtype=np.float32)
+        c = np.full((n, 3), -3.0, dtype=np.float32)
+        ok = []
+        assert L.pt_trace(None, 0, 1, a.ctypes.data) == 0
+        assert L.pt_trace(None, 0, 2, b.ctypes.data) == 0
+        ok.append(a.tobytes() == want[1])                         # complete when the next call has returned
+        assert L.pt_trace(None, 0, 3, a.ctypes.data) == 0
+        ok.append(b.tobytes() == want[2])
+        assert L.pt_trace(None, 0, 4, a.ctypes.data) == 0         # the same buffer again: only what changed is written
+        assert L.pt_trace(None, 0, 5, a.ctypes.data) == 0
+        assert L.pt_trace_batch(6, 1, c.ctypes.data) == 0         # batch entry point: snapshot + copy engine
+        ok.append(a.tobytes() == want[5])
+        assert L.pt_trace(None, 0, 7, a.ctypes.data) == 0
+        ok.append(c.tobytes() == want[6])
+        assert L.pt_trace(None, 0, 8, c.ctypes.data) == 0         # the buffer the copy engine wrote, now written by the launch
+        ok.append(a.tobytes() == want[7])
+        assert L.pt_trace(None, 0, 9, c.ctypes.data) == 0
+        pt.synchronize()
+        ok.append(c.tobytes() == want[9])
+        pt.clear_image()
+        for it in (1, 2, 3):
+            assert L.pt_trace(None, 0, it, c.ctypes.data) == 0
+        pt.synchronize()
+        ok.append(c.tobytes() == want[3])
+        pt.pathtraceFree()
+        for k in env:
+            monkeypatch.delenv(k)
+        return ok
+
+    assert all(run({})), "launch-written"
+    assert all(run({"PTMI355_ASYNC_DIRECT": "0"})), "copy engine"
+    assert all(run({"PTMI355_HOST_SPARSE": "0"})), "launch-written, every pixel"
+
+
 def test_4k_one_iteration_per_call_into_the_host_image(pt, scenes, monkeypatch):
     """C5's frame (3840 x 2160 = 8.3 M paths) through pathtrace() per call with a page-locked host image: one launch per
     iteration although the frame is above the 6 M paths up to which batches run as one launch (the launch hides the PCIe
