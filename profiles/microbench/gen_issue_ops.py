@@ -84,6 +84,21 @@ OPS["v_cvt_i32_f64"] = "v_cvt_i32_f64 %s, %s" % (A, D)
 OPS["v_cvt_u32_f64"] = "v_cvt_u32_f64 %s, %s" % (A, D)
 OPS["v_cvt_f64_f32"] = "v_cvt_f64_f32 %s, %s" % (D, A)
 OPS["v_cvt_f64_u32"] = "v_cvt_f64_u32 %s, %s" % (D, A)
+# scalar instructions (round 4: is the scalar unit a second issue roof?  k_bounce executes 0.73 scalar / branch / message
+# instructions per vector instruction); four independent chains in s40 / s42 / s44 / s46
+OPS["s_add_u32"] = "s_add_u32 s{p}, s{p}, s{q}"
+OPS["s_and_b32"] = "s_and_b32 s{p}, s{p}, %s" % S32
+OPS["s_lshl_b32"] = "s_lshl_b32 s{p}, s{p}, 1"
+OPS["s_mov_b32"] = "s_mov_b32 s{p}, %s" % S32
+OPS["s_and_b64"] = "s_and_b64 s[{p}:{q}], s[{p}:{q}], %s" % S64
+OPS["s_bcnt1_i32_b64"] = "s_bcnt1_i32_b64 s{p}, %s" % S64
+OPS["s_or_saveexec_b64"] = "s_or_saveexec_b64 s[{p}:{q}], exec"
+OPS["s_cmp_lg_u32"] = "s_cmp_lg_u32 s{p}, %s" % S32
+OPS["s_cselect_b32"] = "s_cselect_b32 s{p}, s{p}, %s" % S32
+OPS["s_nop"] = "s_nop 0"
+# a scalar and a vector instruction alternating (both streams independent): do they issue side by side?
+OPS["pair:v_fma_f32+s_add_u32"] = "v_fma_f32 %s, %s, %s, %s\\n\\ts_add_u32 s{p}, s{p}, s{q}" % (A, A, B, C)
+OPS["pair:v_cmp_lt_f32_e64+s_and_b64"] = "v_cmp_lt_f32_e64 s[{p}:{q}], %s, %s\\n\\ts_and_b64 s[{p}:{q}], s[{p}:{q}], %s" % (A, B, S64)
 # memory-side instructions the kernels' inner loops lean on (LDS pipe: per CU, shared by the four SIMDs)
 OPS["ds_read_b32"] = "ds_read_b32 %s, %s" % (A, "%29")
 OPS["ds_read_b128"] = None      # valu_peak.hip measures the LDS forms (they need their own wait structure)
@@ -103,6 +118,7 @@ print("// generated by gen_issue_ops.py -- do not edit")
 print(r'''#include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -129,7 +145,7 @@ __global__ __launch_bounds__(256) void k_issue(unsigned long long *stamps, float
 #define OPERANDS : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), \
                    "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), \
                    "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]) : "v"(b), "v"(c), "v"(bd), "s"(s32), "s"(s64) \
-                 : "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47"''')
+                 : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47"''')
 for k, name in enumerate(names):
     print("        %sif (KIND == %d) {\n            asm volatile(%s OPERANDS);\n        }" % ("" if k == 0 else "else ", k, body(OPS[name])))
 print(r'''    }
@@ -144,8 +160,10 @@ print(r'''    }
     if (s == 12345.678f) sink[0] = s;
 }
 static bool g_first = true;
+static const char *g_filter = nullptr;            // argv[2]: only the opcodes whose name starts with it
 template <int KIND>
 static void run(const char *name, int cus, int k, int iters, unsigned long long *d_st, float *d_sink) {
+    if (g_filter && strncmp(name, g_filter, strlen(g_filter)) != 0) return;
     const int blocks = cus * k;
     size_t lds_req = ((size_t)(156 * 1024) / (size_t)k) & ~(size_t)511;
     if (lds_req > 64 * 1024) lds_req = 64 * 1024;
@@ -169,10 +187,12 @@ static void run(const char *name, int cus, int k, int iters, unsigned long long 
     const double per_simd_span = (double)blocks * 4 * insts / (span_s * med_clk) / (double)(cus * 4);
     printf("%s{\"op\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_wave_inst_per_simd\": %.3f, \"one_wave_cycles_per_inst\": %.3f, \"in_kernel_clock_ghz\": %.3f}",
            g_first ? "" : ",\n  ", name, k, 1.0 / per_simd_span, med_cyc / insts, med_clk / 1e9);
+    fflush(stdout);
     g_first = false;
 }
 int main(int argc, char **argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 1024;
+    if (argc > 2) g_filter = argv[2];
     hipDeviceProp_t prop;
     CHK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
