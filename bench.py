@@ -305,6 +305,66 @@ def per_call_rates(c, n_it=256):
     return out
 
 
+def shared_frame_rate(c, iters):
+    """The north star's cadence -- the frame complete after EVERY iteration -- without an exchange: the ranks hand
+    pathtrace() ONE host frame (shared memory, page-locked by each process) and every rank's launch writes the pixels of its
+    own tile into it while it traces (PT_SHARED_IMAGE, include/ptmi355.h).  One synchronous pathtrace() per iteration per
+    rank, as the reference's host calls it; the frame holds the sum after iteration i once every rank's call has returned.
+    Verified here: every rank compares its tile's pixels in the shared frame with its own accumulation buffer."""
+    torch, dist, pt, args = c.torch, c.dist, c.pt, c.args
+    L = pt.library()
+    path = "/dev/shm/ptmi355_frame_%s" % os.environ.get("MASTER_PORT", "0")          # one job per rendezvous port on a node
+    nbytes = c.npix * 12
+    if c.rank == 0:
+        with open(path, "wb") as f:
+            f.truncate(nbytes)
+    dist.barrier()
+    frame = np.memmap(path, dtype=np.float32, mode="r+", shape=(c.npix, 3))
+    out = {}
+    try:
+        pt.pathtraceInit(c.scene, flags=c.flags | pt.PT_PIN_IMAGE | pt.PT_SHARED_IMAGE, device=c.local_rank,
+                         tile=(c.rank, c.world, args.strip_rows), max_batch=1, pin_image=False)
+        ptr = frame.ctypes.data
+        warm = 8
+        for it in range(1, warm + 1):
+            if L.pt_trace(None, 0, it, ptr) != 0:
+                raise RuntimeError((L.pt_last_error() or b"pt_trace failed").decode(errors="replace"))
+        torch.cuda.synchronize()
+        dist.barrier()
+        rays0 = pt.counters()[0]
+        t0 = time.perf_counter()
+        for it in range(warm + 1, warm + 1 + iters):
+            if L.pt_trace(None, 0, it, ptr) != 0:
+                raise RuntimeError("pt_trace failed")
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        rays = pt.counters()[0] - rays0
+        mine = pt.sharding.tile_pixel_indices(c.rank, c.world, args.strip_rows, c.W, c.H)
+        bad = int((pt.get_image(c.npix)[mine].view(np.uint32) != np.asarray(frame)[mine].view(np.uint32)).sum())
+        pt.pathtraceFree()
+        v = torch.tensor([dt, float(rays), float(bad)], dtype=torch.float64, device="cuda")
+        tmax = v[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        vsum = v[1:].clone(); dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
+        dt, rays, bad = float(tmax.item()), float(vsum[0].item()), int(vsum[1].item())
+        out = {"mrays_per_s": round(rays / dt / 1e6, 2), "ms_per_iteration": round(dt / iters * 1e3, 4), "iterations": iters,
+               "frame_equals_every_ranks_tile": bad == 0,
+               "note": "no exchange: one synchronous pathtrace() per iteration per rank into ONE page-locked host frame in shared memory; "
+                       "every launch writes its own tile's pixels (those whose sum changed) while it traces (PT_SHARED_IMAGE)"}
+        if args.digest and c.rank == 0:
+            import hashlib
+            out["frame_md5"] = hashlib.md5(np.asarray(frame).tobytes()).hexdigest()
+            out["frame_iterations"] = warm + iters
+    finally:
+        del frame
+        dist.barrier()
+        if c.rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+    return out
+
+
 def sub_measurements(c, steps, warmup):
     """N > 1: the north star's questions answered in the default line.  `per_iteration_exchange`: the
     tiles' sums travel to rank 0 after EVERY iteration (1 spp batches), next to the same cadence without the exchange;
@@ -330,6 +390,11 @@ def sub_measurements(c, steps, warmup):
     if "no_exchange" in rates:
         out["per_iteration_exchange"]["no_exchange_mrays_per_s"] = round(rates["no_exchange"][0], 2)
         out["per_iteration_exchange"]["ratio"] = round(r / rates["no_exchange"][0], 3)
+    if c.dist_on and not c.inproc:
+        try:                                          # (every rank fails at the same call or none does: same build, same flags)
+            out["per_iteration_shared_frame"] = shared_frame_rate(c, iters)
+        except Exception as e:
+            out["per_iteration_shared_frame"] = {"failed": str(e)[:300]}
     if c.n_tiles > 1:
         s = Session(c, "strong", args.reduce_every)
         dt, rays, _, _ = s.timed(steps, warmup)

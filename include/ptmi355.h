@@ -117,6 +117,13 @@ enum pt_flags {
                                     (a host that does: PTMI355_HOST_SPARSE=0, every pixel every call).  Without the flag every call copies into whatever buffer
                                     it is given (pageable path), exactly like the reference's cudaMemcpy
                                     (pathtrace.cu:389-390): buffers may be freed or reallocated between calls. */
+    PT_SHARED_IMAGE  = 1u << 9,  /* tiled sessions (tile_count > 1), pt_trace: host_image_sum is ONE frame shared by all the
+                                    ranks that tile it (every process maps the same memory, e.g. POSIX shared memory) under the
+                                    rules of PT_PIN_IMAGE, which it implies.  A rank's launch writes the pixels of its OWN tile
+                                    into it and nothing else, so the ranks assemble the frame in host memory with no exchange
+                                    between them: it holds the sum after iteration i once every rank's call for i has returned.
+                                    Without the flag a tiled session copies its whole accumulation buffer (zeros outside its
+                                    tile).  Needs iterations that run as one launch and a mappable buffer: PT_ERR_INVALID if not. */
     PT_ASYNC_IMAGE   = 1u << 7   /* opt-in: pt_trace / pt_trace_batch return without waiting; the copy of the
                                     running sum into host_image_sum overlaps the NEXT call's tracing and is
                                     complete when the next pt_trace / pt_trace_batch returns, or after

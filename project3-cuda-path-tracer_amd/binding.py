@@ -33,6 +33,7 @@ TRI_DT = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3)])
 MESH_DT = np.dtype([("geom_index", "<i4"), ("first_triangle", "<i4"), ("triangle_count", "<i4")])
 
 PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH, PT_AA_JITTER, PT_ASYNC_IMAGE, PT_PIN_IMAGE = 1, 2, 4, 8, 16, 32, 64, 128, 256
+PT_SHARED_IMAGE = 512
 BVH_NODE_WORDS = 16
 
 

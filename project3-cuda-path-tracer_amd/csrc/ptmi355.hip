@@ -992,7 +992,7 @@ bool pin_host(void *ptr, size_t bytes) {
     // only on the caller's word that the buffer outlives the session (PT_PIN_IMAGE / PT_ASYNC_IMAGE): a registration
     // cannot be re-validated -- a buffer freed and reallocated at the same address looks exactly like the old one to
     // the runtime while the device mapping still points at the old (pinned) pages
-    if (!R.pin_enabled || !(R.flags & (PT_PIN_IMAGE | PT_ASYNC_IMAGE)) || bytes < ((size_t)1 << 20)) return false;
+    if (!R.pin_enabled || !(R.flags & (PT_PIN_IMAGE | PT_ASYNC_IMAGE | PT_SHARED_IMAGE)) || bytes < ((size_t)1 << 20)) return false;
     const char *lo = (const char *)ptr, *hi = lo + bytes;
     for (size_t k = 0; k < R.host_regs.size();) {
         auto &h = R.host_regs[k];
@@ -1861,8 +1861,12 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
     // (page-locked, device-mapped) buffer as they finish, under the tracing of the others (k_iteration's epilogue)
     R.epi_host = nullptr; R.epi_done = false;
     const bool async_image = host_image_sum && (R.flags & PT_ASYNC_IMAGE);
-    if (host_image_sum && (!async_image || R.async_direct_enabled) && R.epi_enabled && !R.use_graphs && R.map.tile_count == 1)
+    // (a tile of a larger frame writes only its own pixels: into a frame its ranks share, PT_SHARED_IMAGE)
+    const bool shared_frame = host_image_sum && (R.flags & PT_SHARED_IMAGE) && R.map.tile_count > 1;
+    if (host_image_sum && (!async_image || R.async_direct_enabled) && R.epi_enabled && !R.use_graphs && (R.map.tile_count == 1 || shared_frame))
         R.epi_host = map_host(host_image_sum, (size_t)R.npix * 12);
+    if (shared_frame && !R.epi_host)
+        return fail(PT_ERR_INVALID, "pt_trace: PT_SHARED_IMAGE needs a host frame of 1 MiB or more that can be page-locked and mapped");
     if (R.epi_host && R.dma_last) {                        // a copy-engine transfer into a host buffer may still be running
         HIPCHK(hipStreamWaitEvent(R.stream, R.dma_last, 0));
         R.dma_last = nullptr;
@@ -1879,6 +1883,9 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
                            R.image, R.npix, iter);
         HIPCHK(hipGetLastError());
     }
+    if (shared_frame && !gathered)
+        return fail(PT_ERR_INVALID, "pt_trace: PT_SHARED_IMAGE needs iterations that run as one launch (PT_COMPACT, no material sort, no mesh, "
+                                    "at most %llu paths per tile)", (unsigned long long)std::max(R.whole_max_paths, R.whole_max_host_paths));
     if (async_image && gathered) {
         // PT_ASYNC_IMAGE and the launch wrote the host image itself: nothing to copy.  The buffer is complete when the launch
         // is; this call returns without waiting for it, but not before the PREVIOUS call's buffer is complete.

@@ -78,13 +78,13 @@ def test_one_iteration_per_call_with_the_host_image():
     assert one["config"]["pcie_host_image_md5"] == per["config"]["pcie_host_image_md5"]     # 136 calls' running sum, on the host
 
 
-def _two(port, *extra, backend="gloo", same_device=True):
+def _two(port, *extra, backend="gloo", same_device=True, per_bounce=True):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3",
            "--warmup", "1", "--no-roofline", "--backend", backend, "--digest", "--sub-iters", "8"] + list(extra)
     if same_device:
         cmd.append("--same-device")
-    return run(cmd)
+    return run(cmd, per_bounce=per_bounce)
 
 
 def test_two_ranks_same_frame():
@@ -109,6 +109,13 @@ def test_two_ranks_same_frame():
         assert ("exchange thread" if "--exchange-thread" in extra else "tracing thread") in pie["transport"] \
             or extra == ["--batch", "2", "--collective", "reduce"], pie
         assert strong["mrays_per_s"] > 10 and strong["spp_per_step_per_frame"] == int(extra[1]), strong
+        # ... and the frame assembled in ONE shared host buffer by the ranks' own launches, no exchange (PT_SHARED_IMAGE):
+        # refused under this helper's kernel-per-bounce plan (it needs one-launch iterations), measured below
+        assert "one launch" in two["config"]["per_iteration_shared_frame"]["failed"], two["config"]["per_iteration_shared_frame"]
+    two = _two(29539, "--batch", "2", per_bounce=False)
+    assert two["image_md5"] == one["image_md5"]
+    shared = two["config"]["per_iteration_shared_frame"]
+    assert shared["frame_equals_every_ranks_tile"] is True and shared["mrays_per_s"] > 10 and shared["iterations"] >= 8, shared
 
 
 def _ranks(n, port, *extra):
@@ -153,6 +160,8 @@ def test_one_rank_rccl():
         assert d["n_gpus"] == 1 and d["config"]["exchanges_per_step"] >= 1, extra
         pie = d["config"]["per_iteration_exchange"]                    # RCCL gather per iteration
         assert pie["mrays_per_s"] > 10 and 0.05 < pie["ratio"] < 20.0 and pie["iterations"] >= 16, pie
+        shared = d["config"]["per_iteration_shared_frame"]          # (a world of one: the plain page-locked host image)
+        assert shared.get("frame_equals_every_ranks_tile") is True or "failed" in shared, shared
         assert d["config"]["rays_per_step"] == one["config"]["rays_per_step"], extra
         assert d["image_md5"] == one["image_md5"], extra
 

@@ -779,6 +779,50 @@ def test_async_image_written_by_the_launch(pt, scenes, monkeypatch):
     assert all(run({"PTMI355_HOST_SPARSE": "0"})), "launch-written, every pixel"
 
 
+def test_shared_host_frame_assembled_by_the_tiles(pt, scenes, launch_plan):
+    """PT_SHARED_IMAGE: the ranks of a tiled frame hand pt_trace ONE host frame and each writes only the pixels of its own
+    tile into it (first call: all of them; later calls: the ones whose sum changed) -- the frame is assembled in host memory
+    with no exchange.  Here the "ranks" are sessions of this process, one after the other, interleaved call by call on two
+    frames: tiles of 2 and of 3 ranks (strips of 8 and of 5 rows: the last strip short) give the 1-session sums, pixel
+    for pixel, and a session never touches a pixel outside its tile."""
+    s = scenes["cornell"]
+    cam = _resized(s["camera"], 400, 300)
+    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
+    n = 400 * 300
+    L = pt.library()
+    if launch_plan == "one launch per bounce":                   # the flag needs one-launch iterations: refused under this plan
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_SHARED_IMAGE, tile=(0, 2, 8), pin_image=False)
+        frame = np.zeros((n, 3), dtype=np.float32)
+        assert L.pt_trace(None, 0, 1, frame.ctypes.data) < 0 and not frame.any()
+        pt.pathtraceFree()
+        return
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, pin_image=False)
+    want = {}
+    for it in (1, 2, 3, 4):
+        want[it] = pt.pathtrace(None, 0, it).reshape(n, 3).copy()
+    pt.pathtraceFree()
+    for ranks, strip in ((2, 8), (3, 5)):
+        frame = np.full((n, 3), -5.0, dtype=np.float32)
+        owned = []
+        for r in range(ranks):
+            rows = pt.sharding.owned_rows(r, ranks, strip, 300)
+            owned.append(np.repeat(rows, 400))
+        for r in range(ranks):                                   # rank r: its four iterations into the shared frame
+            before = frame.copy()
+            pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_SHARED_IMAGE, tile=(r, ranks, strip), pin_image=False)
+            for it in (1, 2, 3, 4):
+                assert L.pt_trace(None, 0, it, frame.ctypes.data) == 0
+                assert frame[owned[r]].tobytes() == want[it][owned[r]].tobytes(), (ranks, r, it)
+            pt.pathtraceFree()
+            assert frame[~owned[r]].tobytes() == before[~owned[r]].tobytes(), (ranks, r)       # nobody else's pixels
+        assert frame.tobytes() == want[4].tobytes(), ranks
+    # what cannot run as one launch is refused, not copied over the other ranks' pixels
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_SORT_MATERIAL | pt.PT_SHARED_IMAGE, tile=(0, 2, 8), pin_image=False)
+    frame = np.zeros((n, 3), dtype=np.float32)
+    assert L.pt_trace(None, 0, 1, frame.ctypes.data) < 0
+    pt.pathtraceFree()
+
+
 def test_4k_one_iteration_per_call_into_the_host_image(pt, scenes, monkeypatch):
     """C5's frame (3840 x 2160 = 8.3 M paths) through pathtrace() per call with a page-locked host image: one launch per
     iteration although the frame is above the 6 M paths up to which batches run as one launch (the launch hides the PCIe
