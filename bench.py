@@ -652,6 +652,19 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
                            "hbm_frac": round(min(1.0, byt_all / timed_step_s / (HBM_PEAK_GBS * 1e9)), 4),
                            "note": "consecutive steps overlap on the device in the timed pass (serial in the event pass): all profiled kernels' "
                                    "issue cycles / HBM bytes per step over the timed pass's time per step"}
+    # the shader clock this kernel family was MEASURED at (a diagnostic build stamps every wave's life with the cycle and the
+    # real-time counter: profiles/tools/wave_clock.py): against it the same issue cycles are a larger share of what the chip
+    # delivered.  A provenance figure from profiles/, like the opcode histogram; `frac` stays against the 2.4 GHz peak.
+    try:
+        import re
+        meds = [float(m) for m in re.findall(r"median ([0-9.]+) GHz", open(os.path.join(ROOT, "profiles", "r04", "wave_clock.txt")).read())]
+        if meds and args.config == "c2":
+            clk = sum(meds) / len(meds)
+            r["valu_issue"]["measured_clock_ghz"] = round(clk, 3)
+            r["valu_issue"]["frac_at_measured_clock"] = round(min(1.0, issue_frac * PEAK_CLOCK_GHZ / clk), 4)
+            r["valu_issue"]["clock_source"] = "profiles/r04/wave_clock.txt: k_bounce on C2, per-wave cycle counter against the 100-MHz real-time counter"
+    except Exception:
+        pass
     if issue_frac >= hbm_frac:
         r.update(bound="valu-issue", achieved=r["valu_issue"]["achieved"], peak=r["valu_issue"]["peak"], unit=r["valu_issue"]["unit"], frac=round(min(1.0, issue_frac), 4))
     else:
