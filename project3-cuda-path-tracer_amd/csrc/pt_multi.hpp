@@ -128,6 +128,7 @@ struct Worker {
     float *stage[XSLOTS] = {};                   // ON THE ROOT DEVICE: where this context's rows land
     size_t floats = 0;                           // tile_pixels * 3
     TileMap map{};
+    float *host_dev = nullptr; const float *host_dev_of = nullptr;   // this device's address of Group::dhost
 
     void loop() {
         t_ctx = &ctx;
@@ -240,6 +241,11 @@ struct Group {
     uint64_t exchanges = 0;                     // exchanges enqueued (by whichever thread issues them)
     uint64_t calls = 0;                         // calls made (caller's thread): call i uses staging slot i % XSLOTS
     uint64_t xseq[XSLOTS] = {};                 // the exchange-thread job that last used slot s (0: none outstanding)
+    // pathtrace() with a host image and no PBO: every context's launch writes its own tile's pixels into the caller's
+    // page-locked image (registered ONCE, portable: every device maps it) -- no pack, no exchange, no frame-to-host copy
+    bool direct_ok = false, direct_enabled = true;   // every context can (asked at pt_init) / PTMI355_MULTI_DIRECT
+    float *dhost = nullptr; size_t dhost_bytes = 0;  // the registered host image
+    bool frame_stale = false;                   // the device frame lacks the peers' rows of such calls: the next exchange brings them
     std::unique_ptr<Exchanger> x;               // asynchronous batches hand their exchange to this thread
     float *frame = nullptr;                     // where the tiles are assembled: context 0's accumulation buffer -- except in the
                                                 // one-context RCCL rehearsal, where it is a buffer of its own (self_frame)
@@ -340,6 +346,23 @@ int enqueue_exchange(int s) {
     return PT_OK;
 }
 
+int exchange_settled(void);
+
+// The frame on device 0 after calls that wrote the host image directly (multi_trace): one exchange of the running sums
+// as they are brings every peer's rows; every exchange does, so `frame_stale` falls with the next one of any kind.
+int multi_refresh(void) {
+    if (!G.frame_stale) return PT_OK;
+    G.frame_stale = false;
+    if (G.K == 1) return PT_OK;
+    const int s = (int)(G.calls % XSLOTS);
+    int rc = exchange_settled();
+    if (rc) return rc;
+    rc = on_all([&](Worker &w) -> int { return worker_pack(w, s); });
+    if (rc) return rc;
+    G.calls++;
+    return enqueue_exchange(s);
+}
+
 // the launches of one call on every device, the packing of the tiles, then the exchange
 // `overlap`: the caller does not wait for this call (pt_trace_batch_async): consecutive batches may overlap on each
 // device's lanes (ptmi355.hip: enqueue_batch_direct); their gathers stay on the launch stream, which the packing waits on
@@ -425,8 +448,12 @@ int multi_enqueue(int iter0, int count, bool overlap = false) {
     return enqueue_exchange(s);
 }
 
+int multi_refresh(void);
+
 int multi_sync(void) {
-    int rc = exchange_settled();
+    int rc = multi_refresh();
+    if (rc) return rc;
+    rc = exchange_settled();
     if (rc) return rc;
     rc = on_all([&](Worker &w) -> int {
         HIPCHK(hipStreamSynchronize(R.stream));
@@ -438,6 +465,7 @@ int multi_sync(void) {
 
 void multi_free(void) {
     if (!G.live && G.w.empty()) return;
+    if (G.dhost) { (void)hipHostUnregister(G.dhost); G.dhost = nullptr; G.dhost_bytes = 0; }
     if (g_xstats.on && g_xstats.calls.load()) {
         const double n = (double)g_xstats.calls.load();
         fprintf(stderr, "[ptmi355] %llu asynchronous calls: caller %.1f us, worker 0 %.1f us, exchange thread waits %.1f us + issues %.1f us per call (%s)\n",
@@ -627,6 +655,13 @@ int multi_init(const pt_scene_desc *d, const std::vector<int> &devs) {
             x->th = std::thread([x] { x->loop(); });
         }
     }
+    {   // can every context take pathtrace() with a host image as one self-gathering launch?
+        std::vector<int> can((size_t)K, 0);
+        (void)on_all([&](Worker &w) -> int { can[(size_t)w.index] = one::whole_host_possible() ? 1 : 0; return PT_OK; });
+        G.direct_ok = true;
+        for (int v : can) G.direct_ok = G.direct_ok && v;
+        if (const char *e = getenv("PTMI355_MULTI_DIRECT")) G.direct_enabled = atoi(e) != 0;
+    }
     G.last_cam = d->camera; G.last_depth = d->trace_depth;
     g_xstats.on = getenv("PTMI355_XCHG_STATS") && atoi(getenv("PTMI355_XCHG_STATS")) != 0;
     t_err[0] = 0;
@@ -712,7 +747,35 @@ int pt_trace_batch_async(int iter0, int count) {
 
 // the calls that hand the image back: launches + exchange enqueued on every device, then the frame -> host copy on the
 // root's exchange stream, then one synchronisation per context (which also folds its statistics)
+// the caller's host image, page-locked once for every device (PT_PIN_IMAGE: it outlives the session)
+static bool multi_pin(float *host, size_t bytes) {
+    if (G.dhost == host && G.dhost_bytes >= bytes) return true;
+    if (G.dhost) { (void)hipHostUnregister(G.dhost); G.dhost = nullptr; G.dhost_bytes = 0; }
+    for (auto &wp : G.w) { wp->host_dev = nullptr; wp->host_dev_of = nullptr; }
+    if (bytes < ((size_t)1 << 20)) return false;
+    if (hipHostRegister(host, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return false; }
+    G.dhost = host; G.dhost_bytes = bytes;
+    return true;
+}
+
 static int multi_trace(uint8_t *pbo_rgba, int iter0, int count, float *host_image_sum) {
+    // pathtrace() with the host image and no PBO, one iteration: no exchange at all -- every context's launch writes its
+    // own tile's pixels (those whose sum changed) into the caller's image while it traces (pt_trace_mapped)
+    if (host_image_sum && !pbo_rgba && count == 1 && G.direct_ok && G.direct_enabled && !G.self_exchange &&
+        (G.w[0]->ctx.flags & PT_PIN_IMAGE) && multi_pin(host_image_sum, (size_t)G.npix * 12)) {
+        int rc = exchange_settled();
+        if (rc) return rc;
+        rc = on_all([&](Worker &w) -> int {
+            if (w.host_dev_of != G.dhost) {
+                void *dp = nullptr;
+                HIPCHK(hipHostGetDevicePointer(&dp, G.dhost, 0));
+                w.host_dev = (float *)dp; w.host_dev_of = G.dhost;
+            }
+            return one::pt_trace_mapped(iter0, w.host_dev);
+        });
+        G.frame_stale = true;
+        return rc;
+    }
     int rc = multi_enqueue(iter0, count);
     if (rc) return rc;
     Worker &root = *G.w[0];

@@ -1853,6 +1853,33 @@ int pt_trace_batch(int iter0, int count, float *host_image_sum) {
     return collect_stats();                               // one stream synchronisation covers the copy as well
 }
 
+// can ONE iteration of this session with a page-locked host image run as one launch that does its own finalGather?
+// (what pt_trace decides per call; the multi-GPU form asks once at pt_init: pt_multi.hpp)
+bool whole_host_possible(void) {
+    return R.live && !(R.flags & (PT_UNFUSED | PT_SORT_MATERIAL | PT_FAKE_SHADER | PT_CACHE_FIRST)) && (R.flags & PT_COMPACT) &&
+           R.mesh_mode == MESH_NONE && R.sort_keys == 0 && R.epi_enabled && !R.use_graphs &&
+           (uint64_t)R.map.tile_pixels <= std::max(R.whole_max_paths, R.whole_max_host_paths);
+}
+
+// One iteration of this context's tile, synchronously, its launch writing the tile's pixels into a host frame that is
+// ALREADY page-locked and mapped (`mapped` = this device's address of it): the in-library multi-GPU form of
+// pathtrace() with a host image -- every context calls this on its own thread, nothing is exchanged.
+int pt_trace_mapped(int iter, float *mapped) {
+    if (!R.live) return fail(PT_ERR_INVALID, "pt_trace: not initialised");
+    if (!whole_host_possible() || !mapped) return fail(PT_ERR_INTERNAL, "pt_trace_mapped: this context cannot trace an iteration as one launch");
+    R.in_step = false;
+    R.epi_host = mapped; R.epi_done = false;
+    R.ov_ok = false;
+    R.want_host_stats = true;
+    const int rc = enqueue_batch(iter, 1);
+    R.want_host_stats = false;
+    const bool gathered = R.epi_done;
+    R.epi_host = nullptr; R.epi_done = false;
+    if (rc) return rc;
+    if (!gathered) return fail(PT_ERR_INTERNAL, "pt_trace_mapped: the iteration did not run as one launch");
+    return collect_stats();
+}
+
 int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
     (void)frame;                                          // unused in the reference too (main.cpp:136)
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace: not initialised");

@@ -117,6 +117,63 @@ def test_c2_frame_over_two_contexts(pt, scenes):
     assert got[0].tobytes() == want[0].tobytes() and got[1].tobytes() == want[1].tobytes() and got[2] == want[2]
 
 
+def test_pathtrace_per_call_several_contexts_no_exchange(pt, scenes, monkeypatch):
+    """pathtrace() with the page-locked host image over several contexts: every context's launch writes its own tile's
+    pixels into the caller's image (registered once for all devices) -- no pack, no exchange, no copy of the frame.  The
+    host image after every call, the device frame whenever it is asked for (it is brought up to date by one exchange),
+    and everything in between -- batches that do exchange, pt_clear_image, pt_set_image, a second host buffer -- equal
+    the single-context run and the run with the direct path switched off."""
+    s = scenes["cornell"]
+    cam = s["camera"].copy()
+    cam["resolution"][0] = (400, 300)
+    yscaled = np.tan(np.float32(cam["fov"][0][1]) * np.float32(np.pi / 180))
+    xscaled = np.float32(yscaled * np.float32(400) / np.float32(300))
+    cam["pixelLength"][0] = (np.float32(2 * xscaled / np.float32(400)), np.float32(2 * yscaled / np.float32(300)))
+    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
+    n = 400 * 300
+    L = pt.library()
+
+    def run(env=(), **kw):
+        for k, v in env:
+            monkeypatch.setenv(k, v)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE, max_batch=4, pin_image=False, **kw)
+        a = np.full((n, 3), -4.0, dtype=np.float32)
+        b = np.full((n, 3), -6.0, dtype=np.float32)
+        out = []
+
+        def call(buf, it, check_device=False):
+            assert L.pt_trace(None, 0, it, buf.ctypes.data) == 0
+            out.append(buf.tobytes())
+            if check_device:
+                assert pt.get_image(n).tobytes() == buf.tobytes(), it
+
+        call(a, 1); call(a, 2); call(a, 3, True)
+        pt.trace_batch_async(4, 4)                                   # exchanges
+        call(a, 8); call(a, 9, True)
+        img = np.zeros((n, 3), dtype=np.float32)
+        pt.trace_batch(10, 2, img)                                   # synchronous batch: frame copied to the host
+        out.append(img.tobytes())
+        call(b, 12); call(a, 13); call(b, 14, True)
+        pt.clear_image()
+        call(a, 1); call(a, 2, True)
+        pt.set_image(np.frombuffer(out[2], dtype=np.float32).reshape(n, 3).copy())
+        call(a, 4); call(a, 5, True)
+        out.append(tuple(int(v) for v in pt.counters()))
+        out.append(pt.tonemap(n, 5).tobytes())
+        pt.pathtraceFree()
+        for k, _ in env:
+            monkeypatch.delenv(k)
+        return out
+
+    monkeypatch.delenv("PTMI355_XCHG", raising=False)
+    monkeypatch.delenv("PTMI355_DEVICES", raising=False)
+    want = run()
+    for devs in ([0, 0], [0, 0, 0]) if gpu_count() < 2 else ([0, 1], [0, 0], [0, 1, 0]):
+        for strip in (8, 7):
+            assert run(devices=devs, tile=(0, 1, strip)) == want, (devs, strip)
+    assert run((("PTMI355_MULTI_DIRECT", "0"),), devices=[0, 0], tile=(0, 1, 8)) == want
+
+
 def test_rccl_calls_with_a_communicator_of_one(pt, scenes, monkeypatch):
     """ncclCommInitAll / ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd / ncclCommDestroy executed from the
     library on this box's one GPU: the one context sends its packed tile to itself and unpacks it into the frame."""
