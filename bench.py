@@ -87,6 +87,68 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n, argv, port):
+    """The driver's own form of an N-rank run (one process per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python3 bench.py --gpus N` from a plain shell (no WORLD_SIZE in the environment): start the N ranks as fresh child
+    processes through torch.distributed.run, relay rank 0's JSON line and the launcher's exit code.  This parent has
+    imported neither torch nor the HIP library -- nothing here has touched the GPU, and nothing is exec'ed: the launcher
+    is a child in a session of its own, so --launch-timeout can end exactly that process group."""
+    import signal
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT") or 0) or free_port()
+    cmd = launch_command(args.gpus, [a for a in argv if a != "--print-launch"], port)
+    if args.print_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("MASTER_PORT", None)
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd[1:10])))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    timer = None
+    if args.launch_timeout > 0:
+        import threading
+
+        def expire():
+            sys.stderr.write("bench.py: the ranks did not finish in %.0f s: ending their process group\n" % args.launch_timeout)
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+                time.sleep(5.0)
+                os.killpg(p.pid, signal.SIGKILL)
+            except OSError:
+                pass
+        timer = threading.Timer(args.launch_timeout, expire)
+        timer.daemon = True
+        timer.start()
+    lines = 0
+    for line in p.stdout:
+        if line.startswith("{"):
+            lines += 1
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    rc = p.wait()
+    if timer:
+        timer.cancel()
+    if rc == 0 and lines == 0:
+        sys.stderr.write("bench.py: the ranks exited without a JSON line\n")
+        return 1
+    return rc
+
+
 def load_scene(pt, name):
     z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
     g = lambda k: z["%s__%s" % (name, k)]
@@ -113,13 +175,14 @@ def setup(args):
     if c.inproc and c.world != 1:
         raise SystemExit("--inproc is one process: do not launch it through torch.distributed.run")
     if c.world != args.gpus and not c.inproc:
-        if c.world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = c.world
+        args.gpus = c.world                    # (a plain `--gpus N` never gets here: main() starts the ranks itself)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if args.same_device:
         c.local_rank = 0
+    if c.local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d of %d: local rank %d but only %d GPU(s) visible (one rank per GPU; --same-device puts "
+                         "every rank on cuda:0 for a rehearsal)" % (c.rank, c.world, c.local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(c.local_rank)
     c.dist_on = (c.world > 1 or args.force_dist) and not c.inproc
     c.n_tiles = args.gpus if c.inproc else c.world          # GPUs the frame is tiled over
@@ -365,12 +428,11 @@ def shared_frame_rate(c, iters):
     return out
 
 
-def sub_measurements(c, steps, warmup):
-    """N > 1: the north star's questions answered in the default line.  `per_iteration_exchange`: the
-    tiles' sums travel to rank 0 after EVERY iteration (1 spp batches), next to the same cadence without the exchange;
-    `strong`: the frame gets `batch` iterations per step whatever N (total work fixed)."""
+def per_iteration_exchange(c):
+    """N > 1, BASELINE.json's north-star cadence: the tiles' running sums travel to rank 0 after EVERY iteration (one
+    iteration of its tile per call on every rank; the reference's host has the whole image after every iteration,
+    src/pathtrace.cu:389-392), next to the same calls without the exchange."""
     args = c.args
-    out = {}
     iters = args.sub_iters
     n_steps = max(1, -(-iters // c.pt.sharding.step_iterations(0, args.batch, c.n_tiles, args.scaling)[1]))
     rates = {}
@@ -382,27 +444,95 @@ def sub_measurements(c, steps, warmup):
         rates[key] = (rays / dt / 1e6, dt / (n_steps * s.per_step_iters) * 1e3, s)
         s.close()
     r, ms, s = rates["exchange"]
-    out["per_iteration_exchange"] = {
-        "mrays_per_s": round(r, 2), "ms_per_iteration": round(ms, 4), "iterations": n_steps * s.per_step_iters,
-        "transport": s.transport or ("%s %s from %s" % (args.backend, args.collective, "an exchange thread (sharding.TileGatherThread)" if s.gather_thread else "the tracing thread")),
-        "mb_per_rank_per_exchange": round(s.bytes_per_rank / 1e6, 3),
-        "note": "%s scaling, 1 spp per batch, every rank's tile sums to rank 0 after every iteration (BASELINE north_star)" % args.scaling}
+    out = {"mrays_per_s": round(r, 2), "ms_per_iteration": round(ms, 4), "iterations": n_steps * s.per_step_iters,
+           "paths_per_rank_per_iteration": int(c.npix / c.n_tiles),
+           "transport": s.transport or ("%s %s from %s" % (args.backend, args.collective, "an exchange thread (sharding.TileGatherThread)" if s.gather_thread else "the tracing thread")),
+           "mb_per_rank_per_exchange": round(s.bytes_per_rank / 1e6, 3),
+           "note": "%s scaling, 1 spp per call, every rank's tile sums to rank 0 after every iteration (BASELINE north_star)" % args.scaling}
     if "no_exchange" in rates:
-        out["per_iteration_exchange"]["no_exchange_mrays_per_s"] = round(rates["no_exchange"][0], 2)
-        out["per_iteration_exchange"]["ratio"] = round(r / rates["no_exchange"][0], 3)
-    if c.dist_on and not c.inproc:
-        try:                                          # (every rank fails at the same call or none does: same build, same flags)
-            out["per_iteration_shared_frame"] = shared_frame_rate(c, iters)
-        except Exception as e:
-            out["per_iteration_shared_frame"] = {"failed": str(e)[:300]}
-    if c.n_tiles > 1:
-        s = Session(c, "strong", args.reduce_every)
-        dt, rays, _, _ = s.timed(steps, warmup)
-        out["strong"] = {"mrays_per_s": round(rays / dt / 1e6, 2), "ms_per_step": round(dt * 1e3 / steps, 4),
-                         "spp_per_step_per_frame": args.batch, "paths_per_rank_per_step": int(args.batch * c.npix / c.n_tiles),
-                         "note": "the frame gets %d spp per step whatever N: per-GPU work shrinks with N" % args.batch}
-        s.close()
+        out["no_exchange_mrays_per_s"] = round(rates["no_exchange"][0], 2)
+        out["ratio"] = round(r / rates["no_exchange"][0], 3)
     return out
+
+
+def strong_scaling(c, steps, warmup):
+    """N > 1: the frame gets `batch` iterations per step whatever N (total work fixed)."""
+    args = c.args
+    s = Session(c, "strong", args.reduce_every)
+    dt, rays, _, _ = s.timed(steps, warmup)
+    s.close()
+    return {"mrays_per_s": round(rays / dt / 1e6, 2), "ms_per_step": round(dt * 1e3 / steps, 4),
+            "spp_per_step_per_frame": args.batch, "paths_per_rank_per_step": int(args.batch * c.npix / c.n_tiles),
+            "note": "the frame gets %d spp per step whatever N: per-GPU work shrinks with N" % args.batch}
+
+
+def rank_identities(c):
+    """What the collective backend actually spans: world size and backend as torch.distributed reports them and, gathered
+    THROUGH that backend, every rank's device (index, PCI domain:bus:device) -- so that `RCCL saw N ranks on N different
+    GPUs` can be read off the line."""
+    torch, dist = c.torch, c.dist
+    p = torch.cuda.get_device_properties(c.local_rank)
+    mine = torch.tensor([c.rank, c.local_rank, int(getattr(p, "pci_domain_id", -1)), int(getattr(p, "pci_bus_id", -1)),
+                         int(getattr(p, "pci_device_id", -1))], dtype=torch.int64,
+                        device="cpu" if c.args.backend == "gloo" else "cuda")      # (gloo gathers host tensors only)
+    every = [torch.zeros_like(mine) for _ in range(c.world)]
+    dist.all_gather(every, mine)
+    torch.cuda.synchronize()
+    rows = [[int(v) for v in t.cpu()] for t in every]
+    devs = ["cuda:%d @ %04x:%02x:%02x" % (r[1], r[2] & 0xffff, r[3] & 0xff, r[4] & 0xff) for r in rows]
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "collective": c.args.collective,
+            "devices": devs, "distinct_devices": len(set(devs)), "device_name": p.name,
+            "note": "gathered with all_gather over this backend ('nccl' is RCCL on ROCm)"}
+
+
+class Watchdog:
+    """N > 1: a collective that never returns must end the run LOUDLY.  Phases arm a deadline; when one passes, rank 0
+    prints the line as far as it got (with `watchdog` saying which phase hung) and every rank leaves with exit code 3.
+    `out` is only touched under `lock`, by the main thread and by this one; once the main thread has printed the line
+    (`emit`) the watchdog never prints."""
+
+    def __init__(self, rank, out):
+        import threading
+        self.rank, self.out = rank, out
+        self.lock = threading.Lock()
+        self.deadline = None
+        self.phase = None
+        self.done = False
+        threading.Thread(target=self._loop, name="bench-watchdog", daemon=True).start()
+
+    def arm(self, seconds, phase):
+        with self.lock:
+            self.deadline, self.phase = time.monotonic() + seconds, phase
+
+    def disarm(self):
+        with self.lock:
+            self.deadline = None
+
+    def put(self, where, key, value):
+        with self.lock:
+            where[key] = value
+
+    def emit(self):
+        with self.lock:
+            self.done = True
+            if self.rank == 0:
+                print(json.dumps(self.out), flush=True)
+
+    def _loop(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                if self.done:
+                    return
+                if self.deadline is None or time.monotonic() < self.deadline:
+                    continue
+                self.done = True
+                if self.rank == 0:
+                    self.out["watchdog"] = "phase '%s' did not finish in time: exit code 3" % self.phase
+                    print(json.dumps(self.out), flush=True)
+            if self.rank != 0:
+                time.sleep(2.0)            # rank 0's line first: a launcher that sees a rank exit tears the others down
+            os._exit(3)
 
 
 def main():
@@ -445,7 +575,15 @@ def main():
                     help="N > 1: skip config.per_iteration_exchange / config.strong (the sub-measurements after the main pass)")
     ap.add_argument("--sub-iters", type=int, default=256, help="iterations of the per-iteration-exchange sub-measurement")
     ap.add_argument("--sub-timeout", type=float, default=120.0,
-                    help="seconds the sub-measurements may take before the main line is printed without them")
+                    help="N > 1: seconds a phase (per-iteration exchange, strong scaling, ...) may take before the watchdog prints "
+                         "the line as far as it got and every rank exits with code 3")
+    ap.add_argument("--shared-frame", action="store_true",
+                    help="N > 1, process form: also measure config.per_iteration_shared_frame (PT_SHARED_IMAGE: one page-locked host "
+                         "frame in shared memory written by every rank's own launches; no exchange)")
+    ap.add_argument("--launch-timeout", type=float, default=0.0,
+                    help="plain `--gpus N` (no launcher): seconds before the self-started ranks' process group is ended (0 = never)")
+    ap.add_argument("--print-launch", action="store_true",
+                    help="plain `--gpus N`: print the torch.distributed.run command line instead of running it")
     ap.add_argument("--exchange-thread", action="store_true",
                     help="process form: issue the tile gathers from sharding.TileGatherThread when there is more than one per step "
                          "(measured SLOWER than the tracing thread's own two-slot gather once the device was no longer the limit: "
@@ -453,10 +591,40 @@ def main():
     ap.add_argument("--no-exchange-thread", action="store_true", help="(the default now; kept for old command lines)")
     args = ap.parse_args()
 
+    # ---- `python3 bench.py --gpus N` from a plain shell: the ranks are started here, as child processes, before
+    # anything in this process has imported torch or the HIP library ----
+    if args.gpus > 1 and not args.inproc and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
+
     c = setup(args)
     pt, torch, dist, rank, world = c.pt, c.torch, c.dist, c.rank, c.world
     inproc, dist_on, n_tiles, scene = c.inproc, c.dist_on, c.n_tiles, c.scene
     W, H, npix, flags = c.W, c.H, c.npix, c.flags
+    multi = dist_on or inproc
+
+    # the line, filled in as the measurements finish (N > 1: the watchdog prints what is there if a phase hangs)
+    out = {"metric": "Mrays/sec (live paths x bounces) at 800x800 Cornell depth 8" if args.config == "c2" else
+                     "Mrays/sec (live paths x bounces), config %s" % args.config,
+           "value": None, "unit": "Mrays/s", "n_gpus": n_tiles, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling if n_tiles > 1 else "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {}}
+    guard = Watchdog(rank, out) if multi else None
+
+    def phase(name, seconds):
+        if guard:
+            guard.arm(seconds, name)
+
+    def put(where, key, value):
+        if guard:
+            guard.put(where, key, value)
+        else:
+            where[key] = value
+
+    if dist_on:
+        phase("process group: all_gather of the ranks' devices", args.sub_timeout)
+        put(out, "ranks", rank_identities(c))
+    elif inproc:
+        put(out, "ranks", {"world_size": 1, "backend": "in-library", "devices": ["cuda:%d" % d for d in ([0] * args.gpus if args.same_device else range(args.gpus))]})
 
     # ---- the drop-in calling pattern, N = 1: one pathtrace() per iteration.  Measured FIRST, in the
     # state a host finds the device in (after a 64-spp session -- 20 GB of pools on five streams -- the copy engine
@@ -466,11 +634,24 @@ def main():
             and not (flags & ~(pt.PT_COMPACT | pt.PT_SORT_MATERIAL)):
         pc = per_call_rates(c)
 
+    # ---- N > 1 (or its one-rank rehearsal), measured FIRST and part of every such line: the north
+    # star's cadence -- the tiles' sums on rank 0 after EVERY iteration -- beside the same calls without the exchange ----
+    if multi and not args.no_sub:
+        phase("per-iteration exchange", args.sub_timeout)
+        try:
+            pie = per_iteration_exchange(c)
+        except Exception as e:                 # stated in the line, never silently absent
+            pie = {"failed": str(e)[:300]}
+        put(out, "per_iteration_exchange", pie)
+
+    phase("main timed pass", max(300.0, args.sub_timeout))
     s = Session(c, args.scaling, args.reduce_every)
     per_step_iters, every = s.per_step_iters, s.every
     profile_on = not args.no_roofline and args.steps * (scene.traceDepth + 2) * -(-per_step_iters // every) <= 2000
     dt, rays, first, rank_rays = s.timed(args.steps, args.warmup)
     value = rays / dt / 1e6
+    put(out, "value", round(value, 2))
+    put(out, "ms_per_step", round(dt * 1e3 / args.steps, 4))
 
     # ---- roofline of the dominant kernel: the timed region is run a second time, identically, with HIP
     # events bracketing every kernel launch on the launch stream (2 events per launch from a preallocated
@@ -509,33 +690,30 @@ def main():
     exchanges_per_step = s.exchanges_per_step
     s.close()
 
-    out = None
-    if rank == 0:
-        out = {
-            "metric": "Mrays/sec (live paths x bounces) at 800x800 Cornell depth 8" if args.config == "c2" else
-                      "Mrays/sec (live paths x bounces), config %s" % args.config,
-            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_tiles, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 4),
-            "higher_is_better": True, "scaling": args.scaling if n_tiles > 1 else "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "scenes/cornell.txt (%s) %dx%d depth %d, compaction on, %d spp per step per GPU-tile"
-                                   % (c.scene_name, W, H, scene.traceDepth, per_step_iters),
-                       "batch_spp": args.batch, "flags": args.flags,
-                       "sharding": ("in the library (one process): interleaved %d-row strips over %d devices, one host thread and "
-                                    "stream per device; %s scaling; after every batch of %d iterations the tiles' running sums "
-                                    "travel to device 0 (%s) and are unpacked into the frame, overlapped with the next batch"
-                                    % (args.strip_rows, n_tiles, args.scaling, every, transport)) if inproc else
-                       "whole frame" if not dist_on else
-                       "interleaved %d-row strips over %d GPUs; %s scaling; tiles' running sums to rank 0 every %d "
-                       "iterations by %s, overlapped with the next batch"
-                       % (args.strip_rows, world, args.scaling, every, gather_desc),
-                       "exchanges_per_step": 0 if not (dist_on or inproc) else exchanges_per_step,
-                       "rays_per_step": int(rays / args.steps)},
-        }
-        if digest:
-            out["image_md5"] = digest
-        if roofline:
-            out["roofline"] = roofline
+    config = {"workload": "scenes/cornell.txt (%s) %dx%d depth %d, compaction on, %d spp per step per GPU-tile"
+                          % (c.scene_name, W, H, scene.traceDepth, per_step_iters),
+              "batch_spp": args.batch, "flags": args.flags,
+              "sharding": ("in the library (one process): interleaved %d-row strips over %d devices, one host thread and "
+                           "stream per device; %s scaling; after every batch of %d iterations the tiles' running sums "
+                           "travel to device 0 (%s) and are unpacked into the frame, overlapped with the next batch"
+                           % (args.strip_rows, n_tiles, args.scaling, every, transport)) if inproc else
+              "whole frame" if not dist_on else
+              "interleaved %d-row strips over %d GPUs; %s scaling; `value`: tiles' running sums to rank 0 every %d "
+              "iterations (once per %s) by %s, overlapped with the next batch; the exchange after EVERY iteration "
+              "(north_star's cadence) is `per_iteration_exchange`"
+              % (args.strip_rows, world, args.scaling, every, "step" if every == per_step_iters else "%d iterations" % every, gather_desc),
+              "exchange_every_iterations": 0 if not multi else every,
+              "exchanges_per_step": 0 if not multi else exchanges_per_step,
+              "rays_per_step": int(rays / args.steps)}
+    if guard:
+        with guard.lock:
+            out["config"].update(config)
+    else:
+        out["config"].update(config)
+    if digest:
+        put(out, "image_md5", digest)
+    if roofline:
+        put(out, "roofline", roofline)
 
     # ---- CPU baseline: the oracle (plain-C port) on this host, rank 0, N = 1 only ----
     if rank == 0 and world == 1 and not inproc and not args.no_cpu_baseline:
@@ -548,35 +726,39 @@ def main():
         if "host_image_md5" in pc:
             out["config"]["pcie_host_image_md5"] = pc["host_image_md5"]
 
-    # ---- N > 1 (or its one-rank rehearsal): per-iteration exchange and strong scaling beside the main number.  A
-    # collective that never returns must not cost the main line: after --sub-timeout seconds every rank gives up (its own
-    # watchdog, same deadline), rank 0 prints the line without the sub-measurements and the processes exit.
-    if (dist_on or inproc) and not args.no_sub:
-        import threading
-        done = threading.Event()
-
-        def watchdog():
-            if done.wait(args.sub_timeout):
-                return
-            if rank == 0:
-                out["config"]["sub_measurements"] = "gave up after %.0f s" % args.sub_timeout
-                print(json.dumps(out), flush=True)
-            else:
-                time.sleep(2.0)                # rank 0's line first: a launcher that sees a rank exit tears the others down
-            os._exit(0)                        # the line says what happened; the timed region was complete
-        threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            sub = sub_measurements(c, args.steps, args.warmup)
-            if rank == 0:
-                out["config"].update(sub)
-        except Exception as e:                 # a sub-measurement must never break the bench line
-            if rank == 0:
-                out["config"]["sub_measurements"] = "failed: %s" % str(e)[:300]
-        done.set()
-    if rank == 0:
+    # ---- N > 1: strong scaling (and, on request, the frame assembled in ONE shared host buffer by the ranks' own
+    # launches) beside the main number; a failure is stated in the line ----
+    if multi and not args.no_sub:
+        if "per_iteration_exchange" in out:
+            put(out["config"], "per_iteration_exchange", out["per_iteration_exchange"])      # (where rounds 3-4 had it)
+        if n_tiles > 1:
+            phase("strong scaling", args.sub_timeout)
+            try:
+                put(out["config"], "strong", strong_scaling(c, args.steps, args.warmup))
+            except Exception as e:
+                put(out["config"], "strong", {"failed": str(e)[:300]})
+        if dist_on and args.shared_frame:
+            phase("shared host frame", args.sub_timeout)
+            try:                                          # (every rank fails at the same call or none does: same build, same flags)
+                put(out["config"], "per_iteration_shared_frame", shared_frame_rate(c, args.sub_iters))
+            except Exception as e:
+                put(out["config"], "per_iteration_shared_frame", {"failed": str(e)[:300]})
+    if guard:
+        guard.emit()
+    elif rank == 0:
         print(json.dumps(out))
     if dist_on:
+        # the line is out and complete; a teardown that never returns must not keep the launcher waiting
+        import threading
+
+        def teardown_expired():
+            sys.stderr.write("bench.py: destroy_process_group did not return in 60 s (the line above is complete)\n")
+            os._exit(0)
+        t = threading.Timer(60.0, teardown_expired)
+        t.daemon = True
+        t.start()
         dist.destroy_process_group()
+        t.cancel()
 
 
 def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s):

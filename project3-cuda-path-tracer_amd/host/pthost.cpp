@@ -183,20 +183,33 @@ M4 inverse_transpose(const M4 &mm) {
     return I;
 }
 
-// utilityCore::safeGetline (utilities.cpp:84-112): \n, \r\n and \r line ends, EOF handling
-bool safe_getline(std::istream &is, std::string &t) {
-    t.clear();
-    std::streambuf *sb = is.rdbuf();
-    for (;;) {
-        int c = sb->sbumpc();
-        switch (c) {
-        case '\n': return true;
-        case '\r': if (sb->sgetc() == '\n') sb->sbumpc(); return true;
-        case EOF: if (t.empty()) { is.setstate(std::ios::eofbit); return false; } return true;
-        default: t += (char)c;
+// The scene text as a sequence of lines.  The whole file is read once and cut at every line end -- "\n", "\r\n" or a
+// lone "\r", so scene files written on any platform load alike (what utilities.cpp:84-112 provides for the reference's
+// loader); a last line without a terminator counts, a terminator at the very end opens no further line.  `next` hands out
+// the lines in order; asking for one when none is left yields "" and ends `good()`, which is the stream state the
+// reference's loops test (scene.cpp:21,66,124).
+class Lines {
+public:
+    explicit Lines(const std::string &text) {
+        size_t from = 0;
+        const size_t n = text.size();
+        while (from < n) {
+            size_t to = text.find_first_of("\r\n", from);
+            if (to == std::string::npos) to = n;
+            rows_.emplace_back(text, from, to - from);
+            from = to + ((to + 1 < n && text[to] == '\r' && text[to + 1] == '\n') ? 2 : 1);
         }
     }
-}
+    void next(std::string &line) {
+        if (at_ < rows_.size()) line = rows_[at_++];
+        else { line.clear(); spent_ = true; }
+    }
+    bool good() const { return !spent_; }
+private:
+    std::vector<std::string> rows_;
+    size_t at_ = 0;
+    bool spent_ = false;
+};
 
 std::vector<std::string> tokens_of(const std::string &s) {       // utilityCore::tokenizeString
     std::stringstream ss(s);
@@ -285,20 +298,29 @@ extern "C" {
 const char *pth_last_error(void) { return g_err; }
 
 void pth_build_geom_matrices(pt_geom *g) {
-    // utilities.cpp:65-72: T * (Rx * Ry * Rz) * S, angles in degrees * (float)PI / 180
-    M4 translationMat = translate(identity(), U(g->translation));
-    M4 rotationMat = rotate(identity(), g->rotation.x * (float)PI_F / 180, v3(1, 0, 0));
-    rotationMat = mul(rotationMat, rotate(identity(), g->rotation.y * (float)PI_F / 180, v3(0, 1, 0)));
-    rotationMat = mul(rotationMat, rotate(identity(), g->rotation.z * (float)PI_F / 180, v3(0, 0, 1)));
-    M4 scaleMat = scale(identity(), U(g->scale));
-    M4 T = mul(mul(translationMat, rotationMat), scaleMat);
-    M4 inv = inverse(T), invT = inverse_transpose(T);
-    memcpy(&g->transform, &T, 64); memcpy(&g->inverseTransform, &inv, 64); memcpy(&g->invTranspose, &invT, 64);
+    // The object-to-world matrix the reference's loader builds (utilities.cpp:65-72): translate * (rotX * rotY * rotZ) *
+    // scale, each factor GLM's, angles given in degrees and converted as (angle * pi) / 180 in binary32, products taken
+    // left to right -- the order of the roundings is what the golden Geom fixtures pin.
+    const float euler[3] = {g->rotation.x, g->rotation.y, g->rotation.z};
+    M4 spin = identity();
+    for (int axis = 0; axis < 3; ++axis) {
+        const V3 unit = v3(axis == 0 ? 1.0f : 0.0f, axis == 1 ? 1.0f : 0.0f, axis == 2 ? 1.0f : 0.0f);
+        const M4 turn = rotate(identity(), euler[axis] * PI_F / 180, unit);
+        spin = axis == 0 ? turn : mul(spin, turn);
+    }
+    const M4 to_world = mul(mul(translate(identity(), U(g->translation)), spin), scale(identity(), U(g->scale)));
+    const M4 to_object = inverse(to_world), normals = inverse_transpose(to_world);
+    memcpy(&g->transform, &to_world, 64);
+    memcpy(&g->inverseTransform, &to_object, 64);
+    memcpy(&g->invTranspose, &normals, 64);
 }
 
 pth_scene *pth_load_scene(const char *path) {
-    std::ifstream fp(path);
-    if (!fp.is_open()) { snprintf(g_err, sizeof g_err, "Error reading from file %s", path); return NULL; }
+    std::ifstream file(path, std::ios::binary);
+    if (!file.is_open()) { snprintf(g_err, sizeof g_err, "Error reading from file %s", path); return NULL; }
+    std::stringstream whole;
+    whole << file.rdbuf();
+    Lines fp(whole.str());
     Builder b;
     pth_scene *s = (pth_scene *)calloc(1, sizeof(pth_scene));
     std::string dir(path);
@@ -307,7 +329,7 @@ pth_scene *pth_load_scene(const char *path) {
     bool have_cam = false;
     std::string line;
     while (fp.good()) {
-        safe_getline(fp, line);
+        fp.next(line);
         if (line.empty()) continue;
         std::vector<std::string> tok = tokens_of(line);
         if (tok.empty()) continue;
@@ -317,7 +339,7 @@ pth_scene *pth_load_scene(const char *path) {
             }
             pt_material m; memset(&m, 0, sizeof m);
             for (int i = 0; i < 7; ++i) {                             // exactly seven property lines
-                safe_getline(fp, line);
+                fp.next(line);
                 std::vector<std::string> t = tokens_of(line);
                 if (t.empty()) continue;
                 if (t[0] == "RGB" && t.size() >= 4) m.color = P(vec3_of(t));
@@ -335,19 +357,19 @@ pth_scene *pth_load_scene(const char *path) {
             }
             pt_geom g; memset(&g, 0, sizeof g);
             std::string mesh_file;
-            safe_getline(fp, line);
+            fp.next(line);
             if (!line.empty() && fp.good()) {
                 std::vector<std::string> t = tokens_of(line);
                 if (line == "sphere") g.type = PT_SPHERE;
                 else if (line == "cube") g.type = PT_CUBE;
                 else if (!t.empty() && t[0] == "mesh" && t.size() >= 2) { g.type = PT_TRIANGLE_MESH; mesh_file = t[1]; }
             }
-            safe_getline(fp, line);
+            fp.next(line);
             if (!line.empty() && fp.good()) {
                 std::vector<std::string> t = tokens_of(line);
                 if (t.size() >= 2) g.materialid = atoi(t[1].c_str());
             }
-            safe_getline(fp, line);
+            fp.next(line);
             while (!line.empty() && fp.good()) {
                 std::vector<std::string> t = tokens_of(line);
                 if (t.size() >= 4) {
@@ -355,7 +377,7 @@ pth_scene *pth_load_scene(const char *path) {
                     else if (t[0] == "ROTAT") g.rotation = P(vec3_of(t));
                     else if (t[0] == "SCALE") g.scale = P(vec3_of(t));
                 }
-                safe_getline(fp, line);
+                fp.next(line);
             }
             pth_build_geom_matrices(&g);
             if (g.type == PT_TRIANGLE_MESH) {
@@ -373,7 +395,7 @@ pth_scene *pth_load_scene(const char *path) {
             memset(&camera, 0, sizeof camera);
             float fovy = 0.0f;
             for (int i = 0; i < 5; ++i) {
-                safe_getline(fp, line);
+                fp.next(line);
                 std::vector<std::string> t = tokens_of(line);
                 if (t.empty()) continue;
                 if (t[0] == "RES" && t.size() >= 3) { camera.resolution[0] = atoi(t[1].c_str()); camera.resolution[1] = atoi(t[2].c_str()); }
@@ -382,7 +404,7 @@ pth_scene *pth_load_scene(const char *path) {
                 else if (t[0] == "DEPTH" && t.size() >= 2) s->trace_depth = atoi(t[1].c_str());
                 else if (t[0] == "FILE" && t.size() >= 2) snprintf(s->image_name, sizeof s->image_name, "%s", t[1].c_str());
             }
-            safe_getline(fp, line);
+            fp.next(line);
             while (!line.empty() && fp.good()) {
                 std::vector<std::string> t = tokens_of(line);
                 if (t.size() >= 4) {
@@ -390,7 +412,7 @@ pth_scene *pth_load_scene(const char *path) {
                     else if (t[0] == "LOOKAT") camera.lookAt = P(vec3_of(t));
                     else if (t[0] == "UP") camera.up = P(vec3_of(t));
                 }
-                safe_getline(fp, line);
+                fp.next(line);
             }
             float yscaled = std::tan(fovy * (PI_F / 180));
             float xscaled = (yscaled * camera.resolution[0]) / camera.resolution[1];

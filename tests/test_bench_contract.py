@@ -81,7 +81,7 @@ def test_one_iteration_per_call_with_the_host_image():
 def _two(port, *extra, backend="gloo", same_device=True, per_bounce=True):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--no-roofline", "--backend", backend, "--digest", "--sub-iters", "8"] + list(extra)
+           "--warmup", "1", "--no-roofline", "--backend", backend, "--digest", "--sub-iters", "8", "--shared-frame"] + list(extra)
     if same_device:
         cmd.append("--same-device")
     return run(cmd, per_bounce=per_bounce)
@@ -109,13 +109,36 @@ def test_two_ranks_same_frame():
         assert ("exchange thread" if "--exchange-thread" in extra else "tracing thread") in pie["transport"] \
             or extra == ["--batch", "2", "--collective", "reduce"], pie
         assert strong["mrays_per_s"] > 10 and strong["spp_per_step_per_frame"] == int(extra[1]), strong
-        # ... and the frame assembled in ONE shared host buffer by the ranks' own launches, no exchange (PT_SHARED_IMAGE):
-        # refused under this helper's kernel-per-bounce plan (it needs one-launch iterations), measured below
+        # the north star's cadence is a top-level object of every N > 1 line, and the line says what the backend spans
+        assert two["per_iteration_exchange"] == pie and two["config"]["exchange_every_iterations"] >= 1
+        assert two["ranks"]["world_size"] == 2 and two["ranks"]["backend"] == "gloo" and len(two["ranks"]["devices"]) == 2
+        # ... and the frame assembled in ONE shared host buffer by the ranks' own launches, no exchange (PT_SHARED_IMAGE,
+        # --shared-frame): refused under this helper's kernel-per-bounce plan (it needs one-launch iterations), measured below
         assert "one launch" in two["config"]["per_iteration_shared_frame"]["failed"], two["config"]["per_iteration_shared_frame"]
     two = _two(29539, "--batch", "2", per_bounce=False)
     assert two["image_md5"] == one["image_md5"]
     shared = two["config"]["per_iteration_shared_frame"]
     assert shared["frame_equals_every_ranks_tile"] is True and shared["mrays_per_s"] > 10 and shared["iterations"] >= 8, shared
+
+
+def test_plain_gpus_2_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` the way the driver runs `--gpus 1` -- no launcher, no WORLD_SIZE: bench.py starts the two
+    ranks itself (child processes of a parent that has not touched the GPU) and relays rank 0's line; same frame as the
+    1-process run, the per-iteration exchange in the line, the backend's world size stated."""
+    one = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
+               "--no-roofline", "--digest"])
+    env = {k: os.environ.pop(k) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT") if k in os.environ}
+    try:
+        two = run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--no-roofline",
+                   "--backend", "gloo", "--same-device", "--digest", "--sub-iters", "8", "--launch-timeout", "500"])
+    finally:
+        os.environ.update(env)
+    assert two["n_gpus"] == 2 and two["image_md5"] == one["image_md5"]
+    assert two["config"]["rays_per_step"] == one["config"]["rays_per_step"]
+    assert two["ranks"]["world_size"] == 2 and two["ranks"]["distinct_devices"] == 1          # (--same-device)
+    pie = two["per_iteration_exchange"]
+    assert pie["mrays_per_s"] > 10 and pie["no_exchange_mrays_per_s"] > 10 and pie["iterations"] >= 8, pie
+    assert "watchdog" not in two and two["config"]["strong"]["mrays_per_s"] > 10
 
 
 def _ranks(n, port, *extra):
@@ -160,8 +183,7 @@ def test_one_rank_rccl():
         assert d["n_gpus"] == 1 and d["config"]["exchanges_per_step"] >= 1, extra
         pie = d["config"]["per_iteration_exchange"]                    # RCCL gather per iteration
         assert pie["mrays_per_s"] > 10 and 0.05 < pie["ratio"] < 20.0 and pie["iterations"] >= 16, pie
-        shared = d["config"]["per_iteration_shared_frame"]          # (a world of one: the plain page-locked host image)
-        assert shared.get("frame_equals_every_ranks_tile") is True or "failed" in shared, shared
+        assert d["ranks"]["world_size"] == 1 and d["ranks"]["backend"] == "nccl" and d["ranks"]["distinct_devices"] == 1
         assert d["config"]["rays_per_step"] == one["config"]["rays_per_step"], extra
         assert d["image_md5"] == one["image_md5"], extra
 
