@@ -356,15 +356,20 @@ def per_call_rates(c, n_it=256):
         return rate, round(el / n_it * 1e3, 4)
 
     out["mrays_per_s"], out["ms_per_call"] = run(c.flags, lambda it: pt.trace_batch_async(it, 1))
-    out["pcie_inclusive_sync"], out["pcie_inclusive_sync_ms_per_call"] = run(c.flags, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
+    # as host/pathtrace_shim.cpp initialises the library for the reference's host: PT_PIN_IMAGE | PT_HOST_SPARSE (that host
+    # only reads state.image: a call writes the pixels whose sum changed) ...
+    out["pcie_inclusive_sync"], out["pcie_inclusive_sync_ms_per_call"] = run(c.flags | pt.PT_HOST_SPARSE, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
     if c.args.digest:
         import hashlib
         out["host_image_md5"] = hashlib.md5(host.tobytes()).hexdigest()       # the host image after the synchronous calls
-    out["pcie_inclusive_async"], _ = run(c.flags | pt.PT_ASYNC_IMAGE, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
+    # ... and for a host that may write into the image between calls: every pixel, every call
+    out["pcie_inclusive_sync_every_pixel"], out["pcie_inclusive_sync_every_pixel_ms_per_call"] = run(c.flags, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
+    out["pcie_inclusive_async"], _ = run(c.flags | pt.PT_ASYNC_IMAGE | pt.PT_HOST_SPARSE, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
     out["calls"] = n_it
     out["note"] = ("one pathtrace() per iteration (src/main.cpp:130-140), 1 spp per call, max_batch = 1: mrays_per_s = calls enqueued back to back "
-                   "(no host image); pcie_inclusive_sync = the running sum in host memory when each call returns (pathtrace.cu:389-392); "
-                   "pcie_inclusive_async = PT_ASYNC_IMAGE")
+                   "(no host image); pcie_inclusive_sync = the running sum in host memory when each call returns (pathtrace.cu:389-392), "
+                   "PT_PIN_IMAGE | PT_HOST_SPARSE as the drop-in shim sets them; ..._every_pixel = without PT_HOST_SPARSE; "
+                   "pcie_inclusive_async = PT_ASYNC_IMAGE | PT_HOST_SPARSE")
     return out
 
 

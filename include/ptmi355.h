@@ -22,6 +22,33 @@
  * Every int-returning entry point returns PT_OK (0) or a negative pt_status;
  * pt_last_error() then describes the failure.  The library never falls back
  * to a CPU path: without a HIP device every call fails with PT_ERR_DEVICE.
+ *
+ * Environment.  The shipped library reads exactly these ten variables, at
+ * pt_init (PTMI355_RCCL_LIB: when RCCL is first needed).  NONE of them changes a
+ * result: images, per-bounce statistics and path order are bit-identical under
+ * every setting (each is exercised against the default by a `-m gpu` test, named
+ * in brackets); they select launch plans, transports and memory budgets.
+ *   PTMI355_DEVICES="0,1,.."|"all"  tile the frame over these GPUs for a host that knows one device
+ *                                   (pt_scene_desc::devices below)          [test_devices_from_the_environment_and_the_reference_host]
+ *   PTMI355_XCHG=rccl|peer          transport of the in-library tile exchange (default: RCCL when every
+ *                                   context has its own device, peer copies otherwise)  [test_rccl_calls_with_a_communicator_of_one]
+ *   PTMI355_RCCL_LIB=/path/librccl.so.1  the RCCL library to dlopen before the default names
+ *                                                                            [test_rccl_library_named_by_the_environment]
+ *   PTMI355_WHOLE_MAX=<paths>       largest batch (paths) traced as ONE launch (k_iteration; default 6 000 000);
+ *                                   0 = a kernel per bounce for every batch   [the launch_plan fixture: most parity tests run under both]
+ *   PTMI355_WHOLE_MAX_HOST=<paths>  the same limit for a pt_trace call that hands over a host image (default
+ *                                   16 000 000)                              [test_4k_one_iteration_per_call_into_the_host_image]
+ *   PTMI355_OVERLAP=0|1|n           consecutive asynchronous batches overlap on n lanes (1 = default lane count,
+ *                                   0 = strictly one after the other)        [test_overlapped_small_batches]
+ *   PTMI355_OVERLAP_GB=<GB>         memory the lanes' extra path pools may take (they are dropped when it does
+ *                                   not suffice)                             [test_overlapped_small_batches]
+ *   PTMI355_GRAPH=1                 batches captured once and replayed with hipGraphLaunch  [test_graph_replay_equals_direct_launches]
+ *   PTMI355_CULL0=0|1               the per-camera bounce-0 candidate masks (k_cull0_mask) off / on  [test_bounce0_candidate_masks]
+ *   PTMI355_SCENE_LDS=0             scene records read through the vector cache instead of staged in LDS (what
+ *                                   scenes too large for LDS get anyway)     [test_scene_gathers_from_global_memory]
+ * Everything else rounds 1-4 switched through the environment (occupancy, stream-layout and transport experiments,
+ * test hooks) exists only in a build with -DPT_EXPERIMENTS (profiles/tools/build_variant.sh); pt_version() of such a
+ * build ends in "+experiments".
  */
 #ifndef PTMI355_H
 #define PTMI355_H
@@ -110,16 +137,22 @@ enum pt_flags {
     PT_PIN_IMAGE     = 1u << 8,  /* opt-in: the host image handed to pt_trace / pt_trace_batch is ONE buffer that stays
                                     allocated at its address until pt_free (the reference's scene->state.image is: sized at
                                     load, scene.cpp:145-147).  The library then page-locks it on first use and, when an
-                                    iteration runs as one launch, lets the kernel write the new sums into it over PCIe
-                                    while it is still tracing -- from the second consecutive pt_trace on only the pixels
-                                    whose sum changed (a path that ends with colour 0 adds nothing): the buffer is the
-                                    library's to keep current, the host READS it between calls and does not write to it
-                                    (a host that does: PTMI355_HOST_SPARSE=0, every pixel every call).  Without the flag every call copies into whatever buffer
-                                    it is given (pageable path), exactly like the reference's cudaMemcpy
-                                    (pathtrace.cu:389-390): buffers may be freed or reallocated between calls. */
+                                    iteration runs as one launch, lets the kernel write the running sums into it over PCIe
+                                    while it is still tracing -- EVERY pixel, every call, like the reference's cudaMemcpy
+                                    (pathtrace.cu:389-390): whatever the host did to the buffer between two calls is
+                                    overwritten.  Without the flag every call copies into whatever buffer it is given
+                                    (pageable path): buffers may be freed or reallocated between calls. */
+    PT_HOST_SPARSE   = 1u << 10, /* opt-in, with PT_PIN_IMAGE / PT_ASYNC_IMAGE: the host promises to only READ the image
+                                    between calls (the reference's host does: main.cpp:78-99 reads it in saveImage, nothing
+                                    writes it).  From the second consecutive pt_trace on the launch then writes only the
+                                    pixels whose sum changed (a path that ends with colour 0 adds nothing: four in five at
+                                    800x800 Cornell): 0.133 ms per call against 0.236.  The library tracks everything IT
+                                    does to the accumulation buffer (batches, pt_clear_image, pt_set_image, another host
+                                    buffer) and writes every pixel again after such a change; a write by the HOST into the
+                                    buffer is not seen -- such pixels stay as the host left them until their sum changes. */
     PT_SHARED_IMAGE  = 1u << 9,  /* tiled sessions (tile_count > 1), pt_trace: host_image_sum is ONE frame shared by all the
                                     ranks that tile it (every process maps the same memory, e.g. POSIX shared memory) under the
-                                    rules of PT_PIN_IMAGE, which it implies.  A rank's launch writes the pixels of its OWN tile
+                                    rules of PT_PIN_IMAGE and PT_HOST_SPARSE, which it implies.  A rank's launch writes the pixels of its OWN tile
                                     into it and nothing else, so the ranks assemble the frame in host memory with no exchange
                                     between them: it holds the sum after iteration i once every rank's call for i has returned.
                                     Without the flag a tiled session copies its whole accumulation buffer (zeros outside its
@@ -128,8 +161,8 @@ enum pt_flags {
                                     running sum into host_image_sum overlaps the NEXT call's tracing and is
                                     complete when the next pt_trace / pt_trace_batch returns, or after
                                     pt_synchronize, pt_get_image or pt_free (pt_get_stats needs pt_synchronize).  (pt_trace: the launch
-                                    writes the page-locked buffer itself, as under PT_PIN_IMAGE, and the same rule holds: the host
-                                    reads the buffer, it does not write to it.)  Off = the reference's synchronous pathtrace()
+                                    writes the page-locked buffer itself, as under PT_PIN_IMAGE; with PT_HOST_SPARSE only the
+                                    pixels that changed.)  Off = the reference's synchronous pathtrace()
                                     (pathtrace.cu:389-392).  Implies the lifetime rule of PT_PIN_IMAGE for the buffers
                                     handed over (they are read by a copy that is still running when the call returns). */
 };

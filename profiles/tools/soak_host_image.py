@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """soak_host_image.py [calls]: the launch-written host image over a long run of pathtrace() calls at 800x800 -- synchronous
 (PT_PIN_IMAGE) and PT_ASYNC_IMAGE -- the host buffer compared with the device's running sum every 97 calls and the final
-sums with the every-pixel-every-call plan (PTMI355_HOST_SPARSE=0)."""
+sums with the every-pixel-every-call plan (PT_PIN_IMAGE without PT_HOST_SPARSE)."""
 import hashlib
 import os
 import sys
@@ -40,8 +40,8 @@ def run(flags, env):
     return md5, bad, same
 
 
-ref = run(pt.PT_COMPACT | pt.PT_PIN_IMAGE, {"PTMI355_HOST_SPARSE": "0"})
-for name, flags in (("synchronous", pt.PT_COMPACT | pt.PT_PIN_IMAGE), ("PT_ASYNC_IMAGE", pt.PT_COMPACT | pt.PT_PIN_IMAGE | pt.PT_ASYNC_IMAGE)):
+ref = run(pt.PT_COMPACT | pt.PT_PIN_IMAGE, {})
+for name, flags in (("synchronous", pt.PT_COMPACT | pt.PT_PIN_IMAGE | pt.PT_HOST_SPARSE), ("PT_ASYNC_IMAGE", pt.PT_COMPACT | pt.PT_PIN_IMAGE | pt.PT_HOST_SPARSE | pt.PT_ASYNC_IMAGE)):
     got = run(flags, {})
     print("%-15s %d calls: host == device at every check: %s, at the end: %s, final sums == every-pixel plan: %s" % (name, N, got[1] == 0, got[2], got[0] == ref[0]))
     assert got[1] == 0 and got[2] and got[0] == ref[0]

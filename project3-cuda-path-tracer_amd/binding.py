@@ -33,6 +33,7 @@ TRI_DT = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3)])
 MESH_DT = np.dtype([("geom_index", "<i4"), ("first_triangle", "<i4"), ("triangle_count", "<i4")])
 
 PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH, PT_AA_JITTER, PT_ASYNC_IMAGE, PT_PIN_IMAGE = 1, 2, 4, 8, 16, 32, 64, 128, 256
+PT_HOST_SPARSE = 1024
 PT_SHARED_IMAGE = 512
 BVH_NODE_WORDS = 16
 
@@ -99,6 +100,7 @@ class Scene:
 
 _lib = None
 _scene = None
+_host_sparse = False
 
 
 def library():
@@ -171,20 +173,32 @@ def version():
     return library().pt_version().decode()
 
 
+def has_experiments():
+    """True for a -DPT_EXPERIMENTS build (profiles/tools/build_variant.sh, loaded through PTMI355_LIB): the library then
+    reads the experiment / test-hook environment variables of rounds 1-4; the shipped build reads the ten documented in
+    include/ptmi355.h and nothing else."""
+    return "+experiments" in version()
+
+
 def pathtraceInit(scene, flags=PT_COMPACT, device=0, stream=None, tile=(0, 1, 8), max_batch=1,
-                  device_image=None, lens=(0.0, 0.0), devices=None, pin_image=True):
+                  device_image=None, lens=(0.0, 0.0), devices=None, pin_image=True, host_sparse=False):
     """pathtraceInit(Scene*) (pathtrace.cu:79-98) + the run-time toggles of include/ptmi355.h.
     devices=[d0, d1, ...]: the frame tiled over several GPUs inside the library (tile[2] = rows per strip).
     pin_image: PT_PIN_IMAGE -- pathtrace() below always hands over scene.image, which lives as long as the scene
-    (like the reference's scene->state.image); callers that pass their own short-lived buffers to pt_trace say False."""
-    global _scene
+    (like the reference's scene->state.image); callers that pass their own short-lived buffers to pt_trace say False.
+    host_sparse: PT_HOST_SPARSE -- the caller only READS the image between calls, so a call writes just the pixels whose
+    sum changed; pathtrace() then returns a read-only view of scene.image (a host that scribbles on it gets an error
+    instead of stale pixels)."""
+    global _scene, _host_sparse
+    _host_sparse = bool(host_sparse or (flags & PT_HOST_SPARSE))
     d = _SceneDesc()
     d.geoms, d.num_geoms = _p(scene.geoms), len(scene.geoms)
     d.materials, d.num_materials = _p(scene.materials), len(scene.materials)
     d.triangles, d.num_triangles = _p(scene.triangles), 0 if scene.triangles is None else len(scene.triangles)
     d.meshes, d.num_meshes = _p(scene.meshes), 0 if scene.meshes is None else len(scene.meshes)
     C.memmove(C.byref(d.camera), scene.camera.tobytes(), 84)
-    d.trace_depth, d.flags, d.device = scene.traceDepth, flags | (PT_PIN_IMAGE if pin_image else 0), device
+    d.trace_depth, d.device = scene.traceDepth, device
+    d.flags = flags | (PT_PIN_IMAGE if pin_image else 0) | (PT_HOST_SPARSE if host_sparse else 0)
     d.stream = stream
     d.tile_index, d.tile_count, d.strip_rows = tile
     d.max_batch = max_batch
@@ -214,6 +228,10 @@ def pathtrace(pbo, frame, iteration, copy_image=True):
     L = library()
     _chk(L.pt_set_camera(_p(_scene.camera), _scene.traceDepth))
     _chk(L.pt_trace(pbo, frame, iteration, _p(_scene.image) if copy_image else None))
+    if _host_sparse:
+        view = _scene.image.view()
+        view.setflags(write=False)
+        return view
     return _scene.image
 
 

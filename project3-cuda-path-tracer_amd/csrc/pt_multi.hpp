@@ -245,7 +245,7 @@ struct Group {
     // page-locked image (registered ONCE, portable: every device maps it) -- no pack, no exchange, no frame-to-host copy
     bool direct_ok = false, direct_enabled = true;   // every context can (asked at pt_init) / PTMI355_MULTI_DIRECT
     float *dhost = nullptr; size_t dhost_bytes = 0;  // the registered host image
-    bool frame_stale = false;                   // the device frame lacks the peers' rows of such calls: the next exchange brings them
+    bool frame_stale = false;  /* (set by the caller's thread when the exchange thread is idle; cleared by either: a late clear only costs one redundant exchange) */              // the device frame lacks the peers' rows of such calls: the next exchange brings them
     std::unique_ptr<Exchanger> x;               // asynchronous batches hand their exchange to this thread
     float *frame = nullptr;                     // where the tiles are assembled: context 0's accumulation buffer -- except in the
                                                 // one-context RCCL rehearsal, where it is a buffer of its own (self_frame)
@@ -296,6 +296,7 @@ int worker_pack(Worker &w, int s) {
 int enqueue_exchange(int s) {
     Worker &root = *G.w[0];
     if (G.K == 1 && !G.self_exchange) { G.exchanges++; return PT_OK; }     // one context, nothing to move: its buffer is the frame
+    G.frame_stale = false;      // every exchange carries the running sums as they are: the peers' rows of direct calls come along
     DeviceGuard guard;
     if (G.use_rccl) {
         for (auto &wp : G.w) {
@@ -433,7 +434,11 @@ int multi_enqueue(int iter0, int count, bool overlap = false) {
         if (g_xstats.on) { g_xstats.main_ns += now_ns() - t_main; g_xstats.calls++; }
         return PT_OK;
     }
-    int rc = on_all([&](Worker &w) -> int {
+    // the slot protocol: whatever the exchange thread still holds (up to XSLOTS asynchronous calls) is issued before this
+    // call's packing re-records the slot's events
+    int rc = exchange_settled();
+    if (rc) return rc;
+    rc = on_all([&](Worker &w) -> int {
         R.in_step = false;
         R.ov_ok = overlap;
         const int r = enqueue_batch(iter0, count);
@@ -594,7 +599,7 @@ int multi_init(const pt_scene_desc *d, const std::vector<int> &devs) {
             // workgroups otherwise take every slot a retiring workgroup frees
             int lo = 0, hi = 0;
             if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
-            if (getenv("PTMI355_XCHG_PRIO") && atoi(getenv("PTMI355_XCHG_PRIO")) == 0) hi = lo = 0;
+            if (pt_experiment("PTMI355_XCHG_PRIO") && atoi(pt_experiment("PTMI355_XCHG_PRIO")) == 0) hi = lo = 0;
             if (hipStreamCreateWithPriority(&w.xs, hipStreamNonBlocking, hi) != hipSuccess) {
                 (void)hipGetLastError();
                 HIPCHK(hipStreamCreateWithFlags(&w.xs, hipStreamNonBlocking));
@@ -648,7 +653,7 @@ int multi_init(const pt_scene_desc *d, const std::vector<int> &devs) {
         // cadence: 0.1 ms of tracing per iteration at 800x800) the host set the pace, not the device.
         // PTMI355_XCHG_THREAD=0 issues it from the caller's thread as rounds 1-3 did.
         bool on = true;
-        if (const char *e = getenv("PTMI355_XCHG_THREAD")) on = atoi(e) != 0;
+        if (const char *e = pt_experiment("PTMI355_XCHG_THREAD")) on = atoi(e) != 0;
         if (on) {
             G.x.reset(new Exchanger());
             Exchanger *x = G.x.get();
@@ -660,10 +665,10 @@ int multi_init(const pt_scene_desc *d, const std::vector<int> &devs) {
         (void)on_all([&](Worker &w) -> int { can[(size_t)w.index] = one::whole_host_possible() ? 1 : 0; return PT_OK; });
         G.direct_ok = true;
         for (int v : can) G.direct_ok = G.direct_ok && v;
-        if (const char *e = getenv("PTMI355_MULTI_DIRECT")) G.direct_enabled = atoi(e) != 0;
+        if (const char *e = pt_experiment("PTMI355_MULTI_DIRECT")) G.direct_enabled = atoi(e) != 0;
     }
     G.last_cam = d->camera; G.last_depth = d->trace_depth;
-    g_xstats.on = getenv("PTMI355_XCHG_STATS") && atoi(getenv("PTMI355_XCHG_STATS")) != 0;
+    g_xstats.on = pt_experiment("PTMI355_XCHG_STATS") && atoi(pt_experiment("PTMI355_XCHG_STATS")) != 0;
     t_err[0] = 0;
     return PT_OK;
 }
@@ -865,7 +870,11 @@ int pt_set_image(const float *host_image_sum) {
     });
 }
 
-float *pt_device_image(void) { return G.live ? G.frame : one::pt_device_image(); }
+float *pt_device_image(void) {
+    if (!G.live) return one::pt_device_image();
+    (void)multi_refresh();      // after calls that wrote the host image directly: the peers' rows travel now (stream-ordered on devices[0]'s exchange stream; pt_synchronize before reading)
+    return G.frame;
+}
 
 long long pt_total_rays(void) {
     if (!G.live) return one::pt_total_rays();

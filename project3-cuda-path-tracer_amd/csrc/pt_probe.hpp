@@ -20,8 +20,9 @@ __global__ void k_probe_rng(const uint32_t *seeds, int n, int draws, uint32_t *s
 
 __global__ void k_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, float *s, float *c, unsigned long long *sum) {
     unsigned long long as = 0, ac = 0;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const float v = x ? x[k] : __uint_as_float(first_bits + k);
+    // 64-bit index: n may be anything up to 2^32 - 1 (the whole binary32 range) and the stride must not wrap
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const float v = x ? x[k] : __uint_as_float(first_bits + (uint32_t)k);
         float sv, cv;
         ptd::sincos_shared(v, sv, cv);
         if (s) s[k] = sv;
@@ -75,7 +76,9 @@ int pt_probe_rng(const uint32_t *seeds, int n, int draws, uint32_t *state, float
 
 int pt_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, float *s, float *c, uint64_t sum[2]) {
     if (n == 0) { if (sum) sum[0] = sum[1] = 0; return PT_OK; }
-    if (!x && (s || c) && n > (1u << 28)) return fail(PT_ERR_INVALID, "pt_probe_sincos: %u outputs", n);
+    // arrays of n floats (inputs or outputs) are bounded; the array-free form (arguments from first_bits, checksums only)
+    // may sweep every binary32 value
+    if ((x || s || c) && n > (1u << 28)) return fail(PT_ERR_INVALID, "pt_probe_sincos: %u elements with arrays (at most 2^28)", n);
     ProbeBufs b;
     float *d_x = x ? (float *)b.get((size_t)n * 4, x) : nullptr;
     float *d_s = s ? (float *)b.get((size_t)n * 4, nullptr) : nullptr;

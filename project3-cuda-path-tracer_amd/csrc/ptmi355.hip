@@ -47,6 +47,20 @@ static_assert(sizeof(pt_triangle) == 36, "triangle ABI");
 
 using ptd::f3;
 
+// The SHIPPED library reads ten environment variables, each documented in include/ptmi355.h ("Environment") and each
+// exercised by a -m gpu test.  Every other switch rounds 1-4 grew -- launch-plan, occupancy and transport experiments,
+// test hooks -- exists only in a build with -DPT_EXPERIMENTS (profiles/tools/build_variant.sh; A/B tooling and the
+// experiment tests load that build through PTMI355_LIB): a product whose point is bit-exactness does not change its
+// launch plan because of a stray variable.
+static inline const char *pt_experiment(const char *name) {
+#ifdef PT_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 #include "pt_types.hpp"
 #include "pt_bvh.hpp"
 #include "pt_cull.hpp"
@@ -181,7 +195,7 @@ struct Renderer {
     float *epi_host = nullptr;    // pt_trace: the caller's image, device-mapped, for k_iteration's own gather (this call only)
     bool epi_done = false;        // ... and k_iteration took it
     bool epi_direct_enabled = true;   // PTMI355_EPI_DIRECT=0: such launches keep the final-colour buffer and gather per wave at their end
-    bool host_sparse_enabled = true;  // PTMI355_HOST_SPARSE=0: ... when a host image is written (every pixel, every call)
+    bool host_sparse_enabled = false; // PT_HOST_SPARSE (implied by PT_SHARED_IMAGE): only the pixels whose sum changed are written to a host image the launch wrote last
     uint64_t image_epoch = 0;     // bumped by everything that changes the accumulation buffer
     float *host_synced = nullptr; // the (device-mapped) host image that held exactly the buffer's content at epoch host_epoch
     uint64_t host_epoch = 0;
@@ -892,9 +906,9 @@ int upload_cull(const pt_scene_desc *d, const pt_camera &cam) {
         float *r = rec.data() + (size_t)i * CULL_WORDS;
         for (int k = 0; k < 3; ++k) { r[2 * k] = boxes[(size_t)i].lo[k]; r[2 * k + 1] = boxes[(size_t)i].hi[k]; }
         int ax = 3;
-        if (d->geoms[i].type == PT_CUBE && !getenv("PTMI355_NO_AXIS_REJECT"))
+        if (d->geoms[i].type == PT_CUBE && !pt_experiment("PTMI355_NO_AXIS_REJECT"))
             ax = ptcull::reject_row(&d->geoms[i].inverseTransform.m[0][0], &r[7]);       // words 7..10: the row
-        if (ax == 4 && getenv("PTMI355_NO_ROW_REJECT")) ax = 3;
+        if (ax == 4 && pt_experiment("PTMI355_NO_ROW_REJECT")) ax = 3;
         const int tw = d->geoms[i].type | (ax << 8);
         memcpy(&r[6], &tw, 4);
     }
@@ -1049,7 +1063,7 @@ int enqueue_async_image(float *host) {
     // PCIe-inclusive).  PTMI355_ASYNC_COPY_WGS=n hands the snapshot over through n workgroups that store into the buffer's
     // device mapping instead (as k_iteration's epilogue does for synchronous calls): measured slower -- 64 workgroups
     // 0.25 ms (profiles/r04/ab_async_copy.log) -- and kept as an experiment switch only.
-    const int copy_wgs = getenv("PTMI355_ASYNC_COPY_WGS") ? atoi(getenv("PTMI355_ASYNC_COPY_WGS")) : 0;
+    const int copy_wgs = pt_experiment("PTMI355_ASYNC_COPY_WGS") ? atoi(pt_experiment("PTMI355_ASYNC_COPY_WGS")) : 0;
     float *mapped = copy_wgs > 0 ? map_host(host, bytes) : nullptr;
     if (mapped && ((uintptr_t)mapped & 15u) == 0) {
         hipLaunchKernelGGL(k_copy_out, dim3((unsigned)copy_wgs), dim3(BLOCK), 0, R.copy_stream, reinterpret_cast<float4 *>(mapped),
@@ -1135,7 +1149,7 @@ int collect_stats(void) {
                 st[0] ? (double)st[2] / st[0] : 0.0, st[2] ? (double)st[3] / st[2] : 0.0, st[4], st[6] ? (double)st[4] / st[6] : 0.0);
     }
 #endif
-    if (getenv("PTMI355_DEBUG_SCAN")) {
+    if (pt_experiment("PTMI355_DEBUG_SCAN")) {
         fprintf(stderr, "[ptmi355] scan us per bounce:");
         for (int d = 0; d < R.trace_depth; ++d) fprintf(stderr, " %.1f", c.scan_ticks[d] / 100.0);
         fprintf(stderr, "\n");
@@ -1155,7 +1169,13 @@ int collect_stats(void) {
 namespace one {
 
 const char *pt_last_error(void) { return g_err; }
-const char *pt_version(void) { return "ptmi355 0.1 (gfx950, fp32 no-contract, wave64)"; }
+const char *pt_version(void) {
+#ifdef PT_EXPERIMENTS
+    return "ptmi355 0.1 (gfx950, fp32 no-contract, wave64) +experiments";
+#else
+    return "ptmi355 0.1 (gfx950, fp32 no-contract, wave64)";
+#endif
+}
 
 void pt_free(void) {
     if (!R.live && !R.scratch) return;
@@ -1431,14 +1451,14 @@ static int init_impl(const pt_scene_desc *d) {
         if (nl >= 2) { R.ov_lanes = std::min(nl, OV_MAX_LANES); R.ov_lanes_set = true; }
     }
     if (const char *e = getenv("PTMI355_OVERLAP_GB")) R.ov_budget_gb = atof(e);
-    if (const char *e = getenv("PTMI355_LANE_STREAMS")) R.ov_streams = std::max(1, atoi(e));
+    if (const char *e = pt_experiment("PTMI355_LANE_STREAMS")) R.ov_streams = std::max(1, atoi(e));
     R.epi_enabled = true;
-    if (const char *e = getenv("PTMI355_HOST_EPILOGUE")) R.epi_enabled = atoi(e) != 0;
-    if (const char *e = getenv("PTMI355_EPI_DIRECT")) R.epi_direct_enabled = atoi(e) != 0;
-    if (const char *e = getenv("PTMI355_HOST_SPARSE")) R.host_sparse_enabled = atoi(e) != 0;
-    if (const char *e = getenv("PTMI355_ASYNC_DIRECT")) R.async_direct_enabled = atoi(e) != 0;
+    if (const char *e = pt_experiment("PTMI355_HOST_EPILOGUE")) R.epi_enabled = atoi(e) != 0;
+    if (const char *e = pt_experiment("PTMI355_EPI_DIRECT")) R.epi_direct_enabled = atoi(e) != 0;
+    R.host_sparse_enabled = (d->flags & (PT_HOST_SPARSE | PT_SHARED_IMAGE)) != 0;
+    if (const char *e = pt_experiment("PTMI355_ASYNC_DIRECT")) R.async_direct_enabled = atoi(e) != 0;
     R.pin_enabled = true;
-    if (const char *e = getenv("PTMI355_PIN")) R.pin_enabled = atoi(e) != 0;
+    if (const char *e = pt_experiment("PTMI355_PIN")) R.pin_enabled = atoi(e) != 0;
     R.npix = W * H;
     R.map.W = W; R.map.H = H; R.map.tile_index = d->tile_index; R.map.tile_count = tile_count;
     R.map.strip_rows = tile_count > 1 ? d->strip_rows : H;
@@ -1475,7 +1495,7 @@ static int init_impl(const pt_scene_desc *d) {
         // launch of such a lane (or not, depending on how many streams the process had made before: 1 spp per call
         // measured anything between 15 and 31 Grays/s with 2-8 lanes and 4 / 8 queues, profiles/r04/ab_hw_queues.log).
         int lo = 0, hi = 0;
-        const char *pe = getenv("PTMI355_MAIN_PRIO");
+        const char *pe = pt_experiment("PTMI355_MAIN_PRIO");
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
         if ((pe && atoi(pe) == 0) || hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, hi) != hipSuccess) {
             (void)hipGetLastError();
@@ -1583,7 +1603,7 @@ static int init_impl(const pt_scene_desc *d) {
         if (const char *e = getenv("PTMI355_SCENE_LDS")) R.scene_lds = atoi(e) != 0 && base + scene <= 64 * 1024;   // tests force the global path
         R.lds_bytes = base + (R.scene_lds ? scene : 0);
         R.lds_bytes = (R.lds_bytes + 15) & ~(size_t)15;
-        if (const char *pad = getenv("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
+        if (const char *pad = pt_experiment("PTMI355_LDS_PAD")) R.lds_bytes += (size_t)atoi(pad);     // occupancy experiments
     }
 
     // PT_SORT_MATERIAL in its fused form (pt_types.hpp: RangeDir): survivors are placed by the material they hit, one span
@@ -1596,11 +1616,11 @@ static int init_impl(const pt_scene_desc *d) {
     if ((R.flags & PT_SORT_MATERIAL) && (R.flags & PT_COMPACT) && !(R.flags & (PT_UNFUSED | PT_FAKE_SHADER | PT_CACHE_FIRST)) &&
         R.mesh_mode != MESH_BVH && d->num_materials <= 64) {
         bool on = true;
-        if (const char *e = getenv("PTMI355_SORT_FUSED")) on = atoi(e) != 0;
+        if (const char *e = pt_experiment("PTMI355_SORT_FUSED")) on = atoi(e) != 0;
         double budget_gb = 96.0;
-        if (const char *e = getenv("PTMI355_SORT_FUSED_GB")) budget_gb = atof(e);
+        if (const char *e = pt_experiment("PTMI355_SORT_FUSED_GB")) budget_gb = atof(e);
         R.sort_runs = 1;              // more runs per wave (each wave a share of every part of the key space): measured slower (profiles/r03/variants_sort.log)
-        if (const char *e = getenv("PTMI355_SORT_RUNS")) R.sort_runs = std::max(1, std::min(8, atoi(e)));
+        if (const char *e = pt_experiment("PTMI355_SORT_RUNS")) R.sort_runs = std::max(1, std::min(8, atoi(e)));
         const double tiles_k = (double)d->num_materials * ((double)((R.cap + 63) / 64) + 8192.0 * R.sort_runs);
         if (on && tiles_k * 2560.0 * 2.0 <= budget_gb * 1e9 && tiles_k * 64.0 < 2147483648.0) R.sort_keys = d->num_materials;
     }
@@ -1629,7 +1649,7 @@ static int init_impl(const pt_scene_desc *d) {
     HIPCHK(hipMalloc(&R.final_mem, R.final_bytes));
     HIPCHK(hipMemsetAsync(R.final_mem, 0, capz * 4 * 4, R.stream));          // no entry carries a stamp yet (stamps start at 1)
     R.fin_serial = 0;
-    if (const char *e = getenv("PTMI355_FIN_SERIAL")) R.fin_serial = (uint32_t)strtoul(e, nullptr, 0);   // tests: start near the wrap
+    if (const char *e = pt_experiment("PTMI355_FIN_SERIAL")) R.fin_serial = (uint32_t)strtoul(e, nullptr, 0);   // tests: start near the wrap
     if (d->device_image) { R.image = d->device_image; R.own_image = false; }
     else {
         HIPCHK(hipMalloc(&R.image, (size_t)R.npix * 3 * 4));
@@ -1667,7 +1687,7 @@ static int init_impl(const pt_scene_desc *d) {
     }
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
-    if (const char *e = getenv("PTMI355_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // occupancy experiments
+    if (const char *e = pt_experiment("PTMI355_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // occupancy experiments
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
     if (R.grid < 1) R.grid = 1;
     if (R.grid * WAVES > 8192) R.grid = 8192 / WAVES;           // the pools' slack and the directory scan are sized for W <= 8192
@@ -1676,12 +1696,12 @@ static int init_impl(const pt_scene_desc *d) {
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
             &n, R.scene_lds ? (const void *)k_iteration<true> : (const void *)k_iteration<false>, BLOCK, R.lds_bytes));
         n = std::max(1, std::min(n, 8));
-        if (const char *e = getenv("PTMI355_WGS_PER_CU")) n = std::max(1, std::min(n, atoi(e)));
+        if (const char *e = pt_experiment("PTMI355_WGS_PER_CU")) n = std::max(1, std::min(n, atoi(e)));
         R.grid_iter = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)n);
         R.grid_iter = std::max(1, std::min(R.grid_iter, 8192 / WAVES));
         R.grid_iter_cur = R.grid_iter; R.cus = cus;
-        if (const char *e = getenv("PTMI355_ITER_TPW")) R.iter_tpw = std::max(0, atoi(e));
-        if (const char *e = getenv("PTMI355_ITER_WGS_ALL")) R.iter_wgs_per_cu_all = std::max(1, atoi(e));
+        if (const char *e = pt_experiment("PTMI355_ITER_TPW")) R.iter_tpw = std::max(0, atoi(e));
+        if (const char *e = pt_experiment("PTMI355_ITER_WGS_ALL")) R.iter_wgs_per_cu_all = std::max(1, atoi(e));
         // its traced counts, [bounce][workgroup], and the page-locked block its last workgroup writes a synchronous call's
         // statistics to (if the host allocation cannot be mapped the control block is copied back as before)
         R.iter_counts_bytes = (size_t)MAX_DEPTH * (size_t)R.grid_iter * 4;
@@ -1717,9 +1737,9 @@ static int init_impl(const pt_scene_desc *d) {
             return fail(PT_ERR_INVALID, "pt_init: PT_SORT_MATERIAL keeps one bin per material in LDS: at most %d materials", SORT_MAX_BINS - 1);
         {
             int per_cu_sort = 8;                              // nothing in these kernels needs co-residency; 8 per CU measured best (5: -4 %)
-            if (const char *e = getenv("PTMI355_SORT_WGS")) per_cu_sort = std::max(1, atoi(e));
+            if (const char *e = pt_experiment("PTMI355_SORT_WGS")) per_cu_sort = std::max(1, atoi(e));
             R.sort_wave = true;
-            if (const char *e = getenv("PTMI355_SORT_WAVE")) R.sort_wave = atoi(e) != 0;
+            if (const char *e = pt_experiment("PTMI355_SORT_WAVE")) R.sort_wave = atoi(e) != 0;
             const uint32_t chunks = (R.cap + SORT_CHUNK - 1) / SORT_CHUNK;
             R.grid_sort = (int)std::max<uint32_t>(1u, std::min<uint32_t>(chunks, (uint32_t)cus * (uint32_t)per_cu_sort));
         }
@@ -1746,7 +1766,7 @@ static int init_impl(const pt_scene_desc *d) {
             if (rc != PT_OK) return rc;
         }
     }
-    if (const char *e = getenv("PTMI355_DBG_COUNTS")) {
+    if (const char *e = pt_experiment("PTMI355_DBG_COUNTS")) {
         R.dbg_words = (size_t)std::max(64, atoi(e));
         HIPCHK(hipMalloc((void **)&R.dbg_counts, R.dbg_words * 4));
         HIPCHK(hipMemsetAsync(R.dbg_counts, 0, R.dbg_words * 4, R.stream));

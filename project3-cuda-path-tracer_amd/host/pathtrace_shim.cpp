@@ -47,8 +47,10 @@ void pathtraceInit(Scene *scene) {
     memcpy(&d.camera, &scene->state.camera, sizeof d.camera);
     d.trace_depth = scene->state.traceDepth;
     // the toggles the assignment asks for: PT_SORT_MATERIAL, PT_CACHE_FIRST.  PT_PIN_IMAGE: scene->state.image is sized
-    // once at load (scene.cpp:145-147) and lives as long as the Scene, so the library may page-lock it
-    d.flags = PT_COMPACT | PT_PIN_IMAGE;
+    // once at load (scene.cpp:145-147) and lives as long as the Scene, so the library may page-lock it.  PT_HOST_SPARSE:
+    // the reference's host only ever READS state.image (saveImage, main.cpp:78-99; nothing else touches it), so a call
+    // need only write the pixels whose sum changed.  A host that writes into state.image between calls drops this flag.
+    d.flags = PT_COMPACT | PT_PIN_IMAGE | PT_HOST_SPARSE;
     d.device = 0;                    // cudaGLSetGLDevice(0), preview.cpp:107
     d.tile_index = 0; d.tile_count = 1; d.strip_rows = 8;
     d.max_batch = 1;

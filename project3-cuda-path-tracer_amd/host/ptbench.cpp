@@ -37,7 +37,7 @@ int main(int argc, char **argv) {
         return 1;
     }
     int iters = -1, batch = 1, device = 0, tile_index = 0, tile_count = 1, strip_rows = 8;
-    unsigned flags = PT_COMPACT | PT_PIN_IMAGE;          // `image` below lives until pt_free
+    unsigned flags = PT_COMPACT | PT_PIN_IMAGE | PT_HOST_SPARSE;      // `image` below lives until pt_free and is only read here
     bool pfm = false, save_sum = false;
     std::string resume;
     int start = -1;

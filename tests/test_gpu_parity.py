@@ -239,8 +239,9 @@ def test_c2_one_iteration_per_call_overlapped(pt, scenes, monkeypatch):
 
     serial = run(False)
     assert run(True) == serial
-    assert run(True, (("PTMI355_ITER_TPW", "1"), ("PTMI355_ITER_WGS_ALL", "2"))) == serial      # a quarter of a workgroup per CU
-    assert run(True, (("PTMI355_ITER_TPW", "0"),)) == serial                                     # the whole grid
+    if pt.has_experiments():          # (grid-size experiments: a -DPT_EXPERIMENTS build only)
+        assert run(True, (("PTMI355_ITER_TPW", "1"), ("PTMI355_ITER_WGS_ALL", "2"))) == serial      # a quarter of a workgroup per CU
+        assert run(True, (("PTMI355_ITER_TPW", "0"),)) == serial                                     # the whole grid
 
 
 def test_c2_compaction_order_hash(pt, po, scenes, golden):
@@ -450,19 +451,21 @@ def test_overlapped_small_batches(pt, po, scenes, monkeypatch):
     serial, overlapped = run(0), run(1)
     assert serial == overlapped
     assert run(2) == serial and run(4) == serial                  # two / four lanes
-    assert run(3, "0xfffffff8") == serial
-    # the lanes share two launch streams by default; one stream for all, one per lane, lanes that do not divide evenly, and
-    # k_iteration's grid under the lanes (whole grid / a tile per wave) change nothing either
-    for lanes, streams, tpw, wgs in ((3, 1, "0", "15"), (6, 6, "8", "15"), (5, 3, "1", "4"), (8, 2, "2", "40")):
-        monkeypatch.setenv("PTMI355_LANE_STREAMS", str(streams))
-        monkeypatch.setenv("PTMI355_ITER_TPW", tpw)
-        monkeypatch.setenv("PTMI355_ITER_WGS_ALL", wgs)
-        assert run(lanes) == serial, (lanes, streams, tpw, wgs)
-    for k in ("PTMI355_LANE_STREAMS", "PTMI355_ITER_TPW", "PTMI355_ITER_WGS_ALL"):
-        monkeypatch.delenv(k)
-    monkeypatch.setenv("PTMI355_MAIN_PRIO", "0")                      # the library's own launch stream at default priority
-    assert run(4) == serial
-    monkeypatch.delenv("PTMI355_MAIN_PRIO")
+    assert run(3) == serial and run(5) == serial and run(8) == serial     # lanes that do not divide the two streams evenly
+    if pt.has_experiments():          # a -DPT_EXPERIMENTS build: the stamp's wrap, stream layouts, grid sizes, stream priority
+        assert run(3, "0xfffffff8") == serial
+        # the lanes share two launch streams by default; one stream for all, one per lane, lanes that do not divide evenly, and
+        # k_iteration's grid under the lanes (whole grid / a tile per wave) change nothing either
+        for lanes, streams, tpw, wgs in ((3, 1, "0", "15"), (6, 6, "8", "15"), (5, 3, "1", "4"), (8, 2, "2", "40")):
+            monkeypatch.setenv("PTMI355_LANE_STREAMS", str(streams))
+            monkeypatch.setenv("PTMI355_ITER_TPW", tpw)
+            monkeypatch.setenv("PTMI355_ITER_WGS_ALL", wgs)
+            assert run(lanes) == serial, (lanes, streams, tpw, wgs)
+        for k in ("PTMI355_LANE_STREAMS", "PTMI355_ITER_TPW", "PTMI355_ITER_WGS_ALL"):
+            monkeypatch.delenv(k)
+        monkeypatch.setenv("PTMI355_MAIN_PRIO", "0")                      # the library's own launch stream at default priority
+        assert run(4) == serial
+        monkeypatch.delenv("PTMI355_MAIN_PRIO")
     monkeypatch.setenv("PTMI355_OVERLAP_GB", "0.0001")                # the lanes' buffers do not fit the budget: the launch stream alone
     assert run(4) == serial
     monkeypatch.delenv("PTMI355_OVERLAP_GB")
@@ -673,9 +676,9 @@ def test_host_image_freed_and_reallocated_between_calls(pt, po, scenes):
 
 
 def test_host_image_kept_current_incrementally(pt, scenes, monkeypatch):
-    """pathtrace() per call with a long-lived page-locked host image (PT_PIN_IMAGE): from the second call on, the launch
-    adds every ending path's colour to its pixel itself and writes only those pixels to the host (BounceArgs::epi_direct;
-    the others still hold their sums).  After every call the host buffer IS the device's running sum, whatever else
+    """pathtrace() per call with a long-lived page-locked host image (PT_PIN_IMAGE | PT_HOST_SPARSE): from the second call
+    on, the launch adds every ending path's colour to its pixel itself and writes only those pixels to the host
+    (BounceArgs::epi_direct; the others still hold their sums).  After every call the host buffer IS the device's running sum, whatever else
     happened in between: overlapped batches (k_gather wrote the buffer), pt_clear_image, pt_set_image, a second host
     buffer, a camera move; and the whole sequence equals the one with every pixel written every call."""
     s = scenes["cornell"]
@@ -686,10 +689,10 @@ def test_host_image_kept_current_incrementally(pt, scenes, monkeypatch):
     cam2 = cam.copy()
     cam2["position"][0][1] += 0.5
 
-    def run(env):
+    def run(env, extra=0):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE, pin_image=False)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE | extra, pin_image=False)
         a = np.full((n, 3), -7.0, dtype=np.float32)
         b = np.full((n, 3), -9.0, dtype=np.float32)
         out = []
@@ -717,10 +720,49 @@ def test_host_image_kept_current_incrementally(pt, scenes, monkeypatch):
             monkeypatch.delenv(k)
         return out
 
-    ref = run({"PTMI355_EPI_DIRECT": "0"})
-    assert run({}) == ref
-    assert run({"PTMI355_HOST_SPARSE": "0"}) == ref
-    assert run({"PTMI355_HOST_EPILOGUE": "0"}) == ref
+    ref = run({})                                         # PT_PIN_IMAGE alone: every pixel, every call
+    assert run({}, pt.PT_HOST_SPARSE) == ref
+    if pt.has_experiments():                              # (a -DPT_EXPERIMENTS build: the plans the default replaced)
+        assert run({"PTMI355_EPI_DIRECT": "0"}, pt.PT_HOST_SPARSE) == ref
+        assert run({"PTMI355_HOST_EPILOGUE": "0"}, pt.PT_HOST_SPARSE) == ref
+
+
+def test_host_writes_between_calls(pt, scenes):
+    """what a host's own writes into the image do.  PT_PIN_IMAGE alone keeps the reference's semantics -- every
+    call hands back the WHOLE running sum (pathtrace.cu:389-390), so scribbles are overwritten; under PT_HOST_SPARSE the
+    host has promised to only read, the binding returns a read-only view, and a scribble through the raw buffer survives
+    exactly on pixels whose sum did not change (documented in include/ptmi355.h) while every other pixel is current."""
+    s = scenes["cornell"]
+    cam = _resized(s["camera"], 400, 300)
+    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
+    n = 400 * 300
+    L = pt.library()
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE, pin_image=False)
+    buf = np.zeros((n, 3), dtype=np.float32)
+    for it in (1, 2, 3, 4):
+        assert L.pt_trace(None, 0, it, buf.ctypes.data) == 0
+        assert buf.tobytes() == pt.get_image(n).tobytes(), it
+        buf /= float(it)                                  # the host normalises in place ...
+        buf[::7] = -1.0                                   # ... and scribbles
+    pt.pathtraceFree()
+
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, host_sparse=True)       # (pin_image=True: scene.image)
+    img = pt.pathtrace(None, 0, 1)
+    assert not img.flags.writeable and img.tobytes() == pt.get_image(n).tobytes()
+    with pytest.raises(ValueError):
+        img[0, 0] = 1.0
+    img = pt.pathtrace(None, 0, 2)
+    before = pt.get_image(n).copy()
+    scene.image[::5] = -3.0                               # behind the binding's back: the promise broken
+    img = pt.pathtrace(None, 0, 3)
+    dev = pt.get_image(n)
+    changed = (dev.view(np.uint32) != before.view(np.uint32)).any(axis=1)
+    assert changed.any() and not changed.all()
+    assert np.asarray(img)[changed].tobytes() == dev[changed].tobytes()         # every pixel whose sum changed is current
+    stale = ~changed
+    stale[np.arange(n) % 5 != 0] = False
+    assert stale.any() and (np.asarray(img)[stale] == -3.0).all()               # the rest is as the host left it
+    pt.pathtraceFree()
 
 
 def test_async_image_written_by_the_launch(pt, scenes, monkeypatch):
@@ -740,10 +782,10 @@ def test_async_image_written_by_the_launch(pt, scenes, monkeypatch):
         want[it] = pt.pathtrace(None, 0, it).tobytes()
     pt.pathtraceFree()
 
-    def run(env):
+    def run(env, extra=0):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_ASYNC_IMAGE, pin_image=False)
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_ASYNC_IMAGE | extra, pin_image=False)
         a = np.full((n, 3), -1.0, dtype=np.float32)
         b = np.full((n, 3), -2.0, dtype=np.float32)
         c = np.full((n, 3), -3.0, dtype=np.float32)
@@ -774,9 +816,10 @@ def test_async_image_written_by_the_launch(pt, scenes, monkeypatch):
             monkeypatch.delenv(k)
         return ok
 
-    assert all(run({})), "launch-written"
-    assert all(run({"PTMI355_ASYNC_DIRECT": "0"})), "copy engine"
-    assert all(run({"PTMI355_HOST_SPARSE": "0"})), "launch-written, every pixel"
+    assert all(run({}, pt.PT_HOST_SPARSE)), "launch-written, the pixels that changed"
+    assert all(run({})), "launch-written, every pixel"
+    if pt.has_experiments():
+        assert all(run({"PTMI355_ASYNC_DIRECT": "0"})), "copy engine"
 
 
 def test_shared_host_frame_assembled_by_the_tiles(pt, scenes, launch_plan):
@@ -1392,7 +1435,7 @@ def test_final_colour_stamps(pt, po, scenes, monkeypatch, graph):
     n = 64 * 64
     if graph:
         monkeypatch.setenv("PTMI355_GRAPH", "1")
-    for start in (None, "0xfffffffd"):                    # the second run wraps after three batches
+    for start in (None, "0xfffffffd") if pt.has_experiments() else (None,):    # the second run wraps after three batches (test hook of a -DPT_EXPERIMENTS build)
         if start:
             monkeypatch.setenv("PTMI355_FIN_SERIAL", start)
         scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
@@ -1411,7 +1454,7 @@ def test_final_colour_stamps(pt, po, scenes, monkeypatch, graph):
             ref.iterate(it)
         assert img.tobytes() == ref.image.tobytes()
         pt.pathtraceFree()
-    monkeypatch.delenv("PTMI355_FIN_SERIAL")
+    monkeypatch.delenv("PTMI355_FIN_SERIAL", raising=False)
 
 
 def test_mesh_bvh_two_meshes_fused(pt, po, scenes):

@@ -85,7 +85,8 @@ def test_contexts_equal_single_device(pt, scenes, pipeline, monkeypatch):
     assert np.isfinite(want[-1]).all() and want[-1].max() > 0
     for devs in device_lists():
         for strip in (8, 5):                                     # 64 rows: 8 strips of 8 (even), 13 of 5 (uneven)
-            # (the uneven runs hand the asynchronous batches' exchanges to the exchange thread: pt_multi.hpp, Exchanger)
+            # (a -DPT_EXPERIMENTS build: the even runs issue the asynchronous batches' exchanges from the caller's thread as
+            # rounds 1-3 did; the shipped library always uses its exchange thread -- pt_multi.hpp, Exchanger)
             monkeypatch.setenv("PTMI355_XCHG_THREAD", "1" if strip == 5 else "0")
             got, glive, gcounters, grgba, gdev, gtransport = run_calls(pt, scene, n, devices=devs, tile=(0, 1, strip), **kw)
             assert gdev == len(devs)
@@ -171,7 +172,8 @@ def test_pathtrace_per_call_several_contexts_no_exchange(pt, scenes, monkeypatch
     for devs in ([0, 0], [0, 0, 0]) if gpu_count() < 2 else ([0, 1], [0, 0], [0, 1, 0]):
         for strip in (8, 7):
             assert run(devices=devs, tile=(0, 1, strip)) == want, (devs, strip)
-    assert run((("PTMI355_MULTI_DIRECT", "0"),), devices=[0, 0], tile=(0, 1, 8)) == want
+    if pt.has_experiments():          # (a -DPT_EXPERIMENTS build: pack + exchange + copy instead of the launch-written host frame)
+        assert run((("PTMI355_MULTI_DIRECT", "0"),), devices=[0, 0], tile=(0, 1, 8)) == want
 
 
 def test_rccl_calls_with_a_communicator_of_one(pt, scenes, monkeypatch):
@@ -193,6 +195,43 @@ def test_rccl_calls_with_a_communicator_of_one(pt, scenes, monkeypatch):
     with pytest.raises(pt.PtError, match="own device"):
         pt.pathtraceInit(scene, devices=[0, 0])
     assert L.pt_num_devices() == 0
+
+
+def test_rccl_library_named_by_the_environment(tmp_path):
+    """PTMI355_RCCL_LIB names the RCCL library the in-library exchange dlopens (a deployment whose librccl is not on the
+    loader path).  Fresh processes (the library is loaded once per process): the variable pointing at this image's
+    library, and at a file that does not exist (the default names are tried next) -- the exchange runs over RCCL both times
+    and the frame is the plain single-device frame."""
+    code = """
+import os, sys, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pt = ge.load_package()
+z = np.load(os.path.join(%r, "tests", "golden", "scenes.npz"))
+g = lambda k: z["cornell_64__" + k]
+scene = pt.Scene(g("geoms"), g("materials"), g("camera"), int(g("depth")))
+devs = [0] if os.environ.get("PTMI355_XCHG") else None
+pt.pathtraceInit(scene, flags=pt.PT_COMPACT, devices=devs, max_batch=2)
+pt.trace_batch(1, 2, None)
+img = pt.pathtrace(None, 0, 3)
+print("RESULT", pt.exchange_transport(), hashlib.md5(img.tobytes()).hexdigest())
+pt.pathtraceFree()
+""" % (ROOT, ROOT)
+
+    def run(env):
+        e = {k: v for k, v in os.environ.items() if k not in ("PTMI355_XCHG", "PTMI355_RCCL_LIB", "PTMI355_DEVICES")}
+        e.update(env)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+        return [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1].split()[1:]
+
+    plain = run({})
+    assert plain[0] == "none"
+    real = os.path.realpath("/opt/rocm/lib/librccl.so.1")
+    assert os.path.exists(real)
+    assert run({"PTMI355_XCHG": "rccl", "PTMI355_RCCL_LIB": real}) == ["rccl", plain[1]]
+    assert run({"PTMI355_XCHG": "rccl", "PTMI355_RCCL_LIB": str(tmp_path / "no_such_librccl.so")}) == ["rccl", plain[1]]
 
 
 @pytest.mark.skipif(gpu_count() < 2, reason="needs two GPUs")
