@@ -796,6 +796,16 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
         algo = rank_rays * BYTES_PER_RAY + survivors * BYTES_PER_SURVIVOR
         common["hbm_algorithmic_unfused_model"] = {"gb_per_s": round(algo / (ms_b * 1e-3) / 1e9, 1), "bytes_per_launch": int(algo / max(1, n_b)),
                                                    "note": "152 B per ray + 88 B per survivor of the reference's separate kernels; not what this kernel moves"}
+        # north_star's own yardstick: ">= 50 % of the HBM roofline on the intersection + compaction pass" -- 8(d)'s algorithmic
+        # bytes of those two stages (intersect 44 B/ray; compaction 4 B/ray + 88 B/survivor) over the time the kernels that
+        # do them take (HIP events of this run), against 8 TB/s.  Needs no counter profile: re-derivable from this line.
+        contract_bytes = (rank_rays * (44 + 4) + survivors * 88) / steps
+        common["contract"] = {"frac": round(contract_bytes / (ms_b * 1e-3 / steps) / (HBM_PEAK_GBS * 1e9), 4),
+                              "gb_per_s": round(contract_bytes / (ms_b * 1e-3 / steps) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                              "bytes_per_step": int(contract_bytes), "kernel_ms_per_step": round(ms_b / steps, 4), "target": 0.5,
+                              "note": "SURVEY 8(d): (intersect 44 B + compaction 4 B) per ray + 88 B per survivor, per step, over the bounce "
+                                      "kernels' time per step and 8 TB/s -- BASELINE north_star's target figure; the fused kernel moves fewer "
+                                      "bytes than this model (hbm_necessary / traffic)"}
     if not t:
         return dict(common, kernel=None, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
                     source="no counter profile for this build and command line (python3 profiles/collect.py)")
@@ -831,6 +841,17 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
                    "active_lane_fraction": round(lanes, 4) if lanes else None,
                    "note": "fp32 operations of the executed opcode histogram (fma = 2) x active lanes (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64)"},
              grays_per_s_in_kernel=round(rank_rays / (stage_ms[st] * 1e-3) / 1e9, 3) if st == "bounce" else None)
+    if st == "bounce" and fused and args.config in ("c2", "c3", "c5"):
+        surv_step, first_step = (rank_rays - first) / steps, first / steps
+        # (b) what the fused kernel MUST move: a pool row (40 B) read per ray that was not generated in registers, a pool
+        # row written per survivor, 16 B per path that ends with a non-zero colour (19.5 % of the ending paths on C2:
+        # profiles/r04/traffic_accounting_c2.md) -- per launch like `traffic`, averaged over the step's launches
+        nz = 0.195 if args.config == "c2" else 0.25
+        need = (40.0 * surv_step + 40.0 * surv_step + 16.0 * nz * first_step) / nl
+        r["hbm_necessary"] = {"bytes_per_launch": int(need), "measured_over_necessary": round(byt / nl / need, 3) if byt else None,
+                              "note": "40 B per pool row read (every ray but the camera rays, which are generated in registers) + 40 B per "
+                                      "survivor written + 16 B per path ending with a non-zero colour (%.1f %% of the ending paths), averaged "
+                                      "over the %d launches of a step like `traffic`" % (100 * nz, nl)}
     cyc_all = sum(k["launches_per_step"] * k.get("issue_cycles_per_launch", 0.0) for k in ks.values())
     byt_all = sum(k["launches_per_step"] * k.get("hbm_bytes_per_launch", 0) for k in ks.values())
     if timed_step_s > 0:

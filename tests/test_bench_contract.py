@@ -49,6 +49,26 @@ def test_default_line_and_its_counter_profile():
     assert d["roofline"]["launches"] == 5 * 8
 
 
+def test_bench_digest_equals_oracle():
+    """The bench's OWN path -- the driver's command line: 64 spp per step, asynchronous batches overlapped on the lanes,
+    default launch plan -- against the oracle: the accumulation image after 1 warm-up + 2 timed
+    steps (iterations 1..192) is, byte for byte, the oracle's sum of the same iterations (summed in iteration order;
+    16 pthreads, one whole iteration each), and so is the rays-per-step count the metric's numerator comes from."""
+    import hashlib
+    import numpy as np
+    from oracle import pyoracle as po
+    d = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-per-call",
+             "--digest"], per_bounce=False)
+    assert d["config"]["batch_spp"] == 64 and d["steps"] == 2
+    z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+    g = lambda k: z["cornell__" + k]
+    tr = po.Tracer(g("geoms"), g("materials"), g("camera"), int(g("depth")), flags=po.F_COMPACT, trig=po.TRIG_SHARED)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    rays = [tr.iterate_parallel(1 + 64 * k, 64, threads) for k in range(3)]
+    assert hashlib.md5(tr.image.tobytes()).hexdigest() == d["image_md5"]
+    assert d["config"]["rays_per_step"] == (rays[1] + rays[2]) // 2
+
+
 def test_single_gpu_line():
     d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
              "--digest", "--pcie"])
