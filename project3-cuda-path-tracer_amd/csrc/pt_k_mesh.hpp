@@ -47,6 +47,17 @@ constexpr int MQ_LEAVE = PT_MQ_LEAVE;         // lanes still busy when the wave 
 static_assert(2 * PT_LEAF_MAX * 64 + 63 <= TQ_SLOTS, "a step's triangles must fit beside the waiting ones");
 constexpr int NT_BITS = 2 * PT_LEAF_MAX < 2 ? 1 : 2 * PT_LEAF_MAX < 4 ? 2 : 2 * PT_LEAF_MAX < 8 ? 3 : 4;   // bits of a step's triangle count per lane
 
+#ifdef PT_MESH_STATS
+// diagnostic build only (profiles/tools/build_variant.sh NAME WORK -DPT_MESH_STATS): where k_mesh's wave-steps go.
+//   [0..8] walks by length (records visited: 1, 2-3, 4-7, ... 256+)   [9] walks  [10] sum of their lengths
+//   [11..18] wave-steps by the number of lanes that walk (1-8, 9-16, ... 57-64)   [19] wave-steps where nobody walks
+//   [20] loop iterations of the flagged form  [21] ... that appended a batch  [22] candidates appended
+//   [23] flag words examined  [24] ... non-zero   [25] waves   [26] triangle passes  [27] their lanes
+__device__ unsigned long long g_mesh_stats[32];
+#define MESH_STAT(k, v) atomicAdd(&g_mesh_stats[k], (unsigned long long)(v))
+#define MESH_STAT_WAVE(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_mesh_stats[k], (unsigned long long)(v)); } while (0)
+#endif
+
 // per-lane state of a walk in flight; it survives across the scanning of further tiles
 struct MeshWalker {
     bool have;
@@ -80,6 +91,9 @@ __device__ __forceinline__ void tri_pass(float *mq, uint32_t head, uint32_t coun
     const int owner = (int)(e & 63u);
     const f3 ro = ptd::mk(__shfl(w.ray.ro.x, owner), __shfl(w.ray.ro.y, owner), __shfl(w.ray.ro.z, owner));
     const f3 rd = ptd::mk(__shfl(w.ray.rd.x, owner), __shfl(w.ray.rd.y, owner), __shfl(w.ray.rd.z, owner));
+#ifdef PT_MESH_STATS
+    MESH_STAT_WAVE(26, 1); MESH_STAT_WAVE(27, min(count, 64u));
+#endif
     if (on) {
         const float4 *t4 = reinterpret_cast<const float4 *>(a.scene.bvh_tris + (size_t)(e >> 6) * TRI_WORDS);
         const float4 P = t4[0], Q = t4[1], S = t4[2];
@@ -164,6 +178,9 @@ __device__ __forceinline__ void mesh_steps(MeshWalker &w, float *mq, const float
     const bool multi = a.scene.bvh_nmesh > 1;
     auto finish = [&]() {
         if (w.have && w.node < 0 && (int32_t)(rg.t_head - w.ticket) >= 0) {    // this mesh is done and fully tested
+#ifdef PT_MESH_STATS
+            { int b = 0; for (int v = w.steps; v > 1 && b < 8; v >>= 1) ++b; MESH_STAT(b, 1); MESH_STAT(9, 1); MESH_STAT(10, w.steps); }
+#endif
             const unsigned long long key = keys[lane];
             if ((uint32_t)key != 0xffffffffu) {                      // completion spec 8.0: distance to origin + dir * bary.z
                 const float tz = __uint_as_float((uint32_t)(key >> 32));
@@ -229,6 +246,12 @@ __device__ __forceinline__ void mesh_steps(MeshWalker &w, float *mq, const float
             const uint64_t id = ballot64(!w.have);
             if (lane == 0 && bb) { atomicAdd(&a.ctl->keep[1], (uint32_t)__popcll((unsigned long long)bb)); atomicAdd(&a.ctl->keep[2], 1u); }
             if (lane == 0) { atomicAdd(&a.ctl->keep[8], (uint32_t)__popcll((unsigned long long)wt)); atomicAdd(&a.ctl->keep[9], (uint32_t)__popcll((unsigned long long)id)); atomicAdd(&a.ctl->keep[10], 1u); }
+            {
+                const int nw = (int)__popcll((unsigned long long)ballot64(w.have && w.node >= 0));     // lanes that will walk in the NEXT step
+                (void)nw;
+                const int nb = (int)__popcll((unsigned long long)bb);
+                if (nb) MESH_STAT_WAVE(11 + (nb - 1) / 8, 1); else MESH_STAT_WAVE(19, 1);
+            }
             atomicMax(&a.ctl->keep[14], (uint32_t)w.steps);
         }
 #endif
@@ -332,6 +355,9 @@ __global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a
     const bool packed_in = COMPACT && a.dir_in.mem != nullptr;
     const uint32_t Wd = a.dir_in.W;                               // waves of the grid that packed the pool
     const uint32_t span_in = packed_in ? *a.dir_in.span() : 0;    // slots per range, as the producer wrote it down
+#ifdef PT_MESH_STATS
+    MESH_STAT_WAVE(25, 1);
+#endif
     MeshRings rg{0, 0, 0, 0};
     MeshWalker w;
     w.have = false; w.src = 0; w.path = 0; w.ray = bvh_ray(ptd::mk(0, 0, 0), ptd::mk(0, 0, 1), ptd::mk(0, 0, 0), ptd::mk(1, 1, 1));
@@ -366,6 +392,10 @@ __global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a
         uint32_t p_take = 0, p_src = 0;                              // the batch in flight: candidates, slot, ray
         f3 p_ro = ptd::mk(0, 0, 0), p_rd = ptd::mk(0, 0, 1);
         for (;;) {
+#ifdef PT_MESH_STATS
+            MESH_STAT_WAVE(20, 1);
+            if (p_take) { MESH_STAT_WAVE(21, 1); MESH_STAT_WAVE(22, p_take); }
+#endif
             if (p_take) {                                            // its loads were issued a block ago
                 if ((uint32_t)lane < p_take) {
                     const uint32_t s = (rg.q_total + (uint32_t)lane) & (MQ_SLOTS - 1);
@@ -384,6 +414,9 @@ __global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a
                 while (done == total && g_next < groups) {
                     f_cur = f_next; g_cur = g_next; ++g_next;
                     f_next = load_group(g_next);
+#ifdef PT_MESH_STATS
+                    if ((uint32_t)lane < FLAG_GROUP) { MESH_STAT(23, 1); if (f_cur) MESH_STAT(24, 1); }
+#endif
                     total = 0; done = 0;
 #pragma unroll
                     for (uint32_t j = 0; j < FLAG_GROUP; ++j)

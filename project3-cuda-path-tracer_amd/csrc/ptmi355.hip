@@ -1137,6 +1137,17 @@ int collect_stats(void) {
         fprintf(stderr, "[ptmi355] longest walk %u records; records where nothing was hit: %u, with a leaf hit: %u\n", c.keep[14], c.keep[12], c.keep[13]);
         fprintf(stderr, "[ptmi355] walks past 5000 steps: %u; last: o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) tz=%g depth %u\n", c.keep[3],
                 f[0], f[1], f[2], f[3], f[4], f[5], f[6], c.keep[11]);
+        unsigned long long ms[32] = {0};
+        (void)hipMemcpyFromSymbol(ms, HIP_SYMBOL(g_mesh_stats), sizeof ms);
+        fprintf(stderr, "[ptmi355] mesh since load: %llu walks, %.2f records each; by length 1 | 2-3 | 4-7 | 8-15 | 16-31 | 32-63 | 64-127 | 128-255 | 256+:", ms[9], ms[9] ? (double)ms[10] / ms[9] : 0.0);
+        for (int k = 0; k < 9; ++k) fprintf(stderr, " %llu", ms[k]);
+        fprintf(stderr, "\n[ptmi355] wave-steps by walking lanes 1-8 | 9-16 | ... | 57-64:");
+        for (int k = 11; k < 19; ++k) fprintf(stderr, " %llu", ms[k]);
+        fprintf(stderr, "; nobody: %llu\n", ms[19]);
+        fprintf(stderr, "[ptmi355] flagged form: %llu loop iterations, %llu appended a batch (%llu candidates: %.1f each); flag words %llu, non-zero %llu; "
+                        "waves %llu (%.1f walks, %.1f loop iterations each); triangle passes %llu at %.1f lanes\n",
+                ms[20], ms[21], ms[22], ms[21] ? (double)ms[22] / ms[21] : 0.0, ms[23], ms[24], ms[25], ms[25] ? (double)ms[9] / ms[25] : 0.0,
+                ms[25] ? (double)ms[20] / ms[25] : 0.0, ms[26], ms[26] ? (double)ms[27] / ms[26] : 0.0);
     }
 #endif
 #ifdef PT_CULL_STATS

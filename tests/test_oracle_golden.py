@@ -2,6 +2,7 @@
 from the reference's own code (tests/golden/make_golden.py).  Bit-exact."""
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -299,3 +300,23 @@ def test_c1_as_stated(po, scenes, golden):
     assert list(st.live[:4]) == list(z["live"][0]) and st.rays == int(z["rays"][0])
     assert hashlib.md5(ref.image.tobytes()).hexdigest() == str(z["img_md5"])
     assert ref.image[::53].tobytes() == z["img_sub"].tobytes()
+
+
+def test_c4_frame_golden_strip(po, golden, scenes):
+    """tests/golden/c4_frame.npz (the oracle's whole-frame C4 iteration, made by tests/golden/make_c4_golden.py) is what
+    this checkout's oracle still produces: one 16-row strip of it re-traced here (a few seconds), md5 and sampled pixels."""
+    import hashlib
+    import __graft_entry__ as ge
+    pt = ge.load_package()                       # host-side mesh generator only
+    z = golden["c4_frame"]
+    s = scenes["cornell"]
+    tris = pt.meshes.uv_sphere()
+    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
+    ref = po.Tracer(geoms, s["materials"], s["camera"], s["depth"], tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
+    r, strip, W = 3, int(z["strip_rows"]), 800
+    ref.iterate_rows(1, r * strip, (r + 1) * strip, threads=min(8, os.cpu_count() or 1))
+    rows = slice(r * strip * W, (r + 1) * strip * W)
+    assert hashlib.md5(ref.image[rows].tobytes()).hexdigest() == str(z["strip_md5"][r])
+    idx = z["sample_index"]
+    inside = (idx >= rows.start) & (idx < rows.stop)
+    assert inside.sum() > 20 and ref.image[idx[inside]].tobytes() == z["sample_value"][inside].tobytes()
