@@ -32,8 +32,10 @@
 //  (4) the world box is the image of the grown cube under A^-1 (computed in binary64 from the float matrix the
 //      reference actually uses, not from `transform`):  centre c = -A^-1 b,  half extent
 //        H_i = sum_k |A^-1_ik| (0.5 + p_k),
-//      plus 64u (R + |c_i| + H_i) for the kernel's own test (v_rcp_f32: 1 ulp; one fused multiply-add per plane:
-//      absolute error u (|plane| + |o|) |1/d| in t, i.e. u (|plane| + |o|) in space).
+//      plus 64u (R + |c_i| + H_i) for the kernel's own test (v_rcp_f32: 1 ulp; n = fl(-o / d) and two fused
+//      multiply-adds per plane, t = fl(fl(c / d + n) -+ H |1/d|) (pt_k_scene.hpp: cull_box, centre / half-extent form):
+//      absolute error <= u (3 |o| + 2 |c| + H) |1/d| in t, i.e. 3u (R + |c_i| + H_i) in space; the kernel's (c, H) are
+//      floats with [c - H, c + H] containing [lo, hi] exactly -- centre_half below).
 // All p_k carry a further factor 4.  A matrix that is singular, non-finite, or has N * max a_k > 2^20 gets the
 // box (-inf, +inf): every ray is a candidate and the exact test decides, as in the reference.
 //
@@ -166,6 +168,17 @@ inline float make_boxes(const float *const *inv16, const bool *is_sphere, const 
         if (fin) out[(size_t)g] = bx;
     }
     return round_down(R);
+}
+
+// The box as the kernel reads it: centre c = fl((lo + hi) / 2) and the smallest float half extent H with
+// [c - H, c + H] containing [lo, hi] in exact arithmetic (c, lo, hi are floats: the differences are evaluated in
+// binary64, bumped one binary64 ulp up in case they were inexact, and rounded up).  Infinite boxes: c = 0, H = +inf.
+inline void centre_half(float lo, float hi, float &c, float &H) {
+    if (!std::isfinite(lo) || !std::isfinite(hi)) { c = 0.0f; H = std::numeric_limits<float>::infinity(); return; }
+    c = (float)(((double)lo + (double)hi) * 0.5);
+    const double h = std::fmax((double)hi - (double)c, (double)c - (double)lo);
+    H = round_up(std::nextafter(h, std::numeric_limits<double>::infinity()));
+    if (!(H >= 0.0f)) H = std::numeric_limits<float>::infinity();
 }
 
 // The kernel's EXACT one-axis early miss for a CUBE (pt_kernels.hpp, cull_scene): with q_k = row k of the

@@ -30,7 +30,7 @@ constexpr int PW_WIN = PW_BEST + 2 * 64 * 2;             // float[2][3][64]: win
 constexpr int PW_RAYS = PW_WIN + 2 * 64 * 3;             // float[2][6][64]: ro.xyz rd.xyz of the tile's paths
 constexpr int PW_WORDS = PW_RAYS + 2 * 6 * 64;           // 1536 dwords = 6 KiB per wave: six workgroups fit a CU's 160 KiB beside a
                                                          // Cornell-sized scene block (round 2: 6.5 KiB, float4 winner records, five)
-constexpr int CULL_WORDS = 12;       // per geom, scalar-loaded: lo.x hi.x lo.y hi.y lo.z hi.z | type + (reject mode << 8) | the reject row:
+constexpr int CULL_WORDS = 12;       // per geom, scalar-loaded: centre.x half.x centre.y half.y centre.z half.z (of the padded world box) | type + (reject mode << 8) | the reject row:
                                      //   m_k0 m_k1 m_k2 m_k3 | spare (48 B: one s_load_dwordx8 + one s_load_dwordx4)
 
 __host__ __device__ constexpr int scene_lds_words(int nmats, int ngeoms) {
@@ -123,15 +123,18 @@ __device__ __forceinline__ CullRay cull_ray(f3 ro, f3 rd, float rmax) {
     c.nx = -ro.x * c.ix; c.ny = -ro.y * c.iy; c.nz = -ro.z * c.iz;
     return c;
 }
-// true unless the ray certainly misses the box [lo, hi] (scalar operands).  NaN-safe towards "true".
-__device__ __forceinline__ bool cull_box(const CullRay &c, float lox, float hix, float loy, float hiy, float loz, float hiz) {
-    const float t1x = __builtin_fmaf(lox, c.ix, c.nx), t2x = __builtin_fmaf(hix, c.ix, c.nx);
-    const float t1y = __builtin_fmaf(loy, c.iy, c.ny), t2y = __builtin_fmaf(hiy, c.iy, c.ny);
-    const float t1z = __builtin_fmaf(loz, c.iz, c.nz), t2z = __builtin_fmaf(hiz, c.iz, c.nz);
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
-                                     __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
-    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
-                                     __builtin_fmaxf(t1z, t2z));
+// true unless the ray certainly misses the box centre +- half (scalar operands, pt_cull.hpp: centre_half).  NaN-safe
+// towards "true".  Per axis the entry / exit parameters are  t_mid -+ half * |1/d|  with  t_mid = centre * (1/d) + n:
+// three fused multiply-adds (|.| and the sign are source modifiers) where lo / hi planes took two plus a v_min and a
+// v_max -- and a min / max issues in 4.2-4.4 SIMD cycles against 2.3 for an fma (profiles/r04/costs_r04.json): 38 issue
+// cycles per (primitive, wave) instead of 57.  Two roundings per parameter instead of one; pt_cull.hpp (4) prices them.
+__device__ __forceinline__ bool cull_box(const CullRay &c, float cx, float hx, float cy, float hy, float cz, float hz) {
+    const float tmx = __builtin_fmaf(cx, c.ix, c.nx), tmy = __builtin_fmaf(cy, c.iy, c.ny), tmz = __builtin_fmaf(cz, c.iz, c.nz);
+    const float tnx = __builtin_fmaf(-hx, __builtin_fabsf(c.ix), tmx), tfx = __builtin_fmaf(hx, __builtin_fabsf(c.ix), tmx);
+    const float tny = __builtin_fmaf(-hy, __builtin_fabsf(c.iy), tmy), tfy = __builtin_fmaf(hy, __builtin_fabsf(c.iy), tmy);
+    const float tnz = __builtin_fmaf(-hz, __builtin_fabsf(c.iz), tmz), tfz = __builtin_fmaf(hz, __builtin_fabsf(c.iz), tmz);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+    const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
     return !(tn > tf);
 }
 
@@ -145,10 +148,10 @@ __device__ __forceinline__ bool cull_box(const CullRay &c, float lox, float hix,
 // One function for k_bounce / k_intersect and for k_cull0_mask, which memoises "some lane" per camera tile.
 // Returns the WAVE MASK of the candidate lanes: every compare goes straight to a scalar register pair and the
 // combination -- box and not(early miss) or wild -- is scalar mask arithmetic, not per-lane selects.
-__device__ __forceinline__ uint64_t cull_candidates(const CullRay &cr, uint64_t m_wild, f3 ro, f3 rd, float lox, float hix,
-                                                    float loy, float hiy, float loz, float hiz, int tw, float m0, float m1,
+__device__ __forceinline__ uint64_t cull_candidates(const CullRay &cr, uint64_t m_wild, f3 ro, f3 rd, float cx, float hx,
+                                                    float cy, float hy, float cz, float hz, int tw, float m0, float m1,
                                                     float m2, float m3) {
-    uint64_t keep = ballot64(cull_box(cr, lox, hix, loy, hiy, loz, hiz));
+    uint64_t keep = ballot64(cull_box(cr, cx, hx, cy, hy, cz, hz));
     const int rmode = (tw >> 8) & 7;                                     // wave-uniform; 0..2 diagonal row, 4 general row, 3 none
     if (rmode != 3) {
         float qk, vk;

@@ -904,7 +904,7 @@ int upload_cull(const pt_scene_desc *d, const pt_camera &cam) {
     std::vector<float> rec((size_t)std::max(1, n) * CULL_WORDS, 0.0f);
     for (int i = 0; i < n; ++i) {
         float *r = rec.data() + (size_t)i * CULL_WORDS;
-        for (int k = 0; k < 3; ++k) { r[2 * k] = boxes[(size_t)i].lo[k]; r[2 * k + 1] = boxes[(size_t)i].hi[k]; }
+        for (int k = 0; k < 3; ++k) ptcull::centre_half(boxes[(size_t)i].lo[k], boxes[(size_t)i].hi[k], r[2 * k], r[2 * k + 1]);
         int ax = 3;
         if (d->geoms[i].type == PT_CUBE && !pt_experiment("PTMI355_NO_AXIS_REJECT"))
             ax = ptcull::reject_row(&d->geoms[i].inverseTransform.m[0][0], &r[7]);       // words 7..10: the row

@@ -7,6 +7,17 @@ F = np.float32
 BIG = F(2.0 ** 100)
 
 
+def centre_half(box):
+    """csrc/pt_cull.hpp: centre_half -- what the kernel's cull record holds for the box [lo, hi]."""
+    lo, hi = box[0].astype(np.float64), box[1].astype(np.float64)
+    c = ((lo + hi) * 0.5).astype(F)
+    h64 = np.nextafter(np.fmax(hi - c.astype(np.float64), c.astype(np.float64) - lo), np.inf)
+    h = h64.astype(F)
+    h = np.where(h.astype(np.float64) < h64, np.nextafter(h, F(np.inf)), h).astype(F)
+    fin = np.isfinite(lo) & np.isfinite(hi)
+    return np.where(fin, c, F(0)).astype(F), np.where(fin, h, F(np.inf)).astype(F)
+
+
 def candidates(rays, box, rmax, reject=None):
     """rays[n, 6] float32 (origin, direction); box[2, 3] (lo, hi); reject = (mode, row[4]) of the exact
     one-axis early miss or None; returns (candidate mask, wild mask)."""
@@ -18,9 +29,11 @@ def candidates(rays, box, rmax, reject=None):
         wild = ~(os_ <= F(rmax)) | ~((ds >= F(2.0 ** -20)) & (ds <= F(2.0 ** 20)))
         ix = np.clip((F(1) / d).astype(F), -BIG, BIG)                      # v_rcp_f32 (1 ulp) + v_med3_f32
         n = (-o * ix).astype(F)
-        t1 = (box[0].astype(np.float64) * ix.astype(np.float64) + n.astype(np.float64)).astype(F)    # v_fma_f32
-        t2 = (box[1].astype(np.float64) * ix.astype(np.float64) + n.astype(np.float64)).astype(F)
-        ta, tb = np.fmin(t1, t2), np.fmax(t1, t2)
+        c, h = centre_half(box)
+        tm = (c.astype(np.float64) * ix.astype(np.float64) + n.astype(np.float64)).astype(F)         # v_fma_f32
+        hw = h.astype(np.float64) * np.abs(ix).astype(np.float64)
+        ta = (tm.astype(np.float64) - hw).astype(F)                                                  # v_fma_f32 (-half, |1/d|, t_mid)
+        tb = (tm.astype(np.float64) + hw).astype(F)
         tn = np.fmax(np.fmax(ta[:, 0], ta[:, 1]), np.fmax(ta[:, 2], F(0)))
         tf = np.fmin(np.fmin(tb[:, 0], tb[:, 1]), tb[:, 2])
         cand = ~(tn > tf)
