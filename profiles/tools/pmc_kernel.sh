@@ -3,8 +3,8 @@
 # One rocprofv3 --pmc pass per counter group (counters never combined with trace domains), summed per kernel name and
 # divided by the number of dispatches -> gpurun_out/pmck_TAG/summary.txt (per-launch averages).
 TAG=$1; shift
-GROUPS=()
-while [ "$1" != "--" ] && [ $# -gt 0 ]; do GROUPS+=("$1"); shift; done
+CGS=()
+while [ "$1" != "--" ] && [ $# -gt 0 ]; do CGS+=("$1"); shift; done
 shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmck_$TAG
@@ -12,7 +12,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-per-call $*"
 k=0
-for g in "${GROUPS[@]}"; do
+for g in "${CGS[@]}"; do
   timeout 300 rocprofv3 --pmc $g --output-format csv -d "$OUT/g$k" -o p -- python3 "$ROOT/bench.py" $ARGS > "$OUT/g$k.log" 2>&1 || echo "group $k ($g) failed: $(tail -2 $OUT/g$k.log)"
   k=$((k+1))
 done

@@ -7,8 +7,12 @@
 // children, so one fetch per step decides two boxes.  A walk is bound by how many address-divergent
 // vector loads the texture path can take, so the record is made small: box planes are 16-bit
 // grid coordinates over the mesh's bounds (rounded outwards; grid step = extent / 65533), two
-// 16-B loads bring both boxes and both links, a third 4-B load the miss link.
-//   [0..2]   left child box   lo.x | lo.y << 16,  lo.z | hi.x << 16,  hi.y | hi.z << 16
+// 16-B loads bring both boxes and both links, a third 4-B load the miss link.  A box is stored as CENTRE and HALF
+// EXTENT on that grid, m = (lo + hi) >> 1 and e = hi - m + 1, i.e. the planes m -+ e, which contain [lo, hi] with a
+// grid step to spare on either side: the slab test then is three fused multiply-adds per axis -- t_mid = m k + b,
+// t_mid -+ e |k| -- instead of two plus a v_min and a v_max (which issue at half an fma's rate), and m needs no
+// integer-to-float conversion (pt_k_bvh.hpp: bvh_slab; the spare step pays for the rounding of that trick).
+//   [0..2]   left child box   m.x | m.y << 16,  m.z | e.x << 16,  e.y | e.z << 16
 //   [3..5]   right child box, same packing
 //   [6]      left link  | info << 24      [7] right link | info << 24
 //              info = count | leaf << 3 | split axis of THIS node << 4   (axis only in the left info)
@@ -36,8 +40,10 @@
 //   * every box on the path from the root to T's leaf contains box(T) widened by `pad` = 2 * spec_pad (the
 //     grid rounding only adds to it), so the accepted point lies inside each of them with spec_pad to spare
 //     on every side;
-//   * the kernel's slab test (v_rcp + fused multiply-adds on grid coordinates, pt_kernels.hpp: bvh_slab)
-//     places a box plane within 4 * 2^-23 * (|plane - o|) of where it is, i.e. below spec_pad for every ray
+//   * the kernel's slab test (v_rcp + fused multiply-adds on grid coordinates, pt_k_bvh.hpp: bvh_slab)
+//     places a box plane within 4.5 * 2^-23 * (|plane - o|) + step / 2 of where it is (the step / 2: the centre enters
+//     the fused multiply-add as the float 2^23 + m and 2^23 k is folded into the ray's offset b, whose rounding is half
+//     a grid step -- the planes m -+ e carry a whole one for it), i.e. below spec_pad for every ray
 //     origin within ~128 * max(1, amax) of the mesh; pt_init knows the bound R on |origin|_1 of every ray that is
 //     not `wild` (it covers the scene and the camera, and pt_set_camera re-derives it and REBUILDS the trees when the
 //     camera leaves it) and widens the pad to spec_pad + 8 * 2^-23 * (R + amax) where that is more (build(): a far
@@ -225,12 +231,15 @@ inline uint32_t grid_hi(float x, float o, float s) {
 }
 
 inline void pack_box(float *r, const Box &b, float pad, const Tree &t, bool empty) {
-    uint32_t lo[3], hi[3];
+    uint32_t m[3], e[3];
     for (int a = 0; a < 3; ++a) {
-        lo[a] = empty ? 2u : grid_lo(b.lo[a] - pad, t.origin[a], t.step[a]);
-        hi[a] = empty ? 1u : grid_hi(b.hi[a] + pad, t.origin[a], t.step[a]);     // inverted: nothing hits it
+        // an empty child is a leaf of zero triangles: whatever hits its (point-sized) box queues nothing
+        const uint32_t lo = empty ? 0u : grid_lo(b.lo[a] - pad, t.origin[a], t.step[a]);
+        const uint32_t hi = empty ? 0u : grid_hi(b.hi[a] + pad, t.origin[a], t.step[a]);
+        m[a] = (lo + hi) >> 1;                                   // m - e <= lo - 1,  m + e = hi + 1
+        e[a] = empty ? 0u : std::min<uint32_t>((uint32_t)GRID_MAX, hi - m[a] + 1u);
     }
-    set_u(&r[0], lo[0] | (lo[1] << 16)); set_u(&r[1], lo[2] | (hi[0] << 16)); set_u(&r[2], hi[1] | (hi[2] << 16));
+    set_u(&r[0], m[0] | (m[1] << 16)); set_u(&r[1], m[2] | (e[0] << 16)); set_u(&r[2], e[1] | (e[2] << 16));
 }
 
 inline void emit(const Work &w, const std::vector<int32_t> &rec, int s, const int32_t miss[8], float pad, Tree &out) {

@@ -16,7 +16,7 @@ namespace {
 // for NaN rays all the same.
 struct BvhRay {                       // what a walk keeps per (ray, mesh)
     f3 ro, rd;
-    float kx, ky, kz, bx, by, bz;     // slab form over the mesh's grid: t = grid * k + b
+    float kx, ky, kz, bx, by, bz;     // slab form over the mesh's grid: t = grid * k + b, with b stored as b - 2^23 k (bvh_slab)
     int oct;
 };
 // origin / step: the mesh's grid (world plane = origin + grid * step)
@@ -31,21 +31,26 @@ __device__ __forceinline__ BvhRay bvh_ray(f3 ro, f3 rd, f3 origin, f3 step) {
     const float ix = __builtin_amdgcn_rcpf(off_axis(rd.x)), iy = __builtin_amdgcn_rcpf(off_axis(rd.y)),
                 iz = __builtin_amdgcn_rcpf(off_axis(rd.z));
     r.kx = step.x * ix; r.ky = step.y * iy; r.kz = step.z * iz;
-    r.bx = (origin.x - ro.x) * ix; r.by = (origin.y - ro.y) * iy; r.bz = (origin.z - ro.z) * iz;
+    // b - 2^23 k in one rounding: bvh_slab multiplies k by the FLOAT 2^23 + m (the centre's 16 bits under the exponent
+    // of 2^23: no conversion instruction), and the 2^23 k cancels exactly inside the fused multiply-add
+    r.bx = __builtin_fmaf(-8388608.0f, r.kx, (origin.x - ro.x) * ix);
+    r.by = __builtin_fmaf(-8388608.0f, r.ky, (origin.y - ro.y) * iy);
+    r.bz = __builtin_fmaf(-8388608.0f, r.kz, (origin.z - ro.z) * iz);
     r.oct = (rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0);
     return r;
 }
-// entry / exit parameters of the box packed in three dwords (pt_bvh.hpp), clipped to t >= 0
+// entry / exit parameters of the box packed in three dwords (pt_bvh.hpp: centre m and half extent e on the grid), clipped
+// to t >= 0: per axis t_mid = (2^23 + m) k + (b - 2^23 k), entry / exit = t_mid -+ e |k|.  Eighteen fused multiply-adds
+// for a record's two boxes and six conversions (e), where planes lo / hi took twelve of each and twelve v_min / v_max.
 __device__ __forceinline__ void bvh_slab(const BvhRay &r, uint32_t w0, uint32_t w1, uint32_t w2, float &tn, float &tf) {
-    const float lx = (float)(w0 & 0xffffu), ly = (float)(w0 >> 16), lz = (float)(w1 & 0xffffu);
-    const float hx = (float)(w1 >> 16), hy = (float)(w2 & 0xffffu), hz = (float)(w2 >> 16);
-    const float t1x = __builtin_fmaf(lx, r.kx, r.bx), t2x = __builtin_fmaf(hx, r.kx, r.bx);
-    const float t1y = __builtin_fmaf(ly, r.ky, r.by), t2y = __builtin_fmaf(hy, r.ky, r.by);
-    const float t1z = __builtin_fmaf(lz, r.kz, r.bz), t2z = __builtin_fmaf(hz, r.kz, r.bz);
-    tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
-                         __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
-    tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
-                         __builtin_fmaxf(t1z, t2z));
+    const float mx = __uint_as_float((w0 & 0xffffu) | 0x4b000000u), my = __uint_as_float((w0 >> 16) | 0x4b000000u);
+    const float mz = __uint_as_float((w1 & 0xffffu) | 0x4b000000u);
+    const float ex = (float)(w1 >> 16), ey = (float)(w2 & 0xffffu), ez = (float)(w2 >> 16);
+    const float tmx = __builtin_fmaf(mx, r.kx, r.bx), tmy = __builtin_fmaf(my, r.ky, r.by), tmz = __builtin_fmaf(mz, r.kz, r.bz);
+    tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(-ex, __builtin_fabsf(r.kx), tmx), __builtin_fmaf(-ey, __builtin_fabsf(r.ky), tmy)),
+                         __builtin_fmaxf(__builtin_fmaf(-ez, __builtin_fabsf(r.kz), tmz), 0.0f));
+    tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(ex, __builtin_fabsf(r.kx), tmx), __builtin_fmaf(ey, __builtin_fabsf(r.ky), tmy)),
+                         __builtin_fmaf(ez, __builtin_fabsf(r.kz), tmz));
 }
 #ifndef PT_BVH_TOP
 #define PT_BVH_TOP 512

@@ -14,11 +14,13 @@ def pt():
 
 
 def _tree(pt, tris):
-    """nodes (uint32 records), child boxes decoded to world space [n, 2, 2, 3] (child, lo/hi, xyz), order, grid"""
+    """nodes (uint32 records), child boxes decoded to grid planes [n, 2, 2, 3] (child, lo/hi, xyz), order, grid.
+    A record stores each box as centre m and half extent e on the grid (csrc/pt_bvh.hpp): planes m - e, m + e."""
     nodes, order, grid = pt.binding.bvh_build(tris)
-    w = nodes[:, 0:6].reshape(-1, 2, 3)
-    g = np.stack([w[:, :, 0] & 0xffff, w[:, :, 0] >> 16, w[:, :, 1] & 0xffff,
-                  w[:, :, 1] >> 16, w[:, :, 2] & 0xffff, w[:, :, 2] >> 16], axis=-1).reshape(-1, 2, 2, 3)
+    w = nodes[:, 0:6].reshape(-1, 2, 3).astype(np.int64)
+    m = np.stack([w[:, :, 0] & 0xffff, w[:, :, 0] >> 16, w[:, :, 1] & 0xffff], axis=-1)
+    e = np.stack([w[:, :, 1] >> 16, w[:, :, 2] & 0xffff, w[:, :, 2] >> 16], axis=-1)
+    g = np.stack([m - e, m + e], axis=2)
     return nodes, g.astype(np.float64), order, grid
 
 
@@ -59,12 +61,15 @@ def test_tree_structure(pt, size):
                 v = verts[order[link:link + count]].reshape(-1, 3)
                 # the box holds its triangles with the padding to spare, and is not wastefully loose
                 assert (v.min(axis=0) - 0.9 * pad > lo).all() and (v.max(axis=0) + 0.9 * pad < hi).all()
-                assert (v.min(axis=0) - pad - 4 * step < lo).all() and (v.max(axis=0) + pad + 4 * step > hi).all()
+                assert (v.min(axis=0) - pad - 6 * step < lo).all() and (v.max(axis=0) + pad + 6 * step > hi).all()
             else:
                 assert k < link < n and count == 0                    # records are laid out parent first
                 parents[link] += 1
-                for cc in (0, 1):                                     # a child's boxes lie inside its own box (grid units)
-                    assert (gbox[link, cc, 0] >= gbox[k, c, 0]).all() and (gbox[link, cc, 1] <= gbox[k, c, 1]).all()
+                # a child's boxes lie inside its own box up to the re-centring of each box on the grid (planes m -+ e:
+                # one spare step on either side, the lower one more when lo + hi is odd) -- the walk needs no exact
+                # nesting: a box only decides which exact triangle tests run
+                for cc in (0, 1):
+                    assert (gbox[link, cc, 0] >= gbox[k, c, 0] - 2).all() and (gbox[link, cc, 1] <= gbox[k, c, 1] + 2).all()
     assert parents[0] == 0 and (parents[1:] == 1).all()
     leaves.sort()
     assert leaves[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(leaves, leaves[1:]))
@@ -232,7 +237,8 @@ def test_walk_on_grazing_soups(pt, po, seed):
 def test_degenerate_inputs(pt):
     # empty mesh, one triangle, coincident triangles (no split separates them)
     nodes, gbox, order, grid = _tree(pt, np.zeros(0, dtype=pt.TRI_DT))
-    assert len(nodes) == 1 and (gbox[0, :, 0] > gbox[0, :, 1]).all()              # both boxes inverted
+    # both children are leaves of ZERO triangles with a point-sized box (centre 0, half extent 0): whatever hits it queues nothing
+    assert len(nodes) == 1 and (gbox[0, :, 0] == 0).all() and (gbox[0, :, 1] == 0).all()
     assert [c[1:] for c in _children(nodes, 0)[0]] == [(0, True), (0, True)]
     assert all(_miss(nodes, 0, o) == -1 for o in range(8))
     one = np.zeros(1, dtype=pt.TRI_DT)
@@ -241,7 +247,7 @@ def test_degenerate_inputs(pt):
     assert len(nodes) == 1 and order.tolist() == [0]
     assert [c[1:] for c in _children(nodes, 0)[0]] == [(1, True), (0, True)]
     box = grid[0:3] + gbox[0, 0] * grid[3:6]
-    assert (box[0] < 0).all() and (box[1] > [1, 1, 0]).all() and (gbox[0, 1, 0] > gbox[0, 1, 1]).all()
+    assert (box[0] < 0).all() and (box[1] > [1, 1, 0]).all() and (gbox[0, 1] == 0).all()
     same = np.repeat(one, 37)
     nodes, gbox, order, grid = _tree(pt, same)
     assert sorted(order.tolist()) == list(range(37))
