@@ -79,6 +79,16 @@ OPS["v_mad_i64_i32"] = "v_mad_i64_i32 %s, vcc, %s, %s, %s" % (D, B, C, D)
 OPS["v_pk_fma_f32"] = "v_pk_fma_f32 %s, %s, %s, %s" % (D, D, BD, BD)
 OPS["v_pk_mul_f32"] = "v_pk_mul_f32 %s, %s, %s" % (D, D, BD)
 OPS["v_pk_add_f32"] = "v_pk_add_f32 %s, %s, %s" % (D, D, BD)
+# packed binary16 (round 5: could the conservative cull test two primitives per instruction?  VERDICT r04 item 3 (i))
+for op in "v_pk_fma_f16".split():
+    OPS[op] = vop3(op)
+for op in "v_pk_min_f16 v_pk_max_f16 v_pk_add_f16 v_pk_mul_f16".split():
+    OPS[op] = "%s %s, %s, %s" % (op, A, A, B)
+OPS["v_cvt_pkrtz_f16_f32"] = "v_cvt_pkrtz_f16_f32 %s, %s, %s" % (A, A, B)
+OPS["v_cmp_gt_f16_e32"] = cmp32("v_cmp_gt_f16")
+OPS["v_or_b32_sdwa"] = "v_or_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" % (A, A, B)
+OPS["v_cvt_f32_u32_sdwa"] = "v_cvt_f32_u32_sdwa %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" % (A, A)
+OPS["v_fma_f32_abs_neg"] = "v_fma_f32 %s, -%s, |%s|, %s" % (A, A, B, C)
 OPS["v_cvt_f32_f64"] = "v_cvt_f32_f64 %s, %s" % (A, D)
 OPS["v_cvt_i32_f64"] = "v_cvt_i32_f64 %s, %s" % (A, D)
 OPS["v_cvt_u32_f64"] = "v_cvt_u32_f64 %s, %s" % (A, D)

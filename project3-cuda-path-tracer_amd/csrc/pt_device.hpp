@@ -449,6 +449,12 @@ PTD bool shade_scatter(PathState &ps, float t, f3 n, int matId, int outside, con
             ps.c = mul(ps.c, scale(mcol, emittance));      // pathtrace.cu:247-249
             return false;
         }
+        // the last bounce: whatever the scatter would produce, the path ends with colour 0 (remainingBounces reaches 0,
+        // completion spec 8.0) -- no engine, no direction (wave-uniform: the whole launch takes this exit)
+        if (last_bounce) {
+            ps.c = mk(0.0f, 0.0f, 0.0f);
+            return false;
+        }
         uint32_t rng = seeded_engine(iter, pixel, depth);
         f3 P = point_on_ray(ps.o, ps.d, t);
         f3 I = ps.d;
@@ -489,10 +495,6 @@ PTD bool shade_scatter(PathState &ps, float t, f3 n, int matId, int outside, con
             ps.d = hemisphere(n, rng);
             ps.o = P;
             ps.c = mul(ps.c, mcol);
-        }
-        if (last_bounce) {
-            ps.c = mk(0.0f, 0.0f, 0.0f);
-            return false;
         }
         return true;
     }

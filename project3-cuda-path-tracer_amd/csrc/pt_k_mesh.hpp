@@ -34,13 +34,7 @@ constexpr int MQ_RAY_WORDS = 8 * MQ_SLOTS;    // src, path, origin xyz, directio
 constexpr int MQ_WORDS = MQ_RAY_WORDS + TQ_SLOTS + 2 * 64;   // + triangle ring + the 64 per-lane best keys (u64)
 constexpr int MESH_TAB = 8;                   // meshes whose {geom, root, top, grid} sit in LDS: starting a walk then costs no global load
 constexpr int MESH_TAB_WORDS = 12;            //   geom root top - | origin xyz step x | step yz - -
-#ifndef PT_MESH_TAIL
-#define PT_MESH_TAIL 16
-#endif
-constexpr int TAIL_LANES = PT_MESH_TAIL;      // a wave with nothing left to hand out and at most this many lanes still walking hands them over (mesh_tail); 0: runs dry
-constexpr int TAIL_WORDS = 15;                // per handed-over walk: src, ray (6), mesh, node, steps, best {t, geom, tri}, key (2)
-static_assert(TAIL_LANES <= 32 && TAIL_WORDS * 32 <= MQ_RAY_WORDS, "handed-over walks are parked in the wave's (empty) ray ring");
-constexpr size_t MESH_LDS_BYTES = ((size_t)MESH_WG_WAVES * MQ_WORDS + (size_t)BVH_TOP * BVH_TOP_STRIDE + MESH_TAB * MESH_TAB_WORDS + MESH_WG_WAVES) * 4;   // 147 904 of 163 840
+constexpr size_t MESH_LDS_BYTES = ((size_t)MESH_WG_WAVES * MQ_WORDS + (size_t)BVH_TOP * BVH_TOP_STRIDE + MESH_TAB * MESH_TAB_WORDS) * 4;   // 147 840 of 163 840
 static_assert(MESH_LDS_BYTES <= 160 * 1024, "k_mesh: per-wave rings + tree tops must fit one CU's LDS");
 #ifndef PT_MQ_STEPS
 #define PT_MQ_STEPS 8
@@ -318,78 +312,6 @@ __device__ __forceinline__ void mesh_drain(MeshWalker &w, float *mq, const float
     }
 }
 
-// The end of a launch.  A wave's supply runs out while a few of its lanes are still deep in long walks (a walk visits 23
-// records on average, one in a hundred more than 64): measured, 17 % of all wave-steps ran with eight or fewer lanes
-// walking, every wave of the chip at about the same time.  So a wave with nothing left to hand out and at most
-// TAIL_LANES lanes still walking does not finish them itself: it tests its queued triangles, completes the walks that are
-// over, PARKS the state of the others in its (empty) ray ring and meets the workgroup's other waves at one barrier; the
-// leftovers of all sixteen waves are then dealt out 64 at a time to as many waves as that takes (one to four), which run
-// them to the end lane-dense.  What travels with a walk is all a box test or a triangle test can depend on -- the ray, the
-// record it stands at, the best key of its current mesh and the best hit of the meshes before it; the remembered sibling
-// pairs are dropped (a forgotten pair only costs the visit) -- so the result is the same, bit for bit.
-// EVERY wave of the workgroup calls this exactly once (it holds the kernel's only barrier after the prologue's).
-__device__ __forceinline__ void mesh_tail(MeshWalker &w, float *lds_raw, float *mq, const float *tops, const float *mtab, uint32_t *tail_cnt,
-                                          MeshRings &rg, const BounceArgs &a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(mq + MQ_RAY_WORDS + TQ_SLOTS);
-    while (rg.t_total != rg.t_head) {                                // queued triangles: test them, their owners may be done then
-        const uint32_t cnt = min(64u, rg.t_total - rg.t_head);
-        tri_pass(mq, rg.t_head, cnt, w, a); rg.t_head += cnt;
-    }
-    mesh_finish(w, keys, mtab, rg, a);                               // (a lane that moves on to its next mesh keeps walking: parked below)
-    const uint64_t left = ballot64(w.have);
-    const uint32_t mine = (uint32_t)__popcll((unsigned long long)left);
-    if (w.have) {
-        const uint32_t r = rank_below(left);
-        uint32_t *mi = reinterpret_cast<uint32_t *>(mq);
-        const unsigned long long key = keys[lane];
-        mi[0 * 32 + r] = w.src;
-        mq[1 * 32 + r] = w.ray.ro.x; mq[2 * 32 + r] = w.ray.ro.y; mq[3 * 32 + r] = w.ray.ro.z;
-        mq[4 * 32 + r] = w.ray.rd.x; mq[5 * 32 + r] = w.ray.rd.y; mq[6 * 32 + r] = w.ray.rd.z;
-        mi[7 * 32 + r] = (uint32_t)w.mesh; mi[8 * 32 + r] = (uint32_t)w.node; mi[9 * 32 + r] = (uint32_t)w.steps;
-        mq[10 * 32 + r] = w.best_t; mi[11 * 32 + r] = (uint32_t)w.best_geom; mi[12 * 32 + r] = (uint32_t)w.best_tri;
-        mi[13 * 32 + r] = (uint32_t)key; mi[14 * 32 + r] = (uint32_t)(key >> 32);
-    }
-    if (lane == 0) tail_cnt[wave] = mine;
-    __syncthreads();
-    // every wave sees the sixteen counts; wave c runs leftovers [64 c, 64 c + 64)
-    const uint32_t cnt_l = (uint32_t)lane < (uint32_t)MESH_WG_WAVES ? tail_cnt[lane] : 0u;
-    uint32_t total = 0, src_wave = 0, src_first = 0;
-    const uint32_t gi = (uint32_t)wave * 64u + (uint32_t)lane;
-#pragma unroll
-    for (int s = 0; s < MESH_WG_WAVES; ++s) {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, s);
-        if (gi >= total && c) { src_wave = (uint32_t)s; src_first = total; }
-        total += c;
-    }
-    if ((uint32_t)wave * 64u >= total) return;                       // nothing for this wave
-    w.have = false;
-    rg = MeshRings{0, 0, 0, 0};
-    if (gi < total) {
-        const float *sq = lds_raw + (size_t)src_wave * MQ_WORDS;
-        const uint32_t *si = reinterpret_cast<const uint32_t *>(sq);
-        const uint32_t r = gi - src_first;
-        const f3 ro = ptd::mk(sq[1 * 32 + r], sq[2 * 32 + r], sq[3 * 32 + r]);
-        const f3 rd = ptd::mk(sq[4 * 32 + r], sq[5 * 32 + r], sq[6 * 32 + r]);
-        const uint32_t src = si[0 * 32 + r];
-        const int mesh = (int)si[7 * 32 + r], node = (int)si[8 * 32 + r], steps = (int)si[9 * 32 + r];
-        const float best_t = sq[10 * 32 + r];
-        const int best_geom = (int)si[11 * 32 + r], best_tri = (int)si[12 * 32 + r];
-        const unsigned long long key = (unsigned long long)si[13 * 32 + r] | ((unsigned long long)si[14 * 32 + r] << 32);
-        mesh_begin(w, mtab, a, mesh, ro, rd);
-        w.src = src; w.path = src; w.node = node; w.steps = steps; w.ticket = 0;
-        w.best_t = best_t; w.best_geom = best_geom; w.best_tri = best_tri;
-#pragma unroll
-        for (int u = 0; u < PT_SKIP_PAIRS; ++u) { w.skip[u] = -1; w.to[u] = -1; }
-        w.have = true;
-        // (this wave's own parked entries sit in its ray ring, which nothing below writes; its key strip is its own)
-        keys[lane] = key;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    mesh_drain(w, mq, tops, mtab, rg, a, 0);
-}
-
 // position of the r-th (0-based) set bit of w, r < popcount(w)
 __device__ __forceinline__ uint32_t kth_set_bit(unsigned long long w, uint32_t r) {
     const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
@@ -420,7 +342,6 @@ __global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a
     float *mq = lds_raw + (threadIdx.x >> 6) * MQ_WORDS;
     float *tops = lds_raw + MESH_WG_WAVES * MQ_WORDS;
     float *mtab = tops + BVH_TOP * BVH_TOP_STRIDE;
-    uint32_t *tail_cnt = reinterpret_cast<uint32_t *>(mtab + MESH_TAB * MESH_TAB_WORDS);
     if ((int)threadIdx.x < MESH_TAB && (int)threadIdx.x < a.scene.bvh_nmesh) {
         const int4 m = a.scene.bvh_meshes[threadIdx.x];
         const float *g = a.scene.geoms + (size_t)m.x * ptd::GEOM_WORDS + ptd::G_INV;
@@ -538,12 +459,9 @@ __global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a
                 }
             }
             const uint64_t busy = mesh_refill(w, mq, mtab, rg, a);
-            // nothing left to hand out: the last few walks go to mesh_tail
-            const bool dry = !p_take && done == total && g_next >= groups && rg.q_total == rg.q_head;
-            if (dry && (int)__popcll((unsigned long long)busy) <= TAIL_LANES) break;
             if (busy) mesh_steps(w, mq, tops, mtab, rg, a);
+            else if (!p_take && done == total && g_next >= groups) break;
         }
-        mesh_tail(w, lds_raw, mq, tops, mtab, tail_cnt, rg, a);
         return;
     }
     const uint32_t rounds = R;
@@ -607,8 +525,7 @@ __global__ __launch_bounds__(MESH_BLOCK, PT_MESH_WAVES) void k_mesh(BounceArgs a
                 mesh_drain(w, mq, tops, mtab, rg, a, MQ_LEAVE);
         }
     }
-    mesh_drain(w, mq, tops, mtab, rg, a, TAIL_LANES + 1);
-    mesh_tail(w, lds_raw, mq, tops, mtab, tail_cnt, rg, a);
+    mesh_drain(w, mq, tops, mtab, rg, a, 0);
 }
 
 }  // namespace
