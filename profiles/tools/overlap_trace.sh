@@ -19,7 +19,7 @@ S=$O/rocprof_${R}_c2_overlap_summary.txt
   for m in on off; do
     echo; echo "== consecutive steps overlapped: $m $( [ $m = off ] && echo '(PTMI355_OVERLAP=0)' )"
     grep -h '^{' $O/ovl_$m.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('line under the profiler: value %.1f Mrays/s, ms_per_step %.4f' % (d['value'], d['ms_per_step']))"
-    python3 profiles/tools/trace_overlap.py $(ls $O/ovl_$m/*/*kernel_trace.csv | head -1) 20 8
+    python3 profiles/tools/trace_overlap.py $(find $O/ovl_$m -name "*kernel_trace.csv" | head -1) 20 8
   done
 } > $S
 cat $S

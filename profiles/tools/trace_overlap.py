@@ -13,9 +13,10 @@ import sys
 
 path, steps = sys.argv[1], int(sys.argv[2])
 per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", ""))
+import re
+rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"^void ", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")))
               for r in csv.DictReader(open(path)))
-ours = [r for r in rows if r[2].startswith(("k_bounce", "k_gather", "k_iteration", "k_mesh", "void k_", "k_"))]
+ours = [r for r in rows if r[2].startswith("k_")]
 bounces = [r for r in ours if r[2].startswith("k_bounce")]
 if len(bounces) < steps * per_step:
     sys.exit("only %d k_bounce launches in the trace, %d wanted" % (len(bounces), steps * per_step))

@@ -11,43 +11,10 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-import __graft_entry__ as ge
+import __graft_entry__ as ge  # noqa: E402,F401
+from gpu_common import pt, launch_plan, bits, rel_l2, assert_paths_equal, _resized, _after  # noqa: E402,F401
 
 pytestmark = pytest.mark.gpu
-
-
-@pytest.fixture(scope="module")
-def pt():
-    p = ge.load_package()
-    p.library()
-    yield p
-    p.pathtraceFree()
-
-
-@pytest.fixture(autouse=True, params=["one launch per bounce", "small batches in one launch"])
-def launch_plan(request, monkeypatch):
-    """Every test runs under both launch plans: a kernel per bounce for every batch (PTMI355_WHOLE_MAX=0), and
-    the default, where batches of up to 3 M paths run all their bounces in one launch (k_iteration)."""
-    if request.param == "one launch per bounce":
-        monkeypatch.setenv("PTMI355_WHOLE_MAX", "0")
-    else:
-        monkeypatch.delenv("PTMI355_WHOLE_MAX", raising=False)
-    return request.param
-
-
-def bits(a):
-    return np.ascontiguousarray(a).view(np.uint32)
-
-
-def rel_l2(a, b):
-    return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / max(1e-30, np.sqrt((b.astype(np.float64) ** 2).sum())))
-
-
-def assert_paths_equal(got, want, n):
-    for f in ("origin", "direction", "color"):
-        assert (bits(got[f][:n]) == bits(want[f][:n])).all(), f
-    assert (got["pixelIndex"][:n] == want["pixelIndex"][:n]).all()
-    assert (got["remainingBounces"][:n] == want["remainingBounces"][:n]).all()
 
 
 def test_raygen(pt, po, scenes, golden):
@@ -164,12 +131,6 @@ def test_bounce_by_bounce(pt, po, scenes, scene_name, flags_name):
     pt.pathtraceFree()
 
 
-def _after(snaps, d, ref):
-    """Oracle path array after bounce d (snapshots hold copies made in the callback,
-    which runs after shade + compaction of that bounce)."""
-    return snaps[d]["paths"]
-
-
 @pytest.mark.parametrize("flags_name", ["fused", "unfused", "nocompact", "sort", "sort2", "sort_nocompact", "cache"])
 def test_c2_full_iteration(pt, po, scenes, golden, flags_name):
     """Config C2 (800x800, depth 8): image, live counts and compaction order vs golden + oracle."""
@@ -210,38 +171,6 @@ def test_c2_forty_iterations_in_batches(pt, po, scenes):
         want += ref.iterate(it, threads=os.cpu_count() or 8).rays
     assert rays == want
     assert img.tobytes() == ref.image.tobytes()
-
-
-def test_c2_one_iteration_per_call_overlapped(pt, scenes, monkeypatch):
-    """C2 at full size through the reference's call pattern, enqueued back to back: every call is ONE k_iteration launch on a
-    PARTIAL grid (csrc/ptmi355.hip: iter_grid_for) overlapping its neighbours on the lanes.  Image, ray count and per-bounce
-    live counts equal those of the same calls waited for one by one (whole grid, in-launch finalGather), which
-    test_c2_full_iteration pins to the oracle and the golden image."""
-    s = scenes["cornell"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    n = scene.resolution[0] * scene.resolution[1]
-
-    def run(overlapped, env=()):
-        for k, v in env:
-            monkeypatch.setenv(k, v)
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=1)
-        for it in range(1, 14):
-            if overlapped:
-                pt.trace_batch_async(it, 1)
-            else:
-                pt.pathtrace(None, 0, it)
-        pt.synchronize()
-        out = (pt.get_image(n).tobytes(), tuple(int(v) for v in pt.counters()))
-        pt.pathtraceFree()
-        for k, _ in env:
-            monkeypatch.delenv(k)
-        return out
-
-    serial = run(False)
-    assert run(True) == serial
-    if pt.has_experiments():          # (grid-size experiments: a -DPT_EXPERIMENTS build only)
-        assert run(True, (("PTMI355_ITER_TPW", "1"), ("PTMI355_ITER_WGS_ALL", "2"))) == serial      # a quarter of a workgroup per CU
-        assert run(True, (("PTMI355_ITER_TPW", "0"),)) == serial                                     # the whole grid
 
 
 def test_c2_compaction_order_hash(pt, po, scenes, golden):
@@ -335,260 +264,6 @@ def test_batch_equals_sequential(pt, scenes):
     pt.pathtraceFree()
 
 
-def test_resumed_accumulation_equals_the_uninterrupted_run(pt, po, scenes, tmp_path):
-    """pt_set_image + ptbench --save-sum / --resume (C5's 5000 spp across GPU leases): the running sum is the whole
-    state the reference carries between iterations (dev_image, pathtrace.cu:71,84,389), so 2 x N/2 iterations with the
-    sum taken through host memory (and a PFM file) in between == N iterations, bit for bit -- per call and batched,
-    one device and three contexts, and through the headless host."""
-    import subprocess
-    s = scenes["cornell_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    npix = 64 * 64
-    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
-    for it in range(1, 13):
-        ref.iterate(it)
-    for devices in (None, [0, 0, 0]):
-        pt.pathtraceInit(scene, max_batch=4, devices=devices)
-        for it in range(1, 7):
-            pt.pathtrace(None, 0, it)
-        half = pt.get_image(npix)
-        pt.pathtraceFree()
-        path = str(tmp_path / "half.6samp.sum.pfm")
-        pt.save_pfm(path, half, 64, 64, 1.0)
-        pt.pathtraceInit(scene, max_batch=4, devices=devices)           # a new session: nothing survives but the file
-        pt.set_image(pt.load_pfm(path, 64, 64))
-        pt.trace_batch(7, 4)
-        pt.pathtrace(None, 0, 11)
-        img = pt.pathtrace(None, 0, 12).copy()
-        pt.pathtraceFree()
-        assert img.tobytes() == ref.image.tobytes(), devices
-    with pytest.raises(pt.PtError):
-        pt.set_image(half)                                              # no session
-    # the headless host: 5 + 7 iterations in two processes == 12 in one
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    txt = open(os.path.join(root, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         64 64")
-    scene_file = tmp_path / "cornell64.txt"
-    scene_file.write_text(txt)
-    exe = pt.build_ptbench()
-    run = lambda *a: subprocess.run([exe, str(scene_file)] + list(a), capture_output=True, text=True, timeout=300)
-    p = run("--iters", "5", "--batch", "2", "--out", str(tmp_path / "a"), "--save-sum")
-    assert p.returncode == 0, p.stdout + p.stderr
-    p = run("--iters", "12", "--batch", "3", "--out", str(tmp_path / "a"), "--resume", str(tmp_path / "a.5samp.sum.pfm"), "--save-sum")
-    assert p.returncode == 0 and "resumed" in p.stdout, p.stdout + p.stderr
-    got = pt.load_pfm(str(tmp_path / "a.12samp.sum.pfm"), 64, 64)
-    assert got.tobytes() == ref.image.tobytes()
-    p = run("--iters", "3", "--resume", str(tmp_path / "a.5samp.sum.pfm"))
-    assert p.returncode != 0                                            # 5 iterations done, 3 wanted
-
-
-def test_async_image_mode(pt, scenes):
-    """PT_ASYNC_IMAGE: pathtrace() returns without waiting for its own copy; the running sum reaches the host while
-    the next call traces.  When call i+1 returns the buffer of call i is complete; pt_synchronize completes the last
-    one; every sum equals the synchronous mode's."""
-    s = scenes["cornell_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    n = scene.resolution[0] * scene.resolution[1]
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
-    sums = [pt.pathtrace(None, 0, it).copy() for it in range(1, 7)]
-    pt.pathtraceFree()
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_ASYNC_IMAGE)
-    bufs = [np.zeros((n, 3), dtype=np.float32) for _ in range(3)]
-    L = pt.library()
-    for it in range(1, 7):
-        assert L.pt_trace(None, 0, it, bufs[it % 3].ctypes.data) == 0
-        if it >= 2:                               # the buffer of the previous call is complete when this one returns
-            assert bufs[(it - 1) % 3].tobytes() == sums[it - 2].tobytes()
-    pt.synchronize()
-    assert bufs[6 % 3].tobytes() == sums[5].tobytes()
-    assert pt.get_image(n).tobytes() == sums[5].tobytes()
-    pt.pathtraceFree()
-
-
-def test_overlapped_small_batches(pt, po, scenes, monkeypatch):
-    """Consecutive small batches whose caller does not wait (pt_trace_batch_async, PT_ASYNC_IMAGE) overlap on lanes
-    that share two launch streams (csrc/ptmi355.hip: enqueue_batch_direct).  The image after every call, the ray counters and the
-    per-bounce statistics equal the serial plan's and the oracle's: batch sizes mixed with larger (serial) batches,
-    the camera moved and the trace depth changed in between, synchronous calls in between, a second session."""
-    s = scenes["cornell_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    n = scene.resolution[0] * scene.resolution[1]
-    cam2 = scene.camera.copy()
-    cam2["position"][0][0] += 0.75
-    plan = [("a", 1, 1), ("a", 2, 1), ("a", 3, 2), ("a", 5, 1), ("a", 6, 1), ("a", 7, 1), ("s", 8, 1), ("a", 9, 1), ("a", 10, 3),
-            ("cam", cam2, s["depth"] - 3), ("a", 13, 1), ("a", 14, 1), ("a", 15, 16), ("a", 31, 1), ("a", 32, 1), ("cam", scene.camera.copy(), s["depth"]),
-            ("a", 33, 1), ("a", 34, 2), ("a", 36, 1)]
-
-    def run(overlap, serial0=None):
-        monkeypatch.setenv("PTMI355_OVERLAP", str(overlap))
-        if serial0 is None:
-            monkeypatch.delenv("PTMI355_FIN_SERIAL", raising=False)
-        else:
-            monkeypatch.setenv("PTMI355_FIN_SERIAL", serial0)     # the final-colour stamp wraps in the middle of the plan
-        out = []
-        for session in range(2):
-            pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=16)
-            for step in plan:
-                if step[0] == "cam":
-                    pt.set_camera(step[1], step[2])
-                elif step[0] == "s":
-                    out.append(pt.pathtrace(None, 0, step[1]).tobytes())
-                else:
-                    pt.trace_batch_async(step[1], step[2])
-            pt.synchronize()
-            out.append(pt.get_image(n).tobytes())
-            out.append(tuple(int(v) for v in pt.counters()))
-            # single calls, each waited for, between overlapped ones
-            pt.trace_batch_async(40, 1)
-            pt.synchronize()
-            img = pt.get_image(n).copy()
-            pt.trace_batch_async(41, 1)
-            pt.trace_batch_async(42, 1)
-            out.append(pt.get_image(n).tobytes())
-            out.append(img.tobytes())
-            pt.pathtraceFree()
-        return out
-
-    serial, overlapped = run(0), run(1)
-    assert serial == overlapped
-    assert run(2) == serial and run(4) == serial                  # two / four lanes
-    assert run(3) == serial and run(5) == serial and run(8) == serial     # lanes that do not divide the two streams evenly
-    if pt.has_experiments():          # a -DPT_EXPERIMENTS build: the stamp's wrap, stream layouts, grid sizes, stream priority
-        assert run(3, "0xfffffff8") == serial
-        # the lanes share two launch streams by default; one stream for all, one per lane, lanes that do not divide evenly, and
-        # k_iteration's grid under the lanes (whole grid / a tile per wave) change nothing either
-        for lanes, streams, tpw, wgs in ((3, 1, "0", "15"), (6, 6, "8", "15"), (5, 3, "1", "4"), (8, 2, "2", "40")):
-            monkeypatch.setenv("PTMI355_LANE_STREAMS", str(streams))
-            monkeypatch.setenv("PTMI355_ITER_TPW", tpw)
-            monkeypatch.setenv("PTMI355_ITER_WGS_ALL", wgs)
-            assert run(lanes) == serial, (lanes, streams, tpw, wgs)
-        for k in ("PTMI355_LANE_STREAMS", "PTMI355_ITER_TPW", "PTMI355_ITER_WGS_ALL"):
-            monkeypatch.delenv(k)
-        monkeypatch.setenv("PTMI355_MAIN_PRIO", "0")                      # the library's own launch stream at default priority
-        assert run(4) == serial
-        monkeypatch.delenv("PTMI355_MAIN_PRIO")
-    monkeypatch.setenv("PTMI355_OVERLAP_GB", "0.0001")                # the lanes' buffers do not fit the budget: the launch stream alone
-    assert run(4) == serial
-    monkeypatch.delenv("PTMI355_OVERLAP_GB")
-    assert serial[:len(serial) // 2] == serial[len(serial) // 2:]
-    # and the oracle: iterations 1..7 with the first camera
-    tr = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
-    for it in range(1, 9):
-        tr.iterate(it)
-    assert tr.image.tobytes() == overlapped[0]
-
-
-@pytest.mark.parametrize("variant", ["jitter_lens", "sort", "no_compaction", "glass_sorted"])
-def test_overlapped_batches_other_pipelines(pt, scenes, monkeypatch, variant):
-    """The lanes under the other fused pipelines: stochastic antialiasing + thin lens (no bounce-0 masks, the lens set
-    between batches), the fused material sort (pools K times as long per lane), no compaction, the glass scene sorted.
-    Overlapped == one stream, call for call."""
-    s = scenes["cornell_glass_64" if variant == "glass_sorted" else "cornell_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    n = scene.resolution[0] * scene.resolution[1]
-    flags = {"jitter_lens": pt.PT_COMPACT | pt.PT_AA_JITTER, "sort": pt.PT_COMPACT | pt.PT_SORT_MATERIAL,
-             "no_compaction": 0, "glass_sorted": pt.PT_COMPACT | pt.PT_SORT_MATERIAL}[variant]
-
-    def run(overlap):
-        monkeypatch.setenv("PTMI355_OVERLAP", str(overlap))
-        pt.pathtraceInit(scene, flags=flags, max_batch=4)
-        out = []
-        it = 1
-        for k, cnt in enumerate((1, 1, 2, 1, 4, 1, 1, 3, 1, 1)):
-            if variant == "jitter_lens" and k in (3, 7):
-                pt.set_lens(0.25 if k == 3 else 0.0, 9.0 if k == 3 else 0.0)
-            pt.trace_batch_async(it, cnt)
-            it += cnt
-            if k in (4, 9):
-                out.append(pt.get_image(n).tobytes())
-        out.append(tuple(int(v) for v in pt.counters()))
-        pt.pathtraceFree()
-        return out
-
-    assert run(0) == run(4) == run(2)
-
-
-def test_overlapped_async_image(pt, scenes, monkeypatch):
-    """PT_ASYNC_IMAGE + one iteration per call (the shim's asynchronous variant) interleaved with overlapped batches:
-    every buffer still holds exactly the sum after its own call."""
-    s = scenes["cornell_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    n = scene.resolution[0] * scene.resolution[1]
-    monkeypatch.setenv("PTMI355_OVERLAP", "0")
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
-    sums = [pt.pathtrace(None, 0, it).copy() for it in range(1, 12)]
-    pt.pathtraceFree()
-    monkeypatch.setenv("PTMI355_OVERLAP", "1")
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_ASYNC_IMAGE)
-    bufs = [np.zeros((n, 3), dtype=np.float32) for _ in range(3)]
-    L = pt.library()
-    last = None                                   # (buffer, iteration) of the previous call that took a host image
-    calls = 0
-    for it in range(1, 12):
-        if it in (3, 4, 7, 10):
-            pt.trace_batch_async(it, 1)           # overlapped on the lanes, between the image calls
-            continue
-        buf = bufs[calls % 3]
-        calls += 1
-        assert L.pt_trace(None, 0, it, buf.ctypes.data) == 0
-        if last is not None:                      # the buffer of the previous image call is complete when this one returns
-            assert last[0].tobytes() == sums[last[1] - 1].tobytes()
-        last = (buf, it)
-    pt.synchronize()
-    assert last[0].tobytes() == sums[last[1] - 1].tobytes()
-    assert pt.get_image(n).tobytes() == sums[10].tobytes()
-    assert pt.counters()[2] == 11
-    pt.pathtraceFree()
-
-
-def test_tiles_equal_whole_frame(pt, scenes):
-    """Interleaved row-strip tiles (multi-GPU sharding) reproduce the 1-tile image exactly:
-    the RNG is keyed by the global pixelIndex."""
-    s = scenes["cornell_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    n = scene.resolution[0] * scene.resolution[1]
-    pt.pathtraceInit(scene)
-    for it in (1, 2):
-        whole = pt.pathtrace(None, 0, it).copy()
-    pt.pathtraceFree()
-    for tiles, strip in ((2, 8), (3, 5), (8, 4)):
-        acc = np.zeros((n, 3), dtype=np.float32)
-        for k in range(tiles):
-            pt.pathtraceInit(scene, tile=(k, tiles, strip))
-            for it in (1, 2):
-                img = pt.pathtrace(None, 0, it)
-            # tiles own disjoint pixels: summing zero-padded frames == RCCL reduce(SUM), exact
-            assert ((acc != 0) & (img != 0)).sum() == 0
-            acc += img
-            pt.pathtraceFree()
-        assert acc.tobytes() == whole.tobytes(), (tiles, strip)
-
-
-def test_tiles_equal_whole_frame_with_mesh_jitter_and_lens(pt, scenes):
-    """The same for everything that is keyed by pixel or path index: a mesh through the hierarchy (mesh pre-pass
-    masks and records), pixel jitter and the lens (random engine keyed by the GLOBAL pixel index), batches."""
-    s = scenes["cornell_glass_64"]
-    tris = pt.meshes.uv_sphere(center=(1.5, 3.0, 1.0), radius=1.5, n_lat=16, n_lon=32)
-    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=2)
-    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
-    n = scene.resolution[0] * scene.resolution[1]
-    kw = dict(flags=pt.PT_COMPACT | pt.PT_MESH_BVH | pt.PT_AA_JITTER, lens=(0.2, 9.0), max_batch=3)
-    whole = np.zeros((n, 3), dtype=np.float32)
-    pt.pathtraceInit(scene, **kw)
-    pt.trace_batch(1, 3, whole)
-    pt.pathtraceFree()
-    assert np.isfinite(whole).all() and whole.max() > 0
-    for tiles, strip in ((2, 8), (5, 3)):
-        acc = np.zeros((n, 3), dtype=np.float32)
-        for k in range(tiles):
-            img = np.zeros((n, 3), dtype=np.float32)
-            pt.pathtraceInit(scene, tile=(k, tiles, strip), **kw)
-            pt.trace_batch(1, 3, img)
-            pt.pathtraceFree()
-            assert ((acc != 0) & (img != 0)).sum() == 0
-            acc += img
-        assert acc.tobytes() == whole.tobytes(), (tiles, strip)
-
-
 def test_fake_shader_as_is(pt, scenes, golden):
     """The reference exactly as shipped: one bounce + shadeFakeMaterial + sendImageToPBO."""
     z = golden["fakeshade"]
@@ -644,297 +319,6 @@ def test_lifecycle_and_errors(pt, scenes):
                 pt.pathtraceInit(pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=m), flags=flags)
 
 
-def test_host_image_freed_and_reallocated_between_calls(pt, po, scenes):
-    """pathtrace() copies the running sum into WHATEVER buffer it is handed (pathtrace.cu:389-390 is a plain
-    cudaMemcpy): without PT_PIN_IMAGE the library keeps no claim on a buffer after the call returns -- the host may
-    free it, and a new allocation (often at the same address) is just another buffer.  1200 x 900 x 12 B: above the
-    1 MiB from which PT_PIN_IMAGE would page-lock.  With the flag the one long-lived buffer gives the same sums."""
-    s = scenes["cornell"]
-    cam = _resized(s["camera"], 1200, 900)
-    scene = pt.Scene(s["geoms"], s["materials"], cam, 3)
-    n = 1200 * 900
-    L = pt.library()
-    ref = po.Tracer(s["geoms"], s["materials"], cam, 3)
-    want = []
-    for it in range(1, 7):
-        ref.iterate(it, threads=8)
-        want.append(ref.image.copy())
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, pin_image=False)
-    for it in range(1, 7):
-        buf = np.empty((n, 3), dtype=np.float32)          # a fresh buffer per call ...
-        buf[:] = -1.0
-        assert L.pt_trace(None, 0, it, buf.ctypes.data) == 0
-        assert buf.tobytes() == want[it - 1].tobytes(), it
-        del buf                                           # ... freed before the next
-    pt.pathtraceFree()
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE, pin_image=False)
-    keep = np.zeros((n, 3), dtype=np.float32)
-    for it in range(1, 7):
-        assert L.pt_trace(None, 0, it, keep.ctypes.data) == 0
-        assert keep.tobytes() == want[it - 1].tobytes(), it
-    pt.pathtraceFree()
-
-
-def test_host_image_kept_current_incrementally(pt, scenes, monkeypatch):
-    """pathtrace() per call with a long-lived page-locked host image (PT_PIN_IMAGE | PT_HOST_SPARSE): from the second call
-    on, the launch adds every ending path's colour to its pixel itself and writes only those pixels to the host
-    (BounceArgs::epi_direct; the others still hold their sums).  After every call the host buffer IS the device's running sum, whatever else
-    happened in between: overlapped batches (k_gather wrote the buffer), pt_clear_image, pt_set_image, a second host
-    buffer, a camera move; and the whole sequence equals the one with every pixel written every call."""
-    s = scenes["cornell"]
-    cam = _resized(s["camera"], 400, 300)                  # 1.44 MB of image: above the 1 MiB from which PT_PIN_IMAGE page-locks
-    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
-    n = 400 * 300
-    L = pt.library()
-    cam2 = cam.copy()
-    cam2["position"][0][1] += 0.5
-
-    def run(env, extra=0):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE | extra, pin_image=False)
-        a = np.full((n, 3), -7.0, dtype=np.float32)
-        b = np.full((n, 3), -9.0, dtype=np.float32)
-        out = []
-
-        def call(buf, it):
-            assert L.pt_trace(None, 0, it, buf.ctypes.data) == 0
-            assert buf.tobytes() == pt.get_image(n).tobytes(), it
-            out.append(buf.tobytes())
-
-        for it in (1, 2, 3):
-            call(a, it)
-        pt.trace_batch_async(4, 1); pt.trace_batch_async(5, 1)            # the buffer changes behind the host's copy
-        call(a, 6); call(a, 7)
-        pt.clear_image()
-        call(a, 8); call(a, 9)
-        call(b, 10); call(a, 11); call(a, 12); call(b, 13)               # two host buffers in turn
-        pt.set_image(np.ascontiguousarray(np.frombuffer(out[2], dtype=np.float32).reshape(n, 3)))
-        call(a, 14); call(a, 15)
-        pt.set_camera(cam2, s["depth"] - 2)
-        call(a, 16); call(a, 17)
-        pt.trace_batch(18, 1, None)                                      # a synchronous batch without a host image
-        call(a, 19)
-        pt.pathtraceFree()
-        for k in env:
-            monkeypatch.delenv(k)
-        return out
-
-    ref = run({})                                         # PT_PIN_IMAGE alone: every pixel, every call
-    assert run({}, pt.PT_HOST_SPARSE) == ref
-    if pt.has_experiments():                              # (a -DPT_EXPERIMENTS build: the plans the default replaced)
-        assert run({"PTMI355_EPI_DIRECT": "0"}, pt.PT_HOST_SPARSE) == ref
-        assert run({"PTMI355_HOST_EPILOGUE": "0"}, pt.PT_HOST_SPARSE) == ref
-
-
-def test_host_writes_between_calls(pt, scenes, launch_plan):
-    """what a host's own writes into the image do.  PT_PIN_IMAGE alone keeps the reference's semantics -- every
-    call hands back the WHOLE running sum (pathtrace.cu:389-390), so scribbles are overwritten; under PT_HOST_SPARSE the
-    host has promised to only read, the binding returns a read-only view, and a scribble through the raw buffer survives
-    exactly on pixels whose sum did not change (documented in include/ptmi355.h) while every other pixel is current."""
-    s = scenes["cornell"]
-    cam = _resized(s["camera"], 400, 300)
-    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
-    n = 400 * 300
-    L = pt.library()
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE, pin_image=False)
-    buf = np.zeros((n, 3), dtype=np.float32)
-    for it in (1, 2, 3, 4):
-        assert L.pt_trace(None, 0, it, buf.ctypes.data) == 0
-        assert buf.tobytes() == pt.get_image(n).tobytes(), it
-        buf /= float(it)                                  # the host normalises in place ...
-        buf[::7] = -1.0                                   # ... and scribbles
-    pt.pathtraceFree()
-
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, host_sparse=True)       # (pin_image=True: scene.image)
-    img = pt.pathtrace(None, 0, 1)
-    assert not img.flags.writeable and img.tobytes() == pt.get_image(n).tobytes()
-    with pytest.raises(ValueError):
-        img[0, 0] = 1.0
-    img = pt.pathtrace(None, 0, 2)
-    before = pt.get_image(n).copy()
-    scene.image[::5] = -3.0                               # behind the binding's back: the promise broken
-    img = pt.pathtrace(None, 0, 3)
-    dev = pt.get_image(n)
-    changed = (dev.view(np.uint32) != before.view(np.uint32)).any(axis=1)
-    assert changed.any() and not changed.all()
-    assert np.asarray(img)[changed].tobytes() == dev[changed].tobytes()         # every pixel whose sum changed is current
-    if launch_plan == "one launch per bounce":            # the flag is a permission: this plan copies the whole image anyway
-        assert np.asarray(img).tobytes() == dev.tobytes()
-        pt.pathtraceFree()
-        return
-    stale = ~changed
-    stale[np.arange(n) % 5 != 0] = False
-    assert stale.any() and (np.asarray(img)[stale] == -3.0).all()               # the rest is as the host left it
-    pt.pathtraceFree()
-
-
-def test_async_image_written_by_the_launch(pt, scenes, monkeypatch):
-    """PT_ASYNC_IMAGE with a page-lockable image (400 x 300 x 12 B > 1 MiB): pt_trace returns without waiting and the
-    launch writes the host buffer itself (only the pixels that changed when the buffer is the one it wrote last).  The
-    contract of the flag holds call for call: a buffer is complete when the NEXT call returns (or after pt_synchronize)
-    and then holds exactly the sum after its own call -- one buffer reused, two buffers in turn, a batch call (snapshot
-    + copy engine) in between -- and equals the copy-engine-only plan and the synchronous sums."""
-    s = scenes["cornell"]
-    cam = _resized(s["camera"], 400, 300)
-    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
-    n = 400 * 300
-    L = pt.library()
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, pin_image=False)
-    want = {}
-    for it in range(1, 15):
-        want[it] = pt.pathtrace(None, 0, it).tobytes()
-    pt.pathtraceFree()
-
-    def run(env, extra=0):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_ASYNC_IMAGE | extra, pin_image=False)
-        a = np.full((n, 3), -1.0, dtype=np.float32)
-        b = np.full((n, 3), -2.0, dtype=np.float32)
-        c = np.full((n, 3), -3.0, dtype=np.float32)
-        ok = []
-        assert L.pt_trace(None, 0, 1, a.ctypes.data) == 0
-        assert L.pt_trace(None, 0, 2, b.ctypes.data) == 0
-        ok.append(a.tobytes() == want[1])                         # complete when the next call has returned
-        assert L.pt_trace(None, 0, 3, a.ctypes.data) == 0
-        ok.append(b.tobytes() == want[2])
-        assert L.pt_trace(None, 0, 4, a.ctypes.data) == 0         # the same buffer again: only what changed is written
-        assert L.pt_trace(None, 0, 5, a.ctypes.data) == 0
-        assert L.pt_trace_batch(6, 1, c.ctypes.data) == 0         # batch entry point: snapshot + copy engine
-        ok.append(a.tobytes() == want[5])
-        assert L.pt_trace(None, 0, 7, a.ctypes.data) == 0
-        ok.append(c.tobytes() == want[6])
-        assert L.pt_trace(None, 0, 8, c.ctypes.data) == 0         # the buffer the copy engine wrote, now written by the launch
-        ok.append(a.tobytes() == want[7])
-        assert L.pt_trace(None, 0, 9, c.ctypes.data) == 0
-        pt.synchronize()
-        ok.append(c.tobytes() == want[9])
-        pt.clear_image()
-        for it in (1, 2, 3):
-            assert L.pt_trace(None, 0, it, c.ctypes.data) == 0
-        pt.synchronize()
-        ok.append(c.tobytes() == want[3])
-        pt.pathtraceFree()
-        for k in env:
-            monkeypatch.delenv(k)
-        return ok
-
-    assert all(run({}, pt.PT_HOST_SPARSE)), "launch-written, the pixels that changed"
-    assert all(run({})), "launch-written, every pixel"
-    if pt.has_experiments():
-        assert all(run({"PTMI355_ASYNC_DIRECT": "0"})), "copy engine"
-
-
-def test_shared_host_frame_assembled_by_the_tiles(pt, scenes, launch_plan):
-    """PT_SHARED_IMAGE: the ranks of a tiled frame hand pt_trace ONE host frame and each writes only the pixels of its own
-    tile into it (first call: all of them; later calls: the ones whose sum changed) -- the frame is assembled in host memory
-    with no exchange.  Here the "ranks" are sessions of this process, one after the other, interleaved call by call on two
-    frames: tiles of 2 and of 3 ranks (strips of 8 and of 5 rows: the last strip short) give the 1-session sums, pixel
-    for pixel, and a session never touches a pixel outside its tile."""
-    s = scenes["cornell"]
-    cam = _resized(s["camera"], 400, 300)
-    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
-    n = 400 * 300
-    L = pt.library()
-    if launch_plan == "one launch per bounce":                   # the flag needs one-launch iterations: refused under this plan
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_SHARED_IMAGE, tile=(0, 2, 8), pin_image=False)
-        frame = np.zeros((n, 3), dtype=np.float32)
-        assert L.pt_trace(None, 0, 1, frame.ctypes.data) < 0 and not frame.any()
-        pt.pathtraceFree()
-        return
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, pin_image=False)
-    want = {}
-    for it in (1, 2, 3, 4):
-        want[it] = pt.pathtrace(None, 0, it).reshape(n, 3).copy()
-    pt.pathtraceFree()
-    for ranks, strip in ((2, 8), (3, 5)):
-        frame = np.full((n, 3), -5.0, dtype=np.float32)
-        owned = []
-        for r in range(ranks):
-            rows = pt.sharding.owned_rows(r, ranks, strip, 300)
-            owned.append(np.repeat(rows, 400))
-        for r in range(ranks):                                   # rank r: its four iterations into the shared frame
-            before = frame.copy()
-            pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_SHARED_IMAGE, tile=(r, ranks, strip), pin_image=False)
-            for it in (1, 2, 3, 4):
-                assert L.pt_trace(None, 0, it, frame.ctypes.data) == 0
-                assert frame[owned[r]].tobytes() == want[it][owned[r]].tobytes(), (ranks, r, it)
-            pt.pathtraceFree()
-            assert frame[~owned[r]].tobytes() == before[~owned[r]].tobytes(), (ranks, r)       # nobody else's pixels
-        assert frame.tobytes() == want[4].tobytes(), ranks
-    # what cannot run as one launch is refused, not copied over the other ranks' pixels
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_SORT_MATERIAL | pt.PT_SHARED_IMAGE, tile=(0, 2, 8), pin_image=False)
-    frame = np.zeros((n, 3), dtype=np.float32)
-    assert L.pt_trace(None, 0, 1, frame.ctypes.data) < 0
-    pt.pathtraceFree()
-
-
-def test_4k_one_iteration_per_call_into_the_host_image(pt, scenes, monkeypatch):
-    """C5's frame (3840 x 2160 = 8.3 M paths) through pathtrace() per call with a page-locked host image: one launch per
-    iteration although the frame is above the 6 M paths up to which batches run as one launch (the launch hides the PCIe
-    transfer).  Host image == device sum after every call == the kernel-per-bounce plan with a copy per call."""
-    s = scenes["cornell"]
-    cam = _resized(s["camera"], 3840, 2160)
-    scene = pt.Scene(s["geoms"], s["materials"], cam, s["depth"])
-    n = 3840 * 2160
-    L = pt.library()
-
-    def run(env):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE, pin_image=False)
-        host = np.full((n, 3), -3.0, dtype=np.float32)
-        out = []
-        for it in (1, 2, 3):
-            assert L.pt_trace(None, 0, it, host.ctypes.data) == 0
-            out.append(hashlib.md5(host.tobytes()).hexdigest())
-        assert host.tobytes() == pt.get_image(n).tobytes()
-        out.append(tuple(int(v) for v in pt.counters()))
-        pt.pathtraceFree()
-        for k in env:
-            monkeypatch.delenv(k)
-        return out
-
-    assert run({}) == run({"PTMI355_WHOLE_MAX_HOST": "0"})
-
-
-@pytest.mark.parametrize("flags_name", ["loop", "bvh"])
-def test_unit_mesh_seen_from_far_away(pt, po, scenes, flags_name):
-    """A unit-size mesh viewed from 300 and then from 5000 units away: the hierarchy's box padding and the
-    every-triangle loop's spheres are derived for ray origins within the scene's bound, which pt_init stretches to
-    the camera and pt_set_camera re-derives (rebuilding the trees) when the camera leaves it.  Image == oracle."""
-    s = scenes["cornell_64"]
-    tris = pt.meshes.uv_sphere(center=(0.0, 5.0, 0.0), radius=0.5, n_lat=12, n_lon=24)
-    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"][:0], tris, material_id=1)        # the mesh alone
-    light = s["geoms"][:1].copy()                                                      # + the scene's light so paths end lit
-    geoms = np.concatenate([geoms, light])
-    flags = pt.PT_COMPACT | (pt.PT_MESH_BVH if flags_name == "bvh" else 0)
-
-    def camera_at(dist):
-        c = _resized(s["camera"], 64, 64)
-        c["position"][0] = (0.0, 5.0, dist)
-        # a narrow field of view so that the mesh fills a good part of the frame from that distance
-        half = np.float32(0.75 / dist)
-        c["pixelLength"][0] = (np.float32(2 * half / 64), np.float32(2 * half / 64))
-        return c
-
-    near = camera_at(300.0)
-    scene = pt.Scene(geoms, s["materials"], near, 4, triangles=tris, meshes=meshes)
-    pt.pathtraceInit(scene, flags=flags)
-    for dist in (300.0, 5000.0, 300.0):
-        cam = camera_at(dist)
-        scene.camera[:] = cam
-        pt.clear_image()
-        img = pt.pathtrace(None, 0, 1).copy()             # re-reads the camera (pathtrace.cu:285-286)
-        ref = po.Tracer(geoms, s["materials"], cam, 4, tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
-        st = ref.iterate(1)
-        assert st.live[1] > 500, dist                      # the mesh is hit
-        assert list(pt.get_stats().live[:4]) == list(st.live[:4]), dist
-        assert img.tobytes() == ref.image.tobytes(), dist
-    pt.pathtraceFree()
-
-
 def test_c1_as_stated(pt, po, scenes, golden):
     """BASELINE configs[0]: scenes/cornell_diffuse.txt as the reference loader reads it -- the Cornell box with the
     sphere made diffuse, 400 x 400, 1 spp, depth 4 -- on the GPU against the oracle's single-thread loop and against
@@ -953,16 +337,6 @@ def test_c1_as_stated(pt, po, scenes, golden):
     assert live == list(st.live[:4]) == list(z["live"][0]) and live[0] == 160000
     assert img.tobytes() == ref.image.tobytes()
     assert hashlib.md5(img.tobytes()).hexdigest() == str(z["img_md5"])
-
-
-def _resized(cam, w, h):
-    """The reference camera at another resolution: pixelLength follows scene.cpp:131-135 (2 * tan(fov) / resolution)."""
-    c = cam.copy()
-    c["resolution"][0] = (w, h)
-    yscaled = np.tan(np.float32(c["fov"][0][1]) * np.float32(np.pi / 180))
-    xscaled = np.float32(yscaled * np.float32(w) / np.float32(h))
-    c["pixelLength"][0] = (np.float32(2 * xscaled / np.float32(w)), np.float32(2 * yscaled / np.float32(h)))
-    return c
 
 
 @pytest.mark.parametrize("shape", [(1, 1), (3, 5), (65, 1), (63, 2), (1, 130)])
@@ -1246,754 +620,6 @@ def test_large_iteration_numbers(pt, po, scenes):
     with pytest.raises(pt.PtError):
         pt.trace_batch((1 << 31) - 2, 3, img)                # would overflow int
     pt.pathtraceFree()
-
-
-def test_pbo_device_pointer(pt, scenes, golden):
-    """pathtrace() writes the tonemapped RGBA8 into a device buffer (the mapped PBO)."""
-    import torch
-    s = scenes["cornell_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    pt.pathtraceInit(scene, flags=pt.PT_FAKE_SHADER)
-    pbo = torch.zeros(64 * 64 * 4, dtype=torch.uint8, device="cuda:0")
-    for it in (1, 2, 3):
-        pt.pathtrace(pbo.data_ptr(), 0, it)
-    torch.cuda.synchronize()
-    assert pbo.cpu().numpy().tobytes() == golden["fakeshade"]["pbo64"].tobytes()
-    pt.pathtraceFree()
-
-
-def test_tile_order_matches_host_sharding(pt, scenes):
-    """csrc local_to_pixel == sharding.tile_pixel_indices (what bench.py / RCCL plumbing assume)."""
-    s = scenes["cornell_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    for rank, world, strip in ((1, 3, 5), (7, 8, 4), (0, 2, 8)):
-        pt.pathtraceInit(scene, tile=(rank, world, strip))
-        pt.trace_begin(1, 1)
-        want = pt.sharding.tile_pixel_indices(rank, world, strip, 64, 64)
-        paths, live = pt.export_paths(len(want))
-        assert live == len(want)
-        assert (paths["pixelIndex"] == want).all()
-        pt.pathtraceFree()
-
-
-def _mesh_scene(pt, scenes, n_lat, n_lon, res_scene="cornell_64"):
-    s = scenes[res_scene]
-    tris = pt.meshes.uv_sphere(n_lat=n_lat, n_lon=n_lon)
-    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
-    return s, geoms, tris, meshes
-
-
-@pytest.mark.parametrize("size", [(8, 16), (30, 60)])       # 224 and 3480 triangles (1 and 4 LDS tiles)
-def test_triangle_mesh(pt, po, scenes, size):
-    """Config C4's path: naive triangle loop through LDS tiles, glm::intersectRayTriangle arithmetic."""
-    s, geoms, tris, meshes = _mesh_scene(pt, scenes, *size)
-    assert len(tris) == pt.meshes.triangle_count(*size)
-    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
-    n = 64 * 64
-    # standalone intersect kernel vs oracle on the camera rays
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED)
-    rays = po.generate_rays(s["camera"], s["depth"])
-    got, got_out = pt.intersect_once(rays.view(pt.PATH_DT))
-    want, want_out = po.compute_intersections(rays, geoms.view(po.GEOM_DT), tris.view(po.TRI_DT),
-                                              meshes.view(po.MESH_DT))
-    assert got.tobytes() == want.tobytes()
-    mesh_hits = (want["t"] > 0) & (want["materialId"] == 1) & (np.abs(want["normal"]).max(axis=1) < 0.999)
-    assert mesh_hits.sum() > 50
-    pt.pathtraceFree()
-    for flags in (pt.PT_COMPACT, pt.PT_COMPACT | pt.PT_UNFUSED, 0):
-        pt.pathtraceInit(scene, flags=flags)
-        ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], s["depth"],
-                        flags=po.F_COMPACT if flags & pt.PT_COMPACT else 0, trig=po.TRIG_SHARED,
-                        tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
-        for it in (1, 2):
-            img = pt.pathtrace(None, 0, it)
-            st = ref.iterate(it)
-            gs = pt.get_stats()
-            assert list(gs.live[:s["depth"]]) == list(st.live[:s["depth"]])
-            assert img.tobytes() == ref.image.tobytes()
-        pt.pathtraceFree()
-
-
-@pytest.mark.parametrize("size", [(8, 16), (30, 60)])
-def test_mesh_bvh_vs_oracle(pt, po, scenes, size):
-    """PT_MESH_BVH: culling the triangle tests with the hierarchy leaves every result unchanged."""
-    s, geoms, tris, meshes = _mesh_scene(pt, scenes, *size)
-    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | pt.PT_MESH_BVH)
-    info = pt.binding.bvh_info()
-    assert info.triangles == len(tris) and info.nodes >= len(tris) // 4 and 0 < info.pad < 1e-2
-    rays = po.generate_rays(s["camera"], s["depth"])
-    got, got_out = pt.intersect_once(rays.view(pt.PATH_DT))
-    want, want_out = po.compute_intersections(rays, geoms.view(po.GEOM_DT), tris.view(po.TRI_DT),
-                                              meshes.view(po.MESH_DT))
-    assert got.tobytes() == want.tobytes()
-    pt.pathtraceFree()
-    for flags in (pt.PT_COMPACT, pt.PT_COMPACT | pt.PT_SORT_MATERIAL, pt.PT_COMPACT | pt.PT_CACHE_FIRST, 0):
-        pt.pathtraceInit(scene, flags=flags | pt.PT_MESH_BVH)
-        ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], s["depth"],
-                        flags=po.F_COMPACT if flags & pt.PT_COMPACT else 0, trig=po.TRIG_SHARED,
-                        tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
-        for it in (1, 2):
-            img = pt.pathtrace(None, 0, it)
-            st = ref.iterate(it)
-            assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
-            assert img.tobytes() == ref.image.tobytes()
-        pt.pathtraceFree()
-
-
-@pytest.mark.parametrize("aa", [False, True])
-def test_camera_tile_mask(pt, po, scenes, aa):
-    """Bounce 0 of the mesh pre-pass skips the 64-pixel tiles that cannot see a mesh (ptmi355.hip: update_cam_mask).
-    Same frames as the oracle with the mesh in full view, half off-screen, seen from very close, from INSIDE its box
-    (a corner behind the eye: no mask), and as the camera moves between batches (pt_set_camera rebuilds the mask)."""
-    s = scenes["cornell_64"]
-    tris = pt.meshes.uv_sphere(center=(1.2, 4.0, 0.5), radius=1.4, n_lat=16, n_lon=32)
-    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"][:6], tris, material_id=2)
-    og, ot, om = geoms.view(po.GEOM_DT), tris.view(po.TRI_DT), meshes.view(po.MESH_DT)
-    gflags = pt.PT_COMPACT | pt.PT_MESH_BVH | (pt.PT_AA_JITTER if aa else 0)
-    oflags = po.F_COMPACT | (po.F_AA if aa else 0)
-    moves = [(0.0, 0.0, 0.0), (3.2, 0.0, 0.0), (1.0, -1.0, -6.5), (1.2, -1.0, -9.8), (0.0, 0.0, 0.0), (-4.0, 2.0, -3.0)]
-    cams = []
-    for dx, dy, dz in moves:
-        cam = np.array(s["camera"], copy=True).reshape(1)
-        cam["position"][0] += np.float32([dx, dy, dz])
-        cams.append(cam)
-    n = int(cams[0]["resolution"][0][0]) * int(cams[0]["resolution"][0][1])
-    # (a) a renderer initialised at each position (mask built by pt_init)
-    for k, cam in enumerate(cams):
-        scene = pt.Scene(geoms, s["materials"], cam, s["depth"], triangles=tris, meshes=meshes)
-        ref = po.Tracer(og, s["materials"], cam, s["depth"], flags=oflags, trig=po.TRIG_SHARED, tris=ot, meshes=om)
-        pt.pathtraceInit(scene, flags=gflags, max_batch=2)
-        img = np.zeros((n, 3), dtype=np.float32)
-        pt.trace_batch(1 + 2 * k, 2, img)
-        pt.pathtraceFree()
-        ref.iterate(1 + 2 * k); ref.iterate(2 + 2 * k)
-        assert img.tobytes() == ref.image.tobytes(), k
-        assert (ref.image.sum(axis=1) > 0).any()
-    # (b) ONE renderer whose camera moves between batches (mask rebuilt by pt_set_camera); the running sum carries over
-    scene = pt.Scene(geoms, s["materials"], cams[0], s["depth"], triangles=tris, meshes=meshes)
-    pt.pathtraceInit(scene, flags=gflags, max_batch=2)
-    img = np.zeros((n, 3), dtype=np.float32)
-    total = np.zeros((n, 3), dtype=np.float32)
-    for k, cam in enumerate(cams):
-        pt.set_camera(cam, s["depth"])
-        pt.trace_batch(1 + 2 * k, 2, img)
-        ref = po.Tracer(og, s["materials"], cam, s["depth"], flags=oflags, trig=po.TRIG_SHARED, tris=ot, meshes=om)
-        ref.image[:] = total
-        ref.iterate(1 + 2 * k); ref.iterate(2 + 2 * k)
-        total = ref.image.copy()
-        assert img.tobytes() == total.tobytes(), k
-    pt.pathtraceFree()
-
-
-def test_bounce0_candidate_masks(pt, po, scenes, monkeypatch):
-    """Bounce 0 of a pinhole camera skips, per 64-pixel camera tile, the cull test of the primitives no ray of the
-    tile is a candidate of (k_cull0_mask, rebuilt by pt_set_camera).  Frames equal the oracle's as the camera moves
-    between batches -- sideways, far outside the scene (the cull boxes are remade for the new reach), looking
-    away from it -- and equal the frames of a renderer with the masks switched off; a tile of a sharded frame and the
-    stepping interface (which loads rays written by k_raygen: no masks) are covered by the other tests."""
-    s = scenes["cornell_64"]
-    moves = [(0.0, 0.0, 0.0), (2.5, 0.5, 0.0), (0.0, 0.0, -40.0), (30.0, 10.0, 5.0), (0.0, 0.0, 0.0), (-3.0, 2.0, -2.0)]
-    cams = []
-    for k, (dx, dy, dz) in enumerate(moves):
-        cam = np.array(s["camera"], copy=True).reshape(1)
-        cam["position"][0] += np.float32([dx, dy, dz])
-        if k == 5:                                           # look away from the box: most tiles see nothing at all
-            cam["view"][0] = np.float32([0.6, 0.0, 0.8])
-            cam["right"][0] = np.float32([-0.8, 0.0, 0.6])
-        cams.append(cam)
-    n = int(cams[0]["resolution"][0][0]) * int(cams[0]["resolution"][0][1])
-    frames = {}
-    for masks in ("1", "0"):
-        monkeypatch.setenv("PTMI355_CULL0", masks)
-        scene = pt.Scene(s["geoms"], s["materials"], cams[0], s["depth"])
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=3)
-        img = np.zeros((n, 3), dtype=np.float32)
-        total = np.zeros((n, 3), dtype=np.float32)
-        for k, cam in enumerate(cams):
-            pt.set_camera(cam, s["depth"])
-            pt.trace_batch(1 + 3 * k, 3, img)
-            if masks == "1":
-                ref = po.Tracer(s["geoms"], s["materials"], cam, s["depth"], flags=po.F_COMPACT, trig=po.TRIG_SHARED)
-                ref.image[:] = total
-                for it in range(3):
-                    ref.iterate(1 + 3 * k + it)
-                total = ref.image.copy()
-                assert img.tobytes() == total.tobytes(), k
-            frames[(masks, k)] = img.copy()
-        pt.pathtraceFree()
-    for k in range(len(cams)):
-        assert frames[("1", k)].tobytes() == frames[("0", k)].tobytes(), k
-    monkeypatch.delenv("PTMI355_CULL0")
-
-
-@pytest.mark.parametrize("graph", [False, True])
-def test_final_colour_stamps(pt, po, scenes, monkeypatch, graph):
-    """(Run with direct launches and under hipGraph replay, PTMI355_GRAPH=1: the stamp then travels through
-    Control::keep[0] because kernel arguments are frozen at capture.)
-    Paths that end with colour 0 write nothing; k_gather tells this batch's entries from stale ones by the batch's
-    stamp (a per-session serial number in the entry's fourth component).  The same iteration traced again after
-    clear_image, batches of different sizes over the same entries, and the serial's wrap-around at 2^32 (the buffer
-    is cleared and the serial restarts) all give the oracle's sums."""
-    s = scenes["cornell_64"]
-    n = 64 * 64
-    if graph:
-        monkeypatch.setenv("PTMI355_GRAPH", "1")
-    for start in (None, "0xfffffffd") if pt.has_experiments() else (None,):    # the second run wraps after three batches (test hook of a -DPT_EXPERIMENTS build)
-        if start:
-            monkeypatch.setenv("PTMI355_FIN_SERIAL", start)
-        scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=4)
-        ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], flags=po.F_COMPACT, trig=po.TRIG_SHARED)
-        img = np.zeros((n, 3), dtype=np.float32)
-        for iter0, count in ((1, 4), (5, 1), (6, 3), (9, 4), (13, 2), (15, 1)):
-            pt.trace_batch(iter0, count, img)
-            for it in range(iter0, iter0 + count):
-                ref.iterate(it)
-            assert img.tobytes() == ref.image.tobytes(), (start, iter0)
-        pt.clear_image()
-        ref.image[:] = 0
-        pt.trace_batch(1, 4, img)                          # the same iterations again: new stamps, same colours
-        for it in range(1, 5):
-            ref.iterate(it)
-        assert img.tobytes() == ref.image.tobytes()
-        pt.pathtraceFree()
-    monkeypatch.delenv("PTMI355_FIN_SERIAL", raising=False)
-
-
-def test_mesh_bvh_two_meshes_fused(pt, po, scenes):
-    """Two meshes (one nested inside the glass ball's silhouette, one overlapping the first) through the mesh
-    pre-pass: every walk visits both trees and keeps the nearer hit, geom order on ties."""
-    s = scenes["cornell_glass_64"]
-    a = pt.meshes.uv_sphere(center=(1.5, 3.0, 1.0), radius=1.5, n_lat=20, n_lon=40)
-    b = pt.meshes.uv_sphere(center=(2.2, 3.5, 1.5), radius=1.2, n_lat=14, n_lon=24)
-    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], a, material_id=1)
-    geoms, tris, meshes = pt.meshes.add_mesh(geoms, b, material_id=4, existing_triangles=tris, existing_meshes=meshes)
-    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
-    for flags, oflags in ((pt.PT_COMPACT, po.F_COMPACT), (0, 0)):
-        ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], s["depth"], flags=oflags, trig=po.TRIG_SHARED,
-                        tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
-        pt.pathtraceInit(scene, flags=flags | pt.PT_MESH_BVH, max_batch=3)
-        n = scene.resolution[0] * scene.resolution[1]
-        img = np.zeros((n, 3), dtype=np.float32)
-        for it in (1, 2):
-            img = pt.pathtrace(None, 0, it)
-            st = ref.iterate(it)
-            assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
-            assert img.tobytes() == ref.image.tobytes()
-        pt.trace_batch(3, 3, img)
-        for it in (3, 4, 5):
-            ref.iterate(it)
-        assert img.tobytes() == ref.image.tobytes()
-        pt.pathtraceFree()
-
-
-@pytest.mark.parametrize("seed", list(range(1, 9)))
-def test_mesh_bvh_triangle_soup(pt, po, scenes, seed):
-    """Random triangle soups -- slivers, zero-area and very large triangles, heavy overlap, coplanar duplicates
-    (exact ties between triangles) -- through the hierarchy and the mesh pre-pass vs the oracle's loop."""
-    rng = np.random.default_rng(7000 + seed)
-    s = scenes["cornell_64"]
-    n = int(rng.integers(200, 2500))
-    c = rng.uniform(-3, 3, (n, 3)) + (0, 5, 0)
-    size = 10 ** rng.uniform(-2.5, 0.6, (n, 1))
-    v0 = c + rng.normal(size=(n, 3)) * size
-    v1 = c + rng.normal(size=(n, 3)) * size
-    v2 = c + rng.normal(size=(n, 3)) * size
-    sl = rng.random(n) < 0.1
-    v2[sl] = v1[sl] + (v1[sl] - v0[sl]) * 1e-4 + rng.normal(size=(sl.sum(), 3)) * 1e-6        # slivers
-    dg = rng.random(n) < 0.03
-    v2[dg] = v1[dg]                                                                          # zero area
-    tris = np.zeros(n + 40, dtype=pt.TRI_DT)
-    tris["v0"][:n], tris["v1"][:n], tris["v2"][:n] = v0, v1, v2
-    dup = rng.integers(n, size=40)                                                           # exact duplicates: ties
-    tris[n:] = tris[dup]
-    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"][:6], tris, material_id=int(rng.integers(1, 5)))
-    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
-    ref = po.Tracer(geoms.view(po.GEOM_DT), s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED,
-                    tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_MESH_BVH, max_batch=2)
-    for it in (1, 2):
-        img = pt.pathtrace(None, 0, it)
-        st = ref.iterate(it)
-        assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
-        assert img.tobytes() == ref.image.tobytes()
-    pt.pathtraceFree()
-    # the camera rays' winners themselves (inline walk of the unfused path)
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | pt.PT_MESH_BVH)
-    rays = po.generate_rays(s["camera"], s["depth"])
-    got, _ = pt.intersect_once(rays.view(pt.PATH_DT))
-    want, _ = po.compute_intersections(rays, geoms.view(po.GEOM_DT), tris.view(po.TRI_DT), meshes.view(po.MESH_DT))
-    assert got.tobytes() == want.tobytes()
-    pt.pathtraceFree()
-
-
-@pytest.mark.parametrize("seed", [17, 37, 101, 102])
-def test_mesh_grazing_rays_and_the_hit_point_test(pt, po, scenes, seed):
-    """Rays that run (almost) inside the plane of their target triangle (tests/mesh_cases.py; seeds 17 and 37 are the
-    ones on which the unfiltered glm test reports noise hits metres away from the triangle -- see
-    tests/test_bvh_cpu.py::test_walk_on_grazing_soups).  The hierarchy, the every-triangle kernel and the mesh
-    pre-pass of whole iterations all agree with the oracle's loop, spec hit-point test included."""
-    import mesh_cases
-    s = scenes["cornell_64"]
-    rng = np.random.default_rng(seed)
-    tris = mesh_cases.soup(pt.TRI_DT, rng) if seed % 2 else pt.meshes.uv_sphere(center=(0.5, 4.0, 0.0), radius=2.0, n_lat=37, n_lon=90)
-    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"][:6], tris, material_id=int(rng.integers(1, 5)))
-    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
-    k = min(len(tris), 1500)
-    origin, d, graze = mesh_cases.aimed_rays(tris, rng, k)
-    paths = np.zeros(k, dtype=pt.PATH_DT)
-    paths["origin"], paths["direction"] = origin.astype(np.float32), d.astype(np.float32)
-    og, ot, om = geoms.view(po.GEOM_DT), tris.view(po.TRI_DT), meshes.view(po.MESH_DT)
-    want, _ = po.compute_intersections(paths.view(po.PATH_DT), og, ot, om)
-    assert (want["t"] > 0).sum() > k // 4
-    for extra in (pt.PT_MESH_BVH, 0):
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | extra)
-        got, _ = pt.intersect_once(paths)
-        pt.pathtraceFree()
-        assert got.tobytes() == want.tobytes(), "hierarchy" if extra else "loop"
-    ref = po.Tracer(og, s["materials"], s["camera"], s["depth"], trig=po.TRIG_SHARED, tris=ot, meshes=om)
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_MESH_BVH, max_batch=2)
-    img = np.zeros((64 * 64, 3), dtype=np.float32)
-    pt.trace_batch(1, 2, img)
-    pt.pathtraceFree()
-    ref.iterate(1); ref.iterate(2)
-    assert img.tobytes() == ref.image.tobytes()
-
-
-def test_mesh_bvh_adversarial_rays(pt, po, scenes):
-    """Rays aimed exactly at vertices and edges (where several triangles tie or just miss), from outside and
-    from inside the mesh, plus two meshes in one scene: winner index and distance come out as the oracle's loop
-    over every triangle has them."""
-    s = scenes["cornell"]                                    # 800x800: room for 20 000 rays
-    a = pt.meshes.uv_sphere(n_lat=40, n_lon=80)
-    b = pt.meshes.uv_sphere(center=(-2.0, 6.0, -1.0), radius=1.0, n_lat=12, n_lon=20)
-    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], a, material_id=1)
-    geoms, tris, meshes = pt.meshes.add_mesh(geoms, b, material_id=2, existing_triangles=tris, existing_meshes=meshes)
-    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
-    rng = np.random.default_rng(11)
-    verts = np.stack([tris["v0"], tris["v1"], tris["v2"]], axis=1).astype(np.float64)
-    n = 20000
-    rays = np.zeros(n, dtype=pt.PATH_DT)
-    T = verts[rng.integers(len(tris), size=n)]
-    w = rng.dirichlet((1, 1, 1), size=n)
-    kind = np.arange(n) % 4
-    w[kind == 0] = np.eye(3)[rng.integers(3, size=(kind == 0).sum())]           # a vertex
-    e = rng.uniform(0, 1, size=(kind == 1).sum())
-    w[kind == 1] = np.stack([e, 1 - e, np.zeros_like(e)], axis=1)                # a point on an edge
-    target = np.einsum("nk,nkc->nc", w, T)
-    target[kind == 3] += rng.normal(size=((kind == 3).sum(), 3))                 # near misses / other triangles
-    o = rng.uniform(-4.5, 9.5, size=(n, 3))
-    inside = np.arange(n) % 10 == 9
-    o[inside] = np.array([1.5, 3.0, 1.0]) + rng.normal(size=(inside.sum(), 3)) * 0.3
-    dvec = target - o
-    dvec /= np.linalg.norm(dvec, axis=1, keepdims=True)
-    par = np.arange(n) % 8 == 5                                                  # exactly axis-parallel rays, half of them
-    axis = rng.integers(3, size=n)                                               # aimed at the chosen point
-    unit = np.eye(3)[axis] * rng.choice([-1.0, 1.0], size=(n, 1))
-    dvec[par] = unit[par]
-    aimed = par & (np.arange(n) % 16 == 5)
-    o[aimed] = target[aimed] - unit[aimed] * rng.uniform(2, 6, size=(aimed.sum(), 1))
-    rays["origin"], rays["direction"] = o, dvec
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | pt.PT_MESH_BVH)
-    got, _ = pt.intersect_once(rays)
-    pt.pathtraceFree()
-    want, _ = po.compute_intersections(rays.view(po.PATH_DT), geoms.view(po.GEOM_DT), tris.view(po.TRI_DT),
-                                       meshes.view(po.MESH_DT))
-    assert got.tobytes() == want.tobytes()
-    assert ((want["t"] > 0) & (want["materialId"] == 1)).sum() > 3000
-    assert ((want["t"] > 0) & (want["materialId"] == 2)).sum() > 100
-
-
-def test_c4_whole_frame_against_the_oracle(pt, scenes, golden):
-    """BASELINE config C4 at full size (800x800, 100 032 triangles, depth 8), the WHOLE frame, against the ORACLE
-    (VERDICT r04 item 5b): the oracle's iteration 1 -- 2.5 * 10^11 ray-triangle tests, glm::intersectRayTriangle per
-    triangle (external/include/glm/gtx/intersect.inl:37-74) -- was traced once in the build container
-    (tests/golden/make_c4_golden.py -> c4_frame.npz: image md5, md5 of each of the 50 16-row strips, live counts, 4096
-    sampled pixels).  The loop over every triangle (the configuration as BASELINE states it) and the hierarchy are each
-    held against those values, not against each other."""
-    import hashlib
-    z = golden["c4_frame"]
-    s = scenes["cornell"]
-    tris = pt.meshes.uv_sphere()
-    assert len(tris) == int(z["triangles"]) == 100032
-    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
-    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
-    W, strip = 800, int(z["strip_rows"])
-    for name, flags in (("loop", pt.PT_COMPACT), ("bvh", pt.PT_COMPACT | pt.PT_MESH_BVH)):
-        pt.pathtraceInit(scene, flags=flags)
-        img = pt.pathtrace(None, 0, 1).copy()
-        live = [int(v) for v in pt.get_stats().live[:s["depth"]]]
-        pt.pathtraceFree()
-        assert live == [int(v) for v in z["live"]], name
-        assert sum(live) == int(z["rays"])
-        bad = [r for r in range(len(z["strip_md5"]))
-               if hashlib.md5(img[r * strip * W:(r + 1) * strip * W].tobytes()).hexdigest() != str(z["strip_md5"][r])]
-        assert not bad, (name, "strips that differ from the oracle", bad)
-        assert img[z["sample_index"]].tobytes() == z["sample_value"].tobytes(), name
-        assert hashlib.md5(img.tobytes()).hexdigest() == str(z["image_md5"]), name
-    assert live[1] > 100000
-
-
-@pytest.mark.parametrize("r", [37, 26])
-def test_c4_strip_against_the_oracle(pt, po, scenes, r):
-    """BASELINE config C4 at full size (800x800, depth 8, 100 032 triangles) held against the ORACLE, not against
-    itself: a whole-frame oracle iteration is 2.5 * 10^11 triangle tests, but every path is keyed by (iteration, global
-    pixelIndex, depth), so one 16-row strip is the same 12 800 paths in both and costs the oracle seconds.  Strip 37
-    (rows 592-607) sees the mesh only through bounces; strip 26 (rows 416-431) runs THROUGH THE MESH'S SILHOUETTE: the
-    camera rays of rows 421 and up hit it, those of rows 416-420 pass its limb (the mesh covers rows 421-551, columns
-    290-390 of the frame), so grazing camera rays, first-bounce mesh hits and their scattered rays are all in it.
-    Loop over every triangle and hierarchy: image and live counts."""
-    import os
-    s = scenes["cornell"]
-    tris = pt.meshes.uv_sphere()
-    assert len(tris) == 100032
-    geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
-    scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
-    W, H = scene.resolution
-    strip = 16
-    rows = slice(r * strip * W, (r + 1) * strip * W)
-    ref = po.Tracer(geoms, s["materials"], s["camera"], s["depth"], tris=tris.view(po.TRI_DT), meshes=meshes.view(po.MESH_DT))
-    st = ref.iterate_rows(1, r * strip, (r + 1) * strip, threads=min(32, os.cpu_count() or 8))
-    assert st.live[0] == strip * W and st.live[1] > 0
-    if r == 26:
-        # the strip does cross the limb: some of its camera rays hit the mesh (they differ from the mesh-less scene's), most do not
-        cam = po.generate_rays(s["camera"], s["depth"])[rows]
-        with_mesh, _ = po.compute_intersections(cam.view(po.PATH_DT), geoms.view(po.GEOM_DT), tris.view(po.TRI_DT), meshes.view(po.MESH_DT))
-        without, _ = po.compute_intersections(cam.view(po.PATH_DT), s["geoms"].view(po.GEOM_DT))
-        on_mesh = (with_mesh["t"] != without["t"]).reshape(strip, W).sum(axis=1)
-        assert on_mesh[:5].sum() == 0 and on_mesh[5] > 0 and on_mesh[-1] > on_mesh[5], on_mesh
-    for flags in (pt.PT_COMPACT, pt.PT_COMPACT | pt.PT_MESH_BVH):
-        pt.pathtraceInit(scene, flags=flags, tile=(r, H // strip, strip))
-        img = pt.pathtrace(None, 0, 1).copy()
-        live = list(pt.get_stats().live[:s["depth"]])
-        pt.pathtraceFree()
-        assert live == list(st.live[:s["depth"]]), flags
-        assert img[rows].tobytes() == ref.image[rows].tobytes(), flags
-        assert not img[:rows.start].any() and not img[rows.stop:].any()
-    # the strip does see the mesh: without it the same rows come out differently
-    plain = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    pt.pathtraceInit(plain, tile=(r, H // strip, strip))
-    assert pt.pathtrace(None, 0, 1)[rows].tobytes() != ref.image[rows].tobytes()
-    pt.pathtraceFree()
-
-
-@pytest.mark.parametrize("mode", ["aa", "lens", "aa+lens"])
-def test_camera_jitter_and_lens(pt, po, scenes, mode):
-    """Stochastic antialiasing and the thin lens (completion spec; pathtrace.cu:134 TODO, INSTRUCTION.md:110-113):
-    the camera rays, every iteration's image and the batched path agree with the oracle bit for bit."""
-    s = scenes["cornell_glass_64"]
-    aa = "aa" in mode
-    lens = (0.35, 9.0) if "lens" in mode else (0.0, 0.0)
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    n = scene.resolution[0] * scene.resolution[1]
-    gflags = pt.PT_COMPACT | (pt.PT_AA_JITTER if aa else 0)
-    oflags = po.F_COMPACT | (po.F_AA if aa else 0)
-    # the rays themselves (stepping interface -> k_raygen)
-    pt.pathtraceInit(scene, flags=gflags, lens=lens)
-    for it in (1, 5):
-        pt.trace_begin(it, 1)
-        paths, live = pt.export_paths(n)
-        want = po.generate_rays_ex(s["camera"], s["depth"], it, aa=aa, lens=lens)
-        assert live == n and paths.tobytes() == want.tobytes()
-        pt.trace_end()
-    pt.pathtraceFree()
-    # whole iterations, one at a time (rays generated inside bounce 0), then as batches
-    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], flags=oflags, trig=po.TRIG_SHARED, lens=lens)
-    pt.pathtraceInit(scene, flags=gflags, lens=lens)
-    for it in range(1, 7):
-        img = pt.pathtrace(None, 0, it)
-        st = ref.iterate(it)
-        assert list(pt.get_stats().live[:s["depth"]]) == list(st.live[:s["depth"]])
-        assert img.tobytes() == ref.image.tobytes()
-    pt.pathtraceFree()
-    pt.pathtraceInit(scene, flags=gflags, lens=lens, max_batch=4)
-    img = np.zeros((n, 3), dtype=np.float32)
-    pt.trace_batch(1, 4, img)
-    pt.trace_batch(5, 2, img)
-    assert img.tobytes() == ref.image.tobytes()
-    pt.pathtraceFree()
-    # sorted batches generate bounce 0 in k_intersect<GEN> / k_shade_sorted_w<GEN> (jitter and lens included)
-    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"], flags=oflags | po.F_SORT, trig=po.TRIG_SHARED,
-                    lens=lens)
-    pt.pathtraceInit(scene, flags=gflags | pt.PT_SORT_MATERIAL, lens=lens)
-    for it in (1, 2):
-        img = pt.pathtrace(None, 0, it)
-        ref.iterate(it)
-        assert img.tobytes() == ref.image.tobytes()
-    pt.pathtraceFree()
-
-
-def test_camera_extensions_exclude_the_first_bounce_cache(pt, scenes):
-    s = scenes["cornell_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    with pytest.raises(pt.PtError, match="PT_CACHE_FIRST"):
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_CACHE_FIRST | pt.PT_AA_JITTER)
-    with pytest.raises(pt.PtError, match="PT_CACHE_FIRST"):
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_CACHE_FIRST, lens=(0.1, 5.0))
-    with pytest.raises(pt.PtError, match="focal_distance"):
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT, lens=(0.1, 0.0))
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT)
-    a = pt.pathtrace(None, 0, 1).copy()
-    pt.set_lens(0.3, 9.0)                        # takes effect from the next iteration on
-    pt.clear_image()
-    b = pt.pathtrace(None, 0, 1).copy()
-    pt.set_lens(0.0, 0.0)
-    pt.clear_image()
-    c = pt.pathtrace(None, 0, 1).copy()
-    assert (a != b).any() and a.tobytes() == c.tobytes()
-    pt.pathtraceFree()
-
-
-@pytest.mark.parametrize("sort", [False, True])
-def test_graph_replay_equals_direct_launches(pt, scenes, monkeypatch, sort):
-    """PTMI355_GRAPH=1: a batch captured once and replayed with hipGraphLaunch (iteration number through
-    Control::iter0) gives the same image as direct launches, across batch sizes and a camera change -- fused, and with
-    the material sort (whose bounce-0 kernels generate the camera rays themselves)."""
-    s = scenes["cornell_glass_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    n = scene.resolution[0] * scene.resolution[1]
-
-    def run():
-        img = np.zeros((n, 3), dtype=np.float32)
-        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | (pt.PT_SORT_MATERIAL if sort else 0), max_batch=4)
-        for it in (1, 2, 3):
-            pt.pathtrace(None, 0, it)                 # batch size 1, three replays
-        pt.trace_batch(4, 4, img)                     # batch size 4
-        pt.trace_batch(8, 4, img)
-        pt.trace_batch(12, 3, img)                    # a third size
-        rays = pt.get_stats().total_rays
-        cam = scene.camera.copy()
-        cam["position"][0][0] += 0.5                  # frozen launch arguments change: graphs are re-captured
-        pt.set_camera(cam, s["depth"])
-        pt.trace_batch(15, 4, img)
-        pt.pathtraceFree()
-        return img, rays
-
-    monkeypatch.delenv("PTMI355_GRAPH", raising=False)
-    direct = run()
-    monkeypatch.setenv("PTMI355_GRAPH", "1")
-    replay = run()
-    assert direct[1] == replay[1]
-    assert direct[0].tobytes() == replay[0].tobytes()
-
-
-def test_ptbench_headless_host(pt, po, scenes, tmp_path):
-    """The C++ headless host (host/ptbench.cpp = main.cpp/runCuda without GLFW): scene file in, PNG out;
-    the PNG equals the oracle's image pushed through the same saveImage pipeline."""
-    import os
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    txt = open(os.path.join(root, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         64 64")
-    scene_file = tmp_path / "cornell64.txt"
-    scene_file.write_text(txt)
-    exe = pt.build_ptbench()
-    p = subprocess.run([exe, str(scene_file), "--iters", "5", "--batch", "2", "--out", str(tmp_path / "r")],
-                       capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stdout + p.stderr
-    assert "Mrays/s" in p.stdout
-    from PIL import Image
-    got = np.asarray(Image.open(str(tmp_path / "r.5samp.png")).convert("RGB"), dtype=np.uint8)
-    s = scenes["cornell_64"]
-    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
-    for it in range(1, 6):
-        ref.iterate(it)
-    want = pt.image_to_rgb8(ref.image, 64, 64, 5.0)
-    assert got.tobytes() == want.tobytes()
-
-
-def test_reference_host_through_the_shim(pt, po, scenes, tmp_path):
-    """The REFERENCE host -- its own scene.cpp / utilities.cpp / image.cpp / stb.cpp and the runCuda sequence of
-    main.cpp:101-147 (free before init, per-call camera re-read, scene->state.image refreshed by every pathtrace()) --
-    linked against host/pathtrace_shim.cpp + libptmi355.so (oracle/_ref/refhost, built in the build container by
-    oracle/Makefile, shipped with the snapshot): the PNG its saveImage() writes decodes to the pixels of ptbench's PNG
-    and of the oracle's image pushed through the same pipeline."""
-    import os
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "oracle", "_ref", "refhost")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/refhost is built where /root/reference exists")
-    txt = open(os.path.join(root, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         64 64")
-    import re
-    txt = re.sub(r"(?m)^ITERATIONS\s+\d+", "ITERATIONS  5", txt)
-    txt = re.sub(r"(?m)^FILE\s+\S+", "FILE        %s" % str(tmp_path / "refhost"), txt)
-    scene_file = tmp_path / "cornell64.txt"
-    scene_file.write_text(txt)
-    p = subprocess.run([exe, str(scene_file), "T0"], capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stdout + p.stderr
-    from PIL import Image
-    got = np.asarray(Image.open(str(tmp_path / "refhost.T0.5samp.png")).convert("RGB"), dtype=np.uint8)
-    bench = pt.build_ptbench()
-    p = subprocess.run([bench, str(scene_file), "--out", str(tmp_path / "ptb")], capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stdout + p.stderr
-    mine = np.asarray(Image.open(str(tmp_path / "ptb.5samp.png")).convert("RGB"), dtype=np.uint8)
-    assert got.tobytes() == mine.tobytes()
-    s = scenes["cornell_64"]
-    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
-    for it in range(1, 6):
-        ref.iterate(it)
-    assert got.tobytes() == pt.image_to_rgb8(ref.image, 64, 64, 5.0).tobytes()
-
-
-def _read_pfm(path):
-    with open(path, "rb") as f:
-        assert f.readline().strip() == b"PF"
-        w, h = [int(v) for v in f.readline().split()]
-        scale = float(f.readline())
-        data = np.frombuffer(f.read(), dtype="<f4" if scale < 0 else ">f4")
-    return data.reshape(h, w, 3)
-
-
-def test_ptbench_tiles(pt, tmp_path):
-    """`ptbench --tile R/K`: K host processes (one per GPU in production) render one frame between them; their raw
-    sums add up -- exactly, a sum with zeros -- to the single-process image."""
-    import os
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    txt = open(os.path.join(root, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         96 80")
-    scene_file = tmp_path / "c.txt"
-    scene_file.write_text(txt)
-    exe = pt.build_ptbench()
-
-    def render(name, *extra):
-        p = subprocess.run([exe, str(scene_file), "--iters", "3", "--batch", "2", "--pfm", "--out", str(tmp_path / name)] + list(extra),
-                           capture_output=True, text=True, timeout=300)
-        assert p.returncode == 0, p.stdout + p.stderr
-        return _read_pfm(str(tmp_path / (name + ".3samp.pfm")))
-
-    whole = render("whole")
-    parts = [render("t%d" % k, "--tile", "%d/3" % k, "--strip-rows", "8") for k in range(3)]
-    assert (parts[0] + parts[1] + parts[2]).tobytes() == whole.tobytes()
-    assert all((p != 0).any() and (p == 0).any() for p in parts)
-
-
-def test_ptbench_mesh_scene_hierarchy_and_camera_options(pt, tmp_path):
-    """ptbench on a scene file with a `mesh file.obj` object: --bvh gives the PNG of the loop over every triangle,
-    byte for byte; --aa / --lens render (and change the image)."""
-    import os
-    import subprocess
-    from PIL import Image
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tris = pt.meshes.uv_sphere(center=(0.0, 0.0, 0.0), radius=1.0, n_lat=24, n_lon=48)
-    with open(tmp_path / "ball.obj", "w") as f:
-        for t in tris:
-            for k in ("v0", "v1", "v2"):
-                f.write("v %.9g %.9g %.9g\n" % tuple(t[k]))
-        for i in range(len(tris)):
-            f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
-    txt = open(os.path.join(root, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         96 96")
-    n_obj = sum(1 for line in txt.splitlines() if line.startswith("OBJECT "))
-    txt = txt.rstrip("\n") + "\n\nOBJECT %d\nmesh ball.obj\nmaterial 2\nTRANS 2 3 1\nROTAT 0 30 0\nSCALE 1.5 1.5 1.5\n" % n_obj
-    scene_file = tmp_path / "cornell_mesh.txt"
-    scene_file.write_text(txt)
-    exe = pt.build_ptbench()
-
-    def render(tag, *opts):
-        p = subprocess.run([exe, str(scene_file), "--iters", "4", "--batch", "2", "--out", str(tmp_path / tag)] + list(opts),
-                           capture_output=True, text=True, timeout=300)
-        assert p.returncode == 0, p.stdout + p.stderr
-        assert "%d triangles" % len(tris) in p.stdout
-        return np.asarray(Image.open(str(tmp_path / (tag + ".4samp.png"))).convert("RGB"), dtype=np.uint8)
-
-    loop, bvh = render("loop"), render("bvh", "--bvh")
-    assert loop.tobytes() == bvh.tobytes()
-    assert (loop[30:70, 55:90] != loop[0, 0]).any()
-    dof = render("dof", "--bvh", "--aa", "--lens", "0.3", "9")
-    assert dof.shape == loop.shape and (dof != loop).any()
-
-
-def test_first_bounce_cache_follows_camera(pt, po, scenes):
-    """PT_CACHE_FIRST (INSTRUCTION.md:87-89): batches reuse the cached bounce-0 intersections; a camera
-    change through pathtrace()'s per-call re-read invalidates them."""
-    s = scenes["cornell_64"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_CACHE_FIRST, max_batch=3)
-    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
-    img = np.zeros((64 * 64, 3), dtype=np.float32)
-    pt.trace_batch(1, 3, img)
-    pt.trace_batch(4, 2, img)
-    for it in range(1, 6):
-        ref.iterate(it)
-    assert img.tobytes() == ref.image.tobytes()
-    cam2 = s["camera"].copy()
-    cam2["position"][0][0] += 0.75                       # move the eye: same resolution, new rays
-    scene.camera = cam2
-    got = pt.pathtrace(None, 0, 6).copy()
-    ref2 = po.Tracer(s["geoms"], s["materials"], cam2, s["depth"])
-    ref2.image[:] = ref.image
-    ref2.iterate(6)
-    assert got.tobytes() == ref2.image.tobytes()
-    pt.pathtraceFree()
-
-
-def test_c5_tile_of_4k_frame(pt, po, scenes):
-    """Config C5's sharding at full size: rank 3 of 8 at 3840x2160 (interleaved 8-row strips); its pixels
-    must equal the same pixels of the oracle's whole-frame iteration (global pixelIndex keys the RNG)."""
-    import os
-    s = scenes["cornell_4k"]
-    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
-    W, H = scene.resolution
-    assert (W, H) == (3840, 2160)
-    pt.pathtraceInit(scene, tile=(3, 8, 8))
-    img = pt.pathtrace(None, 0, 1).copy()
-    gs = pt.get_stats()
-    pt.pathtraceFree()
-    ref = po.Tracer(s["geoms"], s["materials"], s["camera"], s["depth"])
-    ref.iterate(1, threads=min(64, os.cpu_count() or 8))
-    own = pt.sharding.tile_pixel_indices(3, 8, 8, W, H)
-    assert len(own) == gs.live[0] and abs(len(own) - W * H // 8) <= 8 * W
-    assert img[own].tobytes() == ref.image[own].tobytes()
-    other = np.ones(W * H, dtype=bool)
-    other[own] = False
-    assert not img[other].any()                           # zero-padded elsewhere: reduce(SUM) is exact
-
-
-def c5_pooled_statistic(img_sum, samples, golden):
-    """BASELINE C5 against the reference's only rendered artefact: the 4K frame has the 800x800 scene's FOVY, so its
-    central 2160x2160 square IS that view (2.7 x finer); saveImage's x-flip, clamp and 8-bit quantisation, then the 50x50
-    pooled means of tests/golden/png_stat.npz (bins of 43.2 pixels, edges rounded), ball / reflection / shadow masked."""
-    W, H = 3840, 2160
-    img = (np.asarray(img_sum, dtype=np.float32).reshape(H, W, 3) / np.float32(samples))[:, ::-1, :]
-    img = np.floor(np.clip(img, 0, 1) * 255.0) / 255.0
-    sq = img[:, (W - H) // 2:(W + H) // 2, :]
-    edges = np.round(np.arange(51) * (H / 50.0)).astype(int)
-    rows = np.add.reduceat(sq, edges[:-1], axis=0)
-    cells = np.add.reduceat(rows, edges[:-1], axis=1)
-    area = np.diff(edges)[:, None] * np.diff(edges)[None, :]
-    pooled = cells / area[:, :, None]
-    want = golden["png_stat"]["pooled"]
-    mask = np.ones((50, 50), dtype=bool)
-    mask[22:40, 12:32] = False
-    return float(np.sqrt(((pooled - want)[mask] ** 2).sum()) / np.sqrt((want[mask] ** 2).sum()))
-
-
-def test_c5_as_stated_5000spp_through_eight_contexts(pt, golden, tmp_path, launch_plan):
-    """BASELINE config C5 AS STATED, on the one GPU of this box: scenes/cornell_4k.txt (3840x2160, depth 8) for its 5000
-    iterations through the headless host with the frame tiled over EIGHT contexts (`ptbench --devices 0,0,0,0,0,0,0,0`:
-    interleaved 8-row strips, a tile exchange after every batch, as on eight GPUs) -- 1.6 * 10^11 rays.  The image meets
-    the reference's 5000-sample PNG (pooled statistic, relative L2 <= 0.05), and a second render of the same frame --
-    ONE context, other batch size, interrupted after 2500 iterations and resumed from its saved sum in a new process
-    (`--save-sum` / `--resume`) -- gives the same running sum bit for bit."""
-    import subprocess
-    if launch_plan != "small batches in one launch":
-        pytest.skip("one 5000-spp 4K render per suite: the launch plans meet at this batch size")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = pt.build_ptbench()
-    scene = os.path.join(root, "scenes", "cornell_4k.txt")
-    run = lambda *a: subprocess.run([exe, scene] + list(a), capture_output=True, text=True, timeout=900)
-    p = run("--devices", "0,0,0,0,0,0,0,0", "--batch", "4", "--out", str(tmp_path / "m"), "--save-sum")
-    assert p.returncode == 0 and "5000 iterations" in p.stdout and "on 8 device(s)" in p.stdout, p.stdout + p.stderr
-    full = pt.load_pfm(str(tmp_path / "m.5000samp.sum.pfm"), 3840, 2160)
-    stat = c5_pooled_statistic(full, 5000, golden)
-    assert stat <= 0.05, stat
-    assert np.isfinite(full).all() and full.min() >= 0.0
-    p = run("--iters", "2500", "--batch", "5", "--out", str(tmp_path / "s"), "--save-sum")
-    assert p.returncode == 0, p.stdout + p.stderr
-    p = run("--batch", "5", "--out", str(tmp_path / "s"), "--resume", str(tmp_path / "s.2500samp.sum.pfm"), "--save-sum")
-    assert p.returncode == 0 and "resumed" in p.stdout, p.stdout + p.stderr
-    again = pt.load_pfm(str(tmp_path / "s.5000samp.sum.pfm"), 3840, 2160)
-    assert again.tobytes() == full.tobytes()
 
 
 def test_division_fast_path_gates(pt, po, scenes, golden):
