@@ -833,7 +833,7 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
                          "valu_insts_per_ray": round(64.0 * sum(k["launches_per_step"] * k.get("wave_insts_per_launch", {}).get("valu", 0.0) for k in sel) /
                                                      max(1.0, rank_rays / steps), 1),
                          "unpriced_share_of_cycles": round(unpriced, 4),
-                         "issue_cost_table": "profiles/r03/issue_ops_r03.json (one row per opcode)",
+                         "issue_cost_table": "profiles/r05/issue_ops_r05.json (one row per opcode, re-measured in round 5)",
                          "sq_insts_valu_over_counted": [k.get("sq_insts_valu_over_counted") for k in sel]},
              hbm_measured={"achieved": round(byt / per_step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
                            "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch (gfx950 correction)"},

@@ -47,6 +47,17 @@ def test_default_line_and_its_counter_profile():
     assert d["config"]["batch_spp"] == 64 and d["value"] > 1000
     _check_roofline(d["roofline"])
     assert d["roofline"]["launches"] == 5 * 8
+    # figures a reader can re-derive from SURVEY 8(d) and the line itself: north_star's yardstick --
+    # the intersect + compaction bytes (48 B per ray + 88 B per survivor) over the bounce kernels' time and 8 TB/s ...
+    c = d["roofline"]["contract"]
+    rays = d["config"]["rays_per_step"]
+    survivors = rays - 64 * 640000
+    assert abs(c["bytes_per_step"] - (48 * rays + 88 * survivors)) <= 48 * 64 + 88 * 64        # (the event pass's own steps)
+    assert abs(c["frac"] - c["bytes_per_step"] / (c["kernel_ms_per_step"] * 1e-3) / 8e12) < 2e-3 and 0.3 < c["frac"] < 1.0
+    # ... and, when the counter profile is current, what the fused kernel must move beside what it measurably moves
+    if d["roofline"]["frac"] is not None:
+        n = d["roofline"]["hbm_necessary"]
+        assert 0.95 < n["measured_over_necessary"] < 1.3 and abs(n["measured_over_necessary"] - d["roofline"]["traffic"] / n["bytes_per_launch"]) < 2e-3
 
 
 def test_bench_digest_equals_oracle():
