@@ -52,7 +52,7 @@ def test_default_line_and_its_counter_profile():
     c = d["roofline"]["contract"]
     rays = d["config"]["rays_per_step"]
     survivors = rays - 64 * 640000
-    assert abs(c["bytes_per_step"] - (48 * rays + 88 * survivors)) <= 48 * 64 + 88 * 64        # (the event pass's own steps)
+    assert abs(c["bytes_per_step"] / (48 * rays + 88 * survivors) - 1.0) < 1e-3          # (the event pass traces other iterations than the timed pass)
     assert abs(c["frac"] - c["bytes_per_step"] / (c["kernel_ms_per_step"] * 1e-3) / 8e12) < 2e-3 and 0.3 < c["frac"] < 1.0
     # ... and, when the counter profile is current, what the fused kernel must move beside what it measurably moves
     if d["roofline"]["frac"] is not None:
