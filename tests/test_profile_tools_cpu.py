@@ -97,3 +97,32 @@ def test_instrument_and_hist(tmp_path):
     assert abs(h["unpriced_share_of_cycles"] - (2 * 4.0 / 2) / want) < 1e-9
     assert h["flops_fp32_per_launch"] == 64.0 * (10 * 1 + 10 * 2 + 2 * 1) / 2
     assert h["wave_insts_per_launch"]["branch"] == (2 + 10 + 2) / 2     # the two conditional branches and s_endpgm
+
+
+def test_trace_overlap_union_and_sum(tmp_path):
+    """profiles/tools/trace_overlap.py on a synthetic kernel trace: two steps of two k_bounce launches each that overlap
+    pairwise (a launch of the next step starts while the last one of this step still runs), one k_gather per step, an
+    unrelated kernel before the span -- the span starts at the first k_bounce of the last two steps, the union counts
+    overlapped time once, the sum counts it twice."""
+    rows = [("void at::native::fill(float)", 0, 50),
+            ("void (anonymous namespace)::k_bounce<0, true, 0, true, true, false>((anonymous namespace)::BounceArgs)", 1000, 1400),
+            ("void (anonymous namespace)::k_bounce<0, true, 0, true, false, false>((anonymous namespace)::BounceArgs)", 1400, 2000),
+            ("(anonymous namespace)::k_gather(float*)", 2000, 2100),
+            ("void (anonymous namespace)::k_bounce<0, true, 0, true, true, false>((anonymous namespace)::BounceArgs)", 1800, 2300),   # step 2 starts early
+            ("void (anonymous namespace)::k_bounce<0, true, 0, true, false, false>((anonymous namespace)::BounceArgs)", 2300, 2900),
+            ("(anonymous namespace)::k_gather(float*)", 2900, 3000)]
+    p = tmp_path / "t_kernel_trace.csv"
+    with open(p, "w") as f:
+        f.write('"Kind","Kernel_Name","Start_Timestamp","End_Timestamp"\n')
+        for name, s, e in rows:
+            f.write('"KERNEL_DISPATCH","%s",%d,%d\n' % (name, s, e))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "tools", "trace_overlap.py"), str(p), "2", "2"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    text = out.stdout
+    assert "span 2.0 us = 0.0010 ms per step" in text                    # 1000 .. 3000 ns
+    assert "some kernel of the session running: 2.0 us" in text          # no gap inside the span
+    assert "sum of the kernels' own durations:   2.3 us" in text and "1.15 x the span" in text      # 400 + 600 + 100 + 500 + 600 + 100 ns
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "tools", "trace_overlap.py"), str(p), "3", "2"],
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and "only 4 k_bounce launches" in (bad.stderr + bad.stdout)
