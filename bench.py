@@ -778,7 +778,7 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
     construction.  Without a counter profile of exactly this build and command line (profiles/collect.py ->
     profiles/traffic.json) the counter-derived fields are null rather than stale.
     The event pass runs its steps one after the other on the launch stream; in the timed pass consecutive steps overlap
-    on the device (csrc/ptmi355.hip: enqueue_batch_direct), so `value` can exceed `grays_per_s_in_kernel`.
+    on the device (csrc/pt_h_enqueue.hpp: enqueue_batch_direct), so `value` can exceed `grays_per_s_in_kernel`.
     `timed_pass` therefore states the same issue cycles -- of every profiled kernel of a step -- over the timed
     pass's own time per step: the share of the chip's issue cycles the whole pipeline used while `value` was measured."""
     steps = args.steps

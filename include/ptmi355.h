@@ -312,7 +312,7 @@ int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxe
 /* host-only (no GPU): the per-triangle spheres of the every-triangle loop's first stage for ONE mesh of `count` triangles and
  * ray origins with |origin|_1 <= origin_bound: bounds = ((count + 3) & ~3) x {centre xyz, Rs^2} (padding entries: Rs^2 = -1).
  * A ray whose line passes a centre at more than Rs is never accepted for that triangle by the completion spec
- * (glm::intersectRayTriangle + the hit-point test; csrc/ptmi355.hip: make_tri_bounds has the derivation), so the kernel
+ * (glm::intersectRayTriangle + the hit-point test; csrc/pt_h_scene.hpp: make_tri_bounds has the derivation), so the kernel
  * does not run the exact test for the pair.  Returns the number of entries written. */
 int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, float *bounds);
 /* ---- known-answer probes: the DEVICE's own arithmetic on caller data (no session needed, any HIP device) -------

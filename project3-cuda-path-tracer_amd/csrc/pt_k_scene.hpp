@@ -83,7 +83,7 @@ __device__ __forceinline__ cfloat *as_const(const float *p) {
 // length) and the normal -- ~1550 instructions per ray on Cornell although only ~1.25 primitives per ray are hit.
 //
 //  1. CULL.  Per primitive a world-space box, computed at pt_init, that contains every ray the reference's own
-//     float arithmetic could report a hit for (ptmi355.hip: make_cull_boxes, with the error bound).  All lanes
+//     float arithmetic could report a hit for (pt_h_scene.hpp: upload_cull / pt_cull.hpp, with the error bound).  All lanes
 //     test their ray against it with one v_rcp per axis per RAY and six fused multiply-adds + min/max per
 //     primitive (the box comes from wave-uniform scalar loads).  This test only decides which exact tests run,
 //     never their outcome, so it may be approximate as long as it errs towards "candidate": rays outside the

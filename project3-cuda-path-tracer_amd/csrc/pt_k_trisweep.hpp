@@ -14,7 +14,7 @@ namespace {
 //     accepts can report: the spec's hit-point test (tri_point_ok) only counts a triangle whose reported point
 //     P = fl(o + fl(d * tz)) lies inside the triangle's box widened by the mesh's pad, P lies within
 //     sqrt3 * 2^-23 (|o| + |P|) of the ray's line, and the test below misplaces that line by less than
-//     2^-20 (R + |c|) (R = the |origin|_1 bound of the non-wild rays: ptmi355.hip, tri_bounds, with the error budget)
+//     2^-20 (R + |c|) (R = the |origin|_1 bound of the non-wild rays: pt_h_scene.hpp, make_tri_bounds, with the error budget)
 //     -- so a ray whose line passes the centre at more than Rs cannot be accepted for this triangle, whatever
 //     glm::intersectRayTriangle's float arithmetic returns for it.  All lanes test their ray against it:
 //     q = c x d' - o x d' (d' = d scaled to unit length, o x d' hoisted per ray), |q|^2 > Rs^2 -> skip: six fused

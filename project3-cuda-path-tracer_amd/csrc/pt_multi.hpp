@@ -3,7 +3,7 @@
 //
 // The reference renders on one device chosen by the host (cudaGLSetGLDevice(0), preview.cpp:107) and keeps its
 // renderer state in file-static globals (pathtrace.cu:70-75).  Here a session owns one CONTEXT per device
-// (ptmi355.hip: Renderer); with one device the exported functions run the context on the caller's thread, exactly
+// (pt_h_session.hpp: Renderer); with one device the exported functions run the context on the caller's thread, exactly
 // as before.  With several (pt_scene_desc::devices / num_devices, or PTMI355_DEVICES in the environment -- so the
 // reference's host needs no change at all):
 //
@@ -366,7 +366,7 @@ int multi_refresh(void) {
 
 // the launches of one call on every device, the packing of the tiles, then the exchange
 // `overlap`: the caller does not wait for this call (pt_trace_batch_async): consecutive batches may overlap on each
-// device's lanes (ptmi355.hip: enqueue_batch_direct); their gathers stay on the launch stream, which the packing waits on
+// device's lanes (pt_h_enqueue.hpp: enqueue_batch_direct); their gathers stay on the launch stream, which the packing waits on
 // the exchange thread has enqueued everything it was given (an error of its own is the caller's now)
 int exchange_settled(void) {
     if (!G.x) return PT_OK;

@@ -8,7 +8,7 @@ identical to the 1-GPU run.  The only collective on the path brings the tiles' r
   i+1 traces.  Copies are exact, so the assembled frame is bit-identical to a 1-GPU frame.
 * `reduce_frame`: sum of the zero-padded full-frame buffers (N*12 B per rank); adding zeros is exact, same result.
 
-The same row arithmetic lives in csrc/pt_types.hpp:local_to_pixel and csrc/ptmi355.hip:tile_rows."""
+The same row arithmetic lives in csrc/pt_types.hpp:local_to_pixel and csrc/pt_h_session.hpp:tile_rows."""
 import numpy as np
 
 

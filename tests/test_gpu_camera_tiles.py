@@ -80,7 +80,7 @@ def test_tile_order_matches_host_sharding(pt, scenes):
 
 @pytest.mark.parametrize("aa", [False, True])
 def test_camera_tile_mask(pt, po, scenes, aa):
-    """Bounce 0 of the mesh pre-pass skips the 64-pixel tiles that cannot see a mesh (ptmi355.hip: update_cam_mask).
+    """Bounce 0 of the mesh pre-pass skips the 64-pixel tiles that cannot see a mesh (pt_h_scene.hpp: update_cam_mask).
     Same frames as the oracle with the mesh in full view, half off-screen, seen from very close, from INSIDE its box
     (a corner behind the eye: no mask), and as the camera moves between batches (pt_set_camera rebuilds the mask)."""
     s = scenes["cornell_64"]

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 def test_c2_one_iteration_per_call_overlapped(pt, scenes, monkeypatch):
     """C2 at full size through the reference's call pattern, enqueued back to back: every call is ONE k_iteration launch on a
-    PARTIAL grid (csrc/ptmi355.hip: iter_grid_for) overlapping its neighbours on the lanes.  Image, ray count and per-bounce
+    PARTIAL grid (csrc/pt_h_enqueue.hpp: iter_grid_for) overlapping its neighbours on the lanes.  Image, ray count and per-bounce
     live counts equal those of the same calls waited for one by one (whole grid, in-launch finalGather), which
     test_c2_full_iteration pins to the oracle and the golden image."""
     s = scenes["cornell"]
@@ -49,7 +49,7 @@ def test_c2_one_iteration_per_call_overlapped(pt, scenes, monkeypatch):
 
 def test_overlapped_small_batches(pt, po, scenes, monkeypatch):
     """Consecutive small batches whose caller does not wait (pt_trace_batch_async, PT_ASYNC_IMAGE) overlap on lanes
-    that share two launch streams (csrc/ptmi355.hip: enqueue_batch_direct).  The image after every call, the ray counters and the
+    that share two launch streams (csrc/pt_h_enqueue.hpp: enqueue_batch_direct).  The image after every call, the ray counters and the
     per-bounce statistics equal the serial plan's and the oracle's: batch sizes mixed with larger (serial) batches,
     the camera moved and the trace depth changed in between, synchronous calls in between, a second session."""
     s = scenes["cornell_64"]
