@@ -1,0 +1,69 @@
+// sqrt_exhaustive.hip -- is the Newton / Markstein form of sqrt and 1/sqrt EXACTLY the IEEE result on this chip?
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o sqrt_exhaustive sqrt_exhaustive.hip && ./sqrt_exhaustive
+// For every positive normal binary32 x: s_new = markstein(x) against s_ref = the compiler's correctly rounded sqrtf(x),
+// and inv_new (two corrections from 2h) against 1.0f / s_ref (correctly rounded divide).  Prints mismatch counts per
+// binade, so that the range gates of csrc/pt_device.hpp can be set where the counts are zero.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+
+__device__ __forceinline__ void fast_pair(float x, float &s, float &inv) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    const float d = __builtin_fmaf(-g, g, x);
+    s = __builtin_fmaf(d, h, g);
+    float q = h + h;
+    float e = __builtin_fmaf(-s, q, 1.0f);
+    q = __builtin_fmaf(e, q, q);
+    e = __builtin_fmaf(-s, q, 1.0f);
+    inv = __builtin_fmaf(e, q, q);
+}
+
+// per binade (biased exponent 1..254): [0] sqrt mismatches, [1] reciprocal mismatches
+__global__ void k_check(unsigned long long *bad, uint32_t *first) {
+    const uint32_t e = blockIdx.y + 1;                                   // biased exponent
+    unsigned long long b0 = 0, b1 = 0;
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < (1u << 23); m += gridDim.x * blockDim.x) {
+        const uint32_t bits = (e << 23) | m;
+        const float x = __uint_as_float(bits);
+        float s, inv;
+        fast_pair(x, s, inv);
+        const float s_ref = __builtin_sqrtf(x);
+        const float inv_ref = 1.0f / s_ref;
+        if (__float_as_uint(s) != __float_as_uint(s_ref)) { ++b0; atomicMin(&first[2 * e], bits); }
+        if (__float_as_uint(inv) != __float_as_uint(inv_ref)) { ++b1; atomicMin(&first[2 * e + 1], bits); }
+    }
+    if (b0) atomicAdd(&bad[2 * e], b0);
+    if (b1) atomicAdd(&bad[2 * e + 1], b1);
+}
+
+int main() {
+    unsigned long long *d_bad; uint32_t *d_first;
+    hipMalloc(&d_bad, 512 * 8); hipMemset(d_bad, 0, 512 * 8);
+    hipMalloc(&d_first, 512 * 4); hipMemset(d_first, 0xff, 512 * 4);
+    hipLaunchKernelGGL(k_check, dim3(256, 254), dim3(256), 0, 0, d_bad, d_first);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
+    std::vector<unsigned long long> bad(512); std::vector<uint32_t> first(512);
+    hipMemcpy(bad.data(), d_bad, 512 * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(first.data(), d_first, 512 * 4, hipMemcpyDeviceToHost);
+    unsigned long long t0 = 0, t1 = 0;
+    int lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;          // widest clean run of binades around 2^0 (biased 127)
+    for (int e = 127; e >= 1 && !bad[2 * e]; --e) lo0 = e;
+    for (int e = 127; e <= 254 && !bad[2 * e]; ++e) hi0 = e;
+    for (int e = 127; e >= 1 && !bad[2 * e + 1]; --e) lo1 = e;
+    for (int e = 127; e <= 254 && !bad[2 * e + 1]; ++e) hi1 = e;
+    for (int e = 1; e <= 254; ++e) {
+        t0 += bad[2 * e]; t1 += bad[2 * e + 1];
+        if (bad[2 * e] || bad[2 * e + 1])
+            printf("binade 2^%d: sqrt mismatches %llu (first bits 0x%08x), reciprocal mismatches %llu (first 0x%08x)\n", e - 127,
+                   bad[2 * e], first[2 * e], bad[2 * e + 1], first[2 * e + 1]);
+    }
+    printf("all positive normal floats: sqrt mismatches %llu, 1/sqrt mismatches %llu of %llu\n", t0, t1, 254ull << 23);
+    printf("sqrt exact for every x in [2^%d, 2^%d); reciprocal of the root exact for every x in [2^%d, 2^%d)\n", lo0 - 127, hi0 - 126, lo1 - 127, hi1 - 126);
+    return 0;
+}
