@@ -326,10 +326,15 @@ int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, f
  * `first_bits`, reduced to sum[0] = sum over k of bits(sin) * (2k + 1), sum[1] = the same for cos (mod 2^64): the
  * oracle computes the same two sums on the CPU, so every float of [0, 2 pi] can be compared without moving 9 GB.
  * pt_probe_hemisphere: calculateRandomDirectionInHemisphere (interactions.h:10-42) for n (normal, engine seed)
- * pairs; dirs = n x 3 floats. */
+ * pairs; dirs = n x 3 floats.
+ * pt_probe_sqrt: the kernels' sqrt and 1 / sqrt (glm::length / glm::normalize, func_geometric.inl:94-100,153-159:
+ * Newton's iteration on v_rsq_f32, csrc/pt_device.hpp: sqrt_newton) against the correctly rounded sqrtf and divide, for
+ * the `n` consecutive binary32 values from bit pattern `first_bits` on: mismatch[0] = arguments whose root differs,
+ * mismatch[1] = whose reciprocal of the root differs.  Zero for every x in [2^-102, 2^128). */
 int pt_probe_rng(const uint32_t *seeds, int n, int draws, uint32_t *state, float *u);
 int pt_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, float *s, float *c, uint64_t sum[2]);
 int pt_probe_hemisphere(const float *normals, const uint32_t *seeds, int n, float *dirs);
+int pt_probe_sqrt(uint32_t first_bits, uint32_t n, uint64_t mismatch[2]);
 /* devices of the current session (0: not initialised) and how their tiles reach devices[0]: "rccl", "peer"
  * (hipMemcpyPeerAsync) or "none" (one device) */
 int pt_num_devices(void);

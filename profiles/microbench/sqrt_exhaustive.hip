@@ -8,6 +8,9 @@
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
+#ifndef VARIANT
+#define VARIANT 0
+#endif
 
 __device__ __forceinline__ void fast_pair(float x, float &s, float &inv) {
     const float y = __builtin_amdgcn_rsqf(x);
@@ -17,11 +20,34 @@ __device__ __forceinline__ void fast_pair(float x, float &s, float &inv) {
     h = __builtin_fmaf(h, r, h);
     const float d = __builtin_fmaf(-g, g, x);
     s = __builtin_fmaf(d, h, g);
+#if VARIANT == 0          // two corrections from 2h
     float q = h + h;
     float e = __builtin_fmaf(-s, q, 1.0f);
     q = __builtin_fmaf(e, q, q);
     e = __builtin_fmaf(-s, q, 1.0f);
     inv = __builtin_fmaf(e, q, q);
+#elif VARIANT == 1        // ... from the float one ulp above 2h (a start at or above 1/s: the all-ones roots need it)
+    float q = __uint_as_float(__float_as_uint(h + h) + 1u);
+    float e = __builtin_fmaf(-s, q, 1.0f);
+    q = __builtin_fmaf(e, q, q);
+    e = __builtin_fmaf(-s, q, 1.0f);
+    inv = __builtin_fmaf(e, q, q);
+#elif VARIANT == 2        // one correction from one ulp above 2h
+    float q = __uint_as_float(__float_as_uint(h + h) + 1u);
+    float e = __builtin_fmaf(-s, q, 1.0f);
+    inv = __builtin_fmaf(e, q, q);
+#elif VARIANT == 3        // the multiplier of both corrections stays the start value (as csrc/pt_device.hpp: div_by_rcp keeps r)
+    const float r0 = __uint_as_float(__float_as_uint(h + h) + 1u);
+    float q = r0;
+    float e = __builtin_fmaf(-s, q, 1.0f);
+    q = __builtin_fmaf(e, r0, q);
+    e = __builtin_fmaf(-s, q, 1.0f);
+    inv = __builtin_fmaf(e, r0, q);
+#elif VARIANT == 4        // one correction from 2h
+    float q = h + h;
+    float e = __builtin_fmaf(-s, q, 1.0f);
+    inv = __builtin_fmaf(e, q, q);
+#endif
 }
 
 // per binade (biased exponent 1..254): [0] sqrt mismatches, [1] reciprocal mismatches
@@ -59,10 +85,11 @@ int main() {
     for (int e = 127; e <= 254 && !bad[2 * e + 1]; ++e) hi1 = e;
     for (int e = 1; e <= 254; ++e) {
         t0 += bad[2 * e]; t1 += bad[2 * e + 1];
-        if (bad[2 * e] || bad[2 * e + 1])
+        if ((bad[2 * e] || bad[2 * e + 1]) && getenv("VERBOSE"))
             printf("binade 2^%d: sqrt mismatches %llu (first bits 0x%08x), reciprocal mismatches %llu (first 0x%08x)\n", e - 127,
                    bad[2 * e], first[2 * e], bad[2 * e + 1], first[2 * e + 1]);
     }
+    printf("variant %d: ", VARIANT);
     printf("all positive normal floats: sqrt mismatches %llu, 1/sqrt mismatches %llu of %llu\n", t0, t1, 254ull << 23);
     printf("sqrt exact for every x in [2^%d, 2^%d); reciprocal of the root exact for every x in [2^%d, 2^%d)\n", lo0 - 127, hi0 - 126, lo1 - 127, hi1 - 126);
     return 0;

@@ -150,6 +150,7 @@ def library():
             L.pt_probe_rng.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
             L.pt_probe_sincos.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
             L.pt_probe_hemisphere.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+            L.pt_probe_sqrt.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         except AttributeError:
             if not os.environ.get("PTMI355_LIB"):        # only an older A/B build (profiles/tools/ab.sh) may lack them
                 raise
@@ -422,6 +423,14 @@ def probe_sincos_sums(first_bits, count):
     pattern `first_bits` on -- what oracle.pyoracle.sincos_sums computes on the CPU."""
     out = np.zeros(2, dtype=np.uint64)
     _chk(library().pt_probe_sincos(None, int(first_bits), int(count), None, None, _p(out)))
+    return int(out[0]), int(out[1])
+
+
+def probe_sqrt(first_bits, count):
+    """(arguments whose sqrt differs, whose 1 / sqrt differs) between the kernels' Newton forms and the correctly rounded sqrtf /
+    divide, over the `count` consecutive float32 values from bit pattern `first_bits` on."""
+    out = np.zeros(2, dtype=np.uint64)
+    _chk(library().pt_probe_sqrt(int(first_bits), int(count), _p(out)))
     return int(out[0]), int(out[1])
 
 

@@ -208,19 +208,37 @@ PTD float div_by_rcp(float n, float d, float r) {
     e = __builtin_fmaf(-d, q, n);
     return __builtin_fmaf(e, r, q);
 }
-// Correctly rounded sqrt without hipcc's prescale / class fix-up (16 -> 9 instructions): v_sqrt_f32
-// (1 ulp) followed by the same two residual tests the compiler emits, picking s-1ulp, s or s+1ulp.
-// Valid for 2^-96 <= x < inf (below that the compiler's sequence rescales; 0 and inf take its
-// class path).
+// Correctly rounded sqrt and 1 / sqrt by Newton's iteration on v_rsq_f32 (round 5; rounds 2-4: v_sqrt_f32 and the
+// compiler's two residual tests, then v_rcp_f32 + a refinement for the reciprocal -- 9 + 7 instructions of which six
+// issue at half rate):  y = rsq(x);  g = x y;  h = y / 2;  r = 1/2 - h g;  g += g r;  h += h r;  s = g + h (x - g^2)
+// (Markstein's form: eight instructions, one of them transcendental) and, for glm::normalize's 1 / s, two corrections
+// q += q (1 - s q) from the float one ulp ABOVE 2h -- a start at or above 1 / s: from 2h itself the two roots per odd
+// binade whose mantissa is all ones (1 / s a hair above a midpoint next to a power of two) end on the tie and round down.
+// EXACT -- s = RN(sqrt x), q = RN(1 / s), bit for bit the compiler's correctly rounded sqrtf and divide -- for EVERY
+// binary32 x in [2^-102, 2^128): checked exhaustively on the device (profiles/microbench/sqrt_exhaustive.hip: variant 1,
+// 1.93 * 10^9 arguments; tests/test_gpu_pins.py runs the same sweep through pt_probe_sqrt).  The callers' gates
+// (2^-96 <= x for the root, 2^-80 <= x <= 2^80 for normalize) lie inside.
+PTD void sqrt_newton(float x, float &s, float &h) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y;
+    h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    s = __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+}
 PTD float sqrt_normal_range(float x) {
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float sm = __uint_as_float(__float_as_uint(s) - 1u);
-    const float sp = __uint_as_float(__float_as_uint(s) + 1u);
-    const float e1 = __builtin_fmaf(-sm, s, x);
-    const float e2 = __builtin_fmaf(-sp, s, x);
-    float r = (0.0f >= e1) ? sm : s;
-    r = (0.0f < e2) ? sp : r;
-    return r;
+    float s, h;
+    sqrt_newton(x, s, h);
+    return s;
+}
+// s = RN(sqrt x) and RN(1 / s)
+PTD float rsqrt_of_root(float x) {
+    float s, h;
+    sqrt_newton(x, s, h);
+    float q = __uint_as_float(__float_as_uint(h + h) + 1u);
+    q = __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), q, q);
+    return __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), q, q);
 }
 // every active lane agrees: no lane votes against.  (__all() compiles to select 0/1 + compare + compare with exec;
 // the ballot of the NEGATED predicate is the two v_cmp themselves and one scalar compare with zero.)
@@ -245,8 +263,7 @@ PTD bool all_in_range(float x, float lo, float hi) {
 }
 // glm normalize, v * (1 / sqrt(dot)), for 2^-80 <= dot <= 2^80 (sqrt and divide both rescale-free)
 PTD f3 normalize_normal_range(f3 a, float dt) {
-    const float s = sqrt_normal_range(dt);
-    return scale(a, div_by_rcp(1.0f, s, rcp_refined(s)));
+    return scale(a, rsqrt_of_root(dt));
 }
 // Wave-uniform gate for the rescale-free paths of one cube test, evaluated BEFORE the direction is
 // normalised (the squares are the ones the dot product needs anyway): with v = M^-1 d, x = |v|^2,

@@ -951,5 +951,6 @@ int pt_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, float *s, f
     return one::pt_probe_sincos(x, first_bits, n, s, c, sum);
 }
 int pt_probe_hemisphere(const float *normals, const uint32_t *seeds, int n, float *dirs) { return one::pt_probe_hemisphere(normals, seeds, n, dirs); }
+int pt_probe_sqrt(uint32_t first_bits, uint32_t n, uint64_t mismatch[2]) { return one::pt_probe_sqrt(first_bits, n, mismatch); }
 
 }  // extern "C"

@@ -33,6 +33,20 @@ __global__ void k_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, 
     if (sum) { atomicAdd(&sum[0], as); atomicAdd(&sum[1], ac); }
 }
 
+__global__ void k_probe_sqrt(uint32_t first_bits, uint32_t n, unsigned long long *bad) {
+    unsigned long long b0 = 0, b1 = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(first_bits + (uint32_t)k);
+        const float s = ptd::sqrt_normal_range(x), q = ptd::rsqrt_of_root(x);
+        const float s_ref = __builtin_sqrtf(x);                  // (hipcc: correctly rounded by default)
+        const float q_ref = 1.0f / s_ref;
+        b0 += __float_as_uint(s) != __float_as_uint(s_ref);
+        b1 += __float_as_uint(q) != __float_as_uint(q_ref);
+    }
+    if (b0) atomicAdd(&bad[0], b0);
+    if (b1) atomicAdd(&bad[1], b1);
+}
+
 __global__ void k_probe_hemisphere(const float *normals, const uint32_t *seeds, int n, float *dirs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -91,6 +105,21 @@ int pt_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, float *s, f
     if (s) HIPCHK(hipMemcpy(s, d_s, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (c) HIPCHK(hipMemcpy(c, d_c, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (sum) HIPCHK(hipMemcpy(sum, d_sum, 16, hipMemcpyDeviceToHost));
+    HIPCHK(hipDeviceSynchronize());
+    return PT_OK;
+}
+
+int pt_probe_sqrt(uint32_t first_bits, uint32_t n, uint64_t mismatch[2]) {
+    if (!mismatch) return fail(PT_ERR_INVALID, "pt_probe_sqrt: null result");
+    mismatch[0] = mismatch[1] = 0;
+    if (n == 0) return PT_OK;
+    ProbeBufs b;
+    unsigned long long *d_bad = (unsigned long long *)b.get(16, nullptr);
+    if (!d_bad) { (void)hipGetLastError(); return fail(PT_ERR_DEVICE, "pt_probe_sqrt: no HIP device / out of memory (this library has no CPU fallback)"); }
+    const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_probe_sqrt, dim3(blocks), dim3(256), 0, 0, first_bits, n, d_bad);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(mismatch, d_bad, 16, hipMemcpyDeviceToHost));
     HIPCHK(hipDeviceSynchronize());
     return PT_OK;
 }

@@ -111,3 +111,22 @@ def test_shared_sincos_every_argument(pt, po):
     for x, sv, cv in zip(xs, s, c):
         ws, wc = po.sincos(float(x))
         assert (bits(np.float32(sv)), bits(np.float32(cv))) == (bits(np.float32(ws)), bits(np.float32(wc))), float(x)
+
+
+def test_newton_sqrt_every_argument(pt):
+    """glm::length and glm::normalize run sqrt and 1 / sqrt through Newton's iteration on v_rsq_f32 (csrc/pt_device.hpp:
+    sqrt_newton, round 5) instead of v_sqrt_f32 + residual tests and v_rcp_f32 + refinement.  The replacement is only
+    admissible if it is EXACTLY the correctly rounded sqrtf / divide: checked here on every binary32 x in [2^-102, 2^128)
+    -- 1.93 * 10^9 arguments, binade by binade -- and the callers' gates (x >= 2^-96 for the root, 2^-80 <= x <= 2^80
+    for the normalisation) are inside that range.  Outside it the forms DO differ (subnormal intermediates): counted
+    too, so that the test would notice if the sweep were not comparing anything."""
+    lo, hi = 127 - 102, 254                     # biased exponents of 2^-102 and 2^127
+    bad = [0, 0]
+    for e in range(lo, hi + 1, 8):
+        n = (min(hi + 1, e + 8) - e) << 23
+        a, b = pt.probe_sqrt(e << 23, n)
+        bad[0] += a; bad[1] += b
+        assert (a, b) == (0, 0), "binades 2^%d..: sqrt mismatches %d, 1 / sqrt mismatches %d" % (e - 127, a, b)
+    below = pt.probe_sqrt(1 << 23, 16 << 23)   # 2^-126 .. 2^-110: outside the gates
+    assert below[0] > 0 and below[1] > 0
+    assert pt.probe_sqrt(0x3f800000, 0) == (0, 0)
