@@ -39,6 +39,8 @@ int upload_cull(const pt_scene_desc *d, const pt_camera &cam) {
         if (ax == 4 && pt_experiment("PTMI355_NO_ROW_REJECT")) ax = 3;
         const int tw = d->geoms[i].type | (ax << 8);
         memcpy(&r[6], &tw, 4);
+        const uint32_t ent = ((uint32_t)d->geoms[i].type << 7) | ((uint32_t)i << 9);     // the candidate ring's entry for this geom
+        memcpy(&r[11], &ent, 4);
     }
     if (!R.d_cull) HIPCHK(hipMalloc(&R.d_cull, rec.size() * 4));
     HIPCHK(hipMemcpyAsync(R.d_cull, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, R.stream));

@@ -27,37 +27,23 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
     const uint64_t m_act = ballot64(active), m_wild = ballot64(cr.wild);
     CULL_STAT(0, 1); CULL_STAT(5, __popcll((unsigned long long)ballot64(active && cr.wild))); CULL_STAT(6, __popcll((unsigned long long)ballot64(active)));
     const uint32_t tag = (uint32_t)lane | ((uint32_t)par << 6);
-    const int ngeoms = sc.ngeoms;
-    // the records come through wave-uniform scalar loads (s_load_dwordx8 + x4).  Round 2 requested the next primitive's
-    // record before using this one's (its latency then overlaps the test); by round 3 the eleven scalar registers that
-    // keeps alive across the loop cost more than the latency -- the kernel spilled 47 scalar values into VGPR lanes and
-    // reloaded 28 of them per tile; without the prefetch it spills 34, and every configuration gained 2-6 %
-    // (profiles/r03/variants_cull_prefetch.log).  -DPT_CULL_PREFETCH brings it back.
-#ifdef PT_CULL_PREFETCH
-    float nxt[11];
-    {
-        cfloat *c0 = as_const(sc.cull);
+    // The records come through wave-uniform scalar loads (s_load_dwordx8 + x4), walked by POINTER: the geom's number is
+    // only needed on the rare paths (bounce-0 masks, meshes) and the candidate ring's entry -- type << 7 | geom << 9 -- is
+    // word 11 of the record (round 5: k_bounce's scalar pipe is as full as its vector pipe; a loop counter and three
+    // scalar instructions per queued primitive to build that entry were among the 43 scalar instructions per primitive).
+    // Round 2 requested the next primitive's record before using this one's; by round 3 the eleven scalar registers that
+    // keeps alive across the loop cost more than the latency (profiles/r03/variants_cull_prefetch.log).
+    cfloat *cc = as_const(sc.cull);
+    cfloat *const cc_end = cc + sc.ngeoms * CULL_WORDS;
+    for (; cc != cc_end; cc += CULL_WORDS) {
+        float cb[12];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) nxt[k] = ngeoms > 0 ? c0[k] : 0.0f;
-    }
-#endif
-    for (int g = 0; g < ngeoms; ++g) {
-        float cb[11];
-#ifndef PT_CULL_PREFETCH
-        {
-            cfloat *cc = as_const(sc.cull) + g * CULL_WORDS;
-#pragma unroll
-            for (int k = 0; k < 11; ++k) cb[k] = cc[k];
-        }
-#else
-#pragma unroll
-        for (int k = 0; k < 11; ++k) cb[k] = nxt[k];
-        if (g + 1 < ngeoms) {
-            cfloat *cn = as_const(sc.cull) + (g + 1) * CULL_WORDS;
-#pragma unroll
-            for (int k = 0; k < 11; ++k) nxt[k] = cn[k];
-        }
-#endif
+        for (int k = 0; k < 12; ++k) cb[k] = cc[k];
+        uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cb[11]));     // type << 7 | geom << 9 (wave-uniform)
+        // (pinned here: left to itself the compiler sinks this one load into the branch that queues the candidates, where its
+        // latency is exposed once per primitive; with the record's other words it costs nothing)
+        asm volatile("" : "+s"(ent));
+        const int g = (int)(ent >> 9);
         // bounce 0: primitives no camera ray of this tile is a candidate of (k_cull0_mask, bit g of the tile's word)
         if (masked && !((gmask >> (g & 63)) & 1ull)) continue;
         const int tw = __float_as_int(cb[6]);
@@ -93,7 +79,7 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
         if (m) {
             if (lane_of(m)) {
                 const uint32_t s = (q.total + rank_below(m)) & (Q_SLOTS - 1);
-                q.ring()[s] = tag | ((uint32_t)type << 7) | ((uint32_t)g << 9);
+                q.ring()[s] = tag | ent;
             }
             q.total += (uint32_t)__popcll((unsigned long long)m);
             CULL_STAT(1, __popcll((unsigned long long)m));

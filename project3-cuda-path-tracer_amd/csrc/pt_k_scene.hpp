@@ -30,7 +30,7 @@ constexpr int PW_WIN = PW_BEST + 2 * 64 * 2;             // float[2][3][64]: win
 constexpr int PW_RAYS = PW_WIN + 2 * 64 * 3;             // float[2][6][64]: ro.xyz rd.xyz of the tile's paths
 constexpr int PW_WORDS = PW_RAYS + 2 * 6 * 64;           // 1536 dwords = 6 KiB per wave: six workgroups fit a CU's 160 KiB beside a
                                                          // Cornell-sized scene block (round 2: 6.5 KiB, float4 winner records, five)
-constexpr int CULL_WORDS = 12;       // per geom, scalar-loaded: centre.x half.x centre.y half.y centre.z half.z (of the padded world box) | type + (reject mode << 8) | the reject row:
+constexpr int CULL_WORDS = 12;       // per geom (word 11 = type << 7 | geom << 9, the candidate ring's entry), scalar-loaded: centre.x half.x centre.y half.y centre.z half.z (of the padded world box) | type + (reject mode << 8) | the reject row:
                                      //   m_k0 m_k1 m_k2 m_k3 | spare (48 B: one s_load_dwordx8 + one s_load_dwordx4)
 
 __host__ __device__ constexpr int scene_lds_words(int nmats, int ngeoms) {
@@ -148,10 +148,41 @@ __device__ __forceinline__ bool cull_box(const CullRay &c, float cx, float hx, f
 // One function for k_bounce / k_intersect and for k_cull0_mask, which memoises "some lane" per camera tile.
 // Returns the WAVE MASK of the candidate lanes: every compare goes straight to a scalar register pair and the
 // combination -- box and not(early miss) or wild -- is scalar mask arithmetic, not per-lane selects.
+#ifndef PT_CULL_ROW
+#define PT_CULL_ROW 1
+#endif
 __device__ __forceinline__ uint64_t cull_candidates(const CullRay &cr, uint64_t m_wild, f3 ro, f3 rd, float cx, float hx,
                                                     float cy, float hy, float cz, float hz, int tw, float m0, float m1,
                                                     float m2, float m3) {
     uint64_t keep = ballot64(cull_box(cr, cx, hx, cy, hy, cz, hz));
+#if PT_CULL_ROW == 2
+    // one straight-line form for every mode (the rows of modes 0..2 hold exact zeros off the diagonal, mode 3's row is all
+    // zeros): no scalar dispatch per primitive, eight vector instructions more for a diagonal row
+    {
+        (void)tw;
+        const float qk = (m0 * ro.x + m1 * ro.y) + (m2 * ro.z + m3);
+        const float vk = (m0 * rd.x + m1 * rd.y) + m2 * rd.z;
+        keep &= ~(ballot64(__builtin_fabsf(qk) > 0.5f) & ballot64(qk * vk > 0.0f));
+    }
+#elif PT_CULL_ROW == 1
+    // Two forms instead of five.  A GENERAL row (mode 4) is evaluated in the reference's order.  Every other row has at most
+    // one non-zero entry beside the translation (modes 0..2: m_kk; mode 3: none, all zeros), so in
+    //   fma(m2, o_z, fma(m1, o_y, m0 o_x))
+    // two of the three products are exact zeros and the value is fl(m_kk o_k) exactly -- what the reference's
+    // m_kk o_k + 0 + 0 rounds to -- whichever k it is: no dispatch on the mode (round 5: the scalar pipe of k_bounce is as
+    // full as its vector pipe; the dispatch was a dozen scalar instructions per primitive), four vector instructions more.
+    {
+        float qk, vk;
+        if (tw & 0x400) {                                                 // mode 4
+            qk = (m0 * ro.x + m1 * ro.y) + (m2 * ro.z + m3);
+            vk = (m0 * rd.x + m1 * rd.y) + m2 * rd.z;                    // the reference adds m_k3 * 0.0f = +-0: same value when it matters
+        } else {
+            qk = __builtin_fmaf(m2, ro.z, __builtin_fmaf(m1, ro.y, m0 * ro.x)) + m3;
+            vk = __builtin_fmaf(m2, rd.z, __builtin_fmaf(m1, rd.y, m0 * rd.x));
+        }
+        keep &= ~(ballot64(__builtin_fabsf(qk) > 0.5f) & ballot64(qk * vk > 0.0f));
+    }
+#else
     const int rmode = (tw >> 8) & 7;                                     // wave-uniform; 0..2 diagonal row, 4 general row, 3 none
     if (rmode != 3) {
         float qk, vk;
@@ -167,6 +198,7 @@ __device__ __forceinline__ uint64_t cull_candidates(const CullRay &cr, uint64_t 
         }
         keep &= ~(ballot64(__builtin_fabsf(qk) > 0.5f) & ballot64(qk * vk > 0.0f));
     }
+#endif
     return keep | m_wild;
 }
 
