@@ -852,6 +852,17 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
                               "note": "40 B per pool row read (every ray but the camera rays, which are generated in registers) + 40 B per "
                                       "survivor written + 16 B per path ending with a non-zero colour (%.1f %% of the ending paths), averaged "
                                       "over the %d launches of a step like `traffic`" % (100 * nz, nl)}
+    # the scalar pipe beside it (round 5): one scalar ALU / branch / scalar-load instruction per ~4.4 cycles per SIMD, a wait
+    # or nop ~1.2 (profiles/r04/issue_ops_scalar.txt); executed counts from the same instrumented build.  It issues beside
+    # the vector pipe, so the two fractions do not add -- but when both are near 1 a cut on one side only moves the limit
+    sc_cyc = sum(k["launches_per_step"] * (4.42 * (k.get("wave_insts_per_launch", {}).get("salu", 0.0) + k.get("wave_insts_per_launch", {}).get("branch", 0.0) +
+                                                   k.get("wave_insts_per_launch", {}).get("smem", 0.0)) +
+                                           1.2 * k.get("wave_insts_per_launch", {}).get("sopp", 0.0)) for k in sel)
+    if sc_cyc:
+        r["scalar_issue"] = {"frac": round(sc_cyc / per_step_s / (SIMDS * PEAK_CLOCK_GHZ * 1e9), 4),
+                             "scalar_insts_per_ray": round(64.0 * sum(k["launches_per_step"] * sum(k.get("wave_insts_per_launch", {}).get(c, 0.0) for c in ("salu", "branch", "smem", "sopp"))
+                                                                      for k in sel) / max(1.0, rank_rays / steps), 1),
+                             "note": "scalar ALU + branch + scalar-load instructions x 4.42 cycles, waits / nops x 1.2, over 1024 SIMDs x 2.4 GHz x the kernel time"}
     cyc_all = sum(k["launches_per_step"] * k.get("issue_cycles_per_launch", 0.0) for k in ks.values())
     byt_all = sum(k["launches_per_step"] * k.get("hbm_bytes_per_launch", 0) for k in ks.values())
     if timed_step_s > 0:
