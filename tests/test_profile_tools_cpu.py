@@ -126,3 +126,41 @@ def test_trace_overlap_union_and_sum(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "tools", "trace_overlap.py"), str(p), "3", "2"],
                          capture_output=True, text=True)
     assert bad.returncode != 0 and "only 4 k_bounce launches" in (bad.stderr + bad.stdout)
+
+
+def test_line_cycles_by_source_line(tmp_path):
+    """profiles/tools/line_cycles.py: the toy kernel again, its assembly once without and once with .file / .loc
+    directives (what -gline-tables-only adds).  Executed instructions are priced like the histogram and land on the
+    source line of the nearest .loc above them; an assembly whose blocks differ from map.json's is refused."""
+    src, out, mp = tmp_path / "k.s", tmp_path / "k_counted.s", tmp_path / "map.json"
+    src.write_text(KERNEL)
+    run("instrument", str(src), "k_toy", str(out), str(mp))
+    m = json.loads(mp.read_text())
+    g = KERNEL.replace("\t.text\n_Z6k_toyP4Args:", '\t.text\n\t.file\t1 "/src" "toy.hip"\n_Z6k_toyP4Args:\n\t.loc\t1 10 0', 1)
+    g = g.replace("\tv_add_f32_e32 v1, v1, v0\n", "\t.loc\t1 20 3\n\tv_add_f32_e32 v1, v1, v0\n")
+    g = g.replace("\ts_add_i32 s2, s2, -1\n", "\t.loc\t1 21 3\n\ts_add_i32 s2, s2, -1\n")
+    g = g.replace("\tglobal_store_dword", "\t.loc\t1 30 1\n\tglobal_store_dword")
+    gs = tmp_path / "k_g.s"
+    gs.write_text(g)
+    counts = np.zeros(m["words"], dtype=np.uint32)
+    for bid, n in enumerate((2, 10, 2, 2)):
+        counts[bid] = n
+    cf = tmp_path / "c.u32"
+    counts.tofile(cf)
+    costs = tmp_path / "costs.json"
+    costs.write_text(json.dumps({"cycles": {"v_add_f32": 2.25, "v_fma_f32": 2.5, "v_mov_b32": 2.25}, "default": 4.0}))
+    tool = os.path.join(ROOT, "profiles", "tools", "line_cycles.py")
+    r = subprocess.run([sys.executable, tool, str(gs), "k_toy", str(mp), str(cf), str(costs), "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = {l.split()[0]: l.split() for l in r.stdout.split("\n") if l.startswith("toy.hip:")}
+    # line 20: the loop's add + fma, 10 executions in 2 launches; line 21: the v_mul after the back edge inherits the last
+    # .loc (2 executions, default price) and the loop's three scalar instructions (10 x 3 x 4.42)
+    text = r.stdout
+    assert "vector %.4g" % ((2 * 2.25 + 10 * 4.75 + 2 * 4.0) / 2) in text
+    assert "scalar %.4g" % ((2 * (3 * 4.42 + 1.2) + 10 * 3 * 4.42 + 2 * 4.42) / 2) in text
+    assert set(rows) == {"toy.hip:10", "toy.hip:20", "toy.hip:21", "toy.hip:30"}
+    assert rows["toy.hip:20"][-2:] == ["v_add_f32_e32:0.0", "v_fma_f32:0.0"]          # (per launch, in millions)
+    # another build: one instruction more in the loop
+    gs.write_text(g.replace("\tv_fma_f32 v1, v1, v0, v1\n", "\tv_fma_f32 v1, v1, v0, v1\n\tv_mov_b32_e32 v2, v1\n"))
+    bad = subprocess.run([sys.executable, tool, str(gs), "k_toy", str(mp), str(cf), str(costs), "2"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "not the same build" in (bad.stderr + bad.stdout)
