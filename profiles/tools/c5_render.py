@@ -21,7 +21,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05")
     devices = sys.argv[2] if len(sys.argv) > 2 else "0,0,0,0,0,0,0,0"
     os.makedirs(out, exist_ok=True)
     pt = ge.load_package()
@@ -41,7 +41,7 @@ def main():
     from PIL import Image
     Image.fromarray(np.clip(np.round(small), 0, 255).astype(np.uint8)).save(os.path.join(out, "c5_5000spp_960x540.png"), optimize=True)
     golden = {"png_stat": np.load(os.path.join(ROOT, "tests", "golden", "png_stat.npz"))}
-    from test_gpu_parity import c5_pooled_statistic
+    from test_gpu_camera_tiles import c5_pooled_statistic
     line = [l for l in p.stdout.splitlines() if "Mrays/s" in l][-1]
     rec = {"scene": "scenes/cornell_4k.txt", "resolution": [W, H], "iterations": 5000, "devices": devices, "batch": 4,
            "ptbench": line, "wall_s": round(wall, 2), "sum_md5": hashlib.md5(full.tobytes()).hexdigest(),
