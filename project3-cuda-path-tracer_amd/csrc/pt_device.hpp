@@ -37,6 +37,8 @@ PTD float sqrt_gated(float x);
 PTD float length(f3 a) { return length_gated(a); }
 // glm normalize: x * (1 / sqrt(dot(x,x)))   (func_geometric.inl:153-159)
 PTD f3 normalize(f3 a) { return normalize_gated(a); }
+// ... of a vector that already IS a unit vector up to rounding (the reference normalises those again: see normalize_unit)
+PTD f3 normalize_unit(f3 a);
 PTD f3 cross(f3 x, f3 y) {
     return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
 }
@@ -129,7 +131,7 @@ PTD f3 hemisphere(f3 normal, uint32_t &rng) {
     else if (__builtin_fabsf(normal.y) < SQRT_OF_ONE_THIRD) notN = mk(0, 1, 0);
     else notN = mk(0, 0, 1);
     f3 p1 = normalize(cross(normal, notN));
-    f3 p2 = normalize(cross(normal, p1));
+    f3 p2 = normalize_unit(cross(normal, p1));           // two perpendicular unit vectors
     float sa, ca;
     sincos_shared(around, sa, ca);
     return add(add(scale(normal, up), scale(p1, ca * over)), scale(p2, sa * over));
@@ -153,17 +155,19 @@ template <typename P> PTD f3 mv_point(P m, f3 v) {
     r.z = (m[2] * v.x + m[5] * v.y) + (m[8] * v.z + m[11]);
     return r;
 }
-// vec3(m * vec4(v, 0)): the m3 * 0.0f product is kept (it is +-0, or NaN for a non-finite matrix)
+// vec3(m * vec4(v, 0)): the m3 * 0.0f product is kept (it is +-0, or NaN for a non-finite matrix) -- as the addend's
+// multiplier of one fma: the product is EXACT, so fl(fl(m2 v.z) + m3 * 0) has the same single rounding, the same zero
+// signs and the same NaNs as the reference's multiply-then-add (three instructions less per call)
 template <typename P> PTD f3 mv_dir(P m, f3 v) {
     f3 r;
-    r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9] * 0.0f);
-    r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10] * 0.0f);
-    r.z = (m[2] * v.x + m[5] * v.y) + (m[8] * v.z + m[11] * 0.0f);
+    r.x = (m[0] * v.x + m[3] * v.y) + __builtin_fmaf(m[9], 0.0f, m[6] * v.z);
+    r.y = (m[1] * v.x + m[4] * v.y) + __builtin_fmaf(m[10], 0.0f, m[7] * v.z);
+    r.z = (m[2] * v.x + m[5] * v.y) + __builtin_fmaf(m[11], 0.0f, m[8] * v.z);
     return r;
 }
 
 // getPointOnRay (intersections.h:27-29): o + (t - .0001f) * normalize(d)
-PTD f3 point_on_ray(f3 o, f3 d, float t) { return add(o, scale(normalize(d), (t - .0001f))); }
+PTD f3 point_on_ray(f3 o, f3 d, float t) { return add(o, scale(normalize_unit(d), (t - .0001f))); }
 
 struct Hit {
     float t;        // world distance, FLT_MAX while nothing is hit
@@ -239,6 +243,24 @@ PTD float rsqrt_of_root(float x) {
     float q = __uint_as_float(__float_as_uint(h + h) + 1u);
     q = __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), q, q);
     return __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), q, q);
+}
+// fl(1 / fl(sqrt x)) -- glm::normalize's factor -- for x within 2^-12 of 1, i.e. for a vector that is a unit vector up to
+// rounding.  The reference normalises such vectors again in three places per bounce: q.direction in getPointOnRay
+// (intersections.h:27-29, inside both intersection tests), the path's ray in the shader's getPointOnRay, and the cross
+// product of two perpendicular unit vectors in the sampler (interactions.h:33-34).  With e = x - 1, 1 / sqrt(x) =
+// 1 - e/2 + 3 e^2 / 8 - ..., and the chain's two roundings (the root to nearest, then its reciprocal to nearest) come out as
+// "1 - e/2 rounded UP to a multiple of 2^-23": for x > 1 (e = k 2^-23) 1 - (k & ~1) 2^-24, for x < 1 (e = -k 2^-24)
+// 1 + ceil(k / 4) 2^-23.  Rounding up on that grid = rounding to nearest after adding 1.5 * 2^-25 (-e/2 is a multiple of
+// 2^-25: never a tie), done in [1, 2) where the grid is the float spacing: four additions, no transcendental, against
+// the fourteen instructions of rsqrt_of_root.  EXACT for every float from 1 - 8190 * 2^-24 to 1 + 2897 * 2^-23 (each of
+// the 11 088 checked against sqrtf and the divide: tests/test_arith_models_cpu.py; on the device by pt_probe_sqrt, whose
+// sweep takes this path inside the callers' gate [1 - 2^-12, 1 + 2^-12]).
+constexpr float NEAR_ONE_LO = 0x1.ffep-1f, NEAR_ONE_HI = 0x1.001p+0f;
+PTD float rsqrt_near_one(float x) {
+    const float e = x - 1.0f;                                   // exact
+    const float w = __builtin_fmaf(e, -0.5f, 0x1.8p-25f);        // exact: a multiple of 2^-26 below 2^-11
+    const float t = w + (1.0f + 0x1p-10f);                       // the one rounding, to nearest on [1, 2)'s grid
+    return t - 0x1p-10f;                                         // exact
 }
 // every active lane agrees: no lane votes against.  (__all() compiles to select 0/1 + compare + compare with exec;
 // the ballot of the NEGATED predicate is the two v_cmp themselves and one scalar compare with zero.)
@@ -359,6 +381,12 @@ PTD f3 normalize_gated(f3 a) {
     if (all_in_range(x, 8.271806125530277e-25f, 1.2089258196146292e24f)) return normalize_normal_range(a, x);
     return scale(a, 1.0f / __builtin_sqrtf(x));
 }
+PTD f3 normalize_unit(f3 a) {
+    const float x = dot(a, a);
+    if (all_in_range(x, NEAR_ONE_LO, NEAR_ONE_HI)) return scale(a, rsqrt_near_one(x));
+    if (all_in_range(x, 8.271806125530277e-25f, 1.2089258196146292e24f)) return normalize_normal_range(a, x);
+    return scale(a, 1.0f / __builtin_sqrtf(x));
+}
 PTD float sqrt_gated(float x) {
     if (all_in_range(x, 1.2621774483536189e-29f, 3.0e38f)) return sqrt_normal_range(x);
     return __builtin_sqrtf(x);
@@ -368,7 +396,7 @@ PTD float length_gated(f3 a) { return sqrt_gated(dot(a, a)); }
 // shared tail of both tests (intersections.h:85-87,136-143): objP = getPointOnRay(q, t_obj);
 // worldP = transform * objP; t = length(r.origin - worldP).  `fwd` = 12 floats of the transform.
 template <typename P> PTD float world_distance(P fwd, f3 ro, f3 qo, f3 qd, float t_obj, f3 &obj_p) {
-    obj_p = add(qo, scale(normalize_gated(qd), (t_obj - .0001f)));        // getPointOnRay
+    obj_p = add(qo, scale(normalize_unit(qd), (t_obj - .0001f)));         // getPointOnRay (qd = glm::normalize(v))
     return length_gated(sub(ro, mv_point(fwd, obj_p)));
 }
 

@@ -37,7 +37,9 @@ __global__ void k_probe_sqrt(uint32_t first_bits, uint32_t n, unsigned long long
     unsigned long long b0 = 0, b1 = 0;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const float x = __uint_as_float(first_bits + (uint32_t)k);
-        const float s = ptd::sqrt_normal_range(x), q = ptd::rsqrt_of_root(x);
+        const float s = ptd::sqrt_normal_range(x);
+        // (as normalize_unit chooses: the four-addition form inside its gate)
+        const float q = (x >= ptd::NEAR_ONE_LO && x <= ptd::NEAR_ONE_HI) ? ptd::rsqrt_near_one(x) : ptd::rsqrt_of_root(x);
         const float s_ref = __builtin_sqrtf(x);                  // (hipcc: correctly rounded by default)
         const float q_ref = 1.0f / s_ref;
         b0 += __float_as_uint(s) != __float_as_uint(s_ref);

@@ -119,7 +119,9 @@ def test_newton_sqrt_every_argument(pt):
     admissible if it is EXACTLY the correctly rounded sqrtf / divide: checked here on every binary32 x in [2^-102, 2^128)
     -- 1.93 * 10^9 arguments, binade by binade -- and the callers' gates (x >= 2^-96 for the root, 2^-80 <= x <= 2^80
     for the normalisation) are inside that range.  Outside it the forms DO differ (subnormal intermediates): counted
-    too, so that the test would notice if the sweep were not comparing anything."""
+    too, so that the test would notice if the sweep were not comparing anything.  Inside [1 - 2^-12, 1 + 2^-12] the
+    probe's reciprocal root is normalize_unit's four-addition form (rsqrt_near_one, for vectors that are unit vectors
+    up to rounding; tests/test_arith_models_cpu.py has its CPU model): the sweep covers those 6 145 arguments with it."""
     lo, hi = 127 - 102, 254                     # biased exponents of 2^-102 and 2^127
     bad = [0, 0]
     for e in range(lo, hi + 1, 8):
@@ -130,3 +132,4 @@ def test_newton_sqrt_every_argument(pt):
     below = pt.probe_sqrt(1 << 23, 16 << 23)   # 2^-126 .. 2^-110: outside the gates
     assert below[0] > 0 and below[1] > 0
     assert pt.probe_sqrt(0x3f800000, 0) == (0, 0)
+    assert pt.probe_sqrt(0x3f800000 - 4096, 4096 + 2048 + 1) == (0, 0)      # the near-one gate by itself
