@@ -58,3 +58,23 @@ def test_zero_product_folds_into_the_addition():
                 fused = (a.astype(np.float64) * 0.0 + b.astype(np.float64)).astype(np.float32)   # exact product, one rounding
             same = np.where(np.isnan(ref), np.isnan(fused), ref.view(np.uint32) == fused.view(np.uint32))
             assert same.all()
+
+
+def test_exact_products_fold_into_one_fma():
+    """reflect's doubling and the sampler's cross product with an axis: a product that is EXACT (by 2, by 0 or by 1) may be the
+    multiplier pair of an fma without changing the value -- the reference's multiply-then-subtract rounds once as well.
+    Modelled in binary64 (exact products and differences of binary32 values are representable), including subnormal and
+    zero operands of either sign."""
+    rng = np.random.default_rng(11)
+    edge = np.array([0.0, -0.0, 1e-45, -1e-45, 1.1754944e-38, -1.1754942e-38, 3e-39, 1.0, -1.0], dtype=np.float32)
+    p = np.concatenate([rng.standard_normal(5000).astype(np.float32), (rng.standard_normal(2000) * 1e-38).astype(np.float32), edge])
+    i = np.concatenate([rng.standard_normal(5000).astype(np.float32), (rng.standard_normal(2000) * 1e-38).astype(np.float32), edge[::-1]])
+    ref = (i - (p * F(2.0)).astype(np.float32)).astype(np.float32)                      # I - fl(2 p)
+    fused = (i.astype(np.float64) - 2.0 * p.astype(np.float64)).astype(np.float32)      # fma(-2, p, I)
+    assert np.array_equal(ref.view(np.uint32), fused.view(np.uint32))
+    a, c = p, i
+    for b in (F(0.0), F(1.0)):
+        for d in (F(0.0), F(1.0)):
+            ref = ((a * b).astype(np.float32) - (d * c).astype(np.float32)).astype(np.float32)          # x.y * y.z - y.y * x.z
+            fused = (a.astype(np.float64) * float(b) + -((d * c).astype(np.float32)).astype(np.float64)).astype(np.float32)
+            assert np.array_equal(ref.view(np.uint32), fused.view(np.uint32)), (b, d)
