@@ -330,7 +330,8 @@ int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, f
  * pt_probe_sqrt: the kernels' sqrt and 1 / sqrt (glm::length / glm::normalize, func_geometric.inl:94-100,153-159:
  * Newton's iteration on v_rsq_f32, csrc/pt_device.hpp: sqrt_newton) against the correctly rounded sqrtf and divide, for
  * the `n` consecutive binary32 values from bit pattern `first_bits` on: mismatch[0] = arguments whose root differs,
- * mismatch[1] = whose reciprocal of the root differs.  Zero for every x in [2^-102, 2^128). */
+ * mismatch[1] = whose reciprocal of the root differs.  Zero for every x in [2^-102, 2^128).  For x in [1 - 2^-12, 1 + 2^-12]
+ * the reciprocal is the kernels' four-addition form for vectors that are unit vectors up to rounding (rsqrt_near_one). */
 int pt_probe_rng(const uint32_t *seeds, int n, int draws, uint32_t *state, float *u);
 int pt_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, float *s, float *c, uint64_t sum[2]);
 int pt_probe_hemisphere(const float *normals, const uint32_t *seeds, int n, float *dirs);
