@@ -339,37 +339,55 @@ def per_call_rates(c, n_it=256):
     host = np.zeros((c.npix, 3), dtype=np.float32)
     L = pt.library()
 
-    def run(flags, call):
+    def run(flags, call, max_batch=1, rays=None, first=33):
         # (the library's own launch stream, as a host that links libptmi355.so gets it -- not torch's)
-        pt.pathtraceInit(c.scene, flags=flags, device=c.local_rank, max_batch=1)
-        for k in range(32):
+        # `rays`: the rays of iterations first .. first + n_it - 1 as counted by an earlier run over the same iterations -- a
+        # PT_LOOKAHEAD session counts windows when it traces them, ahead of the calls that consume them
+        pt.pathtraceInit(c.scene, flags=flags, device=c.local_rank, max_batch=max_batch)
+        for k in range(first - 1):
             call(1 + k)
         pt.synchronize()
         r0 = pt.total_rays()
         t1 = time.perf_counter()
         for k in range(n_it):
-            call(33 + k)
+            call(first + k)
         pt.synchronize()
         el = time.perf_counter() - t1
-        rate = round((pt.total_rays() - r0) / el / 1e6, 2)
+        traced = pt.total_rays() - r0
         pt.pathtraceFree()
-        return rate, round(el / n_it * 1e3, 4)
+        run.rays = traced
+        return round((traced if rays is None else rays) / el / 1e6, 2), round(el / n_it * 1e3, 4)
 
     out["mrays_per_s"], out["ms_per_call"] = run(c.flags, lambda it: pt.trace_batch_async(it, 1))
-    # as host/pathtrace_shim.cpp initialises the library for the reference's host: PT_PIN_IMAGE | PT_HOST_SPARSE (that host
-    # only reads state.image: a call writes the pixels whose sum changed) ...
-    out["pcie_inclusive_sync"], out["pcie_inclusive_sync_ms_per_call"] = run(c.flags | pt.PT_HOST_SPARSE, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
+    # as host/pathtrace_shim.cpp initialised the library up to round 5: PT_PIN_IMAGE | PT_HOST_SPARSE (the reference's host
+    # only reads state.image: a call writes the pixels whose sum changed), every iteration traced inside its own call ...
+    out["pcie_inclusive_sync_no_lookahead"], out["pcie_inclusive_sync_no_lookahead_ms_per_call"] = run(
+        c.flags | pt.PT_HOST_SPARSE, lambda it: L.pt_trace(None, 0, it, host.ctypes.data), first=85)
+    rays_85 = run.rays
     if c.args.digest:
         import hashlib
+        out["host_image_md5_no_lookahead"] = hashlib.md5(host.tobytes()).hexdigest()
+    # ... and as the shim initialises it now: + PT_LOOKAHEAD, max_batch = 64 -- the library traces windows of 4, 16, 64, 64, ..
+    # iterations ahead of the caller and every call gathers its own sample (include/ptmi355.h).  Same calls, same iteration
+    # numbers, state.image complete at every return; the timed calls start at a window's first iteration (85 = 1 + 4 + 16 + 64)
+    # and span whole windows, and the rate counts the rays of exactly those iterations (counted by the run above)
+    la = c.flags | pt.PT_HOST_SPARSE | pt.PT_LOOKAHEAD
+    out["pcie_inclusive_sync"], out["pcie_inclusive_sync_ms_per_call"] = run(
+        la, lambda it: L.pt_trace(None, 0, it, host.ctypes.data), max_batch=64, rays=rays_85, first=85)
+    if c.args.digest:
         out["host_image_md5"] = hashlib.md5(host.tobytes()).hexdigest()       # the host image after the synchronous calls
+    out["lookahead_no_host_image"], out["lookahead_no_host_image_ms_per_call"] = run(
+        c.flags | pt.PT_LOOKAHEAD, lambda it: L.pt_trace(None, 0, it, None), max_batch=64, rays=rays_85, first=85)
     # ... and for a host that may write into the image between calls: every pixel, every call
     out["pcie_inclusive_sync_every_pixel"], out["pcie_inclusive_sync_every_pixel_ms_per_call"] = run(c.flags, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
     out["pcie_inclusive_async"], _ = run(c.flags | pt.PT_ASYNC_IMAGE | pt.PT_HOST_SPARSE, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
     out["calls"] = n_it
-    out["note"] = ("one pathtrace() per iteration (src/main.cpp:130-140), 1 spp per call, max_batch = 1: mrays_per_s = calls enqueued back to back "
-                   "(no host image); pcie_inclusive_sync = the running sum in host memory when each call returns (pathtrace.cu:389-392), "
-                   "PT_PIN_IMAGE | PT_HOST_SPARSE as the drop-in shim sets them; ..._every_pixel = without PT_HOST_SPARSE; "
-                   "pcie_inclusive_async = PT_ASYNC_IMAGE | PT_HOST_SPARSE")
+    out["note"] = ("one pathtrace() per iteration (src/main.cpp:130-140), 1 spp per call: mrays_per_s = calls enqueued back to back "
+                   "(no host image, max_batch = 1); pcie_inclusive_sync = the running sum in host memory when each call returns "
+                   "(pathtrace.cu:389-392) with PT_PIN_IMAGE | PT_HOST_SPARSE | PT_LOOKAHEAD, max_batch = 64, as the drop-in shim sets "
+                   "them: windows of iterations traced ahead, every call gathers its own sample; ..._no_lookahead = every iteration "
+                   "traced inside its own call (the shim up to round 5); lookahead_no_host_image = the same calls without a host image; "
+                   "..._every_pixel = without PT_HOST_SPARSE and without PT_LOOKAHEAD; pcie_inclusive_async = PT_ASYNC_IMAGE | PT_HOST_SPARSE")
     return out
 
 

@@ -157,6 +157,24 @@ enum pt_flags {
                                     between them: it holds the sum after iteration i once every rank's call for i has returned.
                                     Without the flag a tiled session copies its whole accumulation buffer (zeros outside its
                                     tile).  Needs iterations that run as one launch and a mappable buffer: PT_ERR_INVALID if not. */
+    PT_LOOKAHEAD     = 1u << 11, /* opt-in: pt_trace TRACES AHEAD of its caller.  The reference's host calls ONE pathtrace() per
+                                    iteration (main.cpp:130-140) and a path's whole life is a function of (iteration, pixelIndex,
+                                    depth) alone, so the iterations to come can be traced before they are asked for.  pt_trace(iter)
+                                    then traces a WINDOW [iter, iter + n) as one path pool (n grows 4, 16, .. up to max_batch) and
+                                    keeps every sample's final colours; the calls for iter + 1 .. iter + n - 1 only run finalGather
+                                    for their own sample -- image[pixel] += colour, the same single addition per pixel and
+                                    iteration, in iteration order -- write the pixels whose sum changed into the host image
+                                    (PT_PIN_IMAGE | PT_HOST_SPARSE; every pixel otherwise) and tonemap the PBO, while the NEXT
+                                    window is already being traced beside them.  state.image, the PBO and the device's
+                                    accumulation buffer are complete when each call returns, bit for bit what the same calls
+                                    produce without the flag.  A window is discarded (and the iteration traced afresh) when
+                                    `iter` is not the next consecutive one, when camera, traceDepth or lens differ from what it
+                                    was traced with, and by pt_clear_image, pt_set_image, batches and the stepping interface.
+                                    What differs: pt_get_stats / pt_total_rays / pt_get_counters count a window when it is TRACED
+                                    (a call served from a window reports rays = 0; iterations traced ahead and then discarded
+                                    stay counted).  Single-device sessions that own the whole frame (tile_count <= 1) on the fused
+                                    pipelines; ignored elsewhere (PT_UNFUSED, PT_FAKE_SHADER, PT_CACHE_FIRST, two-kernel sort,
+                                    PT_ASYNC_IMAGE, max_batch < 2). */
     PT_ASYNC_IMAGE   = 1u << 7   /* opt-in: pt_trace / pt_trace_batch return without waiting; the copy of the
                                     running sum into host_image_sum overlaps the NEXT call's tracing and is
                                     complete when the next pt_trace / pt_trace_batch returns, or after

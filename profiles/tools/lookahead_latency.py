@@ -1,0 +1,40 @@
+"""Per-call latency of pathtrace() under PT_LOOKAHEAD by position inside a 64-iteration window (800x800 Cornell):
+the first calls of a window run beside the tracing of the next one, the last ones on an otherwise idle device.
+usage: python profiles/tools/lookahead_latency.py [host|nohost] [windows]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+pt = ge.load_package()
+z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+scene = pt.Scene(z["cornell__geoms"], z["cornell__materials"], z["cornell__camera"], int(z["cornell__depth"]))
+mode = sys.argv[1] if len(sys.argv) > 1 else "host"
+windows = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+L = pt.library()
+n = 800 * 800
+host = np.zeros((n, 3), dtype=np.float32)
+flags = pt.PT_COMPACT | pt.PT_LOOKAHEAD | (pt.PT_PIN_IMAGE | pt.PT_HOST_SPARSE if mode == "host" else 0)
+pt.pathtraceInit(scene, flags=flags, max_batch=64, pin_image=False)
+buf = host.ctypes.data if mode == "host" else None
+for it in range(1, 85):
+    L.pt_trace(None, 0, it, buf)
+lat = np.zeros((windows, 64))
+t_all = time.perf_counter()
+for w in range(windows):
+    for k in range(64):
+        t0 = time.perf_counter()
+        L.pt_trace(None, 0, 85 + 64 * w + k, buf)
+        lat[w, k] = time.perf_counter() - t0
+el = time.perf_counter() - t_all
+pt.pathtraceFree()
+us = lat * 1e6
+print("mode %s: %.1f us per call over %d calls" % (mode, el / (windows * 64) * 1e6, windows * 64))
+print("call 0 of a window (enqueues the next window): median %.1f us" % np.median(us[:, 0]))
+for a, b in ((1, 8), (8, 16), (16, 24), (24, 32), (32, 40), (40, 48), (48, 56), (56, 64)):
+    print("calls %2d-%2d: median %.1f  p10 %.1f  p90 %.1f us" % (a, b - 1, np.median(us[:, a:b]), np.percentile(us[:, a:b], 10), np.percentile(us[:, a:b], 90)))

@@ -4,7 +4,7 @@ include/ptmi355.h).  The directory name carries a hyphen, so import it through
 `__graft_entry__.load_package()` (alias `ptmi355`)."""
 from .binding import (  # noqa: F401
     CAMERA_DT, GEOM_DT, ISECT_DT, MATERIAL_DT, MESH_DT, PATH_DT, TRI_DT,
-    PT_AA_JITTER, PT_ASYNC_IMAGE, PT_PIN_IMAGE, PT_HOST_SPARSE, PT_SHARED_IMAGE, PT_CACHE_FIRST, PT_COMPACT, PT_FAKE_SHADER, PT_MESH_BVH, PT_SORT_MATERIAL, PT_UNFUSED,
+    PT_AA_JITTER, PT_ASYNC_IMAGE, PT_PIN_IMAGE, PT_HOST_SPARSE, PT_SHARED_IMAGE, PT_LOOKAHEAD, PT_CACHE_FIRST, PT_COMPACT, PT_FAKE_SHADER, PT_MESH_BVH, PT_SORT_MATERIAL, PT_UNFUSED,
     PtError, Scene, Stats, library, pathtrace, pathtraceFree, pathtraceInit,
     device_image_ptr, export_intersections, export_paths, get_image, get_stats, intersect_once,
     set_camera, set_lens, synchronize, tonemap, trace_batch, trace_batch_async, trace_begin, trace_bounce,

@@ -35,6 +35,7 @@ MESH_DT = np.dtype([("geom_index", "<i4"), ("first_triangle", "<i4"), ("triangle
 PT_COMPACT, PT_SORT_MATERIAL, PT_FAKE_SHADER, PT_CACHE_FIRST, PT_UNFUSED, PT_MESH_BVH, PT_AA_JITTER, PT_ASYNC_IMAGE, PT_PIN_IMAGE = 1, 2, 4, 8, 16, 32, 64, 128, 256
 PT_HOST_SPARSE = 1024
 PT_SHARED_IMAGE = 512
+PT_LOOKAHEAD = 2048         # pt_trace traces ahead of its caller (include/ptmi355.h)
 BVH_NODE_WORDS = 16
 
 

@@ -68,6 +68,8 @@ void pt_free(void) {
 
 
 static int init_impl(const pt_scene_desc *d);
+int la_discard(int how);            // PT_LOOKAHEAD: forget the windows traced ahead (below, with pt_trace)
+enum { LA_STREAM = 0, LA_HOST = 1, LA_LATER = 2 };
 
 }  // namespace one
 
@@ -474,7 +476,12 @@ int pt_set_camera(const pt_camera *camera, int trace_depth) {
                     R.map.W, R.map.H, camera->resolution[0], camera->resolution[1]);
     if (trace_depth < 1 || trace_depth > MAX_DEPTH)
         return fail(PT_ERR_INVALID, "pt_set_camera: trace_depth %d outside [1, %d]", trace_depth, MAX_DEPTH);
-    if (memcmp(&R.cam, camera, sizeof R.cam) != 0) { R.cache_valid = false; drop_graphs(); }   // refill the bounce-0 cache
+    if (memcmp(&R.cam, camera, sizeof R.cam) != 0) {
+        R.cache_valid = false; drop_graphs();                  // refill the bounce-0 cache
+        // windows traced ahead for the old camera are void, and what follows rewrites masks and boxes their launches read
+        const int rc = la_discard(LA_HOST);
+        if (rc) return rc;
+    }
     bool recull = false;
     {   // the cull boxes hold for ray origins within R.scene.rmax (1-norm); a camera outside that range would only
         // make its rays candidates of every primitive (correct, slow): remake the boxes around the new position
@@ -540,6 +547,7 @@ int pt_synchronize(void) {
 
 int pt_trace_batch_async(int iter0, int count) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_batch_async: not initialised");
+    if (R.flags & PT_LOOKAHEAD) { const int rc = la_discard(LA_STREAM); if (rc) return rc; }
     R.in_step = false;
     R.ov_ok = true;
     const int rc = enqueue_batch(iter0, count);
@@ -549,6 +557,7 @@ int pt_trace_batch_async(int iter0, int count) {
 
 int pt_trace_batch(int iter0, int count, float *host_image_sum) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_batch: not initialised");
+    if (R.flags & PT_LOOKAHEAD) { const int rc = la_discard(LA_STREAM); if (rc) return rc; }
     R.in_step = false;
     R.ov_ok = false;       // (PT_ASYNC_IMAGE calls are bound by their 7.68 MB copy: lanes measured 14.7 against 15.8 Grays/s there)
     R.want_host_stats = !(host_image_sum && (R.flags & PT_ASYNC_IMAGE));
@@ -590,10 +599,135 @@ int pt_trace_mapped(int iter, float *mapped) {
     return collect_stats();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// PT_LOOKAHEAD (include/ptmi355.h): pt_trace traces ahead of its caller.
+//
+// The reference's host asks for ONE iteration per call (main.cpp:130-140) and wants state.image complete when the call
+// returns (pathtrace.cu:389-392).  One iteration is eight DEPENDENT bounces of ~10 us each however few paths are left
+// (k_iteration, DESIGN 6.11: 122 us per call, issue 0.50), while 64 iterations traced as one pool cost 48 us each
+// (k_bounce).  A path is a function of (iteration, pixelIndex, depth) and nothing else, so the iterations the host is
+// going to ask for can be traced before it asks: a WINDOW of consecutive iterations goes through the batched pipeline on
+// a lane (enqueue_window), every sample's final colours stay in that lane's buffer, and the call for iteration i runs
+// finalGather for sample i alone (k_gather_one) -- the same single float addition per pixel and iteration, in iteration
+// order -- with the host-image write and the tonemap folded into that launch.  While window w is consumed, window w + 1
+// is traced on the other lane.  Window sizes grow 4, 16, 64, .. up to max_batch: the first image after a camera move
+// does not wait for 64 iterations.
+// ---------------------------------------------------------------------------------------------------------------------
+bool la_possible(void) {
+    return (R.flags & PT_LOOKAHEAD) && !(R.flags & (PT_UNFUSED | PT_FAKE_SHADER | PT_CACHE_FIRST | PT_ASYNC_IMAGE)) &&
+           (!(R.flags & PT_SORT_MATERIAL) || R.sort_keys > 0) && R.map.tile_count == 1 && R.max_batch >= 2 && R.ov_enabled &&
+           !R.use_graphs && !R.profiling && !R.dbg_counts;
+}
+
+// Forget the windows.  One that may still be tracing keeps its lane's buffers busy -- lane 0's are the session's own --
+// so whatever is enqueued on the launch stream afterwards has to wait for it: LA_STREAM (the default).  LA_HOST: the HOST
+// waits, before it rewrites scene records the launches in flight read (pt_set_camera).  LA_LATER: nothing waits yet --
+// la_trace itself, which goes on with another window on the lanes (stream order does the rest); the window stays
+// marked `inflight` for whoever comes next.
+int la_discard(int how) {
+    for (int j = 0; j < 2; ++j) {
+        Renderer::LaWindow &w = R.la[j];
+        if (w.valid) { w.valid = false; R.la_discards++; }
+        if (!w.inflight || how == LA_LATER || !R.ov_ready) continue;
+        if (how == LA_HOST) HIPCHK(hipStreamSynchronize(R.lane[j].stream));
+        else HIPCHK(hipStreamWaitEvent(R.stream, R.lane[j].traced, 0));
+        w.inflight = false;
+    }
+    return PT_OK;
+}
+
+static bool la_matches(const Renderer::LaWindow &w, int iter) {
+    return w.valid && iter == w.iter0 + w.next && w.depth == R.trace_depth && memcmp(&w.cam, &R.cam, sizeof w.cam) == 0 &&
+           memcmp(&w.lens, &R.lens, sizeof w.lens) == 0;
+}
+
+static int la_trace_window(int slot, int iter0, int count) {
+    count = (int)std::min<int64_t>((int64_t)count, (int64_t)0x7fffffff - (int64_t)iter0 + 1);       // enqueue_begin's range of iteration numbers
+    const int rc = enqueue_window(slot, iter0, count);
+    if (rc) return rc;
+    Renderer::LaWindow &w = R.la[slot];
+    w.valid = true; w.inflight = true; w.iter0 = iter0; w.count = count; w.next = 0; w.stamp = R.fin_serial;
+    w.cam = R.cam; w.depth = R.trace_depth; w.lens = R.lens; w.ctl = R.last_ctl;
+    R.la_windows++;
+    return PT_OK;
+}
+
+// `handled`: the call was served here (else the caller goes on with the plain path)
+int la_trace(uint8_t *pbo_rgba, int iter, float *host_image_sum, bool *handled) {
+    *handled = false;
+    if (!la_possible() || iter < 1) return la_discard(LA_STREAM);
+    int rc = ensure_lanes();
+    if (rc) return rc;
+    if (!R.ov_enabled || R.ov_lanes < 2) return PT_OK;             // the lanes do not fit: the plain path
+    *handled = true;
+    if (!la_matches(R.la[R.la_cur], iter)) {
+        // not the next sample of the window being consumed: is it the first of the one traced ahead?  (it is when the
+        // window before it was consumed to its end: la_cur has moved on already -- this is the out-of-order case)
+        if (R.la[R.la_cur ^ 1].next == 0 && la_matches(R.la[R.la_cur ^ 1], iter)) {
+            if (R.la[R.la_cur].valid) { R.la[R.la_cur].valid = false; R.la_discards++; }
+            R.la_cur ^= 1;
+        } else {
+            rc = la_discard(LA_LATER);
+            if (rc) return rc;
+            R.la_cur = 0;
+            rc = la_trace_window(0, iter, std::min(R.max_batch, 4));
+            if (rc) return rc;
+            R.la_misses++;
+        }
+    }
+    Renderer::LaWindow &w = R.la[R.la_cur];
+    const int s = w.next;
+    Renderer::Lane &lane = R.lane[R.la_cur];
+    if (w.inflight) { HIPCHK(hipStreamWaitEvent(R.stream, lane.traced, 0)); w.inflight = false; }
+    // the host image: the launch writes the sums that changed into the caller's page-locked buffer when that buffer holds
+    // exactly the accumulation buffer's content as of the previous call (PT_HOST_SPARSE); otherwise every pixel is copied
+    float *mapped = host_image_sum ? map_host(host_image_sum, (size_t)R.npix * 12) : nullptr;
+    const bool host_current = mapped && R.host_sparse_enabled && R.own_image && R.host_synced == mapped && R.host_epoch == R.image_epoch;
+    if (host_current && R.dma_last) { HIPCHK(hipStreamWaitEvent(R.stream, R.dma_last, 0)); R.dma_last = nullptr; }
+    const float4 *fin = reinterpret_cast<const float4 *>(lane.b.final_mem) + (size_t)s * (size_t)R.map.tile_pixels;
+    {
+        unsigned wgs = (unsigned)((R.npix + (int)LA_UNROLL * BLOCK - 1) / ((int)LA_UNROLL * BLOCK));
+        if (const char *e = getenv("PTMI355_LA_GRID")) wgs = std::min(wgs, (unsigned)std::max(1, atoi(e)));   // TEMPORARY (tuning)
+        const dim3 grid(wgs);
+        float *host_dev = host_current ? mapped : (float *)nullptr;
+        if (pbo_rgba) hipLaunchKernelGGL(k_gather_one<true>, grid, dim3(BLOCK), 0, R.stream, R.image, fin, host_dev, w.stamp, (uint32_t)R.npix, pbo_rgba, iter);
+        else hipLaunchKernelGGL(k_gather_one<false>, grid, dim3(BLOCK), 0, R.stream, R.image, fin, host_dev, w.stamp, (uint32_t)R.npix, pbo_rgba, iter);
+    }
+    HIPCHK(hipGetLastError());
+    R.image_epoch++;
+    if (host_image_sum && !host_current) {
+        rc = enqueue_image_copy(host_image_sum);
+        if (rc) return rc;
+    }
+    if (mapped && R.own_image) { R.host_synced = mapped; R.host_epoch = R.image_epoch; }
+    w.next++;
+    // the next window, on the other lane, as soon as this one starts being consumed: [end of this one, + 4 x its size)
+    if (s == 0 && !R.la[R.la_cur ^ 1].valid && (int64_t)w.iter0 + w.count <= 0x7fffffff) {
+        rc = la_trace_window(R.la_cur ^ 1, w.iter0 + w.count, (int)std::min<int64_t>((int64_t)R.max_batch, (int64_t)w.count * 4));
+        if (rc) return rc;
+    }
+    if (s == 0) {
+        // the window's statistics, once: its counters were folded on its lane before `traced` was recorded
+        R.last_ctl = w.ctl; R.host_stats_serial = 0; R.step_count = w.count; R.step_iter0 = w.iter0;
+        rc = collect_stats();
+    } else {
+        HIPCHK(hipStreamSynchronize(R.stream));
+        R.stats.bounces = 0; R.stats.rays = 0;
+        memset(R.stats.live, 0, sizeof R.stats.live);
+    }
+    if (w.next >= w.count) { w.valid = false; R.la_cur ^= 1; }     // consumed: on to the window traced meanwhile
+    return rc;
+}
+
 int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
     (void)frame;                                          // unused in the reference too (main.cpp:136)
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace: not initialised");
     R.in_step = false;
+    if (R.flags & PT_LOOKAHEAD) {
+        bool handled = false;
+        const int rc = la_trace(pbo_rgba, iter, host_image_sum, &handled);
+        if (rc || handled) return rc;
+    }
     // synchronous host image: when this iteration runs as one launch, its waves write the new sums into the caller's
     // (page-locked, device-mapped) buffer as they finish, under the tracing of the others (k_iteration's epilogue)
     R.epi_host = nullptr; R.epi_done = false;
@@ -645,6 +779,7 @@ int pt_trace(uint8_t *pbo_rgba, int frame, int iter, float *host_image_sum) {
 
 int pt_trace_begin(int iter0, int count) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_trace_begin: not initialised");
+    if (R.flags & PT_LOOKAHEAD) { const int rc = la_discard(LA_STREAM); if (rc) return rc; }
     int rc = enqueue_begin(iter0, count, true);
     if (rc) return rc;
     R.in_step = true;
@@ -735,6 +870,7 @@ int pt_intersect_once(const pt_path_segment *host_paths, int n, pt_shadeable_int
                       uint8_t *host_outside) {
     R.ov_active = false;
     if (!R.live) return fail(PT_ERR_INVALID, "pt_intersect_once: not initialised");
+    if (R.flags & PT_LOOKAHEAD) { const int rc = la_discard(LA_STREAM); if (rc) return rc; }
     if (n < 0 || (uint32_t)n > R.cap) return fail(PT_ERR_INVALID, "pt_intersect_once: n=%d exceeds the pool capacity %u", n, R.cap);
     if (n == 0) return PT_OK;
     if (!host_paths || !host_isects) return fail(PT_ERR_INVALID, "pt_intersect_once: null buffer");
@@ -783,6 +919,7 @@ int pt_tonemap(uint8_t *host_rgba, int iter) {
 
 int pt_clear_image(void) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_clear_image: not initialised");
+    if (R.flags & PT_LOOKAHEAD) { const int rc = la_discard(LA_STREAM); if (rc) return rc; }
     HIPCHK(hipMemsetAsync(R.image, 0, (size_t)R.npix * 12, R.stream));
     HIPCHK(hipStreamSynchronize(R.stream));
     R.image_epoch++;
@@ -794,6 +931,7 @@ int pt_clear_image(void) {
 int pt_set_image(const float *host_image_sum) {
     if (!R.live) return fail(PT_ERR_INVALID, "pt_set_image: not initialised");
     if (!host_image_sum) return fail(PT_ERR_INVALID, "pt_set_image: null buffer");
+    if (R.flags & PT_LOOKAHEAD) { const int rc = la_discard(LA_STREAM); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(R.stream));
     if (R.copy_stream) HIPCHK(hipStreamSynchronize(R.copy_stream));
     HIPCHK(hipMemcpy(R.image, host_image_sum, (size_t)R.npix * 12, hipMemcpyHostToDevice));

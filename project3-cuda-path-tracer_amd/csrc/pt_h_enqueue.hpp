@@ -259,6 +259,18 @@ int enqueue_fake(void) {
 
 int enqueue_end(void) {
     if (R.self_gathered) { R.whole = false; return PT_OK; }   // finalGather and the counters were done inside k_iteration
+    if (R.la_tracing) {
+        // a window traced ahead of the caller (PT_LOOKAHEAD): its final colours stay where they are until the calls that
+        // consume them (k_gather_one, one sample each); only its counters are folded, on the lane's own stream
+        hipLaunchKernelGGL(k_gather, dim3(1), dim3(BLOCK), 0, R.stream, R.image, R.final_mem, R.cap, R.map, R.step_count, R.ctl,
+                           R.persist, R.trace_depth, 0u, R.whole ? 1 : 0, 1, R.fin_serial, R.iter_counts, (uint32_t)R.grid_iter_cur,
+                           (HostStats *)nullptr);
+        R.whole = false;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(R.lane_cur->traced, R.stream));
+        R.lane_cur->gathered_valid = false;
+        return PT_OK;
+    }
     StageTimer tm(PT_STAGE_GATHER);
     hipStream_t gs = R.stream;
     if (R.lane_cur) {                                         // overlapped batch: gathers stay in call order on the launch stream
@@ -398,17 +410,16 @@ bool overlap_eligible(int count) {
 
 int enqueue_batch_serial(int iter0, int count);
 
-int enqueue_batch_direct(int iter0, int count) {
-    if (!overlap_eligible(count)) return enqueue_batch_serial(iter0, count);
-    int rc = ensure_lanes();
-    if (rc) return rc;
-    if (!R.ov_enabled) return enqueue_batch_serial(iter0, count);       // the lanes do not fit the budget
+// before a batch goes to a lane: the stamp's wrap, and whatever the launch stream holds
+int enter_lanes(void) {
     if (R.fin_serial == 0xffffffffu) {      // the stamp is about to wrap: nothing may be in flight while every lane's colours are forgotten
         HIPCHK(hipStreamSynchronize(R.stream));
+        for (int j = 0; j < R.ov_lanes; ++j) HIPCHK(hipStreamSynchronize(R.lane[j].stream));
         for (int j = 0; j < R.ov_lanes; ++j) HIPCHK(hipMemsetAsync(R.lane[j].b.final_mem, 0, R.final_bytes, R.stream));
         HIPCHK(hipStreamSynchronize(R.stream));
         R.fin_serial = 0;
         R.ov_active = false;
+        for (auto &w : R.la) { w.valid = false; w.inflight = false; }      // (their colours are gone)
     }
     if (!R.ov_active) {
         // whatever the launch stream holds (uploads, masks, serial batches on the session's buffers) comes first
@@ -418,16 +429,43 @@ int enqueue_batch_direct(int iter0, int count) {
             R.lane[k].gathered_valid = false;
         }
     }
-    Renderer::Lane &l = R.lane[R.ov_next];
-    R.ov_next = (R.ov_next + 1) % R.ov_lanes;
+    return PT_OK;
+}
+
+// one batch on lane `l`: its buffers and stream stand in for the session's while the serial enqueue code runs
+int enqueue_on_lane(Renderer::Lane &l, int iter0, int count) {
     if (l.gathered_valid) HIPCHK(hipStreamWaitEvent(l.stream, l.gathered, 0));
     const Renderer::Bufs home = take_bufs();
     R.lane_main = R.stream; R.lane_cur = &l;
     put_bufs(l.b); R.stream = l.stream;
-    rc = enqueue_batch_serial(iter0, count);                            // its gather goes to the launch stream (enqueue_end)
+    const int rc = enqueue_batch_serial(iter0, count);                  // its gather goes to the launch stream (enqueue_end)
     R.stream = R.lane_main; put_bufs(home);
     R.lane_cur = nullptr; R.lane_main = nullptr;
     R.ov_active = rc == PT_OK;
+    return rc;
+}
+
+int enqueue_batch_direct(int iter0, int count) {
+    if (!overlap_eligible(count)) return enqueue_batch_serial(iter0, count);
+    int rc = ensure_lanes();
+    if (rc) return rc;
+    if (!R.ov_enabled) return enqueue_batch_serial(iter0, count);       // the lanes do not fit the budget
+    rc = enter_lanes();
+    if (rc) return rc;
+    Renderer::Lane &l = R.lane[R.ov_next];
+    R.ov_next = (R.ov_next + 1) % R.ov_lanes;
+    return enqueue_on_lane(l, iter0, count);
+}
+
+// PT_LOOKAHEAD: iterations [iter0, iter0 + count) traced on lane `slot` as one pool, nothing gathered (enqueue_end under
+// R.la_tracing): the window's final colours wait in the lane's buffer for the calls that consume them.  The caller has
+// made sure that nothing still reads that lane's buffers (its previous window is consumed or discarded).
+int enqueue_window(int slot, int iter0, int count) {
+    int rc = enter_lanes();
+    if (rc) return rc;
+    R.la_tracing = true;
+    rc = enqueue_on_lane(R.lane[slot], iter0, count);
+    R.la_tracing = false;
     return rc;
 }
 

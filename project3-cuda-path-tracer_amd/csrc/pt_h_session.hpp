@@ -127,6 +127,20 @@ struct Renderer {
     bool ov_ok = false;           // this call does not wait for its own result (async entry points)
     bool ov_active = false;       // the last thing enqueued was an overlapped batch
     int ov_next = 0;
+    // PT_LOOKAHEAD: windows of consecutive iterations traced ahead of pt_trace's caller (pt_h_api.hpp: la_*).  Slot j
+    // traces on lane j; `next` = the sample the next consecutive call consumes; a window is only ever served to calls whose
+    // camera / depth / lens are byte-equal to what it was traced with.
+    struct LaWindow {
+        bool valid = false;       // enqueued and not yet consumed or discarded
+        bool inflight = false;    // enqueued, and the launch stream has not been ordered behind its last launch yet
+        int iter0 = 0, count = 0, next = 0;
+        uint32_t stamp = 0;       // of its final colours
+        pt_camera cam{}; int depth = 0; Lens lens{0, 0.0f, 0.0f};
+        Control *ctl = nullptr;   // its lane's control block (statistics of the window)
+    } la[2];
+    int la_cur = 0;               // the slot being consumed
+    bool la_tracing = false;      // the batch being enqueued is a window: no k_gather, only its counters (enqueue_end)
+    uint64_t la_misses = 0, la_windows = 0, la_discards = 0;   // calls that had to trace their own window first / windows enqueued / windows thrown away
     Control *last_ctl = nullptr;  // the control block of the last batch (collect_stats)
     float *epi_host = nullptr;    // pt_trace: the caller's image, device-mapped, for k_iteration's own gather (this call only)
     bool epi_done = false;        // ... and k_iteration took it

@@ -110,20 +110,68 @@ __global__ __launch_bounds__(BLOCK) void k_copy_out(float4 *dst, const float4 *s
     if (blockIdx.x == 0 && threadIdx.x < ntail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 
-// sendImageToPBO (pathtrace.cu:48-68)
-__global__ __launch_bounds__(BLOCK) void k_tonemap(uint8_t *pbo, const float *image, int npix, int iter) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= npix) return;
+// sendImageToPBO (pathtrace.cu:48-68) for one pixel's running sum
+__device__ __forceinline__ uchar4 tonemap_pixel(float r, float g, float b, int iter) {
+    const float s[3] = {r, g, b};
     int c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double v = (double)(image[3 * i + k] / (float)iter) * 255.0;
+        const double v = (double)(s[k] / (float)iter) * 255.0;
         int q = (int)v;                      // v_cvt_i32_f64: saturating, NaN -> 0
         c[k] = q < 0 ? 0 : (q > 255 ? 255 : q);
     }
     uchar4 o;
     o.x = (unsigned char)c[0]; o.y = (unsigned char)c[1]; o.z = (unsigned char)c[2]; o.w = 0;
-    reinterpret_cast<uchar4 *>(pbo)[i] = o;
+    return o;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_tonemap(uint8_t *pbo, const float *image, int npix, int iter) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= npix) return;
+    reinterpret_cast<uchar4 *>(pbo)[i] = tonemap_pixel(image[3 * i + 0], image[3 * i + 1], image[3 * i + 2], iter);
+}
+
+// PT_LOOKAHEAD: finalGather (pathtrace.cu:269-278) for ONE iteration of a window traced ahead of the caller.  `fin` is that
+// sample's slice of the window's final colours (float4[pixels], index = pixel: such sessions own the whole frame): an entry
+// that carries the window's stamp is a path that ended with a non-zero colour -- image[pixel] += colour, the one addition
+// per pixel and iteration of the reference, in iteration order because the calls come in iteration order.  The other
+// pixels' sums do not change and are not even read, unless a PBO wants every pixel tonemapped (PBO = true).  `host` (the
+// caller's page-locked state.image, device-mapped; PT_HOST_SPARSE) receives the sums that changed: ~6 % of the pixels of a
+// Cornell iteration, the only bytes of the call that cross PCIe.
+// SIXTEEN scalar registers: this launch runs BESIDE the persistent grid that traces the next window, and what that grid
+// leaves free on a SIMD is not wave slots (2 of 8) or vector registers (32 of 512) but scalar ones -- six waves of
+// k_bounce at 106 SGPRs hold 6 x 128 of the 800 (a wave is granted its count rounded up to 16, plus 16); a wave fits
+// into the remaining 32 only with at most 16.  With the default allocation (24) every such launch waited for the bounce
+// kernel beside it to END: 400-650 us instead of 35 (profiles/r06/la_trace_before.txt).
+constexpr uint32_t LA_UNROLL = 2;
+template <bool PBO>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(16), amdgpu_num_vgpr(32))) void k_gather_one(
+        float *__restrict__ image, const float4 *__restrict__ fin, float *__restrict__ host, uint32_t stamp, uint32_t n,
+        uint8_t *__restrict__ pbo, int iter) {
+    // a grid-stride loop, four colour loads in flight per lane: the grid is the caller's throttle on how many stores to
+    // host memory are outstanding at a time (la_trace)
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t j0 = blockIdx.x * BLOCK + threadIdx.x; j0 < n; j0 += LA_UNROLL * stride) {
+        float4 c[LA_UNROLL];
+#pragma unroll
+        for (int u = 0; u < (int)LA_UNROLL; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * stride;
+            c[u] = j < n ? fin[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // (no entry carries stamp 0)
+        }
+#pragma unroll
+        for (int u = 0; u < (int)LA_UNROLL; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * stride;
+            const bool changed = __float_as_uint(c[u].w) == stamp;
+            if (PBO ? j >= n : !changed) continue;
+            float r = image[3 * j + 0], g = image[3 * j + 1], b = image[3 * j + 2];
+            if (changed) {
+                r += c[u].x; g += c[u].y; b += c[u].z;
+                image[3 * j + 0] = r; image[3 * j + 1] = g; image[3 * j + 2] = b;
+                if (host) { host[3 * j + 0] = r; host[3 * j + 1] = g; host[3 * j + 2] = b; }
+            }
+            if (PBO) reinterpret_cast<uchar4 *>(pbo)[j] = tonemap_pixel(r, g, b, iter);
+        }
+    }
 }
 
 // pool <-> reference AoS (debug / parity export and pt_intersect_once)

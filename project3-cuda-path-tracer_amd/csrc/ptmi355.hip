@@ -85,6 +85,15 @@ extern "C" int ptdbg_counts(unsigned int *out, int words) {
     return words;
 }
 
+// diagnostics (not in include/ptmi355.h): PT_LOOKAHEAD's bookkeeping since pt_init -- out[0] = windows enqueued, out[1] = calls
+// that had to trace their own window first (misses), out[2] = windows discarded, out[3] = iterations of the window being consumed
+extern "C" int ptdbg_lookahead(unsigned long long out[4]) {
+    if (!g_single.live) return -1;
+    out[0] = g_single.la_windows; out[1] = g_single.la_misses; out[2] = g_single.la_discards;
+    out[3] = g_single.la[g_single.la_cur].valid ? (unsigned long long)g_single.la[g_single.la_cur].count : 0ull;
+    return 0;
+}
+
 #ifdef PT_WAVE_TIMES
 // diagnostic build only (not in include/ptmi355.h): per-wave start / end ticks and hardware ids of k_bounce's last launches
 extern "C" int ptdbg_wave_times(unsigned long long *times /* [8][8192][2] */, uint32_t *hw /* [8][8192] */) {
