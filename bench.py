@@ -100,53 +100,122 @@ def launch_command(n, argv, port):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def self_launch(args, argv):
-    """`python3 bench.py --gpus N` from a plain shell (no WORLD_SIZE in the environment): start the N ranks as fresh child
-    processes through torch.distributed.run, relay rank 0's JSON line and the launcher's exit code.  This parent has
-    imported neither torch nor the HIP library -- nothing here has touched the GPU, and nothing is exec'ed: the launcher
-    is a child in a session of its own, so --launch-timeout can end exactly that process group."""
+PHASES = ("main", "exchange", "strong", "shared")      # N > 1: what one line consists of; each can run in a launch of its own
+
+
+def run_launch(cmd, env, timeout):
+    """One child launch (a process group of its own): returns (exit code, the JSON objects it printed).  Lines that are
+    not JSON go to stderr as they come.  `timeout` > 0: the group is ended after that many seconds and the exit code is
+    124 (as timeout(1) reports it)."""
     import signal
     import subprocess
-    port = int(os.environ.get("MASTER_PORT") or 0) or free_port()
-    cmd = launch_command(args.gpus, [a for a in argv if a != "--print-launch"], port)
-    if args.print_launch:
-        print(json.dumps({"launch": cmd}))
-        return 0
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.pop("MASTER_PORT", None)
-    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd[1:10])))
+    import threading
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    expired = []
     timer = None
-    if args.launch_timeout > 0:
-        import threading
-
+    if timeout and timeout > 0:
         def expire():
-            sys.stderr.write("bench.py: the ranks did not finish in %.0f s: ending their process group\n" % args.launch_timeout)
+            expired.append(True)
+            sys.stderr.write("bench.py: the ranks did not finish in %.0f s: ending their process group (exit code 124)\n" % timeout)
             try:
                 os.killpg(p.pid, signal.SIGTERM)
                 time.sleep(5.0)
                 os.killpg(p.pid, signal.SIGKILL)
             except OSError:
                 pass
-        timer = threading.Timer(args.launch_timeout, expire)
+        timer = threading.Timer(timeout, expire)
         timer.daemon = True
         timer.start()
-    lines = 0
+    objs = []
     for line in p.stdout:
         if line.startswith("{"):
-            lines += 1
-            sys.stdout.write(line)
-            sys.stdout.flush()
-        else:
-            sys.stderr.write(line)
+            try:
+                objs.append(json.loads(line))
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(line)
     rc = p.wait()
     if timer:
         timer.cancel()
-    if rc == 0 and lines == 0:
-        sys.stderr.write("bench.py: the ranks exited without a JSON line\n")
+    return (124 if expired else rc), objs
+
+
+def merge_phases(main_obj, subs):
+    """The one line of an N > 1 run from the objects its phases printed.  `main_obj`: the main timed pass's line (None when
+    that launch left none); `subs`: {phase: object or {"failed": ...}} of the sub-measurements, each from a launch of its own."""
+    out = main_obj if main_obj is not None else {"value": None, "failed": "the main timed pass left no line"}
+    out.setdefault("config", {})
+    for name, key in (("exchange", "per_iteration_exchange"), ("strong", "strong"), ("shared", "per_iteration_shared_frame")):
+        if name not in subs:
+            continue
+        v = subs[name]
+        v = v.get(key, v) if isinstance(v, dict) else {"failed": "no object"}
+        if key == "per_iteration_exchange":
+            out[key] = v                                       # top-level AND where rounds 3-4 had it
+        out["config"][key] = v
+    out["phases"] = {"launches": "one child launch (fresh processes, rendezvous of its own) per phase, the main timed pass first",
+                     "order": ["main"] + [k for k in PHASES[1:] if k in subs]}
+    return out
+
+
+def self_launch(args, argv):
+    """`python3 bench.py --gpus N` from a plain shell (no WORLD_SIZE in the environment): start the N ranks as fresh child
+    processes through torch.distributed.run and print ONE line.  This parent has imported neither torch nor the HIP library
+    -- nothing here has touched the GPU, and nothing is exec'ed: every launcher is a child in a session of its own, so
+    a time limit can end exactly that process group.
+    ONE LAUNCH PER PHASE, the main timed pass first: `value` must not depend on a collective pattern
+    that has never run with peers -- the per-iteration exchange, strong scaling and the shared host frame each get fresh
+    processes and a rendezvous of their own afterwards; a phase that hangs (the ranks' own watchdog, then the time limit
+    here), dies or leaves no object becomes {"failed": ...} in the line, and the line is still printed with the main
+    pass's number.  Exit code: the main pass's (124: ended by the time limit)."""
+    base = [a for a in argv if a != "--print-launch"]
+    if args.print_launch:
+        print(json.dumps({"launch": launch_command(args.gpus, base, int(os.environ.get("MASTER_PORT") or 0) or free_port())}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("MASTER_PORT", None)
+
+    def launch(phase, timeout):
+        rc, objs = 1, []
+        for attempt in (1, 2):                        # (the port was free when it was looked up, not necessarily when the rendezvous binds it)
+            cmd = launch_command(args.gpus, base + (["--phase", phase] if phase else []), free_port())
+            sys.stderr.write("bench.py: --gpus %d without a launcher, phase '%s': starting %s\n" % (args.gpus, phase or "all", " ".join(cmd[1:10])))
+            t0 = time.monotonic()
+            rc, objs = run_launch(cmd, env, timeout)
+            if objs or rc in (0, 3, 124) or time.monotonic() - t0 > 30.0:
+                break
+            sys.stderr.write("bench.py: the launch ended with code %d after %.0f s without a line: once more on another port\n" % (rc, time.monotonic() - t0))
+        return rc, objs
+
+    single = getattr(args, "phase", "all") != "all" or getattr(args, "one_launch", False)
+    if single:                                         # a named phase (or --one-launch): exactly one launch, relayed as it is
+        rc, objs = launch(None, args.launch_timeout)          # (a --phase on the command line is in `base` already)
+        for o in objs:
+            print(json.dumps(o), flush=True)
+        if rc == 0 and not objs:
+            sys.stderr.write("bench.py: the ranks exited without a JSON line\n")
+            return 1
+        return rc
+    main_limit = args.launch_timeout if args.launch_timeout > 0 else 0.0
+    rc_main, objs = launch("main", main_limit)
+    main_obj = objs[-1] if objs else None
+    subs = {}
+    wanted = [] if args.no_sub else (["exchange", "strong"] + (["shared"] if args.shared_frame else []))
+    for ph in wanted:
+        limit = args.launch_timeout if args.launch_timeout > 0 else 3.0 * args.sub_timeout + 120.0
+        rc, objs = launch(ph, limit)
+        if objs and rc == 0:
+            subs[ph] = objs[-1]
+        else:
+            why = "ended by the time limit of %.0f s" % limit if rc == 124 else "exit code %d" % rc
+            subs[ph] = {"failed": "phase '%s': %s%s" % (ph, why, "" if not objs else "; its ranks said: " + json.dumps(objs[-1])[:300])}
+    print(json.dumps(merge_phases(main_obj, subs)), flush=True)
+    if main_obj is None and rc_main == 0:
+        sys.stderr.write("bench.py: the main pass's ranks exited without a JSON line\n")
         return 1
-    return rc
+    return rc_main
 
 
 def load_scene(pt, name):
@@ -605,6 +674,10 @@ def main():
                          "frame in shared memory written by every rank's own launches; no exchange)")
     ap.add_argument("--launch-timeout", type=float, default=0.0,
                     help="plain `--gpus N` (no launcher): seconds before the self-started ranks' process group is ended (0 = never)")
+    ap.add_argument("--phase", default="all", choices=["all"] + list(PHASES),
+                    help="N > 1: run only this part of the line (a plain `--gpus N` starts one launch per phase itself and merges "
+                         "their objects; under an external launcher `all` runs them in one set of processes, the main timed pass first)")
+    ap.add_argument("--one-launch", action="store_true", help="plain `--gpus N`: every phase in ONE launch, as an external launcher gets it")
     ap.add_argument("--print-launch", action="store_true",
                     help="plain `--gpus N`: print the torch.distributed.run command line instead of running it")
     ap.add_argument("--exchange-thread", action="store_true",
@@ -624,6 +697,8 @@ def main():
     inproc, dist_on, n_tiles, scene = c.inproc, c.dist_on, c.n_tiles, c.scene
     W, H, npix, flags = c.W, c.H, c.npix, c.flags
     multi = dist_on or inproc
+    if args.phase not in ("all", "main"):
+        return sub_phase(c)
 
     # the line, filled in as the measurements finish (N > 1: the watchdog prints what is there if a phase hangs)
     out = {"metric": "Mrays/sec (live paths x bounces) at 800x800 Cornell depth 8" if args.config == "c2" else
@@ -657,16 +732,8 @@ def main():
             and not (flags & ~(pt.PT_COMPACT | pt.PT_SORT_MATERIAL)):
         pc = per_call_rates(c)
 
-    # ---- N > 1 (or its one-rank rehearsal), measured FIRST and part of every such line: the north
-    # star's cadence -- the tiles' sums on rank 0 after EVERY iteration -- beside the same calls without the exchange ----
-    if multi and not args.no_sub:
-        phase("per-iteration exchange", args.sub_timeout)
-        try:
-            pie = per_iteration_exchange(c)
-        except Exception as e:                 # stated in the line, never silently absent
-            pie = {"failed": str(e)[:300]}
-        put(out, "per_iteration_exchange", pie)
-
+    # ---- the main timed pass comes FIRST: `value` must not wait behind a phase whose collective
+    # pattern differs (the per-iteration exchange follows it, then strong scaling) ----
     phase("main timed pass", max(300.0, args.sub_timeout))
     s = Session(c, args.scaling, args.reduce_every)
     per_step_iters, every = s.per_step_iters, s.every
@@ -751,9 +818,15 @@ def main():
 
     # ---- N > 1: strong scaling (and, on request, the frame assembled in ONE shared host buffer by the ranks' own
     # launches) beside the main number; a failure is stated in the line ----
-    if multi and not args.no_sub:
-        if "per_iteration_exchange" in out:
-            put(out["config"], "per_iteration_exchange", out["per_iteration_exchange"])      # (where rounds 3-4 had it)
+    if multi and not args.no_sub and args.phase == "all":
+        # north star's cadence -- the tiles' sums on rank 0 after EVERY iteration -- beside the same calls without the exchange
+        phase("per-iteration exchange", args.sub_timeout)
+        try:
+            pie = per_iteration_exchange(c)
+        except Exception as e:                 # stated in the line, never silently absent
+            pie = {"failed": str(e)[:300]}
+        put(out, "per_iteration_exchange", pie)
+        put(out["config"], "per_iteration_exchange", pie)      # (where rounds 3-4 had it)
         if n_tiles > 1:
             phase("strong scaling", args.sub_timeout)
             try:
@@ -770,18 +843,52 @@ def main():
         guard.emit()
     elif rank == 0:
         print(json.dumps(out))
-    if dist_on:
-        # the line is out and complete; a teardown that never returns must not keep the launcher waiting
-        import threading
+    teardown(c)
 
-        def teardown_expired():
-            sys.stderr.write("bench.py: destroy_process_group did not return in 60 s (the line above is complete)\n")
-            os._exit(0)
-        t = threading.Timer(60.0, teardown_expired)
-        t.daemon = True
-        t.start()
-        dist.destroy_process_group()
-        t.cancel()
+
+def teardown(c):
+    if not c.dist_on:
+        return
+    # the line is out and complete; a teardown that never returns must not keep the launcher waiting
+    import threading
+
+    def teardown_expired():
+        sys.stderr.write("bench.py: destroy_process_group did not return in 60 s (the line above is complete)\n")
+        os._exit(0)
+    t = threading.Timer(60.0, teardown_expired)
+    t.daemon = True
+    t.start()
+    c.dist.destroy_process_group()
+    t.cancel()
+
+
+def sub_phase(c):
+    """`--phase exchange | strong | shared`: ONE sub-measurement of an N > 1 line in processes (and a rendezvous) of its own;
+    rank 0 prints {"phase": ..., <key>: {...}} -- a failure is an object with `failed`, a hang ends with the watchdog's
+    object and exit code 3 -- and the launching parent (self_launch) merges it into the line."""
+    args = c.args
+    multi = c.dist_on or c.inproc
+    key, fn = {"exchange": ("per_iteration_exchange", lambda: per_iteration_exchange(c)),
+               "strong": ("strong", lambda: strong_scaling(c, args.steps, args.warmup)),
+               "shared": ("per_iteration_shared_frame", lambda: shared_frame_rate(c, args.sub_iters))}[args.phase]
+    out = {"phase": args.phase, key: None}
+    guard = Watchdog(c.rank, out) if multi else None
+    if guard:
+        guard.arm(args.sub_timeout, args.phase)
+    if not multi:
+        v = {"failed": "phase '%s' needs more than one rank (or --force-dist / --inproc)" % args.phase}
+    else:
+        try:
+            v = fn()
+        except Exception as e:
+            v = {"failed": str(e)[:300]}
+    if guard:
+        guard.put(out, key, v)
+        guard.emit()
+    elif c.rank == 0:
+        out[key] = v
+        print(json.dumps(out))
+    teardown(c)
 
 
 def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s):

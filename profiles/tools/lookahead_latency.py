@@ -15,12 +15,13 @@ pt = ge.load_package()
 z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
 scene = pt.Scene(z["cornell__geoms"], z["cornell__materials"], z["cornell__camera"], int(z["cornell__depth"]))
 mode = sys.argv[1] if len(sys.argv) > 1 else "host"
+K = int(os.environ.get("LA_K", "64"))
 windows = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 L = pt.library()
 n = 800 * 800
 host = np.zeros((n, 3), dtype=np.float32)
 flags = pt.PT_COMPACT | pt.PT_LOOKAHEAD | (pt.PT_PIN_IMAGE | pt.PT_HOST_SPARSE if mode == "host" else 0)
-pt.pathtraceInit(scene, flags=flags, max_batch=64, pin_image=False)
+pt.pathtraceInit(scene, flags=flags, max_batch=K, pin_image=False)
 buf = host.ctypes.data if mode == "host" else None
 for it in range(1, 85):
     L.pt_trace(None, 0, it, buf)

@@ -16,11 +16,14 @@ def short(n):
 
 
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"], int(r["Grid_Size_X"])) for r in rows)
-g = [e for e in ev if e[2] == "k_gather_one"]
+g = [e for e in ev if e[2] in ("k_gather_one", "k_la_apply")]
 d = np.array([(e[1] - e[0]) / 1e3 for e in g])
 gap = np.array([(g[i + 1][0] - g[i][1]) / 1e3 for i in range(len(g) - 1)])
-print("k_gather_one: %d launches, duration median %.1f p90 %.1f max %.1f us; idle between two: median %.1f p90 %.1f us" %
+print("per-call kernel (k_la_apply / k_gather_one): %d launches, duration median %.1f p90 %.1f max %.1f us; idle between two: median %.1f p90 %.1f us" %
       (len(g), np.median(d), np.percentile(d, 90), d.max(), np.median(gap), np.percentile(gap, 90)))
+cp = [e for e in ev if e[2] == "k_la_compact"]
+if cp:
+    print("k_la_compact: %d launches, median %.1f us (largest grids: %.1f us)" % (len(cp), np.median([(e[1] - e[0]) / 1e3 for e in cp]), max((e[1] - e[0]) / 1e3 for e in cp)))
 b = [e for e in ev if e[2] == "k_bounce"]
 # a window's launches follow each other on ONE queue without a gap (the last eight windows' worth are printed); two windows
 # on the two lanes' queues may overlap in time

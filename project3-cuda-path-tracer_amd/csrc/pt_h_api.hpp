@@ -625,7 +625,7 @@ bool la_possible(void) {
 // la_trace itself, which goes on with another window on the lanes (stream order does the rest); the window stays
 // marked `inflight` for whoever comes next.
 int la_discard(int how) {
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < Renderer::LA_SLOTS; ++j) {
         Renderer::LaWindow &w = R.la[j];
         if (w.valid) { w.valid = false; R.la_discards++; }
         if (!w.inflight || how == LA_LATER || !R.ov_ready) continue;
@@ -652,28 +652,40 @@ static int la_trace_window(int slot, int iter0, int count) {
     return PT_OK;
 }
 
+// the windows that follow the one being consumed: up to LA_AHEAD of them, each four times its predecessor's size up to
+// max_batch, on the ring's next slots -- two in flight, on the two launch streams, like overlapped batches
+static int la_trace_ahead(void) {
+    const Renderer::LaWindow *last = &R.la[R.la_cur];
+    for (int k = 1; k <= Renderer::LA_AHEAD; ++k) {
+        const int slot = (R.la_cur + k) % Renderer::LA_SLOTS;
+        Renderer::LaWindow &w = R.la[slot];
+        const int64_t iter0 = (int64_t)last->iter0 + last->count;
+        if (!w.valid) {
+            if (iter0 > 0x7fffffff) break;
+            const int rc = la_trace_window(slot, (int)iter0, (int)std::min<int64_t>((int64_t)R.max_batch, (int64_t)last->count * 4));
+            if (rc) return rc;
+        }
+        last = &w;
+    }
+    return PT_OK;
+}
+
 // `handled`: the call was served here (else the caller goes on with the plain path)
 int la_trace(uint8_t *pbo_rgba, int iter, float *host_image_sum, bool *handled) {
     *handled = false;
     if (!la_possible() || iter < 1) return la_discard(LA_STREAM);
     int rc = ensure_lanes();
     if (rc) return rc;
-    if (!R.ov_enabled || R.ov_lanes < 2) return PT_OK;             // the lanes do not fit: the plain path
+    if (!R.ov_enabled || R.ov_lanes < Renderer::LA_SLOTS) return PT_OK;             // the lanes do not fit: the plain path
     *handled = true;
     if (!la_matches(R.la[R.la_cur], iter)) {
-        // not the next sample of the window being consumed: is it the first of the one traced ahead?  (it is when the
-        // window before it was consumed to its end: la_cur has moved on already -- this is the out-of-order case)
-        if (R.la[R.la_cur ^ 1].next == 0 && la_matches(R.la[R.la_cur ^ 1], iter)) {
-            if (R.la[R.la_cur].valid) { R.la[R.la_cur].valid = false; R.la_discards++; }
-            R.la_cur ^= 1;
-        } else {
-            rc = la_discard(LA_LATER);
-            if (rc) return rc;
-            R.la_cur = 0;
-            rc = la_trace_window(0, iter, std::min(R.max_batch, 4));
-            if (rc) return rc;
-            R.la_misses++;
-        }
+        // not the next sample of the window being consumed (whose successors on the ring continue it, so none of them
+        // starts at `iter` either): everything traced ahead is void
+        rc = la_discard(LA_LATER);
+        if (rc) return rc;
+        rc = la_trace_window(R.la_cur, iter, std::min(R.max_batch, 4));
+        if (rc) return rc;
+        R.la_misses++;
     }
     Renderer::LaWindow &w = R.la[R.la_cur];
     const int s = w.next;
@@ -684,11 +696,9 @@ int la_trace(uint8_t *pbo_rgba, int iter, float *host_image_sum, bool *handled) 
     float *mapped = host_image_sum ? map_host(host_image_sum, (size_t)R.npix * 12) : nullptr;
     const bool host_current = mapped && R.host_sparse_enabled && R.own_image && R.host_synced == mapped && R.host_epoch == R.image_epoch;
     if (host_current && R.dma_last) { HIPCHK(hipStreamWaitEvent(R.stream, R.dma_last, 0)); R.dma_last = nullptr; }
-    const float4 *fin = reinterpret_cast<const float4 *>(lane.b.final_mem) + (size_t)s * (size_t)R.map.tile_pixels;
     {
-        unsigned wgs = (unsigned)((R.npix + (int)LA_UNROLL * BLOCK - 1) / ((int)LA_UNROLL * BLOCK));
-        if (const char *e = getenv("PTMI355_LA_GRID")) wgs = std::min(wgs, (unsigned)std::max(1, atoi(e)));   // TEMPORARY (tuning)
-        const dim3 grid(wgs);
+        const float4 *fin = reinterpret_cast<const float4 *>(lane.b.final_mem) + (size_t)s * (size_t)R.npix;
+        const dim3 grid((unsigned)((R.npix + (int)LA_UNROLL * BLOCK - 1) / ((int)LA_UNROLL * BLOCK)));
         float *host_dev = host_current ? mapped : (float *)nullptr;
         if (pbo_rgba) hipLaunchKernelGGL(k_gather_one<true>, grid, dim3(BLOCK), 0, R.stream, R.image, fin, host_dev, w.stamp, (uint32_t)R.npix, pbo_rgba, iter);
         else hipLaunchKernelGGL(k_gather_one<false>, grid, dim3(BLOCK), 0, R.stream, R.image, fin, host_dev, w.stamp, (uint32_t)R.npix, pbo_rgba, iter);
@@ -701,12 +711,10 @@ int la_trace(uint8_t *pbo_rgba, int iter, float *host_image_sum, bool *handled) 
     }
     if (mapped && R.own_image) { R.host_synced = mapped; R.host_epoch = R.image_epoch; }
     w.next++;
-    // the next window, on the other lane, as soon as this one starts being consumed: [end of this one, + 4 x its size)
-    if (s == 0 && !R.la[R.la_cur ^ 1].valid && (int64_t)w.iter0 + w.count <= 0x7fffffff) {
-        rc = la_trace_window(R.la_cur ^ 1, w.iter0 + w.count, (int)std::min<int64_t>((int64_t)R.max_batch, (int64_t)w.count * 4));
-        if (rc) return rc;
-    }
     if (s == 0) {
+        // as soon as a window starts being consumed: the windows after it (while the gather just launched runs)
+        rc = la_trace_ahead();
+        if (rc) return rc;
         // the window's statistics, once: its counters were folded on its lane before `traced` was recorded
         R.last_ctl = w.ctl; R.host_stats_serial = 0; R.step_count = w.count; R.step_iter0 = w.iter0;
         rc = collect_stats();
@@ -715,7 +723,7 @@ int la_trace(uint8_t *pbo_rgba, int iter, float *host_image_sum, bool *handled) 
         R.stats.bounces = 0; R.stats.rays = 0;
         memset(R.stats.live, 0, sizeof R.stats.live);
     }
-    if (w.next >= w.count) { w.valid = false; R.la_cur ^= 1; }     // consumed: on to the window traced meanwhile
+    if (w.next >= w.count) { w.valid = false; R.la_cur = (R.la_cur + 1) % Renderer::LA_SLOTS; }     // consumed: on to the window traced meanwhile
     return rc;
 }
 

@@ -127,9 +127,12 @@ struct Renderer {
     bool ov_ok = false;           // this call does not wait for its own result (async entry points)
     bool ov_active = false;       // the last thing enqueued was an overlapped batch
     int ov_next = 0;
-    // PT_LOOKAHEAD: windows of consecutive iterations traced ahead of pt_trace's caller (pt_h_api.hpp: la_*).  Slot j
-    // traces on lane j; `next` = the sample the next consecutive call consumes; a window is only ever served to calls whose
+    // PT_LOOKAHEAD: windows of consecutive iterations traced ahead of pt_trace's caller (pt_h_api.hpp: la_*).  A ring of
+    // LA_SLOTS windows, slot j on lane j (consecutive slots on alternating launch streams): la_cur is the window being
+    // consumed, the slots after it hold the windows that follow it -- up to LA_AHEAD of them traced ahead, two in flight
+    // side by side; `next` = the sample the next consecutive call consumes; a window is only ever served to calls whose
     // camera / depth / lens are byte-equal to what it was traced with.
+    static constexpr int LA_SLOTS = 4, LA_AHEAD = 2;
     struct LaWindow {
         bool valid = false;       // enqueued and not yet consumed or discarded
         bool inflight = false;    // enqueued, and the launch stream has not been ordered behind its last launch yet
@@ -137,7 +140,7 @@ struct Renderer {
         uint32_t stamp = 0;       // of its final colours
         pt_camera cam{}; int depth = 0; Lens lens{0, 0.0f, 0.0f};
         Control *ctl = nullptr;   // its lane's control block (statistics of the window)
-    } la[2];
+    } la[LA_SLOTS];
     int la_cur = 0;               // the slot being consumed
     bool la_tracing = false;      // the batch being enqueued is a window: no k_gather, only its counters (enqueue_end)
     uint64_t la_misses = 0, la_windows = 0, la_discards = 0;   // calls that had to trace their own window first / windows enqueued / windows thrown away

@@ -137,19 +137,17 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap(uint8_t *pbo, const float *im
 // per pixel and iteration of the reference, in iteration order because the calls come in iteration order.  The other
 // pixels' sums do not change and are not even read, unless a PBO wants every pixel tonemapped (PBO = true).  `host` (the
 // caller's page-locked state.image, device-mapped; PT_HOST_SPARSE) receives the sums that changed: ~6 % of the pixels of a
-// Cornell iteration, the only bytes of the call that cross PCIe.
-// SIXTEEN scalar registers: this launch runs BESIDE the persistent grid that traces the next window, and what that grid
+// Cornell iteration, the only bytes of the call that cross PCIe (~30 000 lines of 64 B: ~36 us).
+// SIXTEEN scalar registers: this launch runs BESIDE the persistent grid that traces the next windows, and what that grid
 // leaves free on a SIMD is not wave slots (2 of 8) or vector registers (32 of 512) but scalar ones -- six waves of
 // k_bounce at 106 SGPRs hold 6 x 128 of the 800 (a wave is granted its count rounded up to 16, plus 16); a wave fits
 // into the remaining 32 only with at most 16.  With the default allocation (24) every such launch waited for the bounce
-// kernel beside it to END: 400-650 us instead of 35 (profiles/r06/la_trace_before.txt).
+// kernel beside it to END: 400-650 us instead of 36 (profiles/r06/lookahead_before_sgpr16.txt).
 constexpr uint32_t LA_UNROLL = 2;
 template <bool PBO>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(16), amdgpu_num_vgpr(32))) void k_gather_one(
         float *__restrict__ image, const float4 *__restrict__ fin, float *__restrict__ host, uint32_t stamp, uint32_t n,
         uint8_t *__restrict__ pbo, int iter) {
-    // a grid-stride loop, four colour loads in flight per lane: the grid is the caller's throttle on how many stores to
-    // host memory are outstanding at a time (la_trace)
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t j0 = blockIdx.x * BLOCK + threadIdx.x; j0 < n; j0 += LA_UNROLL * stride) {
         float4 c[LA_UNROLL];

@@ -50,10 +50,17 @@ void pathtraceInit(Scene *scene) {
     // once at load (scene.cpp:145-147) and lives as long as the Scene, so the library may page-lock it.  PT_HOST_SPARSE:
     // the reference's host only ever READS state.image (saveImage, main.cpp:78-99; nothing else touches it), so a call
     // need only write the pixels whose sum changed.  A host that writes into state.image between calls drops this flag.
-    d.flags = PT_COMPACT | PT_PIN_IMAGE | PT_HOST_SPARSE;
+    // PT_LOOKAHEAD: runCuda() asks for iteration 1, 2, 3, .. (main.cpp:130-140), each a function of (iteration, pixel, depth)
+    // alone -- the library traces windows of up to max_batch iterations ahead as one path pool and every pathtrace() only
+    // gathers its own sample; state.image and the PBO are complete at every return, bit for bit as without the flag.
+    d.flags = PT_COMPACT | PT_PIN_IMAGE | PT_HOST_SPARSE | PT_LOOKAHEAD;
     d.device = 0;                    // cudaGLSetGLDevice(0), preview.cpp:107
     d.tile_index = 0; d.tile_count = 1; d.strip_rows = 8;
-    d.max_batch = 1;
+    {   // windows of up to 64 iterations and about 40 M paths (800x800: 64; 3840x2160: 4)
+        const long long pixels = (long long)d.camera.resolution[0] * d.camera.resolution[1];
+        long long k = pixels > 0 ? 41000000LL / pixels : 1;
+        d.max_batch = (int32_t)(k < 4 ? 4 : (k > 64 ? 64 : k));
+    }
     CHECK(pt_init(&d), "pathtraceInit");
 }
 

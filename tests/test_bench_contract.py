@@ -89,7 +89,10 @@ def test_single_gpu_line():
     # the reference's calling pattern (one pathtrace() per iteration): without the host image, with it synchronously, PT_ASYNC_IMAGE
     assert d["config"]["pcie_inclusive_mrays_per_s"] > 100 and d["config"]["pcie_inclusive_async_mrays_per_s"] > 100
     pc = d["config"]["per_call"]
-    assert pc["mrays_per_s"] > pc["pcie_inclusive_sync"] > 100 and pc["pcie_inclusive_async"] > 100 and pc["calls"] >= 64
+    # one pathtrace() per iteration with the host image: traced ahead of the caller (PT_LOOKAHEAD, what the shim sets) against
+    # every iteration inside its own call
+    assert pc["pcie_inclusive_sync"] > pc["pcie_inclusive_sync_no_lookahead"] > 100 and pc["lookahead_no_host_image"] > pc["pcie_inclusive_sync"]
+    assert pc["mrays_per_s"] > pc["pcie_inclusive_sync_no_lookahead"] and pc["pcie_inclusive_async"] > 100 and pc["calls"] >= 64
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["value"] > 100
     _check_roofline(d["roofline"])
     assert d["roofline"]["launches"] == 3 * 8
