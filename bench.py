@@ -641,6 +641,8 @@ def main():
     ap.add_argument("--flags", default="compact", help="comma list: compact,sort,unfused,cache,bvh,aa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="N = 1: skip roofline.sustained (the timed steps repeated for --sustain-seconds)")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0)
     ap.add_argument("--strip-rows", type=int, default=8)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank traces batch*N iterations of its tile per step (per-GPU work fixed); "
@@ -761,6 +763,38 @@ def main():
         pt.set_profiling(False)
         roofline = roofline_object(args, n_tiles if inproc else world, flags, pt, prof, rank_rays, first, dt / args.steps)
 
+    # ---- sustained: the timed region is 20 steps = 62 ms; pathtrace.cu:284-393 runs 5000 times per image.
+    # The same steps again for at least two seconds of wall time, with the shader clock read (one wave, cycle counter against
+    # the 100-MHz counter: pt_probe_clock) while they run; `steps` / `ms_per_step` / `value` stay the short pass's.
+    sustained = None
+    if not args.no_sustained and args.sustain_seconds > 0 and not multi:
+        n_chunk = max(1, args.steps)
+        s.barrier()
+        r0, _, _ = pt.counters()
+        t0 = time.perf_counter()
+        done, clocks = 0, []
+        while True:
+            for _ in range(n_chunk):
+                s.step()
+            done += n_chunk
+            if len(clocks) < 8:
+                try:
+                    clocks.append(pt.probe_clock(300))      # beside the steps just enqueued
+                except Exception:
+                    pass
+            s.barrier()
+            if time.perf_counter() - t0 >= args.sustain_seconds:
+                break
+        el = time.perf_counter() - t0
+        r1, _, _ = pt.counters()
+        sustained = {"seconds": round(el, 3), "steps": done, "mrays_per_s": round((r1 - r0) / el / 1e6, 2),
+                     "ms_per_step": round(el / done * 1e3, 4), "ratio_to_value": round((r1 - r0) / el / 1e6 / value, 4),
+                     "shader_clock_ghz": round(sorted(clocks)[len(clocks) // 2], 3) if clocks else None,
+                     "shader_clock_samples": [round(x, 3) for x in clocks],
+                     "note": "the timed steps repeated for >= %.0f s of wall time in chunks of %d steps (one synchronisation per chunk); "
+                             "shader clock = one wave counting its cycle counter against the 100-MHz counter for 300 us beside each of the first "
+                             "chunks (include/ptmi355.h: pt_probe_clock); the issue roof of `roofline` is priced at %.1f GHz" % (args.sustain_seconds, n_chunk, PEAK_CLOCK_GHZ)}
+
     digest = None
     if args.digest:
         import hashlib
@@ -803,7 +837,11 @@ def main():
     if digest:
         put(out, "image_md5", digest)
     if roofline:
+        if sustained:
+            roofline["sustained"] = sustained
         put(out, "roofline", roofline)
+    elif sustained:
+        put(out, "sustained", sustained)
 
     # ---- CPU baseline: the oracle (plain-C port) on this host, rank 0, N = 1 only ----
     if rank == 0 and world == 1 and not inproc and not args.no_cpu_baseline:
@@ -943,6 +981,7 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
     per_step_s = stage_ms[st] * 1e-3 / steps
     nl = sum(k["launches_per_step"] for k in sel)
     cyc = sum(k["launches_per_step"] * k.get("issue_cycles_per_launch", 0.0) for k in sel)
+    cyc_guide = sum(k["launches_per_step"] * k.get("issue_cycles_guide_rates_per_launch", 0.0) for k in sel)
     byt = sum(k["launches_per_step"] * k.get("hbm_bytes_per_launch", 0) for k in sel)
     flops = sum(k["launches_per_step"] * k.get("flops_fp32_per_launch_64_lanes", 0.0) * k.get("active_lane_fraction", 1.0) for k in sel)
     lanes = sum(k["launches_per_step"] * k.get("issue_cycles_per_launch", 0.0) * k.get("active_lane_fraction", 0.0) for k in sel) / cyc if cyc else None
@@ -955,6 +994,12 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
              source="profiles/traffic.json@build:%s (profiles/collect.py: instrumented-build opcode histogram, rocprofv3 --pmc passes)" % t["build_sha16"],
              valu_issue={"achieved": round(cyc / per_step_s / 1e9, 1), "peak": round(SIMDS * PEAK_CLOCK_GHZ, 1), "unit": "G SIMD issue-cycles/s",
                          "frac": round(issue_frac, 4), "issue_cycles_per_launch": int(cyc / nl),
+                         # the same executed-opcode histogram at the GUIDE's issue rates (full rate 2 cycles per wave-instruction
+                         # per SIMD, half rate 4, transcendental 8: each opcode in the class its measured cost is nearest to) --
+                         # `frac` prices a full-rate opcode at the 2.3-2.5 cycles this repository's own microbenchmark measured
+                         # (ramp and tail included); and the part of it that ran lanes that were switched on
+                         "frac_guide_rates": round(cyc_guide / per_step_s / (SIMDS * PEAK_CLOCK_GHZ * 1e9), 4) if cyc_guide else None,
+                         "useful_frac": round(cyc_guide / per_step_s / (SIMDS * PEAK_CLOCK_GHZ * 1e9) * lanes, 4) if (cyc_guide and lanes) else None,
                          "valu_insts_per_ray": round(64.0 * sum(k["launches_per_step"] * k.get("wave_insts_per_launch", {}).get("valu", 0.0) for k in sel) /
                                                      max(1.0, rank_rays / steps), 1),
                          "unpriced_share_of_cycles": round(unpriced, 4),
@@ -1004,8 +1049,9 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
         meds = [float(m) for m in re.findall(r"median ([0-9.]+) GHz", open(os.path.join(ROOT, "profiles", "r04", "wave_clock.txt")).read())]
         if meds and args.config == "c2":
             clk = sum(meds) / len(meds)
+            # (round 5's `frac_at_measured_clock` is gone: dividing by the clock the chip throttles to states a utilisation of
+            # what was delivered, not an efficiency; the clock THIS run held is `sustained.shader_clock_ghz`)
             r["valu_issue"]["measured_clock_ghz"] = round(clk, 3)
-            r["valu_issue"]["frac_at_measured_clock"] = round(min(1.0, issue_frac * PEAK_CLOCK_GHZ / clk), 4)
             r["valu_issue"]["clock_source"] = "profiles/r04/wave_clock.txt: k_bounce on C2, per-wave cycle counter against the 100-MHz real-time counter"
     except Exception:
         pass

@@ -350,6 +350,10 @@ int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, f
  * the `n` consecutive binary32 values from bit pattern `first_bits` on: mismatch[0] = arguments whose root differs,
  * mismatch[1] = whose reciprocal of the root differs.  Zero for every x in [2^-102, 2^128).  For x in [1 - 2^-12, 1 + 2^-12]
  * the reciprocal is the kernels' four-addition form for vectors that are unit vectors up to rounding (rsqrt_near_one). */
+/* pt_probe_clock: the shader clock (GHz) the device holds WHILE whatever is enqueued runs -- one wave counts its cycle counter
+ * against the constant 100-MHz counter for `microseconds` on a stream of its own, beside the session's launches (bench.py's
+ * `sustained` object: the issue roof is priced at the 2.4 GHz peak, the chip holds 2.1-2.2 under this library's kernels). */
+int pt_probe_clock(int microseconds, double *ghz);
 int pt_probe_rng(const uint32_t *seeds, int n, int draws, uint32_t *state, float *u);
 int pt_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, float *s, float *c, uint64_t sum[2]);
 int pt_probe_hemisphere(const float *normals, const uint32_t *seeds, int n, float *dirs);

@@ -24,7 +24,7 @@ import subprocess
 import sys
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("PT_ROUND", "r04")
+ROUND = os.environ.get("PT_ROUND", "r06")
 OUT = os.path.join(ROOT, "gpurun_out", ROUND)
 SIMDS, PEAK_GHZ = 1024, 2.4
 
@@ -185,6 +185,7 @@ def main(which):
                 e.update({"valu_insts_per_launch_counted": hist["valu_per_launch"], "counted_run": {k: cj[k] for k in ("steps", "batch", "image_md5")},
                           "sq_insts_valu_over_counted": round(scale, 4),
                           "issue_cycles_per_launch": hist["issue_cycles_per_launch"] * scale,
+                          "issue_cycles_guide_rates_per_launch": hist.get("issue_cycles_guide_rates_per_launch", 0.0) * scale,
                           "cycles_per_valu_inst": hist["issue_cycles_per_launch"] / hist["valu_per_launch"],
                           "unpriced_share_of_cycles": hist["unpriced_share_of_cycles"],
                           "flops_fp32_per_launch_64_lanes": hist["flops_fp32_per_launch"] * scale,

@@ -185,7 +185,7 @@ def hist(map_path, counts_path, cost_path, launches):
         cls[op_class(op)] = cls.get(op_class(op), 0) + n
     valu = {op: n for op, n in ops.items() if op_class(op) == 'valu'}
     total_valu = sum(valu.values())
-    cyc, unpriced = 0.0, 0.0
+    cyc, unpriced, cyc_guide = 0.0, 0.0, 0.0
     rows = []
     for op, n in sorted(valu.items(), key=lambda kv: -kv[1]):
         key = op if op in per_op else re.sub(r'_(e32|e64|dpp|sdwa)$', '', op)
@@ -194,6 +194,10 @@ def hist(map_path, counts_path, cost_path, launches):
         else:
             cost, known = default, False
         cyc += n * cost
+        # the same opcode at the GUIDE's rate class (MI355X_MICROARCH.md: full rate 2 cycles per wave-instruction per SIMD,
+        # half rate 4, transcendental 8): the class the measured cost is nearest to -- a roof that owes nothing to this
+        # repository's own microbenchmark (its rows include ramp and tail: 2.3-2.5 for a full-rate opcode)
+        cyc_guide += n * min((2.0, 4.0, 8.0), key=lambda g: abs(g - cost))
         if not known:
             unpriced += n * cost
         rows.append((op, n, cost, known))
@@ -205,6 +209,7 @@ def hist(map_path, counts_path, cost_path, launches):
             print("%-28s %14.0f %6.1f%% %7.2f%s" % (op, n / launches, 100.0 * n / total_valu, cost, "" if known else "  (class default)"))
     out = {"kernel": m["kernel"], "launches": launches, "wave_insts_per_launch": {k: v / launches for k, v in cls.items()},
            "valu_per_launch": total_valu / launches, "issue_cycles_per_launch": cyc / launches,
+           "issue_cycles_guide_rates_per_launch": cyc_guide / launches,
            "unpriced_share_of_cycles": unpriced / max(1.0, cyc),
            "valu_opcodes_per_launch": {op: n / launches for op, n in valu.items()},
            "flops_fp32_per_launch": 64.0 * sum(n * (2 if re.match(r'v_(fma|fmac|mad|mac|pk_fma)_f32', op) else 1)

@@ -152,6 +152,7 @@ def library():
             L.pt_probe_sincos.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
             L.pt_probe_hemisphere.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
             L.pt_probe_sqrt.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+            L.pt_probe_clock.argtypes = [C.c_int, C.POINTER(C.c_double)]
         except AttributeError:
             if not os.environ.get("PTMI355_LIB"):        # only an older A/B build (profiles/tools/ab.sh) may lack them
                 raise
@@ -433,6 +434,13 @@ def probe_sqrt(first_bits, count):
     out = np.zeros(2, dtype=np.uint64)
     _chk(library().pt_probe_sqrt(int(first_bits), int(count), _p(out)))
     return int(out[0]), int(out[1])
+
+
+def probe_clock(microseconds=200):
+    """The shader clock in GHz while whatever is enqueued keeps running (one wave, cycle counter against the 100-MHz counter)."""
+    ghz = C.c_double(0.0)
+    _chk(library().pt_probe_clock(int(microseconds), C.byref(ghz)))
+    return float(ghz.value)
 
 
 def probe_hemisphere(normals, seeds):

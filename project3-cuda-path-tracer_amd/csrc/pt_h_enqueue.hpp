@@ -235,9 +235,9 @@ int enqueue_bounce(int depth) {
     }
     HIPCHK(hipGetLastError());
     if (R.mesh_mode == MESH_BVH) {
-        // this bounce's flags are spent; the array is the NEXT bounce's output flags.  Only a fused bounce marks
-        // the candidates of the next one (the cached / unfused pipelines leave the finding to k_mesh's scan)
-        HIPCHK(hipMemsetAsync(R.mesh_flags[depth & 1], 0, R.flag_words * sizeof(unsigned long long), R.stream));
+        // this bounce's flags are spent, and zero again: the fused kernel's waves clear every word they read (run_tiles).
+        // The array is the NEXT bounce's output flags.  Only a fused bounce marks the candidates of the next one (the
+        // cached / unfused pipelines leave the finding to k_mesh's scan, and never touch the flags)
         R.mesh_marked = !cached0 && !unfused;
     }
     if (compact) { R.cur ^= 1; R.cur_dir = depth; }

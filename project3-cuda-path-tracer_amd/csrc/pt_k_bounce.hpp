@@ -290,8 +290,14 @@ __device__ __forceinline__ void run_tiles(const BounceArgs &a, const TileCtx &c,
             const float4 *pre_hit = nullptr;
             if (MESH == MESH_PRE && tr.active) {
                 // slots whose flag is set carry a mesh result from k_mesh (a hit, or "walked, nothing hit")
-                const unsigned long long *fl = c.kargs ? karg_field<unsigned long long *>(offsetof(BounceArgs, mesh_flags_in)) : a.mesh_flags_in;
-                if ((fl[src >> 6] >> (src & 63u)) & 1ull) pre_hit = (c.kargs ? karg_field<float4 *>(offsetof(BounceArgs, mesh_hit)) : a.mesh_hit) + src;
+                unsigned long long *fl = c.kargs ? karg_field<unsigned long long *>(offsetof(BounceArgs, mesh_flags_in)) : a.mesh_flags_in;
+                const unsigned long long word = fl[src >> 6];
+                if ((word >> (src & 63u)) & 1ull) pre_hit = (c.kargs ? karg_field<float4 *>(offsetof(BounceArgs, mesh_hit)) : a.mesh_hit) + src;
+                // ... and this wave is the word's last reader (k_mesh read it a launch ago; a tile of this kernel is one
+                // PHYSICAL tile of the pool -- dense, or aligned to the ranges -- so nobody else looks at this word): it puts
+                // it back to zero, ready to be the output flags of the next bounce.  Round 5 cleared the whole array with a
+                // hipMemsetAsync per bounce (eight extra launches per batch: profiles/r05/rocprof_r05_c4_bvh_summary.txt).
+                if (word != 0ull && (uint32_t)lane == (uint32_t)__builtin_ctzll((unsigned long long)ballot64(tr.active))) fl[src >> 6] = 0ull;
             }
             cull_scene<MESH>(a.scene, c.acc, q, par, c.tri_lds, tr.active, ro, rd, tr.mb, pre_hit, masked, gmask);
             const uint32_t ticket = q.total;

@@ -952,5 +952,6 @@ int pt_probe_sincos(const float *x, uint32_t first_bits, uint32_t n, float *s, f
 }
 int pt_probe_hemisphere(const float *normals, const uint32_t *seeds, int n, float *dirs) { return one::pt_probe_hemisphere(normals, seeds, n, dirs); }
 int pt_probe_sqrt(uint32_t first_bits, uint32_t n, uint64_t mismatch[2]) { return one::pt_probe_sqrt(first_bits, n, mismatch); }
+int pt_probe_clock(int microseconds, double *ghz) { return one::pt_probe_clock(microseconds, ghz); }
 
 }  // extern "C"

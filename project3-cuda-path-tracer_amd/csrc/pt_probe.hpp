@@ -57,6 +57,18 @@ __global__ void k_probe_hemisphere(const float *normals, const uint32_t *seeds, 
     dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
 }
 
+// the shader clock while whatever else is running runs: one wave counts its cycle counter (s_memtime) against the constant
+// 100-MHz counter (s_memrealtime) for `ticks` of the latter.  Sixteen scalar registers: it has to fit beside a persistent
+// grid that leaves 32 of a SIMD's 800 free (pt_k_image.hpp: k_gather_one).  Ends by itself: the real-time counter advances.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(16), amdgpu_num_vgpr(32))) void k_probe_clock(unsigned long long *out, unsigned ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64(), c0 = clock64();
+    unsigned long long t1 = t0;
+    while (t1 - t0 < (unsigned long long)ticks) { __builtin_amdgcn_s_sleep(8); t1 = wall_clock64(); }
+    const unsigned long long c1 = clock64();
+    out[0] = c1 - c0; out[1] = t1 - t0;
+}
+
 // device scratch of one probe call: freed on every exit path
 struct ProbeBufs {
     std::vector<void *> mem;
@@ -123,6 +135,34 @@ int pt_probe_sqrt(uint32_t first_bits, uint32_t n, uint64_t mismatch[2]) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(mismatch, d_bad, 16, hipMemcpyDeviceToHost));
     HIPCHK(hipDeviceSynchronize());
+    return PT_OK;
+}
+
+int pt_probe_clock(int microseconds, double *ghz) {
+    if (!ghz || microseconds < 1 || microseconds > 100000) return fail(PT_ERR_INVALID, "pt_probe_clock: bad argument");
+    *ghz = 0.0;
+    unsigned long long *h = nullptr, *d = nullptr;
+    hipStream_t st = nullptr;
+    int lo = 0, hi = 0;
+    if (hipHostMalloc((void **)&h, 16, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (h) (void)hipHostFree(h);
+        return fail(PT_ERR_DEVICE, "pt_probe_clock: no HIP device / no mappable host memory (this library has no CPU fallback)");
+    }
+    h[0] = h[1] = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+    hipError_t e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_clock, dim3(1), dim3(64), 0, st, d, (unsigned)microseconds * 100u);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);       // (this stream only: whatever else is enqueued keeps running)
+        (void)hipStreamDestroy(st);
+    }
+    const unsigned long long cycles = h[0], ticks = h[1];
+    (void)hipHostFree(h);
+    if (e != hipSuccess) return fail(PT_ERR_DEVICE, "pt_probe_clock: %s", hipGetErrorString(e));
+    if (!ticks) return fail(PT_ERR_INTERNAL, "pt_probe_clock: the probe left no counts");
+    *ghz = (double)cycles / ((double)ticks * 10.0);              // cycles per nanosecond
     return PT_OK;
 }
 

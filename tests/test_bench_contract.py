@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(cmd, timeout=600, per_bounce=True):
+def run(cmd, timeout=600, per_bounce=True, sustained=False):
+    if not sustained:
+        cmd = list(cmd) + ["--no-sustained"]          # (roofline.sustained repeats the timed steps for two seconds: one test looks at it)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if per_bounce:
@@ -43,10 +45,20 @@ def _check_roofline(r):
 def test_default_line_and_its_counter_profile():
     """The driver's command line (defaults: C2, 64 spp per step): when profiles/traffic.json holds this build's profile
     the roofline object carries measured fractions; they are checked for consistency either way."""
-    d = run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], per_bounce=False)
+    d = run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], per_bounce=False, sustained=True)
     assert d["config"]["batch_spp"] == 64 and d["value"] > 1000
     _check_roofline(d["roofline"])
     assert d["roofline"]["launches"] == 5 * 8
+    # what round 5's line left out (VERDICT r05 item 3): the timed steps repeated for two seconds with the shader clock read
+    # beside them, the issue fraction at the guide's rates and the part of it that ran switched-on lanes
+    su = d["roofline"]["sustained"]
+    assert su["seconds"] >= 2.0 and su["steps"] >= 5 and su["mrays_per_s"] > 1000 and 0.6 < su["ratio_to_value"] < 1.2
+    assert abs(su["mrays_per_s"] - d["config"]["rays_per_step"] * su["steps"] / su["seconds"] / 1e6) / su["mrays_per_s"] < 0.02
+    assert su["shader_clock_ghz"] is not None and 1.0 < su["shader_clock_ghz"] < 2.6
+    if d["roofline"]["frac"] is not None:
+        v = d["roofline"]["valu_issue"]
+        assert "frac_at_measured_clock" not in v and 0.0 < v["useful_frac"] < v["frac_guide_rates"] < v["frac"] <= 1.0
+        assert abs(v["useful_frac"] - v["frac_guide_rates"] * d["roofline"]["fp32"]["active_lane_fraction"]) < 2e-3
     # figures a reader can re-derive from SURVEY 8(d) and the line itself (VERDICT r04 item 4): north_star's yardstick --
     # the intersect + compaction bytes (48 B per ray + 88 B per survivor) over the bounce kernels' time and 8 TB/s ...
     c = d["roofline"]["contract"]
