@@ -333,6 +333,12 @@ int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxe
  * (glm::intersectRayTriangle + the hit-point test; csrc/pt_h_scene.hpp: make_tri_bounds has the derivation), so the kernel
  * does not run the exact test for the pair.  Returns the number of entries written. */
 int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, float *bounds);
+/* host-only (no GPU): the same spheres as the every-triangle loop's first stage reads them -- it evaluates "line passes the centre
+ * at more than Rs" on the matrix pipe (v_mfma_f32_16x16x32_f16) as ONE bilinear form per (ray, triangle) pair, in the mesh's own
+ * frame (centre g, scale 1 / Rm: every sphere in the unit ball): records = ((count + 63) & ~63) x 32 binary16 K-slots (the triangle's
+ * side of the form: csrc/pt_h_scene.hpp: make_tri_records; padding records reach nobody), frame = {gx, gy, gz, 1 / Rm}.  The ray's
+ * side and the error budget: csrc/pt_k_trisweep.hpp.  Returns the number of records written. */
+int pt_tri_records(const pt_triangle *triangles, int count, float origin_bound, uint16_t *records, float frame[4]);
 /* ---- known-answer probes: the DEVICE's own arithmetic on caller data (no session needed, any HIP device) -------
  * pt_probe_rng: thrust::default_random_engine (minstd_rand) as makeSeededRandomEngine constructs it
  * (pathtrace.cu:41-45 -> engine(seed)): for each of the n seeds, seed the engine and draw `draws` times through

@@ -8,7 +8,7 @@ from .binding import (  # noqa: F401
     PtError, Scene, Stats, library, pathtrace, pathtraceFree, pathtraceInit,
     device_image_ptr, export_intersections, export_paths, get_image, get_stats, intersect_once,
     set_camera, set_lens, synchronize, tonemap, trace_batch, trace_batch_async, trace_begin, trace_bounce,
-    trace_end, clear_image, version, has_experiments, set_profiling, get_profile, STAGES, total_rays, counters, cull_boxes, num_devices, exchange_transport, tri_bounds,
+    trace_end, clear_image, version, has_experiments, set_profiling, get_profile, STAGES, total_rays, counters, cull_boxes, num_devices, exchange_transport, tri_bounds, tri_records,
     set_image, probe_rng, probe_sincos, probe_sincos_sums, probe_hemisphere, probe_sqrt, probe_clock,
 )
 from .build import build  # noqa: F401

@@ -146,6 +146,7 @@ def library():
         L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pt_cull_boxes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
         L.pt_tri_bounds.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.pt_tri_records.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         try:
             L.pt_set_image.argtypes = [C.c_void_p]
             L.pt_probe_rng.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -385,6 +386,17 @@ def tri_bounds(triangles, origin_bound):
     out = np.zeros(((len(t) + 3) & ~3, 4), dtype=np.float32)
     _chk(library().pt_tri_bounds(_p(t), len(t), float(origin_bound), _p(out)))
     return out[:len(t)]
+
+
+def tri_records(triangles, origin_bound):
+    """Host-only: the triangles' side of the bilinear form the every-triangle loop's first stage evaluates on the matrix pipe:
+    (records [n64, 32] float16, frame {gx, gy, gz, 1 / Rm})."""
+    t = np.ascontiguousarray(triangles, dtype=TRI_DT)
+    n64 = (len(t) + 63) & ~63
+    rec = np.zeros((max(n64, 1), 32), dtype=np.float16)
+    frame = np.zeros(4, dtype=np.float32)
+    n = _chk(library().pt_tri_records(_p(t), len(t), float(origin_bound), _p(rec), _p(frame)))
+    return rec[:n], frame
 
 
 def total_rays():

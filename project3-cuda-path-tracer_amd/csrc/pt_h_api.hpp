@@ -274,6 +274,7 @@ static int init_impl(const pt_scene_desc *d) {
     R.desc.triangles = R.tris_keep.empty() ? nullptr : R.tris_keep.data();
     if (d->num_meshes > 0) R.meshes_keep.assign(d->meshes, d->meshes + d->num_meshes);
     R.desc.meshes = R.meshes_keep.empty() ? nullptr : R.meshes_keep.data();
+    R.grec_frames.assign((size_t)std::max(1, d->num_geoms) * 4, 0.0f);
     {
         const int rc = upload_cull(&R.desc, R.cam);
         if (rc != PT_OK) return rc;
@@ -981,6 +982,17 @@ int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, f
     if (count < 0 || (count > 0 && !triangles) || !bounds) return fail(PT_ERR_INVALID, "pt_tri_bounds: bad argument");
     make_tri_bounds(triangles, count, (double)origin_bound, bounds);
     return (count + 3) & ~3;
+}
+
+int pt_tri_records(const pt_triangle *triangles, int count, float origin_bound, uint16_t *records, float frame[4]) {
+    if (count < 0 || (count > 0 && !triangles) || !records || !frame) return fail(PT_ERR_INVALID, "pt_tri_records: bad argument");
+    const size_t n64 = (size_t)((count + 63) & ~63);
+    std::vector<float> sph(std::max<size_t>(n64, 1) * 4, 0.0f);
+    make_tri_bounds(triangles, count, (double)origin_bound, sph.data());
+    for (size_t i = (size_t)((count + 3) & ~3); i < n64; ++i) sph[i * 4 + 3] = -1.0f;
+    static_assert(sizeof(_Float16) == sizeof(uint16_t), "binary16");
+    make_tri_records(sph.data(), (int)n64, reinterpret_cast<_Float16 *>(records), frame);
+    return (int)n64;
 }
 
 int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound, float *reject) {

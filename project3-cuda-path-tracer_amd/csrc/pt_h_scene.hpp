@@ -97,27 +97,82 @@ void make_tri_bounds(const pt_triangle *tris, int count, double Rorigin, float *
     }
 }
 
+// The same spheres as the matrix pipe reads them (pt_k_trisweep.hpp: mesh_sweep, stage 1): in the mesh's own frame -- centre g
+// of the finite spheres' bounding box, scaled by 1 / Rm with Rm = max (|c - g| + Rs), so that every sphere lies in the unit
+// ball -- a triangle is the 32 binary16 K-slots of
+//     [-cx^2 -cy^2 -cz^2 -2cxcy -2cxcz -2cycz | cx cy cz | K = |c|^2 - Rs^2 | 1]          (a term's three slots: hi, hi, lo)
+// evaluated in binary64 from the sphere's floats and split into (hi, lo) pairs.  spheres: n x {cx, cy, cz, Rs^2} as
+// make_tri_bounds writes them (Rs^2 = -1: padding, +inf: a non-finite triangle); records: n x 32 binary16; frame: {g, 1 / Rm}.
+void make_tri_records(const float *spheres, int n, _Float16 *records, float frame[4]) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n; ++i) {
+        const float *sp = spheres + (size_t)i * 4;
+        if (!(sp[3] >= 0.0f) || !std::isfinite(sp[3])) continue;
+        for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], (double)sp[a]); hi[a] = std::fmax(hi[a], (double)sp[a]); }
+    }
+    double g[3] = {0.0, 0.0, 0.0}, Rm = 0.0;
+    if (lo[0] <= hi[0]) for (int a = 0; a < 3; ++a) g[a] = (double)(float)(0.5 * (lo[a] + hi[a]));       // (the kernel subtracts the float)
+    for (int i = 0; i < n; ++i) {
+        const float *sp = spheres + (size_t)i * 4;
+        if (!(sp[3] >= 0.0f) || !std::isfinite(sp[3])) continue;
+        const double dx = sp[0] - g[0], dy = sp[1] - g[1], dz = sp[2] - g[2];
+        Rm = std::fmax(Rm, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)sp[3]));
+    }
+    Rm = Rm > 0.0 ? Rm * (1.0 + 0x1p-20) : 1.0;
+    float ir = (float)(1.0 / Rm);
+    if (!(ir > 0.0f) || !std::isfinite(ir)) ir = 1.0f;
+    frame[0] = (float)g[0]; frame[1] = (float)g[1]; frame[2] = (float)g[2]; frame[3] = ir;
+    auto pair = [](double v, _Float16 &h, _Float16 &l) { h = (_Float16)(float)v; l = (_Float16)(float)(v - (double)(float)h); };
+    for (int i = 0; i < n; ++i) {
+        const float *sp = spheres + (size_t)i * 4;
+        _Float16 *a = records + (size_t)i * 32;
+        for (int k = 0; k < 32; ++k) a[k] = (_Float16)0.0f;
+        a[29] = (_Float16)1.0f; a[30] = (_Float16)1.0f;                       // x M (hi, lo)
+        if (!(sp[3] >= 0.0f)) { a[27] = (_Float16)30000.0f; continue; }       // padding: v = 30000 + M > 0 for every ray, wild ones included
+        if (!std::isfinite(sp[3])) { a[27] = (_Float16)-30000.0f; continue; } // a non-finite triangle: everybody's candidate (never accepted)
+        // (the kernel's scale is the FLOAT ir applied to float differences: the record uses the same scale)
+        const double c[3] = {(sp[0] - g[0]) * (double)ir, (sp[1] - g[1]) * (double)ir, (sp[2] - g[2]) * (double)ir};
+        const double v[9] = {-c[0] * c[0], -c[1] * c[1], -c[2] * c[2], -2.0 * c[0] * c[1], -2.0 * c[0] * c[2], -2.0 * c[1] * c[2], c[0], c[1], c[2]};
+        for (int t = 0; t < 9; ++t) { _Float16 h, l; pair(v[t], h, l); a[3 * t] = h; a[3 * t + 1] = h; a[3 * t + 2] = l; }
+        _Float16 h, l;
+        pair((c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) - (double)sp[3] * (double)ir * (double)ir, h, l);
+        a[27] = h; a[28] = l;
+    }
+}
+
 int upload_tri_bounds(const pt_scene_desc *d, double Rorigin) {
     if (R.mesh_mode != MESH_TILES || d->num_meshes <= 0) return PT_OK;
-    size_t words = 0;
-    for (int k = 0; k < d->num_meshes; ++k) words += (size_t)((d->meshes[k].triangle_count + 63) & ~63) * 4;
-    std::vector<float> tb(std::max<size_t>(words, 256), 0.0f);
+    size_t recs = 0;
+    for (int k = 0; k < d->num_meshes; ++k) recs += (size_t)((d->meshes[k].triangle_count + 63) & ~63);
+    std::vector<_Float16> tr(std::max<size_t>(recs, 64) * 32, (_Float16)0.0f);
+    std::vector<float> sph;
     size_t off = 0;
     for (int k = 0; k < d->num_meshes; ++k) {
         const pt_mesh &m = d->meshes[k];
-        make_tri_bounds(d->triangles + m.first_triangle, m.triangle_count, Rorigin, tb.data() + off);
-        const size_t n4 = (size_t)((m.triangle_count + 3) & ~3), n64 = (size_t)((m.triangle_count + 63) & ~63);
-        for (size_t i = n4; i < n64; ++i) { float *o = tb.data() + off + i * 4; o[0] = o[1] = o[2] = 0.0f; o[3] = -1.0f; }
-        off += n64 * 4;
+        const size_t n64 = (size_t)((m.triangle_count + 63) & ~63);
+        sph.assign(n64 * 4, 0.0f);
+        make_tri_bounds(d->triangles + m.first_triangle, m.triangle_count, Rorigin, sph.data());
+        for (size_t i = (size_t)((m.triangle_count + 3) & ~3); i < n64; ++i) sph[i * 4 + 3] = -1.0f;
+        float frame[4];
+        make_tri_records(sph.data(), (int)n64, tr.data() + off * 32, frame);
+        // the mesh's frame rides in its geom record (words G_INV + 7 .. + 10; a mesh's matrices are never read)
+        float *r = R.grec_frames.data() + (size_t)m.geom_index * 4;
+        for (int a = 0; a < 4; ++a) r[a] = frame[a];
+        off += n64;
     }
-    if (!R.d_tri_bound || R.tri_bound_words < tb.size()) {
+    if (!R.d_tri_bound || R.tri_bound_words < tr.size() / 2) {
         if (R.d_tri_bound) { HIPCHK(hipStreamSynchronize(R.stream)); (void)hipFree(R.d_tri_bound); R.d_tri_bound = nullptr; }
-        HIPCHK(hipMalloc(&R.d_tri_bound, tb.size() * 4));
-        R.tri_bound_words = tb.size();
+        HIPCHK(hipMalloc(&R.d_tri_bound, tr.size() * 2));
+        R.tri_bound_words = tr.size() / 2;
     }
-    HIPCHK(hipMemcpyAsync(R.d_tri_bound, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, R.stream));
-    HIPCHK(hipStreamSynchronize(R.stream));            // `tb` is pageable host memory about to go out of scope
-    R.scene.tri_bound = R.d_tri_bound;
+    HIPCHK(hipMemcpyAsync(R.d_tri_bound, tr.data(), tr.size() * 2, hipMemcpyHostToDevice, R.stream));
+    // ... and the frames into the device's geom records
+    for (int k = 0; k < d->num_meshes; ++k) {
+        const int gi = d->meshes[k].geom_index;
+        HIPCHK(hipMemcpyAsync(R.d_geoms + (size_t)gi * ptd::GEOM_WORDS + ptd::G_INV + 7, R.grec_frames.data() + (size_t)gi * 4, 16, hipMemcpyHostToDevice, R.stream));
+    }
+    HIPCHK(hipStreamSynchronize(R.stream));            // `tr` is pageable host memory about to go out of scope
+    R.scene.tri_rec = R.d_tri_bound;
     return PT_OK;
 }
 

@@ -57,8 +57,9 @@ struct Renderer {
     bool own_image = false;
     float *d_geoms = nullptr, *d_mats = nullptr, *d_tris = nullptr;
     float *d_cull = nullptr, *d_grec = nullptr;
-    float *d_tri_bound = nullptr;  // every-triangle loop, stage 1: {centre, Rs^2} per triangle (upload_tri_bounds)
+    float *d_tri_bound = nullptr;  // every-triangle loop, stage 1: the triangles' 64-byte records for the matrix pipe (upload_tri_bounds)
     size_t tri_bound_words = 0;
+    std::vector<float> grec_frames;   // per geom {g, 1 / Rm} of a mesh's records (device copy: geom record words G_INV + 7 .. + 10)
     uint32_t *d_ginfo = nullptr;
     double cull_eye_reach = 0.0;  // |camera position|_1 the cull boxes were made for
     std::vector<pt_geom> geoms_keep;   // host copies (pt_set_camera may have to remake the cull boxes)

@@ -66,7 +66,8 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
                 const int first = __float_as_int(rec[2]);
                 const int count = __float_as_int(rec[3]);
                 const int boff = __float_as_int(rec[ptd::G_INV + 6]);
-                mesh_sweep(sc, q, par, tri_lds, first, count, boff, ro, rd, m_act, m_wild, best, best_i);
+                mesh_sweep(sc, q, par, tri_lds, first, count, boff, rec[ptd::G_INV + 7], rec[ptd::G_INV + 8], rec[ptd::G_INV + 9], rec[ptd::G_INV + 10],
+                           ro, rd, m_act, m_wild, best, best_i);
             }
             if (active && best_i >= 0) {
                 f3 p = ptd::add(ro, ptd::scale(rd, best));

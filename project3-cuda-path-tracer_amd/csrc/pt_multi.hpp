@@ -943,6 +943,9 @@ int pt_bvh_build(const pt_triangle *triangles, int count, float *nodes, int node
 int pt_tri_bounds(const pt_triangle *triangles, int count, float origin_bound, float *bounds) {
     return one::pt_tri_bounds(triangles, count, origin_bound, bounds);
 }
+int pt_tri_records(const pt_triangle *triangles, int count, float origin_bound, uint16_t *records, float frame[4]) {
+    return one::pt_tri_records(triangles, count, origin_bound, records, frame);
+}
 int pt_cull_boxes(const pt_geom *geoms, int count, const float *eye, float *boxes, float *origin_bound, float *reject) {
     return one::pt_cull_boxes(geoms, count, eye, boxes, origin_bound, reject);
 }

@@ -30,7 +30,9 @@ namespace {
                                              // `all6`; round 3 had measured the cap neutral)
 #endif
 #ifndef PT_LOOP_WAVES
-#define PT_LOOP_WAVES 4                      // k_bounce<MESH_TILES>: measured 41.9 Mrays/s on C4 against 36.9 at 3 and 40.1 at 5 (profiles/r03)
+#define PT_LOOP_WAVES 3                      // k_bounce<MESH_TILES>: round 6 (stage 1 on the matrix pipe: four B operands, four A operands in flight,
+                                             // sixteen accumulators): 170.2 Mrays/s on C4 at 3 waves per SIMD (168 VGPRs, no spill), 165.7 at 4 (35-47
+                                             // registers spilled), 158.9 at 2 (profiles/r06/ab_c4_loop_waves.txt); round 3's vector form: 41.9 at 4
 #endif
 constexpr int BLOCK = 256;                 // 4 waves of 64
 constexpr int WAVES = BLOCK / 64;
@@ -263,8 +265,9 @@ struct SceneDev {
     float rmax;                            // |origin|_1 bound the cull boxes were derived for
     const float *mats;   int nmats;        // MAT_WORDS dwords each
     const float *tris;   int ntris;        // v0, e1, e2 + pad (12 dwords each)
-    const float *tri_bound;                // per triangle {centre xyz, Rs^2} of the every-triangle loop's first stage (scalar loads;
-                                           //   per mesh padded to a multiple of 64, offset in word G_INV + 6 of its geom record)
+    const void *tri_rec;                   // per triangle the 32 binary16 K-slots (64 B) of the every-triangle loop's first stage
+                                           //   (pt_h_scene.hpp: make_tri_records; per mesh padded to a multiple of 64 records, offset in
+                                           //   word G_INV + 6 of its geom record, the mesh's frame {g, 1 / Rm} in words G_INV + 7 .. + 10)
     const float *bvh_nodes;                // PT_MESH_BVH: all meshes' trees, BVH_NODE_WORDS per node
     const float *bvh_tris;                 //   leaf-ordered triangle records, word 9 = original index
     float bvh_prune;  int bvh_guard;       //   prune margin; upper bound on nodes visited per walk

@@ -40,7 +40,58 @@ def check(pt, po, tris, origin, direction, origin_bound):
     margin = 2.0 ** -18 * origin_bound
     bad = acc & inside[:, None] & (dist > (rs - margin)[None, :])
     assert not bad.any(), (int(bad.sum()), np.argwhere(bad)[:5].tolist())
+    matrix_form_keeps(pt, tris, rays, acc, inside, origin_bound)
     return acc, dist, rs
+
+
+E_FORM, FAR_M2 = np.float32(4.0e-5), np.float32(1.21)          # csrc/pt_k_trisweep.hpp: TRI_FORM_E, TRI_FAR_M2
+
+
+def half_pair(v):
+    hi = v.astype(np.float16)
+    lo = (v - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def matrix_form_keeps(pt, tris, rays, acc, inside, origin_bound):
+    """Round 6: the kernel evaluates the same spheres on the matrix pipe, as ONE bilinear form per pair (csrc/pt_k_trisweep.hpp:
+    mesh_sweep; the triangles' side from pt_tri_records, the rays' side restated here in the kernel's own single-precision
+    operations).  Products of binary16 slots are exact; the MFMA's 31 binary32 additions may round in any order, so the
+    model adds the worst case, 32 x 2^-24 x the sum of the terms' absolute values: a pair the oracle accepts must still
+    come out NEGATIVE (a candidate), and its ray must not have been classified as passing the mesh at a distance."""
+    rec, frame = pt.tri_records(tris, origin_bound)
+    a = rec[:len(tris)].astype(np.float64)                          # [triangles, 32]
+    o, d = rays["origin"].astype(np.float32), rays["direction"].astype(np.float32)
+    f32 = np.float32
+    with np.errstate(all="ignore"):
+        n2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        sc = (f32(1.0) / np.sqrt(n2)).astype(f32)                   # (v_rsq_f32: within an ulp or two of this)
+        dn = d * sc[:, None]
+        op = ((o - frame[None, :3]) * frame[3]).astype(f32)
+        m = np.cross(op.astype(np.float64), dn.astype(np.float64)).astype(f32)      # (three fma each: one rounding, like the kernel's)
+        M = ((m.astype(np.float64) ** 2).sum(axis=1)).astype(f32)
+        w = np.cross(dn, m).astype(f32)
+        v = np.stack([dn[:, 0] * dn[:, 0], dn[:, 1] * dn[:, 1], dn[:, 2] * dn[:, 2], dn[:, 0] * dn[:, 1], dn[:, 0] * dn[:, 2], dn[:, 1] * dn[:, 2],
+                      f32(-2) * w[:, 0], f32(-2) * w[:, 1], f32(-2) * w[:, 2]], axis=1).astype(f32)
+        b = np.zeros((len(o), 32), dtype=np.float64)
+        hi, lo = half_pair(v)
+        b[:, 0:27:3], b[:, 1:27:3], b[:, 2:27:3] = hi, lo, hi           # a term's slots here: hi, lo, hi (there: hi, hi, lo)
+        b[:, 27] = b[:, 28] = 1.0
+        mh, ml = half_pair((M - E_FORM).astype(f32))
+        b[:, 29], b[:, 30] = mh, ml
+        far = ~(M <= FAR_M2)
+        val = b @ a.T                                               # exact products, summed in binary64
+        mag = np.abs(b) @ np.abs(a).T
+    worst = val + 32 * 2.0 ** -24 * mag
+    must = acc & inside[:, None]
+    assert not (must & far[:, None]).any(), "an accepted pair's ray was classified as passing the mesh at a distance"
+    lost = must & ~(worst < 0)
+    assert not lost.any(), (int(lost.sum()), np.argwhere(lost)[:5].tolist(), worst[lost][:5].tolist())
+    # the stage is still worth having on this mesh: what it keeps is a small multiple of what round 5's fp32 form kept
+    ok = inside & ~far
+    if ok.any() and len(tris) >= 64:
+        kept = (val[ok] < 0).mean()
+        assert kept < 0.5, kept
 
 
 @pytest.mark.parametrize("size", [(8, 16), (30, 60)])
