@@ -11,7 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-pt = ge.load_package(); L = pt.library()
+pt = ge.load_package()
+if not pt.has_experiments():
+    raise SystemExit("percall_contexts.py flips experiment variables (PTMI355_MULTI_DIRECT, ...): load a -DPT_EXPERIMENTS build through PTMI355_LIB"); L = pt.library()
 z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
 g = lambda k: z["cornell__%s" % k]
 scene = pt.Scene(g("geoms"), g("materials"), g("camera"), int(g("depth")))

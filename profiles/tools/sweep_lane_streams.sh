@@ -1,3 +1,4 @@
+. "$(dirname "$0")/need_experiments.sh"      # (experiment variables: the shipped library ignores them)
 one() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
 for r in 1 2; do
 for b in 1 2 4 8; do

@@ -1,3 +1,4 @@
+. "$(dirname "$0")/need_experiments.sh"      # (experiment variables: the shipped library ignores them)
 one() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'], (d['config'].get('per_call') or {}).get('mrays_per_s'))"; }
 export PTMI355_OVERLAP=4 PTMI355_LANE_STREAMS=2
 for g in 8 10 12 15 18 20; do

@@ -334,8 +334,10 @@ inline void build(const float *v, int count, Tree &out, double origin_bound = -1
         out.nodes.assign((size_t)next * NODE_WORDS, 0.0f);
         detail::emit(w, rec, 0, end, out.pad, out);
     } else {
-        // at most LEAF_MAX triangles: one record whose left child is that leaf (its box when there is
-        // one, else inverted) and whose right child is an empty leaf with an inverted box nothing hits
+        // at most LEAF_MAX triangles: one record whose left child is that leaf (its box when there is one) and whose
+        // right child is an EMPTY leaf: pack_box gives an empty child a point box at the grid's origin (m = 0, e = 0) --
+        // a ray through that point "hits" it, and finds a leaf of zero triangles: nothing to test.  The invariant the
+        // walk relies on is that an empty child always carries INFO_LEAF and count 0 (pack_box; test_bvh_cpu.py)
         out.nodes.assign(NODE_WORDS, 0.0f);
         float *r = out.nodes.data();
         detail::pack_box(&r[0], w.split[0].box, out.pad, out, count == 0);

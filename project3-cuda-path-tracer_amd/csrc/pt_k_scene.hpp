@@ -84,8 +84,8 @@ __device__ __forceinline__ cfloat *as_const(const float *p) {
 //
 //  1. CULL.  Per primitive a world-space box, computed at pt_init, that contains every ray the reference's own
 //     float arithmetic could report a hit for (pt_h_scene.hpp: upload_cull / pt_cull.hpp, with the error bound).  All lanes
-//     test their ray against it with one v_rcp per axis per RAY and six fused multiply-adds + min/max per
-//     primitive (the box comes from wave-uniform scalar loads).  This test only decides which exact tests run,
+//     test their ray against it with one v_rcp per axis per RAY and, per primitive, nine fused multiply-adds, a v_max3,
+//     a v_min3, a v_max and one compare (the box as centre and half extent, from wave-uniform scalar loads; round 5).  This test only decides which exact tests run,
 //     never their outcome, so it may be approximate as long as it errs towards "candidate": rays outside the
 //     range the bound was derived for (huge or non-finite origins, odd direction magnitudes) are candidates of
 //     everything (`wild`); for the others every slab parameter is finite (cull_ray).

@@ -245,7 +245,7 @@ struct Group {
     // page-locked image (registered ONCE, portable: every device maps it) -- no pack, no exchange, no frame-to-host copy
     bool direct_ok = false, direct_enabled = true;   // every context can (asked at pt_init) / PTMI355_MULTI_DIRECT
     float *dhost = nullptr; size_t dhost_bytes = 0;  // the registered host image
-    bool frame_stale = false;  /* (set by the caller's thread when the exchange thread is idle; cleared by either: a late clear only costs one redundant exchange) */              // the device frame lacks the peers' rows of such calls: the next exchange brings them
+    bool frame_stale = false;  /* (set by the caller's thread, cleared by it or by the exchange thread -- always through __atomic_load_n / __atomic_store_n, relaxed: a late clear only costs one redundant exchange) */              // the device frame lacks the peers' rows of such calls: the next exchange brings them
     std::unique_ptr<Exchanger> x;               // asynchronous batches hand their exchange to this thread
     float *frame = nullptr;                     // where the tiles are assembled: context 0's accumulation buffer -- except in the
                                                 // one-context RCCL rehearsal, where it is a buffer of its own (self_frame)
@@ -296,7 +296,7 @@ int worker_pack(Worker &w, int s) {
 int enqueue_exchange(int s) {
     Worker &root = *G.w[0];
     if (G.K == 1 && !G.self_exchange) { G.exchanges++; return PT_OK; }     // one context, nothing to move: its buffer is the frame
-    G.frame_stale = false;      // every exchange carries the running sums as they are: the peers' rows of direct calls come along
+    __atomic_store_n(&G.frame_stale, false, __ATOMIC_RELAXED);      // every exchange carries the running sums as they are: the peers' rows of direct calls come along
     DeviceGuard guard;
     if (G.use_rccl) {
         for (auto &wp : G.w) {
@@ -352,8 +352,8 @@ int exchange_settled(void);
 // The frame on device 0 after calls that wrote the host image directly (multi_trace): one exchange of the running sums
 // as they are brings every peer's rows; every exchange does, so `frame_stale` falls with the next one of any kind.
 int multi_refresh(void) {
-    if (!G.frame_stale) return PT_OK;
-    G.frame_stale = false;
+    if (!__atomic_load_n(&G.frame_stale, __ATOMIC_RELAXED)) return PT_OK;
+    __atomic_store_n(&G.frame_stale, false, __ATOMIC_RELAXED);
     if (G.K == 1) return PT_OK;
     const int s = (int)(G.calls % XSLOTS);
     int rc = exchange_settled();
@@ -778,7 +778,7 @@ static int multi_trace(uint8_t *pbo_rgba, int iter0, int count, float *host_imag
             }
             return one::pt_trace_mapped(iter0, w.host_dev);
         });
-        G.frame_stale = true;
+        __atomic_store_n(&G.frame_stale, true, __ATOMIC_RELAXED);
         return rc;
     }
     int rc = multi_enqueue(iter0, count);

@@ -2,7 +2,8 @@
 //
 // MI355X-native replacement for the hot path of the reference's src/pathtrace.cu (pathtraceInit / pathtrace /
 // pathtraceFree and its five kernels).  Design:
-//   * path state lives in a pool that is SoA per 64-path tile (ten 256-B rows: ox..oz dx..dz cr..cb pid) and holds
+//   * path state lives in a pool that is SoA per 64-path tile (2560 B: two rows of 16 B per lane, [ox oy oz dx] and
+//     [dy dz cr cg], and one of 8 B, [cb pid] -- three memory instructions per tile and direction) and holds
 //     `batch` iterations of the tile's pixels; two pools ping-pong;
 //   * a persistent grid; every WAVE owns one contiguous run of 64-path tiles per bounce and walks it with two
 //     tiles in flight: cull against per-primitive world boxes -> candidate ring in LDS -> lane-dense exact
@@ -21,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>

@@ -110,6 +110,8 @@ def main():
                           rng.integers(0, 2 ** 32, 955, dtype=np.uint64).astype(np.uint32)])
     hout = np.array([A.ref_utilhash(int(x)) for x in hin], dtype=np.uint32)
     assert hout[64] == 4090419040                      # SURVEY a12 probe
+    BL.ref_utilhash.restype = C.c_uint
+    assert (hout == np.array([BL.ref_utilhash(int(x)) for x in hin], dtype=np.uint32)).all(), "TU_A != TU_B: utilhash"
     seeds = np.concatenate([np.array([0, 1, 2147483647, 2147483648, 0xffffffff, 12345, 2147483646],
                                      dtype=np.uint32),
                             rng.integers(0, 2 ** 32, 249, dtype=np.uint64).astype(np.uint32)])
@@ -194,6 +196,15 @@ def main():
     mv_o = np.zeros((256, 3), dtype=np.float32)
     for i in range(256):
         A.ref_multiply_mv(P(mv_m[i]), P(mv_v[i]), P(mv_o[i]))
+    # TU_A (g++, the genuine cuda_runtime.h) == TU_B (hipcc --offload-host-only, the forwarding header) on every function both
+    # contain, not only the box / sphere tests: what TU_B alone pins (sampler, ray generation, fake shader, the iteration) sits
+    # on exactly these
+    tmp = np.zeros(3, dtype=np.float32)
+    for i in range(256):
+        BL.ref_get_point_on_ray(P(gp_r[i]), C.c_float(gp_t[i]), P(tmp))
+        assert tmp.tobytes() == gp_o[i].tobytes(), "TU_A != TU_B: getPointOnRay %d" % i
+        BL.ref_multiply_mv(P(mv_m[i]), P(mv_v[i]), P(tmp))
+        assert tmp.tobytes() == mv_o[i].tobytes(), "TU_A != TU_B: multiplyMV %d" % i
     # glm reflect / refract / intersectRayTriangle
     I = rng.normal(size=(512, 3)).astype(np.float32); I /= np.linalg.norm(I, axis=1, keepdims=True).astype(np.float32)
     Nn = rng.normal(size=(512, 3)).astype(np.float32); Nn /= np.linalg.norm(Nn, axis=1, keepdims=True).astype(np.float32)
@@ -202,6 +213,10 @@ def main():
     for i in range(512):
         A.ref_glm_reflect(P(I[i]), P(Nn[i]), P(refl[i]))
         A.ref_glm_refract(P(I[i]), P(Nn[i]), C.c_float(eta[i]), P(refr[i]))
+        BL.ref_glm_reflect(P(I[i]), P(Nn[i]), P(tmp))
+        assert tmp.tobytes() == refl[i].tobytes(), "TU_A != TU_B: glm::reflect %d" % i
+        BL.ref_glm_refract(P(I[i]), P(Nn[i]), C.c_float(eta[i]), P(tmp))
+        assert tmp.tobytes() == refr[i].tobytes(), "TU_A != TU_B: glm::refract %d" % i
     tri_o = rng.uniform(-3, 3, (2048, 3)).astype(np.float32)
     tri_v = rng.uniform(-2, 2, (2048, 9)).astype(np.float32)
     tgt = (tri_v[:, 0:3] * .3 + tri_v[:, 3:6] * .3 + tri_v[:, 6:9] * .4) + rng.normal(scale=.6, size=(2048, 3)).astype(np.float32)
