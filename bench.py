@@ -47,6 +47,7 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
 PEAK_CLOCK_GHZ = 2.4           # MI355X_MICROARCH.md: max clock
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense f16 / bf16
 # SURVEY 8(d) algorithmic bytes: intersect 44 B/ray + shade/scatter 104 B/ray +
 # compaction 4 B/ray, + 88 B per surviving path -- all done by the fused k_bounce launch
 BYTES_PER_RAY = 44 + 104 + 4
@@ -763,7 +764,20 @@ def main():
         pt.set_profiling(False)
         roofline = roofline_object(args, n_tiles if inproc else world, flags, pt, prof, rank_rays, first, dt / args.steps)
 
-    # ---- sustained: the timed region is 20 steps = 62 ms; pathtrace.cu:284-393 runs 5000 times per image.
+    digest = None
+    if args.digest:
+        import hashlib
+        s.barrier()
+        final = s.image
+        if inproc:
+            final = torch.from_numpy(pt.get_image(npix))        # the frame device 0 assembled
+        if dist_on:
+            # the frame rank 0 holds after the last exchange IS the result (gather: copies; reduce: sum with zeros)
+            final = s.frame
+        torch.cuda.synchronize()
+        if rank == 0:
+            digest = hashlib.md5(final.cpu().numpy().tobytes()).hexdigest()
+    # ---- sustained (after the digest, which is of the timed steps): the timed region is 20 steps = 62 ms; pathtrace.cu:284-393 runs 5000 times per image.
     # The same steps again for at least two seconds of wall time, with the shader clock read (one wave, cycle counter against
     # the 100-MHz counter: pt_probe_clock) while they run; `steps` / `ms_per_step` / `value` stay the short pass's.
     sustained = None
@@ -795,19 +809,6 @@ def main():
                              "shader clock = one wave counting its cycle counter against the 100-MHz counter for 300 us beside each of the first "
                              "chunks (include/ptmi355.h: pt_probe_clock); the issue roof of `roofline` is priced at %.1f GHz" % (args.sustain_seconds, n_chunk, PEAK_CLOCK_GHZ)}
 
-    digest = None
-    if args.digest:
-        import hashlib
-        s.barrier()
-        final = s.image
-        if inproc:
-            final = torch.from_numpy(pt.get_image(npix))        # the frame device 0 assembled
-        if dist_on:
-            # the frame rank 0 holds after the last exchange IS the result (gather: copies; reduce: sum with zeros)
-            final = s.frame
-        torch.cuda.synchronize()
-        if rank == 0:
-            digest = hashlib.md5(final.cpu().numpy().tobytes()).hexdigest()
     gather_desc = ("a gather of the packed tile rows (%.2f MB per rank)" % (s.bytes_per_rank / 1e6)) if (s.gather or s.gather_thread) \
         else "reduce(SUM) of the zero-padded frames (%.2f MB per rank)" % (npix * 12 / 1e6)
     transport = s.transport
@@ -1003,7 +1004,7 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
                          "valu_insts_per_ray": round(64.0 * sum(k["launches_per_step"] * k.get("wave_insts_per_launch", {}).get("valu", 0.0) for k in sel) /
                                                      max(1.0, rank_rays / steps), 1),
                          "unpriced_share_of_cycles": round(unpriced, 4),
-                         "issue_cost_table": "profiles/r05/issue_ops_r05.json (one row per opcode, re-measured in round 5)",
+                         "issue_cost_table": "profiles/r06/costs_r06.json (profiles/r05/issue_ops_r05.json: one row per opcode, measured in round 5; round 6 added the matrix-pipe stage's opcodes at the guide's figures)",
                          "sq_insts_valu_over_counted": [k.get("sq_insts_valu_over_counted") for k in sel]},
              hbm_measured={"achieved": round(byt / per_step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
                            "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch (gfx950 correction)"},
@@ -1011,6 +1012,14 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
                    "active_lane_fraction": round(lanes, 4) if lanes else None,
                    "note": "fp32 operations of the executed opcode histogram (fma = 2) x active lanes (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64)"},
              grays_per_s_in_kernel=round(rank_rays / (stage_ms[st] * 1e-3) / 1e9, 3) if st == "bounce" else None)
+    mf = sum(k["launches_per_step"] * k.get("mfma_flops_per_launch", 0.0) for k in sel)
+    if mf:
+        # the matrix pipe (C4 as stated: the sphere reject of every (ray, triangle) pair as one bilinear form, v_mfma_f32_16x16x32_f16):
+        # executed MFMAs of the counted build x 16 x 16 x 32 x 2 over the kernel time, against the dense binary16 peak
+        r["mfma"] = {"achieved": round(mf / per_step_s / 1e12, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mf / per_step_s / (MFMA_F16_PEAK_TFLOPS * 1e12), 4),
+                     "pairs_per_s": round(mf / (2.0 * 32) / per_step_s, 0),
+                     "note": "v_mfma_f32_16x16x32_f16 wave-instructions of the instrumented build x 16384 flops, over the kernel time; peak = MI355X dense f16 (MI355X_MICROARCH.md); "
+                             "one output element = one (ray, triangle) pair of the bounding-sphere reject (csrc/pt_k_trisweep.hpp)"}
     if st == "bounce" and fused and args.config in ("c2", "c3", "c5"):
         surv_step, first_step = (rank_rays - first) / steps, first / steps
         # (b) what the fused kernel MUST move: a pool row (40 B) read per ray that was not generated in registers, a pool
@@ -1055,7 +1064,9 @@ def roofline_object(args, world, flags, pt, prof, rank_rays, first, timed_step_s
             r["valu_issue"]["clock_source"] = "profiles/r04/wave_clock.txt: k_bounce on C2, per-wave cycle counter against the 100-MHz real-time counter"
     except Exception:
         pass
-    if issue_frac >= hbm_frac:
+    if mf and r["mfma"]["frac"] >= max(issue_frac, hbm_frac):
+        r.update(bound="mfma", achieved=r["mfma"]["achieved"], peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(min(1.0, r["mfma"]["frac"]), 4))
+    elif issue_frac >= hbm_frac:
         r.update(bound="valu-issue", achieved=r["valu_issue"]["achieved"], peak=r["valu_issue"]["peak"], unit=r["valu_issue"]["unit"], frac=round(min(1.0, issue_frac), 4))
     else:
         r.update(bound="hbm", achieved=r["hbm_measured"]["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(min(1.0, hbm_frac), 4))

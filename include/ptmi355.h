@@ -160,7 +160,8 @@ enum pt_flags {
     PT_LOOKAHEAD     = 1u << 11, /* opt-in: pt_trace TRACES AHEAD of its caller.  The reference's host calls ONE pathtrace() per
                                     iteration (main.cpp:130-140) and a path's whole life is a function of (iteration, pixelIndex,
                                     depth) alone, so the iterations to come can be traced before they are asked for.  pt_trace(iter)
-                                    then traces a WINDOW [iter, iter + n) as one path pool (n grows 4, 16, .. up to max_batch) and
+                                    then traces a WINDOW [iter, iter + n) as one path pool (n grows 4, 16, .. up to max_batch; up to two
+                                    further windows are traced ahead, beside the one being consumed) and
                                     keeps every sample's final colours; the calls for iter + 1 .. iter + n - 1 only run finalGather
                                     for their own sample -- image[pixel] += colour, the same single addition per pixel and
                                     iteration, in iteration order -- write the pixels whose sum changed into the host image
@@ -170,9 +171,10 @@ enum pt_flags {
                                     produce without the flag.  A window is discarded (and the iteration traced afresh) when
                                     `iter` is not the next consecutive one, when camera, traceDepth or lens differ from what it
                                     was traced with, and by pt_clear_image, pt_set_image, batches and the stepping interface.
-                                    What differs: pt_get_stats / pt_total_rays / pt_get_counters count a window when it is TRACED
-                                    (a call served from a window reports rays = 0; iterations traced ahead and then discarded
-                                    stay counted).  Single-device sessions that own the whole frame (tile_count <= 1) on the fused
+                                    What differs: pt_get_stats reports a window's counts ONCE, with the call that starts
+                                    consuming it (the calls served from it afterwards report rays = 0: the sums over a run of
+                                    calls are exact), and pt_total_rays / pt_get_counters count a window when it is traced,
+                                    ahead of its calls (iterations traced ahead and then discarded stay counted).  Single-device sessions that own the whole frame (tile_count <= 1) on the fused
                                     pipelines; ignored elsewhere (PT_UNFUSED, PT_FAKE_SHADER, PT_CACHE_FIRST, two-kernel sort,
                                     PT_ASYNC_IMAGE, max_batch < 2). */
     PT_ASYNC_IMAGE   = 1u << 7   /* opt-in: pt_trace / pt_trace_batch return without waiting; the copy of the

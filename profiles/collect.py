@@ -189,6 +189,7 @@ def main(which):
                           "cycles_per_valu_inst": hist["issue_cycles_per_launch"] / hist["valu_per_launch"],
                           "unpriced_share_of_cycles": hist["unpriced_share_of_cycles"],
                           "flops_fp32_per_launch_64_lanes": hist["flops_fp32_per_launch"] * scale,
+                          "mfma_flops_per_launch": hist.get("mfma_flops_per_launch", 0.0) * scale,
                           "wave_insts_per_launch": {k: v * scale for k, v in hist["wave_insts_per_launch"].items()}})
                 avail = SIMDS * PEAK_GHZ * 1e3 * avg_us
                 e["issue_frac_of_peak_clock"] = round(e["issue_cycles_per_launch"] / avail, 4)

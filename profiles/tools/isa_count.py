@@ -212,6 +212,8 @@ def hist(map_path, counts_path, cost_path, launches):
            "issue_cycles_guide_rates_per_launch": cyc_guide / launches,
            "unpriced_share_of_cycles": unpriced / max(1.0, cyc),
            "valu_opcodes_per_launch": {op: n / launches for op, n in valu.items()},
+           # matrix pipe: a v_mfma_*_16x16x32_* is 16 x 16 x 32 multiply-adds per wave-instruction (the every-triangle loop's stage 1)
+           "mfma_flops_per_launch": 2.0 * 16 * 16 * 32 * sum(n for op, n in valu.items() if re.match(r'v_mfma_\w*16x16x32', op)) / launches,
            "flops_fp32_per_launch": 64.0 * sum(n * (2 if re.match(r'v_(fma|fmac|mad|mac|pk_fma)_f32', op) else 1)
                                                for op, n in valu.items()
                                                if re.match(r'v_(add|sub|subrev|mul|fma|fmac|mad|mac|min|max|min3|max3|med3|rcp|rsq|sqrt|exp|log|sin|cos|fract|floor|ceil|trunc|rndne|ldexp|div_fixup|div_fmas|div_scale|cmp\w*|pk_fma|pk_mul|pk_add)_f32', op)) / launches}

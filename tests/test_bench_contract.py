@@ -31,7 +31,7 @@ def run(cmd, timeout=600, per_bounce=True, sustained=False):
 def _check_roofline(r):
     """A fraction comes from measured counters of exactly this build and command line (profiles/traffic.json) and never
     exceeds 1; without such a profile every counter-derived field is null, never stale, never a model's number."""
-    assert r["bound"] in ("valu-issue", "hbm") and "traffic" in r and "source" in r and "frac" in r
+    assert r["bound"] in ("valu-issue", "hbm", "mfma") and "traffic" in r and "source" in r and "frac" in r
     if r["frac"] is not None:
         assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - min(1.0, r["achieved"] / r["peak"])) < 2e-3
         assert r["traffic"] > 0 and r["valu_issue"]["unpriced_share_of_cycles"] < 0.05

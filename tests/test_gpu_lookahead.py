@@ -166,6 +166,29 @@ def test_lookahead_equals_the_plain_calls_at_full_size(pt, scenes, monkeypatch):
     assert (bits(dev0) == bits(dev1)).all()
 
 
+def test_4k_frame_in_windows_of_four(pt, scenes, monkeypatch):
+    """C5's frame (3840x2160, 99.5 MB of host image) as the shim initialises it: windows of at most four iterations (33 M paths).
+    The host image after every call against the plain calls'."""
+    monkeypatch.delenv("PTMI355_WHOLE_MAX", raising=False)
+    s = scenes["cornell_4k"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = 3840 * 2160
+    L = pt.library()
+    import hashlib
+
+    def run(extra, max_batch):
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_PIN_IMAGE | pt.PT_HOST_SPARSE | extra, max_batch=max_batch, pin_image=False)
+        host = np.zeros((n, 3), dtype=np.float32)
+        out = []
+        for it in range(1, 12):
+            assert L.pt_trace(None, 0, it, host.ctypes.data) == 0
+            out.append(hashlib.md5(host.tobytes()).hexdigest())
+        pt.pathtraceFree()
+        return out
+
+    assert run(pt.PT_LOOKAHEAD, 4) == run(0, 1)
+
+
 def test_flag_is_ignored_where_it_cannot_apply(pt, scenes, launch_plan):
     """max_batch = 1, the fake shader, the unfused pipeline: pt_trace takes its plain path and the image is the usual one."""
     s = scenes["cornell_64"]
