@@ -442,19 +442,21 @@ def per_call_rates(c, n_it=256):
     # numbers, state.image complete at every return; the timed calls start at a window's first iteration (85 = 1 + 4 + 16 + 64)
     # and span whole windows, and the rate counts the rays of exactly those iterations (counted by the run above)
     la = c.flags | pt.PT_HOST_SPARSE | pt.PT_LOOKAHEAD
+    la_batch = max(4, min(64, 41000000 // c.npix))       # the shim's rule (host/pathtrace_shim.cpp): windows of up to 64 iterations and ~40 M paths
+    out["lookahead_max_batch"] = la_batch
     out["pcie_inclusive_sync"], out["pcie_inclusive_sync_ms_per_call"] = run(
-        la, lambda it: L.pt_trace(None, 0, it, host.ctypes.data), max_batch=64, rays=rays_85, first=85)
+        la, lambda it: L.pt_trace(None, 0, it, host.ctypes.data), max_batch=la_batch, rays=rays_85, first=85)
     if c.args.digest:
         out["host_image_md5"] = hashlib.md5(host.tobytes()).hexdigest()       # the host image after the synchronous calls
     out["lookahead_no_host_image"], out["lookahead_no_host_image_ms_per_call"] = run(
-        c.flags | pt.PT_LOOKAHEAD, lambda it: L.pt_trace(None, 0, it, None), max_batch=64, rays=rays_85, first=85)
+        c.flags | pt.PT_LOOKAHEAD, lambda it: L.pt_trace(None, 0, it, None), max_batch=la_batch, rays=rays_85, first=85)
     # ... and for a host that may write into the image between calls: every pixel, every call
     out["pcie_inclusive_sync_every_pixel"], out["pcie_inclusive_sync_every_pixel_ms_per_call"] = run(c.flags, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
     out["pcie_inclusive_async"], _ = run(c.flags | pt.PT_ASYNC_IMAGE | pt.PT_HOST_SPARSE, lambda it: L.pt_trace(None, 0, it, host.ctypes.data))
     out["calls"] = n_it
     out["note"] = ("one pathtrace() per iteration (src/main.cpp:130-140), 1 spp per call: mrays_per_s = calls enqueued back to back "
                    "(no host image, max_batch = 1); pcie_inclusive_sync = the running sum in host memory when each call returns "
-                   "(pathtrace.cu:389-392) with PT_PIN_IMAGE | PT_HOST_SPARSE | PT_LOOKAHEAD, max_batch = 64, as the drop-in shim sets "
+                   "(pathtrace.cu:389-392) with PT_PIN_IMAGE | PT_HOST_SPARSE | PT_LOOKAHEAD, max_batch = lookahead_max_batch, as the drop-in shim sets "
                    "them: windows of iterations traced ahead, every call gathers its own sample; ..._no_lookahead = every iteration "
                    "traced inside its own call (the shim up to round 5); lookahead_no_host_image = the same calls without a host image; "
                    "..._every_pixel = without PT_HOST_SPARSE and without PT_LOOKAHEAD; pcie_inclusive_async = PT_ASYNC_IMAGE | PT_HOST_SPARSE")
