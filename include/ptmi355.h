@@ -160,7 +160,7 @@ enum pt_flags {
     PT_LOOKAHEAD     = 1u << 11, /* opt-in: pt_trace TRACES AHEAD of its caller.  The reference's host calls ONE pathtrace() per
                                     iteration (main.cpp:130-140) and a path's whole life is a function of (iteration, pixelIndex,
                                     depth) alone, so the iterations to come can be traced before they are asked for.  pt_trace(iter)
-                                    then traces a WINDOW [iter, iter + n) as one path pool (n grows 4, 16, .. up to max_batch; up to two
+                                    then traces a WINDOW [iter, iter + n) as one path pool (n grows 4, 16, .. up to max_batch; up to three
                                     further windows are traced ahead, beside the one being consumed) and
                                     keeps every sample's final colours; the calls for iter + 1 .. iter + n - 1 only run finalGather
                                     for their own sample -- image[pixel] += colour, the same single addition per pixel and

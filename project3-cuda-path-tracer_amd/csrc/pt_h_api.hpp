@@ -654,7 +654,7 @@ static int la_trace_window(int slot, int iter0, int count) {
 }
 
 // the windows that follow the one being consumed: up to LA_AHEAD of them, each four times its predecessor's size up to
-// max_batch, on the ring's next slots -- two in flight, on the two launch streams, like overlapped batches
+// max_batch, on the ring's next slots -- overlapping on the two launch streams, like asynchronous batches
 static int la_trace_ahead(void) {
     const Renderer::LaWindow *last = &R.la[R.la_cur];
     for (int k = 1; k <= Renderer::LA_AHEAD; ++k) {

@@ -130,10 +130,12 @@ struct Renderer {
     int ov_next = 0;
     // PT_LOOKAHEAD: windows of consecutive iterations traced ahead of pt_trace's caller (pt_h_api.hpp: la_*).  A ring of
     // LA_SLOTS windows, slot j on lane j (consecutive slots on alternating launch streams): la_cur is the window being
-    // consumed, the slots after it hold the windows that follow it -- up to LA_AHEAD of them traced ahead, two in flight
-    // side by side; `next` = the sample the next consecutive call consumes; a window is only ever served to calls whose
-    // camera / depth / lens are byte-equal to what it was traced with.
-    static constexpr int LA_SLOTS = 4, LA_AHEAD = 2;
+    // consumed, the slots after it hold the windows that follow it -- up to LA_AHEAD of them traced ahead, overlapping on
+    // the two launch streams like asynchronous batches; `next` = the sample the next consecutive call consumes; a window is
+    // only ever served to calls whose camera / depth / lens are byte-equal to what it was traced with.  Three ahead on four
+    // lanes measured 0.066 ms per call against 0.070 for two (and 0.054 against 0.056 without a host image); six lanes with
+    // four or five ahead: the same as three (profiles/r06/lookahead_ab_windows_ahead.txt).
+    static constexpr int LA_SLOTS = 4, LA_AHEAD = 3;
     struct LaWindow {
         bool valid = false;       // enqueued and not yet consumed or discarded
         bool inflight = false;    // enqueued, and the launch stream has not been ordered behind its last launch yet

@@ -80,10 +80,10 @@ def test_host_image_after_every_call_equals_the_oracle(pt, po, scenes, launch_pl
     for it in range(1, 3 * K - 3):                         # 1..20: windows [1,4] [5,12] [13,20], the last consumed to its end
         call(a, it)
     assert sum(served) == ref.rays                         # statistics are additive: every window reported once, whole
-    assert bookkeeping(pt) == (5, 1, 0, K)                 # [1,4] traced by call 1; [5,12] .. [29,36] ahead, two at a time; nothing thrown away
-    assert pt.counters()[0] >= ref.rays                    # (the device has traced, or is tracing, [21, 36] ahead as well)
+    assert bookkeeping(pt) == (6, 1, 0, K)                 # [1,4] traced by call 1; [5,12] .. [37,44] ahead, three at a time; nothing thrown away
+    assert pt.counters()[0] >= ref.rays                    # (the device has traced, or is tracing, [21, 44] ahead as well)
     call(a, 22)                                            # 21 is skipped: the window traced ahead starts at 21 and is void
-    assert bookkeeping(pt) == (8, 2, 2, 4)                 # [21,28] [29,36] thrown away; [22,25] by this call, [26,33] [34,41] ahead
+    assert bookkeeping(pt) == (10, 2, 3, 4)                # [21,28] [29,36] [37,44] thrown away; [22,25] by this call, [26,33] [34,41] [42,49] ahead
     call(a, 23); call(b, 24); call(a, 25); call(a, 26)     # (24: a second host buffer; the 4-iteration window ends at 25)
     call(a, 26)                                            # the same number again: not consecutive either
     call(a, 27)
@@ -160,7 +160,7 @@ def test_lookahead_equals_the_plain_calls_at_full_size(pt, scenes, monkeypatch):
 
     want, dev0 = run(0, 1)
     got, dev1 = run(pt.PT_LOOKAHEAD, 64)
-    assert book == [(7, 1, 0, 64)]                          # [1,4] [5,20] [21,84] [85,148] [149,212] (+ [213,276] [277,340] ahead): only call 1 traced its own window
+    assert book == [(8, 1, 0, 64)]                          # [1,4] [5,20] [21,84] [85,148] [149,212] (+ three ahead, up to [341,404]): only call 1 traced its own window
     for it, (g, wnt) in enumerate(zip(got, want), 1):
         assert (bits(g) == bits(wnt)).all(), it
     assert (bits(dev0) == bits(dev1)).all()
