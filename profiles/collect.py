@@ -76,7 +76,7 @@ def build_digest():
 def rocprof(tag, what, bench_args):
     d = os.path.join(OUT, tag, what.split()[0].replace("--", "").replace("-", "_") if what.startswith("--kernel") else "pmc_" + what.split()[1])
     cmd = ["rocprofv3"] + what.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3", os.path.join(ROOT, "bench.py")] + \
-          bench_args.split() + ["--no-cpu-baseline", "--no-roofline", "--no-per-call", "--no-sub"]      # the main pass only: its last launches are the timed steps
+          bench_args.split() + ["--no-cpu-baseline", "--no-roofline", "--no-per-call", "--no-sub", "--no-sustained"]      # the main pass only: its last launches are the timed steps
     # one launch at a time: in the timed pass of bench.py consecutive steps overlap on the device, which stretches every
     # launch in a trace; the roofline is the kernel's own (bench.py's event pass runs serially too)
     sh(cmd, d + ".log", env={"PTMI355_OVERLAP": "0"})

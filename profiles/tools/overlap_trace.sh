@@ -5,7 +5,7 @@
 R=${1:-r05}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/$R; mkdir -p $O
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-per-call $*"
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-per-call --no-sustained $*"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/ovl_on $O/ovl_off
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ovl_on -o t -- python3 $ROOT/bench.py $ARGS > $O/ovl_on.log 2>&1

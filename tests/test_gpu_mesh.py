@@ -216,10 +216,13 @@ def test_mesh_grazing_rays_and_the_hit_point_test(pt, po, scenes, seed):
     assert img.tobytes() == ref.image.tobytes()
 
 
-def test_mesh_bvh_adversarial_rays(pt, po, scenes):
+@pytest.mark.parametrize("form", ["hierarchy", "loop"])
+def test_mesh_bvh_adversarial_rays(pt, po, scenes, form):
     """Rays aimed exactly at vertices and edges (where several triangles tie or just miss), from outside and
     from inside the mesh, plus two meshes in one scene: winner index and distance come out as the oracle's loop
-    over every triangle has them."""
+    over every triangle has them -- through the hierarchy and through the every-triangle loop, whose first stage runs
+    on the matrix pipe since round 6 (6 240 + 432 triangles: neither a multiple of 64; lines that pass the meshes at a
+    distance, origins far outside the bound the spheres were derived for, non-finite and zero-length rays)."""
     s = scenes["cornell"]                                    # 800x800: room for 20 000 rays
     a = pt.meshes.uv_sphere(n_lat=40, n_lon=80)
     b = pt.meshes.uv_sphere(center=(-2.0, 6.0, -1.0), radius=1.0, n_lat=12, n_lon=20)
@@ -249,8 +252,13 @@ def test_mesh_bvh_adversarial_rays(pt, po, scenes):
     dvec[par] = unit[par]
     aimed = par & (np.arange(n) % 16 == 5)
     o[aimed] = target[aimed] - unit[aimed] * rng.uniform(2, 6, size=(aimed.sum(), 1))
+    # rays the conservative stages were not derived for: huge origins (still aimed at the mesh), non-finite numbers, no direction
+    odd = np.arange(n) % 97 == 3
+    o[odd] = target[odd] - dvec[odd] * 3.0e6
     rays["origin"], rays["direction"] = o, dvec
-    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | pt.PT_MESH_BVH)
+    rays["origin"][7] = (np.nan, 0.0, 0.0); rays["direction"][11] = (0.0, 0.0, 0.0); rays["origin"][13] = (np.inf, 1.0, 1.0)
+    rays["direction"][17] = (np.inf, 0.0, 0.0); rays["direction"][19] *= np.float32(1e-30)
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_UNFUSED | (pt.PT_MESH_BVH if form == "hierarchy" else 0))
     got, _ = pt.intersect_once(rays)
     pt.pathtraceFree()
     want, _ = po.compute_intersections(rays.view(po.PATH_DT), geoms.view(po.GEOM_DT), tris.view(po.TRI_DT),

@@ -133,3 +133,25 @@ def test_newton_sqrt_every_argument(pt):
     assert below[0] > 0 and below[1] > 0
     assert pt.probe_sqrt(0x3f800000, 0) == (0, 0)
     assert pt.probe_sqrt(0x3f800000 - 4096, 4096 + 2048 + 1) == (0, 0)      # the near-one gate by itself
+
+
+def test_shader_clock_probe(pt, scenes):
+    """pt_probe_clock (bench.py's roofline.sustained): one wave counts its cycle counter against the 100-MHz counter -- a plausible
+    shader clock on an idle device, and beside a session's launches (the wave is compiled for sixteen scalar registers so that it
+    fits beside the persistent grid: it must come back while batches are still enqueued)."""
+    idle = pt.probe_clock(200)
+    assert 0.1 < idle < 2.6, idle
+    s = scenes["cornell"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT, max_batch=16)
+    try:
+        for k in range(12):
+            pt.trace_batch_async(1 + 16 * k, 16)
+        busy = [pt.probe_clock(200) for _ in range(3)]
+        pt.synchronize()
+    finally:
+        pt.pathtraceFree()
+    assert all(0.5 < b < 2.6 for b in busy), busy
+    with pytest.raises(pt.PtError):
+        pt.probe_clock(0)
+
