@@ -45,7 +45,8 @@
 //     the fused multiply-add as the float 2^23 + m and 2^23 k is folded into the ray's offset b, whose rounding is half
 //     a grid step -- the planes m -+ e carry a whole one for it), i.e. below spec_pad for every ray
 //     origin within ~128 * max(1, amax) of the mesh; pt_init knows the bound R on |origin|_1 of every ray that is
-//     not `wild` (it covers the scene and the camera, and pt_set_camera re-derives it and REBUILDS the trees when the
+//     not `wild` (wild rays -- only a caller's own, through pt_intersect_once -- take the whole tree: pt_k_bvh.hpp: bvh_walk;
+//     the bound covers the scene and the camera, and pt_set_camera re-derives it and REBUILDS the trees when the
 //     camera leaves it) and widens the pad to spec_pad + 8 * 2^-23 * (R + amax) where that is more (build(): a far
 //     camera) -- so along each axis the computed entry parameter is <= tz <= the computed exit
 //     parameter: the box is hit, and it is entered no later than tz;

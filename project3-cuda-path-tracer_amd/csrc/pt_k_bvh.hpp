@@ -155,10 +155,16 @@ __device__ __forceinline__ int bvh_step(const float *__restrict__ nodes, const f
     return next;
 }
 // `grid`: origin xyz, step xyz of the mesh (six floats of its geom record)
+// `wild`: the ray lies outside what the boxes' padding was derived for (pt_bvh.hpp: |origin|_1 beyond the scene's bound, a
+// non-finite or absurdly scaled direction: cull_ray) -- only caller-supplied rays can (pt_intersect_once): paths start at the
+// camera, which the bound covers, and continue from points of the scene.  Such a ray takes the whole tree: with k = b = 0
+// every box's entry and exit parameters are 0, every box is "hit", and the links spell out one depth-first order, so each
+// record is visited once (`guard` = the record count + 1) and every triangle gets the exact test, like the loop's.
 template <typename P>
 __device__ __forceinline__ void bvh_walk(const float *__restrict__ nodes, const float *__restrict__ btris, P grid,
-                                         float prune, int guard, f3 ro, f3 rd, float &best, int &best_i) {
-    const BvhRay r = bvh_ray(ro, rd, ptd::mk(grid[0], grid[1], grid[2]), ptd::mk(grid[3], grid[4], grid[5]));
+                                         float prune, int guard, f3 ro, f3 rd, float &best, int &best_i, bool wild = false) {
+    BvhRay r = bvh_ray(ro, rd, ptd::mk(grid[0], grid[1], grid[2]), ptd::mk(grid[3], grid[4], grid[5]));
+    if (wild) { r.kx = r.ky = r.kz = 0.0f; r.bx = r.by = r.bz = 0.0f; }
     int node = 0;
     for (int it = 0; it < guard && node >= 0; ++it) node = bvh_step(nodes, btris, prune, r, node, best, best_i);
 }

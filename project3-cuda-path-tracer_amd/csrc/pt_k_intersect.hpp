@@ -60,7 +60,7 @@ __device__ __forceinline__ void cull_scene(const SceneDev &sc, const SceneAcc &a
                 const int count = __float_as_int(rec[3]);
                 if (active && count > 0)
                     bvh_walk(sc.bvh_nodes + (size_t)root * BVH_NODE_WORDS, sc.bvh_tris, rec + ptd::G_INV, sc.bvh_prune,
-                             sc.bvh_guard, ro, rd, best, best_i);
+                             sc.bvh_guard, ro, rd, best, best_i, cr.wild);
             } else {
                 // every triangle of the mesh, for every ray (the completion spec's loop, 8.0): mesh_sweep
                 const int first = __float_as_int(rec[2]);
