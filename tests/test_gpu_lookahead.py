@@ -189,6 +189,62 @@ def test_4k_frame_in_windows_of_four(pt, scenes, monkeypatch):
     assert run(pt.PT_LOOKAHEAD, 4) == run(0, 1)
 
 
+def test_jittered_camera_and_a_lens_change_mid_window(pt, scenes, launch_plan):
+    """PT_AA_JITTER and the thin lens draw from the engine of (iteration, pixel): still functions of the iteration number alone, so
+    windows stay valid -- and a pt_set_lens in the middle of one voids it (the window was traced with the old lens).  Against
+    the plain calls, image by image."""
+    s = scenes["cornell_64"]
+    scene = pt.Scene(s["geoms"], s["materials"], s["camera"], s["depth"])
+    n = 64 * 64
+
+    def run(extra, max_batch):
+        pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_AA_JITTER | extra, max_batch=max_batch, lens=(0.05, 9.0))
+        out = []
+        for it in range(1, 20):
+            if it == 7:
+                pt.set_lens(0.2, 7.5)
+            if it == 15:
+                pt.set_lens(0.0, 0.0)
+            out.append(pt.pathtrace(None, 0, it).copy())
+        pt.pathtraceFree()
+        return out
+
+    want = run(0, 1)
+    got = run(pt.PT_LOOKAHEAD, K)
+    for it, (g, w) in enumerate(zip(got, want), 1):
+        assert (bits(g) == bits(w)).all(), it
+    assert not (bits(want[5]) == bits(want[7])).all()
+
+
+@pytest.mark.parametrize("pipeline", ["sorted glass", "mesh hierarchy", "mesh loop"])
+def test_other_pipelines_behind_the_windows(pt, scenes, launch_plan, pipeline):
+    """The windows go through whatever batched pipeline the session runs: the material sort folded into the compaction (C3's
+    glass ball, depth 16), the mesh pre-pass + hierarchy, the loop over every triangle.  Image after every call against the
+    plain calls (each of those pipelines is held against the oracle by its own tests)."""
+    if pipeline == "sorted glass":
+        s = scenes["cornell_glass"]
+        cam = _resized(s["camera"], 96, 54)
+        scene, flags, depth = pt.Scene(s["geoms"], s["materials"], cam, s["depth"]), pt.PT_COMPACT | pt.PT_SORT_MATERIAL, s["depth"]
+    else:
+        s = scenes["cornell_64"]
+        tris = pt.meshes.uv_sphere(n_lat=12, n_lon=24)
+        geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
+        scene = pt.Scene(geoms, s["materials"], s["camera"], s["depth"], triangles=tris, meshes=meshes)
+        flags, depth = pt.PT_COMPACT | (pt.PT_MESH_BVH if pipeline == "mesh hierarchy" else 0), s["depth"]
+
+    def run(extra, max_batch):
+        pt.pathtraceInit(scene, flags=flags | extra, max_batch=max_batch)
+        out = [pt.pathtrace(None, 0, it).copy() for it in range(1, 2 * K + 4)]
+        pt.pathtraceFree()
+        return out
+
+    want = run(0, 1)
+    got = run(pt.PT_LOOKAHEAD, K)
+    for it, (g, w) in enumerate(zip(got, want), 1):
+        assert (bits(g) == bits(w)).all(), (pipeline, it)
+    assert want[-1].sum() > 0
+
+
 def test_flag_is_ignored_where_it_cannot_apply(pt, scenes, launch_plan):
     """max_batch = 1, the fake shader, the unfused pipeline: pt_trace takes its plain path and the image is the usual one."""
     s = scenes["cornell_64"]
