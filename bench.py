@@ -582,7 +582,8 @@ def rank_identities(c):
 
 class Watchdog:
     """N > 1: a collective that never returns must end the run LOUDLY.  Phases arm a deadline; when one passes, rank 0
-    prints the line as far as it got (with `watchdog` saying which phase hung) and every rank leaves with exit code 3.
+    prints the line as far as it got (with `watchdog` saying which phase hung) and every rank leaves -- with exit code 3, or 0
+    when the line already carries `value` (the main timed pass is the first phase).
     `out` is only touched under `lock`, by the main thread and by this one; once the main thread has printed the line
     (`emit`) the watchdog never prints."""
 
@@ -622,12 +623,16 @@ class Watchdog:
                 if self.deadline is None or time.monotonic() < self.deadline:
                     continue
                 self.done = True
+                # the main timed pass comes first: when it is a LATER phase that hangs, `value` is in the line already and the
+                # run has delivered what the contract asks for -- every rank then leaves with exit code 0 (a launcher that sees
+                # a non-zero code may throw the line away); a hang before `value` exists is exit code 3
+                code = 0 if self.out.get("value") is not None else 3
                 if self.rank == 0:
-                    self.out["watchdog"] = "phase '%s' did not finish in time: exit code 3" % self.phase
+                    self.out["watchdog"] = "phase '%s' did not finish in time: exit code %d" % (self.phase, code)
                     print(json.dumps(self.out), flush=True)
             if self.rank != 0:
                 time.sleep(2.0)            # rank 0's line first: a launcher that sees a rank exit tears the others down
-            os._exit(3)
+            os._exit(code)
 
 
 def main():

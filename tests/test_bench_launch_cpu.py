@@ -139,3 +139,23 @@ def test_phases_run_under_gloo_in_their_own_launches():
         assert p.returncode != 0 and d["value"] is None and "failed" in d["per_iteration_exchange"] and "failed" in d["config"]["strong"]
     else:
         assert p.returncode == 0 and d["value"] > 0 and d["phases"]["order"] == ["main", "exchange", "strong"]
+
+
+def test_watchdog_exit_code_follows_the_main_pass():
+    """A rank's own watchdog (N > 1 under an external launcher, where the phases share one set of processes): a phase that
+    hangs BEFORE the main timed pass has left `value` ends the rank with exit code 3; one that hangs after it, with 0 -- the
+    line is printed either way, with `watchdog` naming the phase."""
+    code = textwrap.dedent("""
+        import sys, time, json
+        import bench
+        out = {"value": VALUE, "config": {}}
+        g = bench.Watchdog(0, out)
+        g.arm(0.2, "per-iteration exchange")
+        time.sleep(30)
+    """)
+    for value, rc in (("None", 3), ("7.0", 0)):
+        p = subprocess.run([sys.executable, "-c", code.replace("VALUE", value)], cwd=ROOT, capture_output=True, text=True, timeout=60)
+        assert p.returncode == rc, (value, p.returncode, p.stderr[-500:])
+        d = json.loads(p.stdout.strip().splitlines()[-1])
+        assert "per-iteration exchange" in d["watchdog"] and d["value"] == (None if value == "None" else 7.0)
+
