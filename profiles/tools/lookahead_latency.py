@@ -20,6 +20,21 @@ windows = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 L = pt.library()
 n = 800 * 800
 host = np.zeros((n, 3), dtype=np.float32)
+if os.environ.get("LA_HUGE"):
+    # the host image on transparent huge pages (2 MiB-aligned anonymous mapping + MADV_HUGEPAGE): do the device's scattered
+    # 12-byte writes into it cost less when the frame is four pages instead of 1875?
+    import ctypes, mmap
+    size = ((n * 12 + (2 << 20) - 1) // (2 << 20) + 1) * (2 << 20)
+    m = mmap.mmap(-1, size, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    off = (-base) % (2 << 20)
+    libc = ctypes.CDLL(None, use_errno=True)
+    rc = libc.madvise(ctypes.c_void_p(base + off), ctypes.c_size_t(size - (2 << 20)), 14)
+    host = np.frombuffer(m, dtype=np.float32, count=n * 3, offset=off).reshape(n, 3)
+    host[:] = 0.0
+    thp = open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip() if os.path.exists("/sys/kernel/mm/transparent_hugepage/enabled") else "?"
+    anon = [l for l in open("/proc/self/smaps_rollup") if "AnonHugePages" in l]
+    print("huge pages: madvise rc %d, THP %s, %s" % (rc, thp, anon[0].strip() if anon else "?"))
 flags = pt.PT_COMPACT | pt.PT_LOOKAHEAD | (pt.PT_PIN_IMAGE | pt.PT_HOST_SPARSE if mode == "host" else 0)
 pt.pathtraceInit(scene, flags=flags, max_batch=K, pin_image=False)
 buf = host.ctypes.data if mode == "host" else None
