@@ -51,6 +51,7 @@ el = time.perf_counter() - t_all
 pt.pathtraceFree()
 us = lat * 1e6
 print("mode %s: %.1f us per call over %d calls" % (mode, el / (windows * 64) * 1e6, windows * 64))
-print("call 0 of a window (enqueues the next window): median %.1f us" % np.median(us[:, 0]))
+print("call 0 of a window (enqueues the next window): median %.1f us, mean %.1f; the other calls: mean %.1f, max %.1f us" %
+      (np.median(us[:, 0]), us[:, 0].mean(), us[:, 1:].mean(), us[:, 1:].max()))
 for a, b in ((1, 8), (8, 16), (16, 24), (24, 32), (32, 40), (40, 48), (48, 56), (56, 64)):
     print("calls %2d-%2d: median %.1f  p10 %.1f  p90 %.1f us" % (a, b - 1, np.median(us[:, a:b]), np.percentile(us[:, a:b], 10), np.percentile(us[:, a:b], 90)))

@@ -16,7 +16,7 @@ def short(n):
 
 
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"], int(r["Grid_Size_X"])) for r in rows)
-g = [e for e in ev if e[2] in ("k_gather_one", "k_la_apply")]
+g = [e for e in ev if e[2] in ("k_gather_one", "k_la_apply", "k_gather_bits")]
 d = np.array([(e[1] - e[0]) / 1e3 for e in g])
 gap = np.array([(g[i + 1][0] - g[i][1]) / 1e3 for i in range(len(g) - 1)])
 print("per-call kernel (k_la_apply / k_gather_one): %d launches, duration median %.1f p90 %.1f max %.1f us; idle between two: median %.1f p90 %.1f us" %
