@@ -21,6 +21,12 @@ const char *pt_version(void) {
 void pt_free(void) {
     if (!R.live && !R.scratch) return;
     if (R.stream) (void)hipStreamSynchronize(R.stream);
+    // batches and windows may still be running on the lanes (lane 0's buffers are the session's own, freed next)
+    for (int k = 0; k < OV_MAX_LANES; ++k) {
+        if (R.lane[k].stream) (void)hipStreamSynchronize(R.lane[k].stream);
+        if (R.lane[k].la_stream) (void)hipStreamSynchronize(R.lane[k].la_stream);
+    }
+    if (R.la_gstream) (void)hipStreamSynchronize(R.la_gstream);
     for (int k = 0; k < 2; ++k) if (R.pool_mem[k]) (void)hipFree(R.pool_mem[k]);
     if (R.isect_mem) (void)hipFree(R.isect_mem);
     if (R.sort_table) (void)hipFree(R.sort_table);
@@ -382,6 +388,8 @@ static int init_impl(const pt_scene_desc *d) {
     if (per_cu > 8) per_cu = 8;
     if (const char *e = pt_experiment("PTMI355_WGS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // occupancy experiments
     R.grid = (int)std::min<uint32_t>((R.max_tiles + WAVES - 1) / WAVES, (uint32_t)cus * (uint32_t)per_cu);
+    R.per_cu = per_cu;
+    if (const char *e = pt_experiment("PTMI355_LA_CUS")) R.la_cus = std::max(0, std::min(64, atoi(e) & ~7));
     if (R.grid < 1) R.grid = 1;
     if (R.grid * WAVES > 8192) R.grid = 8192 / WAVES;           // the pools' slack and the directory scan are sized for W <= 8192
     {   // k_iteration has no directory and no cross-workgroup step: its grid is its own co-resident count
@@ -630,7 +638,7 @@ int la_discard(int how) {
         Renderer::LaWindow &w = R.la[j];
         if (w.valid) { w.valid = false; R.la_discards++; }
         if (!w.inflight || how == LA_LATER || !R.ov_ready) continue;
-        if (how == LA_HOST) HIPCHK(hipStreamSynchronize(R.lane[j].stream));
+        if (how == LA_HOST) HIPCHK(hipStreamSynchronize(w.masked ? R.lane[j].la_stream : R.lane[j].stream));
         else HIPCHK(hipStreamWaitEvent(R.stream, R.lane[j].traced, 0));
         w.inflight = false;
     }
@@ -642,14 +650,15 @@ static bool la_matches(const Renderer::LaWindow &w, int iter) {
            memcmp(&w.lens, &R.lens, sizeof w.lens) == 0;
 }
 
-static int la_trace_window(int slot, int iter0, int count) {
+static int la_trace_window(int slot, int iter0, int count, bool masked) {
     count = (int)std::min<int64_t>((int64_t)count, (int64_t)0x7fffffff - (int64_t)iter0 + 1);       // enqueue_begin's range of iteration numbers
-    const int rc = enqueue_window(slot, iter0, count);
+    const int rc = enqueue_window(slot, iter0, count, masked);
     if (rc) return rc;
     Renderer::LaWindow &w = R.la[slot];
     w.valid = true; w.inflight = true; w.iter0 = iter0; w.count = count; w.next = 0; w.stamp = R.fin_serial;
-    w.cam = R.cam; w.depth = R.trace_depth; w.lens = R.lens; w.ctl = R.last_ctl;
+    w.cam = R.cam; w.depth = R.trace_depth; w.lens = R.lens; w.ctl = R.last_ctl; w.masked = masked;
     R.la_windows++;
+    if (masked) R.la_masked_windows++;
     return PT_OK;
 }
 
@@ -663,7 +672,7 @@ static int la_trace_ahead(void) {
         const int64_t iter0 = (int64_t)last->iter0 + last->count;
         if (!w.valid) {
             if (iter0 > 0x7fffffff) break;
-            const int rc = la_trace_window(slot, (int)iter0, (int)std::min<int64_t>((int64_t)R.max_batch, (int64_t)last->count * 4));
+            const int rc = la_trace_window(slot, (int)iter0, (int)std::min<int64_t>((int64_t)R.max_batch, (int64_t)last->count * 4), R.la[R.la_cur].masked);
             if (rc) return rc;
         }
         last = &w;
@@ -679,30 +688,46 @@ int la_trace(uint8_t *pbo_rgba, int iter, float *host_image_sum, bool *handled) 
     if (rc) return rc;
     if (!R.ov_enabled || R.ov_lanes < Renderer::LA_SLOTS) return PT_OK;             // the lanes do not fit: the plain path
     *handled = true;
-    if (!la_matches(R.la[R.la_cur], iter)) {
-        // not the next sample of the window being consumed (whose successors on the ring continue it, so none of them
-        // starts at `iter` either): everything traced ahead is void
-        rc = la_discard(LA_LATER);
-        if (rc) return rc;
-        rc = la_trace_window(R.la_cur, iter, std::min(R.max_batch, 4));
-        if (rc) return rc;
-        R.la_misses++;
-    }
-    Renderer::LaWindow &w = R.la[R.la_cur];
-    const int s = w.next;
-    Renderer::Lane &lane = R.lane[R.la_cur];
-    if (w.inflight) { HIPCHK(hipStreamWaitEvent(R.stream, lane.traced, 0)); w.inflight = false; }
     // the host image: the launch writes the sums that changed into the caller's page-locked buffer when that buffer holds
     // exactly the accumulation buffer's content as of the previous call (PT_HOST_SPARSE); otherwise every pixel is copied
     float *mapped = host_image_sum ? map_host(host_image_sum, (size_t)R.npix * 12) : nullptr;
     const bool host_current = mapped && R.host_sparse_enabled && R.own_image && R.host_synced == mapped && R.host_epoch == R.image_epoch;
-    if (host_current && R.dma_last) { HIPCHK(hipStreamWaitEvent(R.stream, R.dma_last, 0)); R.dma_last = nullptr; }
+    if (!la_matches(R.la[R.la_cur], iter)) {
+        // not the next sample of the window being consumed (whose successors on the ring continue it, so none of them
+        // starts at `iter` either): everything traced ahead is void.  The new chain of windows goes to the lanes' masked
+        // streams when its calls are going to write a host image (ensure_la_masks); a lane's two streams know nothing of
+        // each other, so a change of kind waits for what is in flight (through the launch stream: enqueue_window)
+        const bool masked = mapped && R.host_sparse_enabled && R.own_image && ensure_la_masks();
+        rc = la_discard(masked != R.la_masked_last ? LA_STREAM : LA_LATER);
+        if (rc) return rc;
+        rc = la_trace_window(R.la_cur, iter, std::min(R.max_batch, 4), masked);
+        if (rc) return rc;
+        R.la_misses++;
+        if (masked) {                                     // the gathers' stream starts behind whatever the launch stream holds
+            HIPCHK(hipEventRecord(R.la_rs_event, R.stream));
+            HIPCHK(hipStreamWaitEvent(R.la_gstream, R.la_rs_event, 0));
+        }
+    }
+    Renderer::LaWindow &w = R.la[R.la_cur];
+    const int s = w.next;
+    Renderer::Lane &lane = R.lane[R.la_cur];
+    // a call that writes the host image itself launches on the gathers' compute units when its window was traced on the
+    // others; every call ends with its stream drained, so consecutive calls may use different ones
+    hipStream_t gs = (w.masked && host_current) ? R.la_gstream : R.stream;
+    if (w.inflight) {
+        HIPCHK(hipStreamWaitEvent(R.stream, lane.traced, 0));
+        if (gs != R.stream) HIPCHK(hipStreamWaitEvent(gs, lane.traced, 0));
+        w.inflight = false;
+    }
+    if (gs != R.stream) R.la_masked_calls++;
+    if (host_current && R.dma_last) { HIPCHK(hipStreamWaitEvent(gs, R.dma_last, 0)); R.dma_last = nullptr; }
     {
         const float4 *fin = reinterpret_cast<const float4 *>(lane.b.final_mem) + (size_t)s * (size_t)R.npix;
-        const dim3 grid((unsigned)((R.npix + (int)LA_UNROLL * BLOCK - 1) / ((int)LA_UNROLL * BLOCK)));
+        dim3 grid((unsigned)((R.npix + (int)LA_UNROLL * BLOCK - 1) / ((int)LA_UNROLL * BLOCK)));
+        if (gs != R.stream) grid = dim3((unsigned)std::min<int>((int)grid.x, R.la_cus * (pt_experiment("PTMI355_LA_GWGS") ? std::max(1, atoi(pt_experiment("PTMI355_LA_GWGS"))) : 12)));       // (a round and a half of what its compute units hold: 0.058 against 0.060 ms with one)       // what fits its compute units at once (a grid-stride kernel)
         float *host_dev = host_current ? mapped : (float *)nullptr;
-        if (pbo_rgba) hipLaunchKernelGGL(k_gather_one<true>, grid, dim3(BLOCK), 0, R.stream, R.image, fin, host_dev, w.stamp, (uint32_t)R.npix, pbo_rgba, iter);
-        else hipLaunchKernelGGL(k_gather_one<false>, grid, dim3(BLOCK), 0, R.stream, R.image, fin, host_dev, w.stamp, (uint32_t)R.npix, pbo_rgba, iter);
+        if (pbo_rgba) hipLaunchKernelGGL(k_gather_one<true>, grid, dim3(BLOCK), 0, gs, R.image, fin, host_dev, w.stamp, (uint32_t)R.npix, pbo_rgba, iter);
+        else hipLaunchKernelGGL(k_gather_one<false>, grid, dim3(BLOCK), 0, gs, R.image, fin, host_dev, w.stamp, (uint32_t)R.npix, pbo_rgba, iter);
     }
     HIPCHK(hipGetLastError());
     R.image_epoch++;
@@ -719,8 +744,9 @@ int la_trace(uint8_t *pbo_rgba, int iter, float *host_image_sum, bool *handled) 
         // the window's statistics, once: its counters were folded on its lane before `traced` was recorded
         R.last_ctl = w.ctl; R.host_stats_serial = 0; R.step_count = w.count; R.step_iter0 = w.iter0;
         rc = collect_stats();
+        if (gs != R.stream) HIPCHK(hipStreamSynchronize(gs));
     } else {
-        HIPCHK(hipStreamSynchronize(R.stream));
+        HIPCHK(hipStreamSynchronize(gs));
         R.stats.bounces = 0; R.stats.rays = 0;
         memset(R.stats.live, 0, sizeof R.stats.live);
     }

@@ -327,6 +327,7 @@ void free_lanes(void) {
     for (int k = 0; k < OV_MAX_LANES; ++k) {
         Renderer::Lane &l = R.lane[k];
         if (l.stream && k < R.ov_streams) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }   // lanes k, k + ov_streams, ... share one
+        if (l.la_stream && k < R.ov_streams) { (void)hipStreamSynchronize(l.la_stream); (void)hipStreamDestroy(l.la_stream); }
         if (l.traced) (void)hipEventDestroy(l.traced);
         if (l.gathered) (void)hipEventDestroy(l.gathered);
         if (k > 0) {                                          // lane 0 borrows the session's own buffers
@@ -339,6 +340,9 @@ void free_lanes(void) {
         }
         l = Renderer::Lane{};
     }
+    if (R.la_gstream) { (void)hipStreamSynchronize(R.la_gstream); (void)hipStreamDestroy(R.la_gstream); R.la_gstream = nullptr; }
+    if (R.la_rs_event) { (void)hipEventDestroy(R.la_rs_event); R.la_rs_event = nullptr; }
+    R.la_masks_ready = false; R.la_masked_last = false;
     if (R.ov_enter) (void)hipEventDestroy(R.ov_enter);
     R.ov_enter = nullptr;
     R.ov_ready = false;
@@ -400,6 +404,38 @@ int ensure_lanes(void) {
     return PT_OK;
 }
 
+// PT_LOOKAHEAD with a host image: compute units set aside for the calls' gathers.  A call's ~37 000 PCIe writes, issued by
+// the whole chip within microseconds, queue in the memory system for the ~36 us the link needs, and the windows traced
+// meanwhile run at 0.8 of their speed behind them; issued by la_cus = 24 compute units (three of each XCD: the first
+// la_cus bits of a CU mask, profiles/r06/cu_mask_census.txt) they arrive at about the link's rate, and the windows -- on
+// the other 232 through streams masked the other way, their persistent grid sized for those -- lose less than the 24 CUs
+// cost: 0.060-0.063 against 0.068-0.072 ms per call at 800x800, 0.42 against 0.48 at 3840x2160.  Without
+// a host image the masks only cost (-9 % on C3's and C5's frames): such calls keep the plain streams.  Sessions whose
+// windows need k_mesh's grid (PT_MESH_BVH), devices that are not 256 compute units in 8 XCDs, and a runtime that refuses
+// the masks take the plain streams as well.
+bool ensure_la_masks(void) {
+    if (R.la_masks_ready) return true;
+    if (R.la_masks_failed || !R.ov_ready || R.la_cus < 8 || R.cus != 256 || R.mesh_mode == MESH_BVH) return false;
+    uint32_t trace_mask[8], gather_mask[8];
+    for (int b = 0; b < 8; ++b) { trace_mask[b] = 0xffffffffu; gather_mask[b] = 0; }
+    for (int b = 0; b < R.la_cus; ++b) { trace_mask[b / 32] &= ~(1u << (b % 32)); gather_mask[b / 32] |= 1u << (b % 32); }
+    bool ok = hipExtStreamCreateWithCUMask(&R.la_gstream, 8, gather_mask) == hipSuccess &&
+              hipEventCreateWithFlags(&R.la_rs_event, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; ok && k < R.ov_streams; ++k) ok = hipExtStreamCreateWithCUMask(&R.lane[k].la_stream, 8, trace_mask) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (int k = 0; k < R.ov_streams; ++k) if (R.lane[k].la_stream) { (void)hipStreamDestroy(R.lane[k].la_stream); R.lane[k].la_stream = nullptr; }
+        if (R.la_gstream) { (void)hipStreamDestroy(R.la_gstream); R.la_gstream = nullptr; }
+        if (R.la_rs_event) { (void)hipEventDestroy(R.la_rs_event); R.la_rs_event = nullptr; }
+        R.la_masks_failed = true;
+        return false;
+    }
+    for (int k = R.ov_streams; k < R.ov_lanes; ++k) R.lane[k].la_stream = R.lane[k % R.ov_streams].la_stream;
+    R.grid_la = (int)std::min<uint32_t>((uint32_t)R.grid, (uint32_t)(R.cus - R.la_cus) * (uint32_t)std::max(1, R.per_cu));
+    R.la_masks_ready = true;
+    return true;
+}
+
 // the fused pipelines only: the unfused / two-kernel-sort / fake-shader ones keep intersection planes and sort tables
 // (one set), the first-bounce cache is filled by the first batch that needs it
 bool overlap_eligible(int count) {
@@ -415,6 +451,7 @@ int enter_lanes(void) {
     if (R.fin_serial == 0xffffffffu) {      // the stamp is about to wrap: nothing may be in flight while every lane's colours are forgotten
         HIPCHK(hipStreamSynchronize(R.stream));
         for (int j = 0; j < R.ov_lanes; ++j) HIPCHK(hipStreamSynchronize(R.lane[j].stream));
+        for (int j = 0; j < R.ov_lanes; ++j) if (R.lane[j].la_stream) HIPCHK(hipStreamSynchronize(R.lane[j].la_stream));
         for (int j = 0; j < R.ov_lanes; ++j) HIPCHK(hipMemsetAsync(R.lane[j].b.final_mem, 0, R.final_bytes, R.stream));
         HIPCHK(hipStreamSynchronize(R.stream));
         R.fin_serial = 0;
@@ -426,6 +463,7 @@ int enter_lanes(void) {
         HIPCHK(hipEventRecord(R.ov_enter, R.stream));
         for (int k = 0; k < R.ov_lanes; ++k) {
             HIPCHK(hipStreamWaitEvent(R.lane[k].stream, R.ov_enter, 0));
+            if (R.lane[k].la_stream && k < R.ov_streams) HIPCHK(hipStreamWaitEvent(R.lane[k].la_stream, R.ov_enter, 0));
             R.lane[k].gathered_valid = false;
         }
     }
@@ -450,6 +488,7 @@ int enqueue_batch_direct(int iter0, int count) {
     int rc = ensure_lanes();
     if (rc) return rc;
     if (!R.ov_enabled) return enqueue_batch_serial(iter0, count);       // the lanes do not fit the budget
+    if (R.la_masked_last) { R.ov_active = false; R.la_masked_last = false; }     // (windows on the lanes' masked streams: la_discard has put the launch stream behind them)
     rc = enter_lanes();
     if (rc) return rc;
     Renderer::Lane &l = R.lane[R.ov_next];
@@ -460,12 +499,22 @@ int enqueue_batch_direct(int iter0, int count) {
 // PT_LOOKAHEAD: iterations [iter0, iter0 + count) traced on lane `slot` as one pool, nothing gathered (enqueue_end under
 // R.la_tracing): the window's final colours wait in the lane's buffer for the calls that consume them.  The caller has
 // made sure that nothing still reads that lane's buffers (its previous window is consumed or discarded).
-int enqueue_window(int slot, int iter0, int count) {
+// `masked`: on the lane's stream of the tracing compute units, with the persistent grid that fits them (ensure_la_masks).  A
+// lane's two streams are ordered against each other through the launch stream: whoever changes the kind starts from
+// enter_lanes' event (every batch's gather, and every window some call has consumed or discarded, is behind that).
+int enqueue_window(int slot, int iter0, int count, bool masked) {
+    if (masked != R.la_masked_last) R.ov_active = false;
     int rc = enter_lanes();
     if (rc) return rc;
+    Renderer::Lane &l = R.lane[slot];
+    const hipStream_t plain = l.stream;
+    const int grid = R.grid;
+    if (masked) { l.stream = l.la_stream; R.grid = R.grid_la; }
     R.la_tracing = true;
-    rc = enqueue_on_lane(R.lane[slot], iter0, count);
+    rc = enqueue_on_lane(l, iter0, count);
     R.la_tracing = false;
+    l.stream = plain; R.grid = grid;
+    R.la_masked_last = masked;
     return rc;
 }
 

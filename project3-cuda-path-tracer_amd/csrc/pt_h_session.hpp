@@ -116,6 +116,7 @@ struct Renderer {
         Bufs b{};                                 // lane 0: the session's own
         hipEvent_t traced = nullptr, gathered = nullptr;
         bool gathered_valid = false;
+        hipStream_t la_stream = nullptr;          // PT_LOOKAHEAD: its stream of the tracing compute units (ensure_la_masks)
     } lane[OV_MAX_LANES];
     Lane *lane_cur = nullptr;     // the lane whose buffers and stream currently stand in for the session's (while its batch is enqueued)
     hipStream_t lane_main = nullptr;   // ... and the session's launch stream meanwhile
@@ -143,8 +144,17 @@ struct Renderer {
         uint32_t stamp = 0;       // of its final colours
         pt_camera cam{}; int depth = 0; Lens lens{0, 0.0f, 0.0f};
         Control *ctl = nullptr;   // its lane's control block (statistics of the window)
+        bool masked = false;      // traced on the lane's masked stream
     } la[LA_SLOTS];
     int la_cur = 0;               // the slot being consumed
+    // Calls that write a host image: their gathers run on la_cus compute units of their own (la_gstream, CU-masked), the
+    // windows on the others (Lane::la_stream, a persistent grid of grid_la workgroups) -- DESIGN 6.13.  0: never.
+    int la_cus = 24, grid_la = 0, per_cu = 0;
+    bool la_masks_ready = false, la_masks_failed = false;
+    uint64_t la_masked_windows = 0, la_masked_calls = 0;
+    bool la_masked_last = false;  // the last batch on a lane went to its masked stream (the next one on a plain stream orders itself behind the launch stream)
+    hipStream_t la_gstream = nullptr;
+    hipEvent_t la_rs_event = nullptr;
     bool la_tracing = false;      // the batch being enqueued is a window: no k_gather, only its counters (enqueue_end)
     uint64_t la_misses = 0, la_windows = 0, la_discards = 0;   // calls that had to trace their own window first / windows enqueued / windows thrown away
     Control *last_ctl = nullptr;  // the control block of the last batch (collect_stats)

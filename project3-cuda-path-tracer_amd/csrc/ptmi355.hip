@@ -96,6 +96,13 @@ extern "C" int ptdbg_lookahead(unsigned long long out[4]) {
     return 0;
 }
 
+// ... and the windows among out[0] that went to the lanes' CU-masked streams / the calls whose gather ran on the compute units set aside for it
+extern "C" int ptdbg_lookahead_masked(unsigned long long out[2]) {
+    if (!g_single.live) return -1;
+    out[0] = g_single.la_masked_windows; out[1] = g_single.la_masked_calls;
+    return 0;
+}
+
 #ifdef PT_WAVE_TIMES
 // diagnostic build only (not in include/ptmi355.h): per-wave start / end ticks and hardware ids of k_bounce's last launches
 extern "C" int ptdbg_wave_times(unsigned long long *times /* [8][8192][2] */, uint32_t *hw /* [8][8192] */) {

@@ -82,6 +82,10 @@ def test_host_image_after_every_call_equals_the_oracle(pt, po, scenes, launch_pl
     assert sum(served) == ref.rays                         # statistics are additive: every window reported once, whole
     assert bookkeeping(pt) == (6, 1, 0, K)                 # [1,4] traced by call 1; [5,12] .. [37,44] ahead, three at a time; nothing thrown away
     assert pt.counters()[0] >= ref.rays                    # (the device has traced, or is tracing, [21, 44] ahead as well)
+    if host_flags == "pin+sparse":                         # such calls take the CU-masked streams (256 compute units in 8 XCDs) ...
+        assert masked_bookkeeping(pt) in ((6, 19), (0, 0)) # ... every window, and every call but the first (a whole-frame copy)
+    else:
+        assert masked_bookkeeping(pt) == (0, 0)
     call(a, 22)                                            # 21 is skipped: the window traced ahead starts at 21 and is void
     assert bookkeeping(pt) == (10, 2, 3, 4)                # [21,28] [29,36] [37,44] thrown away; [22,25] by this call, [26,33] [34,41] [42,49] ahead
     call(a, 23); call(b, 24); call(a, 25); call(a, 26)     # (24: a second host buffer; the 4-iteration window ends at 25)
@@ -105,6 +109,62 @@ def test_host_image_after_every_call_equals_the_oracle(pt, po, scenes, launch_pl
     served.clear()
     for it in range(1, K):
         call(a, it)
+    pt.pathtraceFree()
+
+
+def masked_bookkeeping(pt):
+    """(windows traced on the lanes' CU-masked streams, calls whose gather ran on the compute units set aside for it)"""
+    import ctypes as C
+    out = (C.c_uint64 * 2)()
+    assert pt.library().ptdbg_lookahead_masked(out) == 0
+    return tuple(int(v) for v in out)
+
+
+def test_calls_of_every_kind_on_windows_of_the_masked_streams(pt, po, scenes, launch_plan):
+    """Calls that write a page-locked host image take windows traced on CU-masked streams and gather on compute units of
+    their own (csrc/pt_h_enqueue.hpp: ensure_la_masks).  One chain of such windows serves calls with the host image, without
+    one, with a PBO, with another buffer; asynchronous batches (the lanes' plain streams, the same buffers) come in between."""
+    import torch
+    s = scenes["cornell"]
+    w, h = 400, 300
+    cam = _resized(s["camera"], w, h)
+    n = w * h
+    depth = s["depth"]
+    scene = pt.Scene(s["geoms"], s["materials"], cam, depth)
+    L = pt.library()
+    a = np.full((n, 3), -7.0, dtype=np.float32)
+    b = np.full((n, 3), -9.0, dtype=np.float32)
+    pbo = torch.zeros(n * 4, dtype=torch.uint8, device="cuda:0")
+    pt.pathtraceInit(scene, flags=pt.PT_COMPACT | pt.PT_LOOKAHEAD | pt.PT_PIN_IMAGE | pt.PT_HOST_SPARSE, max_batch=K, pin_image=False)
+    ref = Oracle(po, s, cam, depth)
+
+    def call(it, buf=None, with_pbo=False):
+        assert L.pt_trace(pbo.data_ptr() if with_pbo else None, 0, it, buf.ctypes.data if buf is not None else None) == 0, L.pt_last_error()
+        want = ref.iterate(it)
+        if buf is not None:
+            assert (bits(buf) == bits(want)).all(), "host image after iteration %d" % it
+        assert (bits(pt.get_image(n)) == bits(want)).all(), "device image after iteration %d" % it
+        if with_pbo:
+            assert pbo.cpu().numpy().tobytes() == pt.tonemap(n, it).tobytes(), it
+
+    it = 1
+    for kind in ("a", "a", "a", None, "a", "a", "pbo+a", "a", "b", "b", "a", "a", "pbo", "a", "a", None, None, "a", "a", "a"):
+        call(it, {"a": a, "b": b, "pbo+a": a}.get(kind), with_pbo=kind in ("pbo", "pbo+a"))
+        it += 1
+    windows, misses, discards, _ = bookkeeping(pt)
+    masked_windows, masked_calls = masked_bookkeeping(pt)
+    assert (misses, discards) == (1, 0)
+    if masked_windows:                                     # (a device that is not 256 compute units in 8 XCDs keeps the plain streams)
+        assert masked_windows == windows                   # one chain: every window the kind its first call asked for
+        assert masked_calls == 10                          # the calls that found the buffer they write current: a a | a a | a | b | a | a | a a
+    for rounds in range(2):                                # batches on the lanes' plain streams, then calls again: twice over
+        for k in range(3):
+            pt.trace_batch_async(100 * (rounds + 1) + 4 * k, 4)
+            for j in range(4):
+                ref.iterate(100 * (rounds + 1) + 4 * k + j)
+        for j in range(K + 2):
+            call(200 * (rounds + 1) + j, a)
+    assert masked_bookkeeping(pt)[0] in (0, bookkeeping(pt)[0])
     pt.pathtraceFree()
 
 
