@@ -174,7 +174,10 @@ enum pt_flags {
                                     What differs: pt_get_stats reports a window's counts ONCE, with the call that starts
                                     consuming it (the calls served from it afterwards report rays = 0: the sums over a run of
                                     calls are exact), and pt_total_rays / pt_get_counters count a window when it is traced,
-                                    ahead of its calls (iterations traced ahead and then discarded stay counted).  Single-device sessions that own the whole frame (tile_count <= 1) on the fused
+                                    ahead of its calls (iterations traced ahead and then discarded stay counted).  With a
+                                    page-locked host image (PT_PIN_IMAGE | PT_HOST_SPARSE) on a 256-CU device the windows are
+                                    traced on 232 compute units and the calls' gathers write the image from the other 24
+                                    (CU-masked streams of the library's own; results unchanged).  Single-device sessions that own the whole frame (tile_count <= 1) on the fused
                                     pipelines; ignored elsewhere (PT_UNFUSED, PT_FAKE_SHADER, PT_CACHE_FIRST, two-kernel sort,
                                     PT_ASYNC_IMAGE, max_batch < 2). */
     PT_ASYNC_IMAGE   = 1u << 7   /* opt-in: pt_trace / pt_trace_batch return without waiting; the copy of the
