@@ -115,7 +115,11 @@ def test_c2_frame_over_two_contexts(pt, scenes):
     want = run()
     devs = [0, 1] if gpu_count() >= 2 else [0, 0]
     got = run(devices=devs)
-    assert got[0].tobytes() == want[0].tobytes() and got[1].tobytes() == want[1].tobytes() and got[2] == want[2]
+    assert got[2] == want[2], "rays traced: %d over two contexts, %d over one" % (got[2], want[2])
+    for name, a, b in (("host image after the batch of 8", got[0], want[0]), ("device image after the single call", got[1], want[1])):
+        bad = np.flatnonzero((a.view(np.uint32) != b.view(np.uint32)).reshape(n, 3).any(axis=1))
+        assert bad.size == 0, "%s: %d pixels differ, rows %d..%d (first: pixel %d, %r against %r)" % (
+            name, bad.size, bad[0] // 800, bad[-1] // 800, bad[0], a.reshape(n, 3)[bad[0]], b.reshape(n, 3)[bad[0]])
 
 
 def test_pathtrace_per_call_several_contexts_no_exchange(pt, scenes, monkeypatch):
