@@ -1,6 +1,6 @@
 """Per-call latency of pathtrace() under PT_LOOKAHEAD by position inside a 64-iteration window (800x800 Cornell):
 the first calls of a window run beside the tracing of the next one, the last ones on an otherwise idle device.
-usage: python profiles/tools/lookahead_latency.py [host|nohost] [windows]"""
+usage: python profiles/tools/lookahead_latency.py [host|nohost|hostpbo|pbo] [windows]"""
 import os
 import sys
 import time
@@ -35,17 +35,23 @@ if os.environ.get("LA_HUGE"):
     thp = open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip() if os.path.exists("/sys/kernel/mm/transparent_hugepage/enabled") else "?"
     anon = [l for l in open("/proc/self/smaps_rollup") if "AnonHugePages" in l]
     print("huge pages: madvise rc %d, THP %s, %s" % (rc, thp, anon[0].strip() if anon else "?"))
-flags = pt.PT_COMPACT | pt.PT_LOOKAHEAD | (pt.PT_PIN_IMAGE | pt.PT_HOST_SPARSE if mode == "host" else 0)
+flags = pt.PT_COMPACT | pt.PT_LOOKAHEAD | (pt.PT_PIN_IMAGE | pt.PT_HOST_SPARSE if mode in ("host", "hostpbo") else 0)
 pt.pathtraceInit(scene, flags=flags, max_batch=K, pin_image=False)
-buf = host.ctypes.data if mode == "host" else None
+buf = host.ctypes.data if mode in ("host", "hostpbo") else None
+pbo = None
+if mode in ("hostpbo", "pbo"):                # the reference's GL host hands over a PBO every call (main.cpp:131-137)
+    import torch
+    pbo_t = torch.zeros(n * 4, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    pbo = pbo_t.data_ptr()
 for it in range(1, 85):
-    L.pt_trace(None, 0, it, buf)
+    L.pt_trace(pbo, 0, it, buf)
 lat = np.zeros((windows, 64))
 t_all = time.perf_counter()
 for w in range(windows):
     for k in range(64):
         t0 = time.perf_counter()
-        L.pt_trace(None, 0, 85 + 64 * w + k, buf)
+        L.pt_trace(pbo, 0, 85 + 64 * w + k, buf)
         lat[w, k] = time.perf_counter() - t0
 el = time.perf_counter() - t_all
 pt.pathtraceFree()
