@@ -409,7 +409,14 @@ def per_call_rates(c, n_it=256):
     host = np.zeros((c.npix, 3), dtype=np.float32)
     L = pt.library()
 
-    def run(flags, call, max_batch=1, rays=None, first=33):
+    def masked_streams():
+        # what the library did with the windows (csrc/pt_h_enqueue.hpp: ensure_la_masks): windows traced on the lanes' CU-masked
+        # streams / calls whose gather ran on the compute units set aside for it
+        import ctypes
+        out = (ctypes.c_uint64 * 2)()
+        return [int(v) for v in out] if L.ptdbg_lookahead_masked(out) == 0 else None
+
+    def run(flags, call, max_batch=1, rays=None, first=33, probe=None):
         # (the library's own launch stream, as a host that links libptmi355.so gets it -- not torch's)
         # `rays`: the rays of iterations first .. first + n_it - 1 as counted by an earlier run over the same iterations -- a
         # PT_LOOKAHEAD session counts windows when it traces them, ahead of the calls that consume them
@@ -424,6 +431,7 @@ def per_call_rates(c, n_it=256):
         pt.synchronize()
         el = time.perf_counter() - t1
         traced = pt.total_rays() - r0
+        run.probe = probe() if probe else None
         pt.pathtraceFree()
         run.rays = traced
         return round((traced if rays is None else rays) / el / 1e6, 2), round(el / n_it * 1e3, 4)
@@ -445,7 +453,10 @@ def per_call_rates(c, n_it=256):
     la_batch = max(4, min(64, 41000000 // c.npix))       # the shim's rule (host/pathtrace_shim.cpp): windows of up to 64 iterations and ~40 M paths
     out["lookahead_max_batch"] = la_batch
     out["pcie_inclusive_sync"], out["pcie_inclusive_sync_ms_per_call"] = run(
-        la, lambda it: L.pt_trace(None, 0, it, host.ctypes.data), max_batch=la_batch, rays=rays_85, first=85)
+        la, lambda it: L.pt_trace(None, 0, it, host.ctypes.data), max_batch=la_batch, rays=rays_85, first=85, probe=masked_streams)
+    if run.probe:
+        out["lookahead_cu_masked"] = {"windows": run.probe[0], "calls": run.probe[1],
+                                      "note": "since pathtraceInit: windows traced on 232 of the 256 compute units, calls whose gather wrote the host image from the other 24"}
     if c.args.digest:
         out["host_image_md5"] = hashlib.md5(host.tobytes()).hexdigest()       # the host image after the synchronous calls
     out["lookahead_no_host_image"], out["lookahead_no_host_image_ms_per_call"] = run(
