@@ -305,6 +305,51 @@ def test_other_pipelines_behind_the_windows(pt, scenes, launch_plan, pipeline):
     assert want[-1].sum() > 0
 
 
+@pytest.mark.parametrize("pipeline", ["sorted glass + jitter + lens", "mesh loop", "mesh hierarchy"])
+def test_other_pipelines_on_the_masked_streams(pt, scenes, launch_plan, pipeline):
+    """The same with a page-locked host image of more than 1 MiB (PT_PIN_IMAGE | PT_HOST_SPARSE): such chains of windows go to
+    the lanes' CU-masked streams with a smaller persistent grid, their calls gather on compute units of their own -- except
+    under PT_MESH_BVH (k_mesh's grid is sized for the whole chip: plain streams).  The host image after every call against
+    the plain calls'."""
+    w, h = 416, 304
+    n = w * h
+    if pipeline.startswith("sorted glass"):
+        s = scenes["cornell_glass"]
+        scene = pt.Scene(s["geoms"], s["materials"], _resized(s["camera"], w, h), s["depth"])
+        flags, lens = pt.PT_COMPACT | pt.PT_SORT_MATERIAL | pt.PT_AA_JITTER, (0.15, 8.0)
+    else:
+        s = scenes["cornell"]
+        tris = pt.meshes.uv_sphere(n_lat=12, n_lon=24)
+        geoms, tris, meshes = pt.meshes.add_mesh(s["geoms"], tris, material_id=1)
+        scene = pt.Scene(geoms, s["materials"], _resized(s["camera"], w, h), s["depth"], triangles=tris, meshes=meshes)
+        flags, lens = pt.PT_COMPACT | (pt.PT_MESH_BVH if pipeline == "mesh hierarchy" else 0), None
+    L = pt.library()
+
+    def run(extra, max_batch):
+        pt.pathtraceInit(scene, flags=flags | pt.PT_PIN_IMAGE | pt.PT_HOST_SPARSE | extra, max_batch=max_batch, pin_image=False)
+        if lens:
+            pt.set_lens(*lens)
+        host = np.full((n, 3), -3.0, dtype=np.float32)
+        out = []
+        for it in range(1, 2 * K + 4):
+            assert L.pt_trace(None, 0, it, host.ctypes.data) == 0, L.pt_last_error()
+            out.append(host.copy())
+        masked = masked_bookkeeping(pt) if extra else None
+        windows = bookkeeping(pt)[0] if extra else None
+        pt.pathtraceFree()
+        return out, masked, windows
+
+    want, _, _ = run(0, 1)
+    got, masked, windows = run(pt.PT_LOOKAHEAD, K)
+    for it, (g, v) in enumerate(zip(got, want), 1):
+        assert (bits(g) == bits(v)).all(), (pipeline, it)
+    assert want[-1].sum() > 0 and windows >= 4
+    if pipeline == "mesh hierarchy":
+        assert masked == (0, 0)
+    else:
+        assert masked in ((windows, 2 * K + 2), (0, 0))    # every window, every call but the first (256 compute units in 8 XCDs; else none)
+
+
 def test_flag_is_ignored_where_it_cannot_apply(pt, scenes, launch_plan):
     """max_batch = 1, the fake shader, the unfused pipeline: pt_trace takes its plain path and the image is the usual one."""
     s = scenes["cornell_64"]
