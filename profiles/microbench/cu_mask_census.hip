@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <set>
 #include <vector>
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -38,6 +39,22 @@ static int run(const char *name, hipStream_t st, uint32_t *d, int wgs) {
     printf("%-34s %4zu distinct compute units; per XCC:", name, cus.size());
     for (int x = 0; x < 8; ++x) printf(" %zu", per[x].size());
     printf("\n");
+    if (getenv("CENSUS_LIST") && cus.size() <= 64) {          // where they are: xcc.se.sh.cu
+        printf("   ");
+        for (uint32_t k : cus) printf(" %u.%u.%u.%u", k >> 16, (k >> 8) & 0xff, (k >> 4) & 0xf, k & 0xf);
+        printf("\n");
+    }
+    if (getenv("CENSUS_LIST") && cus.size() > 64) {           // per XCC and shader engine: how many
+        printf("    per xcc / se:");
+        for (int x = 0; x < 8; ++x) {
+            int per_se[8] = {0};
+            for (uint32_t k : per[x]) per_se[(k >> 8) & 7]++;
+            printf("  [");
+            for (int e = 0; e < 8; ++e) if (per_se[e]) printf(" %d:%d", e, per_se[e]);
+            printf(" ]");
+        }
+        printf("\n");
+    }
     (void)per_xcc;
     return 0;
 }
@@ -51,7 +68,8 @@ int main() {
     if (run("no mask", plain, d, wgs)) return 1;
     struct { const char *name; int first, count; } cases[] = {
         {"bits 0..7 set", 0, 8}, {"bits 0..7 cleared", 8, cus - 8}, {"bit 0 set", 0, 1}, {"bits 0..31 set", 0, 32},
-        {"bits 32..63 set", 32, 32}, {"bits 0..15 set", 0, 16}, {"bits 0..3 set", 0, 4}, {"bits 0..127 set", 0, 128}};
+        {"bits 32..63 set", 32, 32}, {"bits 0..15 set", 0, 16}, {"bits 0..3 set", 0, 4}, {"bits 0..127 set", 0, 128},
+        {"bits 0..23 set", 0, 24}, {"bits 0..23 cleared", 24, cus - 24}};
     for (auto &c : cases) {
         uint32_t mask[16] = {0};
         for (int b = c.first; b < c.first + c.count; ++b) mask[b >> 5] |= 1u << (b & 31);
