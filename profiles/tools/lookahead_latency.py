@@ -20,7 +20,20 @@ windows = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 L = pt.library()
 n = 800 * 800
 host = np.zeros((n, 3), dtype=np.float32)
-if os.environ.get("LA_HUGE"):
+if os.environ.get("LA_NUMA"):
+    # the host image on one NUMA node (mbind before the first touch): do the calls' PCIe writes care how far it is from the GPU?
+    import ctypes, mmap
+    node = int(os.environ["LA_NUMA"])
+    size = ((n * 12 + 4095) // 4096) * 4096
+    m = mmap.mmap(-1, size, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    libc = ctypes.CDLL(None, use_errno=True)
+    mask = ctypes.c_ulong(1 << node)
+    rc = libc.syscall(237, ctypes.c_void_p(base), ctypes.c_ulong(size), 2, ctypes.byref(mask), ctypes.c_ulong(64), 0)      # mbind(MPOL_BIND)
+    host = np.frombuffer(m, dtype=np.float32, count=n * 3).reshape(n, 3)
+    host[:] = 0.0
+    print("host image bound to NUMA node %d: mbind rc %d errno %d" % (node, rc, ctypes.get_errno()))
+elif os.environ.get("LA_HUGE"):
     # the host image on transparent huge pages (2 MiB-aligned anonymous mapping + MADV_HUGEPAGE): do the device's scattered
     # 12-byte writes into it cost less when the frame is four pages instead of 1875?
     import ctypes, mmap
