@@ -724,7 +724,8 @@ int la_trace(uint8_t *pbo_rgba, int iter, float *host_image_sum, bool *handled) 
     {
         const float4 *fin = reinterpret_cast<const float4 *>(lane.b.final_mem) + (size_t)s * (size_t)R.npix;
         dim3 grid((unsigned)((R.npix + (int)LA_UNROLL * BLOCK - 1) / ((int)LA_UNROLL * BLOCK)));
-        if (gs != R.stream) grid = dim3((unsigned)std::min<int>((int)grid.x, R.la_cus * (pt_experiment("PTMI355_LA_GWGS") ? std::max(1, atoi(pt_experiment("PTMI355_LA_GWGS"))) : 12)));       // (a round and a half of what its compute units hold: 0.058 against 0.060 ms with one)       // what fits its compute units at once (a grid-stride kernel)
+        // on its own compute units: a round and a half of what they hold at once (a grid-stride kernel; 0.058 against 0.060 ms with one round)
+        if (gs != R.stream) grid = dim3((unsigned)std::min<int>((int)grid.x, R.la_cus * (pt_experiment("PTMI355_LA_GWGS") ? std::max(1, atoi(pt_experiment("PTMI355_LA_GWGS"))) : 12)));
         float *host_dev = host_current ? mapped : (float *)nullptr;
         if (pbo_rgba) hipLaunchKernelGGL(k_gather_one<true>, grid, dim3(BLOCK), 0, gs, R.image, fin, host_dev, w.stamp, (uint32_t)R.npix, pbo_rgba, iter);
         else hipLaunchKernelGGL(k_gather_one<false>, grid, dim3(BLOCK), 0, gs, R.image, fin, host_dev, w.stamp, (uint32_t)R.npix, pbo_rgba, iter);
