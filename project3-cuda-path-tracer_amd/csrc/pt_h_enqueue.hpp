@@ -409,7 +409,7 @@ int ensure_lanes(void) {
 // meanwhile run at 0.8 of their speed behind them; issued by la_cus = 24 compute units (three of each XCD: the first
 // la_cus bits of a CU mask, profiles/r06/cu_mask_census.txt) they arrive at about the link's rate, and the windows -- on
 // the other 232 through streams masked the other way, their persistent grid sized for those -- lose less than the 24 CUs
-// cost: 0.060-0.063 against 0.068-0.072 ms per call at 800x800, 0.42 against 0.48 at 3840x2160.  Without
+// cost: 0.060-0.061 against 0.068-0.072 ms per call at 800x800, 0.40 against 0.47 at 3840x2160.  Without
 // a host image the masks only cost (-9 % on C3's and C5's frames): such calls keep the plain streams.  Sessions whose
 // windows need k_mesh's grid (PT_MESH_BVH), devices that are not 256 compute units in 8 XCDs, and a runtime that refuses
 // the masks take the plain streams as well.
