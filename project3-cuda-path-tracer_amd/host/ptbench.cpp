@@ -6,6 +6,10 @@
 //           [--cache-first] [--bvh] [--aa] [--lens RADIUS FOCAL] [--pfm] [--device D] [--tile R/K] [--strip-rows S]
 //           [--gpus K | --devices D0,D1,...] [--save-sum] [--resume SUMFILE.pfm [--start N]]
 //
+// --batch B: iterations per launch sequence (default: up to 64 and ~40 M paths, as the shim sizes its windows; 1 = one
+// pathtrace() per iteration); every batch but the last is enqueued without waiting, so consecutive batches overlap on the
+// device.  The image is the same bit for bit whatever B.
+//
 // --save-sum / --resume: a render across several runs (C5's 5000 spp across GPU leases).  The running sum is the whole
 // state the reference carries from one iteration to the next (dev_image, pathtrace.cu:71,84,389): --save-sum writes it
 // raw (BASE.<N>samp.sum.pfm, exact), --resume loads it (pt_set_image) and continues with iteration N + 1 (N from
@@ -36,7 +40,7 @@ int main(int argc, char **argv) {
                "[--gpus K | --devices D0,D1,...] [--save-sum] [--resume SUMFILE.pfm [--start N]]\n", argv[0]);
         return 1;
     }
-    int iters = -1, batch = 1, device = 0, tile_index = 0, tile_count = 1, strip_rows = 8;
+    int iters = -1, batch = 0, device = 0, tile_index = 0, tile_count = 1, strip_rows = 8;
     unsigned flags = PT_COMPACT | PT_PIN_IMAGE | PT_HOST_SPARSE;      // `image` below lives until pt_free and is only read here
     bool pfm = false, save_sum = false;
     std::string resume;
@@ -77,7 +81,11 @@ int main(int argc, char **argv) {
     pth_scene *sc = pth_load_scene(argv[1]);
     if (!sc) { fprintf(stderr, "%s\n", pth_last_error()); return 1; }
     if (iters < 0) iters = sc->iterations;
-    if (batch < 1) batch = 1;
+    if (batch < 1) {                                      // not given: as the shim sizes its windows -- up to 64 iterations and ~40 M paths per batch
+        const long long pixels = (long long)sc->camera.resolution[0] * sc->camera.resolution[1];
+        const long long k = 41000000LL / (pixels > 0 ? pixels : 1);
+        batch = (int)(k < 4 ? 4 : (k > 64 ? 64 : k));
+    }
     const int W = sc->camera.resolution[0], H = sc->camera.resolution[1];
     printf("scene %s: %d geoms, %d materials, %d triangles, %dx%d, depth %d, %d iterations\n", argv[1],
            sc->num_geoms, sc->num_materials, sc->num_triangles, W, H, sc->trace_depth, iters);
@@ -116,8 +124,11 @@ int main(int argc, char **argv) {
     while (iteration < iters) {                            // runCuda: iteration++ ; pathtrace(pbo, 0, iteration)
         const int n = (iters - iteration < batch) ? iters - iteration : batch;
         const int last = (iteration + n == iters);
+        // every batch but the last is only enqueued: consecutive batches overlap on the device; the last one
+        // waits for all of them and brings the image
         int rc = (n == 1) ? pt_trace(NULL, 0, iteration + 1, last ? image.data() : NULL)
-                          : pt_trace_batch(iteration + 1, n, last ? image.data() : NULL);
+                 : last   ? pt_trace_batch(iteration + 1, n, image.data())
+                          : pt_trace_batch_async(iteration + 1, n);
         if (rc != PT_OK) { fprintf(stderr, "pathtrace: %s\n", pt_last_error()); return 1; }
         iteration += n;
     }
